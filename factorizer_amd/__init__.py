@@ -1,0 +1,17 @@
+"""factorizer_amd — MI355X-native drop-in for the hot path of pashtari/factorizer.
+
+``import factorizer_amd as ft`` exposes the reference's flat names for that path
+(factorizer/__init__.py:1-6): ft.NMF, ft.SWMatricize, ft.FactorizerBlock, ft.Factorizer, ...
+Device tensors run hand-written gfx950 kernels through libfactorizer_hip.so
+(include/factorizer_hip.h); there is no silent fallback when the library is missing.
+"""
+from .utils import as_tuple, has_args, is_partializable, partialize
+from .matricize import Matricize, Reshape, SWMatricize
+from .nmf import (NMF, BCDSolver, Compose, CoordinateDescent, Initializer, MatrixFactorization,
+                  MultiplicativeUpdate, RandomInit, relative_error)
+from .layers import MLP, LayerNorm, Linear, PosEmbed, PositionalEmbedding
+from .blocks import FactMixer, FactorizerBlock, FactorizerStage
+from .unet import (Factorizer, Same, UNet, UNetDecoder, UNetDecoderBlock, UNetEncoder,
+                   UNetEncoderBlock, UNetStage)
+
+__version__ = "0.1.0"

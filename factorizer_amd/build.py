@@ -1,0 +1,78 @@
+"""Build libfactorizer_hip.so (gfx950) in-tree with hipcc.  `python -m factorizer_amd.build`.
+
+The .so is git-ignored but travels to the GPU box with the gpurun snapshot.  hipcc
+cross-compiles for gfx950 without a GPU present.
+"""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "csrc", "build")
+LIB = os.path.join(HERE, "libfactorizer_hip.so")
+ARCH = "gfx950"
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-comment",
+         "-ffp-contract=fast"]
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: cannot build libfactorizer_hip.so")
+    return exe
+
+
+def sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _deps_mtime() -> float:
+    m = 0.0
+    for root in (CSRC, os.path.join(os.path.dirname(HERE), "include")):
+        for f in os.listdir(root):
+            if f.endswith((".h", ".inc", ".hip")):
+                m = max(m, os.path.getmtime(os.path.join(root, f)))
+    return m
+
+
+def needs_build() -> bool:
+    return not os.path.exists(LIB) or os.path.getmtime(LIB) < _deps_mtime()
+
+
+def _compile(src: str) -> str:
+    obj = os.path.join(OBJ, src[:-4] + ".o")
+    cmd = [_hipcc(), *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-4000:]}")
+    return obj
+
+
+def build(force: bool = False, verbose: bool = True, jobs: int | None = None) -> str:
+    if not force and not needs_build():
+        return LIB
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = sources()
+    jobs = jobs or min(len(srcs), os.cpu_count() or 4)
+    if verbose:
+        print(f"[factorizer_amd] hipcc {ARCH}: {len(srcs)} translation units, {jobs} jobs", flush=True)
+    with cf.ThreadPoolExecutor(jobs) as ex:
+        objs = list(ex.map(_compile, srcs))
+    tmp = LIB + ".tmp"
+    r = subprocess.run([_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", tmp, *objs],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stderr[-4000:])
+    os.replace(tmp, LIB)
+    if verbose:
+        print(f"[factorizer_amd] built {LIB}", flush=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,17 @@
+// api.hip — library-level entry points of the C ABI (include/factorizer_hip.h).
+#include "fz_common.h"
+
+namespace fz {
+std::string& last_error() {
+  static thread_local std::string s;
+  return s;
+}
+std::atomic<int64_t>& launch_counter() {
+  static std::atomic<int64_t> c{0};
+  return c;
+}
+}  // namespace fz
+
+extern "C" int fz_version(void) { return 100; }  // 0.1.0
+extern "C" const char* fz_last_error_string(void) { return fz::last_error().c_str(); }
+extern "C" int64_t fz_launch_count(void) { return fz::launch_counter().load(); }

@@ -1,0 +1,199 @@
+"""Device ops of the hot path as autograd Functions over the C ABI (include/factorizer_hip.h).
+
+Every Function here runs ONLY the native gfx950 kernels; CPU tensors never get here (modules
+route them to `composed.py`).  Backward passes are hand-written kernels as well
+(SURVEY.md Appendix A for NMF).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import _native as N
+
+
+def _dev_guard(t: torch.Tensor):
+    return torch.cuda.device(t.device)
+
+
+class Geometry:
+    """Static shape contract of a shifted-window matricize (operations.py:299-355, 381-415):
+    channels C = h·d, spatial S_i = G_i·p_i, windows with cyclic shifts s_w."""
+
+    def __init__(self, channels, spatial, head_dim, patch, shifts):
+        self.C = int(channels)
+        self.spatial = tuple(int(s) for s in spatial)
+        self.d = int(head_dim)
+        self.patch = tuple(int(p) for p in patch)
+        self.shifts = [tuple(int(v) for v in s) for s in shifts]
+        if self.C % self.d:
+            raise ValueError(f"channels {self.C} not divisible by head_dim {self.d}")
+        for s, p in zip(self.spatial, self.patch):
+            if s % p:
+                raise ValueError(f"spatial size {self.spatial} not divisible by patch size {self.patch}")
+        self.h = self.C // self.d
+        self.grid = tuple(s // p for s, p in zip(self.spatial, self.patch))
+        self.G = math.prod(self.grid)
+        self.P = math.prod(self.patch)
+        self.nshift = len(self.shifts)
+        # the native kernels are 3-D; lower-D problems are padded with leading unit axes
+        nd = len(self.spatial)
+        if nd > 3:
+            raise ValueError("at most 3 spatial dims")
+        pad = 3 - nd
+        self.s3 = (1,) * pad + self.spatial
+        self.p3 = (1,) * pad + self.patch
+        self.shifts3 = [(0,) * pad + s for s in self.shifts]
+        self._carr = N.shifts_array(self.shifts3)
+
+    def y_shape(self, B):
+        return (self.nshift * B * self.h, self.G, self.d, self.P)
+
+
+def _swm_fwd_raw(x, geo: Geometry, relu=False, div=1):
+    B = x.shape[0]
+    y = torch.empty(geo.y_shape(B), dtype=x.dtype, device=x.device)
+    if x.dtype == torch.float32:
+        es = 4
+    elif x.dtype in (torch.bfloat16, torch.float16):
+        es = 2
+    else:
+        raise TypeError(f"SWMatricize: unsupported dtype {x.dtype}")
+    with _dev_guard(x):
+        rc = N.lib().fz_swm_fwd(x.data_ptr(), y.data_ptr(), B, geo.C, *geo.s3, geo.d, *geo.p3, geo.nshift,
+                                geo._carr, es, int(relu), int(div), N.stream_ptr(x))
+    N.check(rc, "fz_swm_fwd")
+    return y
+
+
+def _swm_inv_raw(y, geo: Geometry, average=True, gate=None):
+    if y.dtype != torch.float32:
+        raise TypeError("SWMatricize.inverse_forward: float32 only on device")
+    B = y.shape[0] // (geo.nshift * geo.h)
+    x = torch.empty((B, geo.C, *geo.spatial), dtype=y.dtype, device=y.device)
+    with _dev_guard(y):
+        rc = N.lib().fz_swm_inv(y.data_ptr(), x.data_ptr(), B, geo.C, *geo.s3, geo.d, *geo.p3, geo.nshift,
+                                geo._carr, int(average), N.ptr(gate), N.stream_ptr(y))
+    N.check(rc, "fz_swm_inv")
+    return x
+
+
+class SWMForwardFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, geo):
+        ctx.geo = geo
+        return _swm_fwd_raw(x.contiguous(), geo)
+
+    @staticmethod
+    def backward(ctx, gy):
+        if gy.dtype != torch.float32:
+            return _swm_inv_raw(gy.float().contiguous(), ctx.geo, average=False).to(gy.dtype), None
+        return _swm_inv_raw(gy.contiguous(), ctx.geo, average=False), None
+
+
+class SWMInverseFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, geo):
+        ctx.geo = geo
+        return _swm_inv_raw(y.contiguous(), geo, average=True)
+
+    @staticmethod
+    def backward(ctx, gx):
+        return _swm_fwd_raw(gx.contiguous(), ctx.geo, div=ctx.geo.nshift), None
+
+
+def swm_forward(x, geo):
+    return SWMForwardFn.apply(x, geo)
+
+
+def swm_inverse(y, geo):
+    return SWMInverseFn.apply(y, geo)
+
+
+# ---- batched NMF --------------------------------------------------------------------------
+def nmf_supported(M, N_, R, T, G) -> bool:
+    return bool(N.lib().fz_nmf_supported(int(M), int(N_), int(R), int(T), int(G)))
+
+
+def _nmf_fwd_raw(x, u0, v0, T, solver, eps, want_uv=False):
+    M, Nn = x.shape[-2:]
+    R = u0.shape[1]
+    nmat = x.numel() // (M * Nn)
+    y = torch.empty_like(x)
+    u = v = None
+    if want_uv:
+        u = torch.empty((*x.shape[:-2], M, R), dtype=x.dtype, device=x.device)
+        v = torch.empty((*x.shape[:-2], Nn, R), dtype=x.dtype, device=x.device)
+    with _dev_guard(x):
+        rc = N.lib().fz_nmf_fwd(x.data_ptr(), u0.data_ptr(), v0.data_ptr(), y.data_ptr(), N.ptr(u), N.ptr(v),
+                                nmat, M, Nn, R, T, N.SOLVER_ID[solver], eps, N.stream_ptr(x))
+    N.check(rc, "fz_nmf_fwd")
+    return y, u, v
+
+
+def _nmf_bwd_raw(x, u0, v0, gy, gu, gv, T, G, solver, eps):
+    M, Nn = x.shape[-2:]
+    R = u0.shape[1]
+    nmat = x.numel() // (M * Nn)
+    gx = torch.empty_like(x)
+    with _dev_guard(x):
+        rc = N.lib().fz_nmf_bwd(x.data_ptr(), u0.data_ptr(), v0.data_ptr(), N.ptr(gy), N.ptr(gu), N.ptr(gv),
+                                gx.data_ptr(), nmat, M, Nn, R, T, G, N.SOLVER_ID[solver], eps,
+                                N.stream_ptr(x))
+    N.check(rc, "fz_nmf_bwd")
+    return gx
+
+
+class NMFFn(torch.autograd.Function):
+    """y = u_T v_Tᵀ after T unrolled iterations (matrix_factorization.py:514-546)."""
+
+    @staticmethod
+    def forward(ctx, x, u0, v0, T, G, solver, eps):
+        x = x.contiguous()
+        u0 = u0.contiguous()
+        v0 = v0.contiguous()
+        y, _, _ = _nmf_fwd_raw(x, u0, v0, T, solver, eps)
+        ctx.save_for_backward(x, u0, v0)
+        ctx.cfg = (T, G, solver, eps)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, u0, v0 = ctx.saved_tensors
+        T, G, solver, eps = ctx.cfg
+        if G <= 0:
+            return torch.zeros_like(x), None, None, None, None, None, None
+        gx = _nmf_bwd_raw(x, u0, v0, gy.contiguous(), None, None, T, G, solver, eps)
+        return gx, None, None, None, None, None, None
+
+
+class NMFDecomposeFn(torch.autograd.Function):
+    """(u_T, v_T) of the same iterations — NMF.decompose (matrix_factorization.py:514-530)."""
+
+    @staticmethod
+    def forward(ctx, x, u0, v0, T, G, solver, eps):
+        x = x.contiguous()
+        u0 = u0.contiguous()
+        v0 = v0.contiguous()
+        _, u, v = _nmf_fwd_raw(x, u0, v0, T, solver, eps, want_uv=True)
+        ctx.save_for_backward(x, u0, v0)
+        ctx.cfg = (T, G, solver, eps)
+        return u, v
+
+    @staticmethod
+    def backward(ctx, gu, gv):
+        x, u0, v0 = ctx.saved_tensors
+        T, G, solver, eps = ctx.cfg
+        if G <= 0:
+            return torch.zeros_like(x), None, None, None, None, None, None
+        gx = _nmf_bwd_raw(x, u0, v0, None, gu.contiguous(), gv.contiguous(), T, G, solver, eps)
+        return gx, None, None, None, None, None, None
+
+
+def nmf(x, u0, v0, T, G, solver, eps=1e-16):
+    return NMFFn.apply(x, u0, v0, T, G, solver, eps)
+
+
+def nmf_decompose(x, u0, v0, T, G, solver, eps=1e-16):
+    return NMFDecomposeFn.apply(x, u0, v0, T, G, solver, eps)

@@ -1,0 +1,141 @@
+// TEST INFRASTRUCTURE — host lock-step emulation of the per-wave NMF program.
+// Compiles factorizer_amd/csrc/nmf_core.h with F = 64-lane vector so the exact source that
+// runs on gfx950 can be checked against the oracle on a machine without a GPU (and under
+// host sanitizers).  Never shipped, never used by the product path.
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+struct V64 {
+  float a[64];
+  V64() {}
+  V64(float s) { for (int i = 0; i < 64; ++i) a[i] = s; }
+};
+#define BINOP(op)                                                                       \
+  inline V64 operator op(const V64& x, const V64& y) { V64 r; for (int i = 0; i < 64; ++i) r.a[i] = x.a[i] op y.a[i]; return r; } \
+  inline V64 operator op(const V64& x, float y) { V64 r; for (int i = 0; i < 64; ++i) r.a[i] = x.a[i] op y; return r; }           \
+  inline V64 operator op(float x, const V64& y) { V64 r; for (int i = 0; i < 64; ++i) r.a[i] = x op y.a[i]; return r; }
+BINOP(+) BINOP(-) BINOP(*) BINOP(/)
+
+namespace fz {
+inline V64 fz_relu(const V64& v) { V64 r; for (int i = 0; i < 64; ++i) r.a[i] = v.a[i] > 0.f ? v.a[i] : 0.f; return r; }
+inline V64 fz_gate(const V64& w, const V64& g) { V64 r; for (int i = 0; i < 64; ++i) r.a[i] = w.a[i] > 0.f ? g.a[i] : 0.f; return r; }
+}  // namespace fz
+
+#include "../../factorizer_amd/csrc/nmf_core.h"
+
+
+template <int M, int NPL>
+struct EmuWave {
+  using F = V64;
+  int mreal, nreal;
+  int col(int j, int lane) const { return j * 64 + lane; }
+  // same reduction tree as the device: xor 1,2 ; half-mirror ; mirror ; row bcast
+  F sum(const F& v) const {
+    float t[64];
+    std::memcpy(t, v.a, sizeof(t));
+    float n[64];
+    for (int i = 0; i < 64; ++i) n[i] = t[i] + t[i ^ 1];
+    for (int i = 0; i < 64; ++i) t[i] = n[i] + n[i ^ 2];
+    for (int i = 0; i < 64; ++i) n[i] = t[i] + t[(i & ~7) | (7 - (i & 7))];
+    for (int i = 0; i < 64; ++i) t[i] = n[i] + n[(i & ~15) | (15 - (i & 15))];
+    float r0 = t[15], r1 = t[31], r2 = t[47], r3 = t[63];
+    float tot = (r3 + r2) + (r1 + r0);
+    return F(tot);
+  }
+  void st_priv(float* base, int idx, const F& v) const { std::memcpy(base + idx * 64, v.a, 256); }
+  F ld_priv(const float* base, int idx) const { F r; std::memcpy(r.a, base + idx * 64, 256); return r; }
+  void st_uni(float* base, int idx, const F& v) const { base[idx] = v.a[0]; }
+  F ld_uni(const float* base, int idx) const { return F(base[idx]); }
+  F ld_uni_global(const float* p, int idx) const { return F(p[idx]); }
+  F ld_v0(const float* v0, int j, int r, int R) const {
+    F o;
+    for (int l = 0; l < 64; ++l) { int n = col(j, l); o.a[l] = n < nreal ? v0[n * R + r] : 0.f; }
+    return o;
+  }
+  F keep_col(int j, const F& v) const {
+    F o;
+    for (int l = 0; l < 64; ++l) o.a[l] = col(j, l) < nreal ? v.a[l] : 0.f;
+    return o;
+  }
+  void fence() const {}
+  void load_mat(const float* X, F (&x)[M][NPL]) const {
+    for (int m = 0; m < M; ++m)
+      for (int j = 0; j < NPL; ++j)
+        for (int l = 0; l < 64; ++l) {
+          int n = col(j, l);
+          x[m][j].a[l] = (m < mreal && n < nreal) ? X[m * nreal + n] : 0.f;
+        }
+  }
+  void store_mat(float* Y, const F (&x)[M][NPL]) const {
+    for (int m = 0; m < mreal; ++m)
+      for (int j = 0; j < NPL; ++j)
+        for (int l = 0; l < 64; ++l) {
+          int n = col(j, l);
+          if (n < nreal) Y[m * nreal + n] = x[m][j].a[l];
+        }
+  }
+};
+
+template <int M, int NPL, int R, int S>
+static void run_fwd(const float* x, const float* u0, const float* v0, float* y, float* uo, float* vo,
+                    int64_t nmat, int mreal, int nreal, int T, float eps) {
+  for (int64_t k = 0; k < nmat; ++k) {
+    EmuWave<M, NPL> w{mreal, nreal};
+    V64 xm[M][NPL], u[M][R], v[NPL][R];
+    w.load_mat(x + k * mreal * nreal, xm);
+    fz::nmf_forward_wave<M, NPL, R, S>(w, u0, v0, xm, u, v, mreal, T, eps);
+    w.store_mat(y + k * mreal * nreal, xm);
+    if (uo) for (int m = 0; m < mreal; ++m) for (int r = 0; r < R; ++r) uo[(k * mreal + m) * R + r] = u[m][r].a[0];
+    if (vo) for (int j = 0; j < NPL; ++j) for (int l = 0; l < 64; ++l) { int n = j * 64 + l; if (n < nreal) for (int r = 0; r < R; ++r) vo[(k * nreal + n) * R + r] = v[j][r].a[l]; }
+  }
+}
+
+template <int M, int NPL, int R, int S>
+static void run_bwd(const float* x, const float* u0, const float* v0, const float* gy, const float* gu,
+                    const float* gv, float* gx, int64_t nmat, int mreal, int nreal, int T, int G, float eps) {
+  std::vector<float> lds(fz::Hist<M, NPL, R>::floats(G));
+  std::vector<float> zeros((size_t)mreal * nreal, 0.f);
+  for (int64_t k = 0; k < nmat; ++k) {
+    EmuWave<M, NPL> w{mreal, nreal};
+    fz::Hist<M, NPL, R> h;
+    h.carve(lds.data(), G);
+    V64 xm[M][NPL], g[M][NPL];
+    w.load_mat(x + k * mreal * nreal, xm);
+    w.load_mat(gy ? gy + k * mreal * nreal : zeros.data(), g);
+    fz::nmf_backward_wave<M, NPL, R, S>(w, u0, v0, xm, g, h, mreal, T, G, eps,
+                                        gu ? gu + k * mreal * R : nullptr, gv ? gv + k * nreal * R : nullptr);
+    w.store_mat(gx + k * mreal * nreal, g);
+  }
+}
+
+#define DISPATCH_R(FN, M, NPL, ...)                                            \
+  switch (R * 2 + solver) {                                                    \
+    case 2: FN<M, NPL, 1, 0>(__VA_ARGS__); return 0;                           \
+    case 3: FN<M, NPL, 1, 1>(__VA_ARGS__); return 0;                           \
+    case 4: FN<M, NPL, 2, 0>(__VA_ARGS__); return 0;                           \
+    case 5: FN<M, NPL, 2, 1>(__VA_ARGS__); return 0;                           \
+    case 6: FN<M, NPL, 3, 0>(__VA_ARGS__); return 0;                           \
+    case 7: FN<M, NPL, 3, 1>(__VA_ARGS__); return 0;                           \
+    case 8: FN<M, NPL, 4, 0>(__VA_ARGS__); return 0;                           \
+    case 9: FN<M, NPL, 4, 1>(__VA_ARGS__); return 0;                           \
+    default: return -2;                                                        \
+  }
+
+extern "C" int emu_nmf_fwd(const float* x, const float* u0, const float* v0, float* y, float* uo, float* vo,
+                           int64_t nmat, int M, int N, int R, int T, int solver, float eps) {
+  if (M <= 8 && N <= 512) { DISPATCH_R(run_fwd, 8, 8, x, u0, v0, y, uo, vo, nmat, M, N, T, eps) }
+  if (M <= 16 && N <= 256) { DISPATCH_R(run_fwd, 16, 4, x, u0, v0, y, uo, vo, nmat, M, N, T, eps) }
+  if (M <= 32 && N <= 128) { DISPATCH_R(run_fwd, 32, 2, x, u0, v0, y, uo, vo, nmat, M, N, T, eps) }
+  return -2;
+}
+
+extern "C" int emu_nmf_bwd(const float* x, const float* u0, const float* v0, const float* gy, const float* gu,
+                           const float* gv, float* gx, int64_t nmat, int M, int N, int R, int T, int G,
+                           int solver, float eps) {
+  if (M <= 8 && N <= 512) { DISPATCH_R(run_bwd, 8, 8, x, u0, v0, gy, gu, gv, gx, nmat, M, N, T, G, eps) }
+  if (M <= 16 && N <= 256) { DISPATCH_R(run_bwd, 16, 4, x, u0, v0, gy, gu, gv, gx, nmat, M, N, T, G, eps) }
+  if (M <= 32 && N <= 128) { DISPATCH_R(run_bwd, 32, 2, x, u0, v0, gy, gu, gv, gx, nmat, M, N, T, G, eps) }
+  return -2;
+}

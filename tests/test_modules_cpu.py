@@ -1,0 +1,218 @@
+"""Host-side mirrors of the reference modules (factorizer_amd/*) on CPU tensors: constructor
+surface, RNG / state_dict parity with the reference, and values vs the reference goldens.
+(The composed CPU path is plumbing — BASELINE config 0 — the device path is tested in -m gpu.)"""
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+import factorizer_amd as ft
+from test_oracle_golden import G1_CASES, NMF_CASES
+
+
+@pytest.mark.parametrize("name", sorted(G1_CASES))
+def test_swmatricize_cpu_bit_exact(golden, name):
+    g = golden("g1_swmatricize").case(name)
+    shape, kw = G1_CASES[name]
+    x = torch.arange(int(np.prod(shape)), dtype=torch.float32).reshape(shape)
+    m = ft.SWMatricize((None, *shape[1:]), **kw)
+    y = m(x)
+    assert torch.equal(y.to(torch.int32), g["y"])
+    assert [(-1 if s is None else s) for s in m.output_size] == g["output_size"].tolist()
+    z = m.inverse_forward(y)
+    assert torch.equal(z, g["z"])
+    if "yr" in g:
+        assert torch.equal(m.inverse_forward(g["yr"]), g["zr"])
+
+
+def test_matricize_single_window_roundtrip():
+    m = ft.Matricize((None, 16, 8, 8, 8), num_heads=1, grid_size=1)
+    assert m.output_size == (None, 1, 16, 512)
+    x = torch.rand(2, 16, 8, 8, 8)
+    y = m(x)
+    assert y.shape == (2, 1, 16, 512)
+    assert torch.equal(y.reshape(2, 16, 512), x.reshape(2, 16, 512))
+    assert torch.equal(m.inverse_forward(y), x)
+    m2 = ft.Matricize((None, 8, 8, 8), head_dim=4, patch_size=4, shifts=1)  # 2-D
+    x2 = torch.rand(3, 8, 8, 8)
+    assert torch.equal(m2.inverse_forward(m2(x2)), x2)
+
+
+def test_matricize_validation():
+    with pytest.raises(ValueError):
+        ft.SWMatricize((None, 32, 10, 12, 10), head_dim=8, patch_size=8)  # BASELINE cfg 5 shape, p=8
+    with pytest.raises(ValueError):
+        ft.SWMatricize((None, 30, 8, 8, 8), head_dim=8, patch_size=4)
+    with pytest.raises(AssertionError):
+        ft.SWMatricize((None, 32, 8, 8, 8), patch_size=4)
+    ft.SWMatricize((None, 32, 10, 12, 10), head_dim=8, patch_size=(5, 6, 5))  # the valid cfg-5 choice
+
+
+@pytest.mark.parametrize("name", sorted(NMF_CASES))
+def test_nmf_cpu_vs_reference(golden, name):
+    g = golden("g2_nmf").case(name)
+    kw = dict(NMF_CASES[name])
+    M, N = g["x"].shape[-2:]
+    R = g["u0"].shape[1]
+    torch.manual_seed(0)  # same seed + same construction order => same buffers (a-3)
+    rank = None if name == "rank_auto" else R
+    nmf = ft.NMF(size=(M, N), rank=rank, init="uniform", **kw)
+    assert nmf.rank == R
+    assert torch.equal(nmf.init.u0, g["u0"]) and torch.equal(nmf.init.v0, g["v0"])
+    x = g["x"].clone().requires_grad_(True)
+    u, v = nmf.decompose(x)
+    y = nmf(x)
+    assert torch.allclose(u, g["u"], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(v, g["v"], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(y, g["y"], rtol=1e-5, atol=1e-6)
+    (gx,) = torch.autograd.grad(y, x, g["gy"])
+    s = g["gx"].abs().max().item()
+    assert (gx - g["gx"]).abs().max().item() <= 2e-5 * s + 1e-6
+    assert torch.allclose(nmf.loss(x, u, v), g["loss"], rtol=1e-5, atol=1e-7)
+
+
+class TestNMFContract:
+    """Restates the reference's tests/test_nmf.py:9-39 (shape / sign contract)."""
+
+    size = (2, 4, 8, 16)
+    rank = 3
+
+    def setup_method(self):
+        self.nmf = ft.NMF(size=self.size[-2:], rank=self.rank, init="uniform", solver="hals")
+
+    def test_decompose(self):
+        x = torch.rand(self.size, requires_grad=True)
+        u, v = self.nmf.decompose(x)
+        assert u.shape == (*self.size[:-2], self.size[-2], self.rank)
+        assert v.shape == (*self.size[:-2], self.size[-1], self.rank)
+        assert (u >= 0).all() and (v >= 0).all()
+
+    def test_forward(self):
+        x = torch.rand(self.size, requires_grad=True)
+        assert self.nmf(x).shape == x.shape
+
+    def test_reconstruct_and_loss(self):
+        x = torch.rand(self.size)
+        u = torch.rand(*self.size[:-2], self.size[-2], self.rank)
+        v = torch.rand(*self.size[:-2], self.size[-1], self.rank)
+        assert self.nmf.reconstruct(u, v).shape == self.size
+        loss = self.nmf.loss(x, u, v)
+        assert loss.shape == self.size[:1] and (loss >= 0).all()
+
+
+def test_solver_string_table_and_partial_specs():
+    assert isinstance(ft.NMF((8, 16), rank=2, solver="mu").solver, ft.MultiplicativeUpdate)
+    assert isinstance(ft.NMF((8, 16), rank=2, solver="hals").solver.project, nn.ReLU)
+    assert isinstance(ft.MatrixFactorization((8, 16), rank=2).solver.project, nn.Identity)  # "cd"
+    comp = ft.NMF((8, 16), rank=2, solver=["mu", "hals"])
+    assert isinstance(comp.solver, ft.Compose) and len(comp.solver.solvers) == 2
+    ft.NMF((8, 16), rank=2, solver=[ft.MultiplicativeUpdate, {"eps": 1e-8}])  # YAML-style list spec
+    with pytest.raises(NotImplementedError):
+        ft.NMF((8, 16), rank=2, solver="fmu")
+    with pytest.raises(ValueError):
+        ft.NMF((8, 16), rank=2, solver="nope")
+    f = ft.partialize((nn.Linear, (3,), {"out_features": 4}))
+    assert f().weight.shape == (4, 3)
+
+
+BLOCK_KW = {
+    "hals_r1": dict(rank=1, num_iters=5, solver="hals"),
+    "mu_r2": dict(rank=2, num_iters=3, solver="mu"),
+}
+
+
+@pytest.mark.parametrize("name", sorted(BLOCK_KW))
+def test_block_seed_state_dict_and_values(golden, name):
+    g = golden("g5_block").case(name)
+    torch.manual_seed(0)
+    blk = ft.FactorizerBlock(channels=16, spatial_size=(8, 8, 8), norm=ft.LayerNorm,
+                             reshape=(ft.SWMatricize, {"head_dim": 8, "patch_size": 4}), act=nn.ReLU,
+                             factorize=ft.NMF, init="uniform", mlp_ratio=2, dropout=0.0, **BLOCK_KW[name])
+    sd = blk.state_dict()
+    ref = {k[3:]: v for k, v in g.items() if k.startswith("sd:")}
+    assert sorted(sd) == sorted(ref)
+    for k in sd:  # same seed + same construction order => identical parameters AND buffers
+        assert torch.equal(sd[k], ref[k]), k
+    x = g["x"].clone().requires_grad_(True)
+    y = blk(x)
+    assert torch.allclose(y, g["y"], rtol=1e-4, atol=1e-5)
+    names = [k for k, _ in blk.named_parameters()]
+    grads = torch.autograd.grad(y, [x] + list(blk.parameters()), g["gy"])
+    assert torch.allclose(grads[0], g["gx"], rtol=1e-3, atol=2e-4)
+    for k, gr in zip(names, grads[1:]):
+        r = g["grad:" + k]
+        assert (gr - r).abs().max().item() <= 1e-3 * (r.abs().max().item() + 1e-6), k
+
+
+def _tiny_model():
+    return ft.Factorizer(in_channels=4, out_channels=3, spatial_size=(16, 16, 16), encoder_depth=(1, 1, 1),
+                         encoder_width=(8, 16, 32), strides=(1, 2, 2), decoder_depth=(1, 1),
+                         norm=ft.LayerNorm, reshape=(ft.SWMatricize, {"head_dim": 8, "patch_size": 4}),
+                         act=nn.ReLU, factorize=ft.NMF, rank=1, num_iters=5, init="uniform",
+                         solver="hals", mlp_ratio=2, dropout=0.1)
+
+
+def test_model_seed_state_dict_and_values(golden):
+    g = golden("g6_model")
+    torch.manual_seed(0)
+    model = _tiny_model().eval()
+    ref = g.case("sd")
+    sd = model.state_dict()
+    assert sorted(sd) == sorted(ref)
+    for k in sd:
+        assert torch.equal(sd[k], ref[k]), k
+    assert sum(p.numel() for p in model.parameters()) == int(g["num_params"][0])
+    x = g["x"].clone().requires_grad_(True)
+    y = model(x)
+    assert torch.allclose(y, g["y"], rtol=1e-4, atol=1e-5)
+    names = [k for k, _ in model.named_parameters()]
+    grads = torch.autograd.grad(y, [x] + list(model.parameters()), g["gy"])
+    assert torch.allclose(grads[0], g["gx"], rtol=1e-3, atol=1e-4)
+    for k, gr in zip(names, grads[1:]):
+        r = g["grad:" + k]
+        assert (gr - r).abs().max().item() <= 2e-3 * (r.abs().max().item() + 1e-6), k
+    # dropout only reaches the bottleneck pos_drop (SURVEY headline 6)
+    drops = {n: m.p for n, m in model.named_modules() if isinstance(m, nn.Dropout)}
+    assert [n for n, p in drops.items() if p > 0] == ["encoder.blocks.2.block.pos_drop"]
+
+
+def test_readme_model_state_dict_inventory(golden):
+    """Keys and shapes of the README Swin Factorizer (128^3, widths 32..512) match the
+    reference's, so its checkpoints load."""
+    g = golden("g6_readme_model_keys")
+    with torch.device("meta"):
+        model = ft.Factorizer(in_channels=4, out_channels=3, spatial_size=(128, 128, 128),
+                              norm=ft.LayerNorm, reshape=(ft.SWMatricize, {"head_dim": 8, "patch_size": 8}),
+                              act=nn.ReLU, factorize=ft.NMF, rank=1, num_iters=5, init="uniform",
+                              solver="hals", mlp_ratio=2, dropout=0.1)
+    sd = model.state_dict()
+    ref = {k: tuple(g[k].tolist()) for k in g.keys() if k != "__num_params__"}
+    assert sorted(sd) == sorted(ref)
+    for k, v in sd.items():
+        assert tuple(v.shape) == ref[k], k
+    assert sum(p.numel() for p in model.parameters()) == int(g["__num_params__"][0]) == 5855619
+
+
+def test_variable_batch_and_reference_factorizer_test_config():
+    """Restates tests/test_factorizer.py:112-165 at reduced spatial size (num_heads=8 form:
+    M = C/8 varies per stage, N = 64)."""
+    model = ft.Factorizer(in_channels=4, out_channels=3, spatial_size=(16, 16, 16),
+                          encoder_depth=(1, 1, 1), encoder_width=(32, 64, 128), strides=(1, 2, 2),
+                          decoder_depth=(1, 1), reshape=(ft.SWMatricize, {"num_heads": 8, "patch_size": 4}),
+                          act=nn.ReLU, factorize=ft.NMF, rank=1, num_iters=5, num_grad_steps=None,
+                          init="uniform", solver="hals", mlp_ratio=2, dropout=0.1)
+    for b in (1, 2, 3):
+        y = model(torch.rand(b, 4, 16, 16, 16))
+        assert y.shape == (b, 3, 16, 16, 16) and torch.isfinite(y).all()
+
+
+def test_factmixer_global_matricize_mu():
+    """tests/test_factorizer.py:14-48 at reduced size: global Matricize, MU, rank 1."""
+    fm = ft.FactMixer(in_channels=16, out_channels=16, spatial_size=(8, 8, 8),
+                      reshape=(ft.Matricize, {"num_heads": 1, "grid_size": 1}), act=nn.ReLU,
+                      factorize=ft.NMF, rank=1, num_iters=5, init="uniform", solver="mu", dropout=0.1)
+    x = torch.rand(1, 16, 8, 8, 8, requires_grad=True)
+    y = fm(x)
+    assert y.shape == x.shape and torch.isfinite(y).all()
+    y.sum().backward()
+    assert torch.isfinite(x.grad).all()
