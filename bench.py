@@ -1,0 +1,191 @@
+"""bench.py — headline benchmark of the Factorizer hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): volumes/sec, forward+backward(+AdamW) of the README Swin Factorizer
+(in=4, out=3, 128^3, widths 32-512, head_dim 8, patch 8, HALS rank 1 x 5 iterations), per-GPU
+batch 2, data-parallel over N GPUs with one flat-bucket RCCL all-reduce per step
+(BASELINE.json configs[3]; weak scaling).  Synthetic inputs, random-init weights, fp32.
+
+One JSON line is printed by rank 0.  `roofline` describes the dominant native kernel of the
+timed region (HIP events on the launch stream, algorithmic bytes of SURVEY.md §8d);
+`cpu_baseline` is the CPU oracle (oracle/cpu_ref.py, a port of the reference's CPU path) timed
+on this host on a bounded sample (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import factorizer_amd as ft  # noqa: E402
+from factorizer_amd import functional as Fn  # noqa: E402
+from factorizer_amd.parallel import FlatGradSync  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+MODEL_KW = dict(in_channels=4, out_channels=3, spatial_size=(128, 128, 128),
+                encoder_depth=(1, 1, 1, 1, 1), encoder_width=(32, 64, 128, 256, 512),
+                strides=(1, 2, 2, 2, 2), decoder_depth=(1, 1, 1, 1), norm=ft.LayerNorm,
+                reshape=(ft.SWMatricize, {"head_dim": 8, "patch_size": 8}), act=nn.ReLU,
+                factorize=ft.NMF, rank=1, num_iters=5, init="uniform", solver="hals", mlp_ratio=2,
+                dropout=0.1)
+
+
+def dice_bce_loss(logits, target, smooth=1e-5):
+    """BCEWithLogits + soft Dice (sigmoid, squared denominators): the form of the bundle's
+    DiceCELoss(sigmoid=True, squared_pred=True) (train.yaml:67-70); timing only."""
+    p = torch.sigmoid(logits)
+    dims = tuple(range(2, logits.ndim))
+    inter = (p * target).sum(dims)
+    den = (p * p).sum(dims) + (target * target).sum(dims)
+    dice = 1.0 - (2.0 * inter + smooth) / (den + smooth)
+    return dice.mean() + nn.functional.binary_cross_entropy_with_logits(logits, target)
+
+
+def cpu_baseline_sample():
+    """CPU oracle on a bounded sample of the same workload: one stage-0 FactorizerBlock
+    (C=32, head_dim 8, patch 8, HALS R=1 T=5) forward+backward on a 32x128x128 quarter volume.
+    The two full-resolution stages hold >85 % of the model's CPU time, so
+    volumes/s of the whole model is bounded above by 1 / (2 blocks x 4 quarters x t_sample)."""
+    from oracle import cpu_ref as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    torch.manual_seed(0)
+    blk = ft.FactorizerBlock(channels=32, spatial_size=(32, 128, 128), norm=ft.LayerNorm,
+                             reshape=(ft.SWMatricize, {"head_dim": 8, "patch_size": 8}), act=nn.ReLU,
+                             factorize=ft.NMF, rank=1, num_iters=5, init="uniform", solver="hals",
+                             mlp_ratio=2, dropout=0.0)
+    sd = {k: v.clone() for k, v in blk.state_dict().items()}
+    params = {k: v.requires_grad_(True) for k, v in sd.items() if not k.endswith(("u0", "v0"))}
+    full = dict(sd)
+    full.update(params)
+    cfg = dict(reshape=dict(head_dim=8, patch_size=8), num_iters=5, solver="hals")
+    x = torch.rand(1, 32, 32, 128, 128, requires_grad=True)
+    g = torch.rand(1, 32, 32, 128, 128)
+    times = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        y = O.factorizer_block(x, full, "", cfg)
+        torch.autograd.grad(y, [x] + list(params.values()), g)
+        times.append(time.perf_counter() - t0)
+    t = min(times)
+    vol_per_s = 1.0 / (2 * 4 * t)
+    return {"value": vol_per_s, "unit": "volumes/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle FactorizerBlock(C=32,d=8,p=8,HALS R1 T5) fwd+bwd on a 32x128x128 quarter "
+                      f"volume: {t:.2f} s; scaled x4 quarters x2 full-res stages (upper bound on the "
+                      "whole-model CPU rate)",
+            "seconds_sample": t}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch-per-gpu", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks "
+                         f"(WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    torch.manual_seed(0)
+    model = ft.Factorizer(**MODEL_KW).to(dev).train()
+    sync = FlatGradSync(model, num_buckets=2, overlap=True)
+    sync.broadcast_state(0)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-5)
+    B = args.batch_per_gpu
+    torch.manual_seed(1234 + rank)
+    x = torch.rand(B, 4, 128, 128, 128, device=dev)
+    target = (torch.rand(B, 3, 128, 128, 128, device=dev) > 0.5).float()
+
+    def step():
+        sync.zero_grad()
+        loss = dice_bce_loss(model(x), target)
+        loss.backward()
+        sync.finish()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    timer = Fn.KernelTimer()
+    Fn.set_timer(timer)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    Fn.set_timer(None)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(loss).item(), "loss is not finite"
+
+    if rank == 0:
+        agg = timer.summary()
+        roof = None
+        if agg:
+            name, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
+            avg_ms = a["ms"] / a["calls"]
+            gbs = a["bytes"] / a["calls"] / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                    "avg_launch_ms": round(avg_ms, 4), "launches": a["calls"],
+                    "algorithmic_bytes_per_launch": a["bytes"] // a["calls"],
+                    "share_of_step": round(a["ms"] / (elapsed * 1e3), 4),
+                    "native_kernels_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in agg.items()}}
+        out = {
+            "metric": "volumes/sec fwd+bwd, Swin Factorizer 128^3",
+            "value": round(world * B * args.steps / elapsed, 4),
+            "unit": "volumes/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "Swin Factorizer (in4,out3,128^3,widths 32-512,d8,p8,HALS R1 T5) "
+                                   "training step fwd+bwd+AdamW (BASELINE configs[3])",
+                       "global_batch": world * B, "batch_per_gpu": B, "parallelism": f"dp{world}"},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_sample()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

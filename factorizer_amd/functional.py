@@ -17,6 +17,49 @@ def _dev_guard(t: torch.Tensor):
     return torch.cuda.device(t.device)
 
 
+class KernelTimer:
+    """Optional per-launch timing of the native kernels with HIP events recorded on the
+    stream the kernels are launched on (torch's current stream).  bench.py installs one over
+    its timed region to get the dominant kernel's average launch duration and algorithmic
+    bytes for the roofline line."""
+
+    def __init__(self):
+        self.records = []  # (name, algorithmic_bytes, start_event, end_event)
+
+    def launch(self, name, nbytes, fn):
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        out = fn()
+        e.record()
+        self.records.append((name, nbytes, s, e))
+        return out
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, nbytes, s, e in self.records:
+            a = agg.setdefault(name, {"calls": 0, "ms": 0.0, "bytes": 0})
+            a["calls"] += 1
+            a["ms"] += s.elapsed_time(e)
+            a["bytes"] += nbytes
+        return agg
+
+
+_timer = None
+
+
+def set_timer(t):
+    global _timer
+    _timer = t
+
+
+def _timed(name, nbytes, fn):
+    if _timer is None:
+        return fn()
+    return _timer.launch(name, nbytes, fn)
+
+
 class Geometry:
     """Static shape contract of a shifted-window matricize (operations.py:299-355, 381-415):
     channels C = h·d, spatial S_i = G_i·p_i, windows with cyclic shifts s_w."""
@@ -61,8 +104,9 @@ def _swm_fwd_raw(x, geo: Geometry, relu=False, div=1):
     else:
         raise TypeError(f"SWMatricize: unsupported dtype {x.dtype}")
     with _dev_guard(x):
-        rc = N.lib().fz_swm_fwd(x.data_ptr(), y.data_ptr(), B, geo.C, *geo.s3, geo.d, *geo.p3, geo.nshift,
-                                geo._carr, es, int(relu), int(div), N.stream_ptr(x))
+        rc = _timed("swm_fwd", (1 + geo.nshift) * x.numel() * es, lambda: N.lib().fz_swm_fwd(
+            x.data_ptr(), y.data_ptr(), B, geo.C, *geo.s3, geo.d, *geo.p3, geo.nshift, geo._carr, es,
+            int(relu), int(div), N.stream_ptr(x)))
     N.check(rc, "fz_swm_fwd")
     return y
 
@@ -73,8 +117,9 @@ def _swm_inv_raw(y, geo: Geometry, average=True, gate=None):
     B = y.shape[0] // (geo.nshift * geo.h)
     x = torch.empty((B, geo.C, *geo.spatial), dtype=y.dtype, device=y.device)
     with _dev_guard(y):
-        rc = N.lib().fz_swm_inv(y.data_ptr(), x.data_ptr(), B, geo.C, *geo.s3, geo.d, *geo.p3, geo.nshift,
-                                geo._carr, int(average), N.ptr(gate), N.stream_ptr(y))
+        rc = _timed("swm_inv", (1 + geo.nshift) * x.numel() * 4, lambda: N.lib().fz_swm_inv(
+            y.data_ptr(), x.data_ptr(), B, geo.C, *geo.s3, geo.d, *geo.p3, geo.nshift, geo._carr,
+            int(average), N.ptr(gate), N.stream_ptr(y)))
     N.check(rc, "fz_swm_inv")
     return x
 
@@ -126,8 +171,9 @@ def _nmf_fwd_raw(x, u0, v0, T, solver, eps, want_uv=False):
         u = torch.empty((*x.shape[:-2], M, R), dtype=x.dtype, device=x.device)
         v = torch.empty((*x.shape[:-2], Nn, R), dtype=x.dtype, device=x.device)
     with _dev_guard(x):
-        rc = N.lib().fz_nmf_fwd(x.data_ptr(), u0.data_ptr(), v0.data_ptr(), y.data_ptr(), N.ptr(u), N.ptr(v),
-                                nmat, M, Nn, R, T, N.SOLVER_ID[solver], eps, N.stream_ptr(x))
+        rc = _timed(f"nmf_fwd_{M}x{Nn}", 2 * x.numel() * 4, lambda: N.lib().fz_nmf_fwd(
+            x.data_ptr(), u0.data_ptr(), v0.data_ptr(), y.data_ptr(), N.ptr(u), N.ptr(v), nmat, M, Nn, R, T,
+            N.SOLVER_ID[solver], eps, N.stream_ptr(x)))
     N.check(rc, "fz_nmf_fwd")
     return y, u, v
 
@@ -138,9 +184,9 @@ def _nmf_bwd_raw(x, u0, v0, gy, gu, gv, T, G, solver, eps):
     nmat = x.numel() // (M * Nn)
     gx = torch.empty_like(x)
     with _dev_guard(x):
-        rc = N.lib().fz_nmf_bwd(x.data_ptr(), u0.data_ptr(), v0.data_ptr(), N.ptr(gy), N.ptr(gu), N.ptr(gv),
-                                gx.data_ptr(), nmat, M, Nn, R, T, G, N.SOLVER_ID[solver], eps,
-                                N.stream_ptr(x))
+        rc = _timed(f"nmf_bwd_{M}x{Nn}", 3 * x.numel() * 4, lambda: N.lib().fz_nmf_bwd(
+            x.data_ptr(), u0.data_ptr(), v0.data_ptr(), N.ptr(gy), N.ptr(gu), N.ptr(gv), gx.data_ptr(), nmat,
+            M, Nn, R, T, G, N.SOLVER_ID[solver], eps, N.stream_ptr(x)))
     N.check(rc, "fz_nmf_bwd")
     return gx
 

@@ -1,0 +1,84 @@
+"""world_size-2 gloo test of the data-parallel gradient path (factorizer_amd/parallel.py):
+after backward + finish(), every rank holds the average of the per-rank gradients, and one
+optimizer step keeps the replicas bit-identical."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from torch import nn
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, overlap, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import factorizer_amd as ft
+        from factorizer_amd.parallel import FlatGradSync
+        torch.manual_seed(100 + rank)  # different init per rank on purpose: broadcast must fix it
+        model = ft.Factorizer(in_channels=2, out_channels=2, spatial_size=(8, 8, 8), encoder_depth=(1, 1),
+                              encoder_width=(8, 16), strides=(1, 2), decoder_depth=(1,),
+                              reshape=(ft.SWMatricize, {"head_dim": 8, "patch_size": 4}), act=nn.ReLU,
+                              factorize=ft.NMF, rank=1, num_iters=3, solver="hals", mlp_ratio=2, dropout=0.0)
+        sync = FlatGradSync(model, num_buckets=3, overlap=overlap)
+        sync.broadcast_state(0)
+        opt = torch.optim.SGD(model.parameters(), lr=0.1)
+        torch.manual_seed(7 + rank)
+        x = torch.rand(2, 2, 8, 8, 8)
+        sync.zero_grad()
+        model(x).square().mean().backward()
+        local = torch.cat([p.grad.reshape(-1).clone() for p in model.parameters()]) if False else None
+        sync.finish()
+        g = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+        opt.step()
+        w = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+        b = torch.cat([t.reshape(-1) for t in model.buffers()])
+        gathered = [torch.zeros_like(g) for _ in range(world)]
+        dist.all_gather(gathered, g)
+        wg = [torch.zeros_like(w) for _ in range(world)]
+        dist.all_gather(wg, w)
+        bg = [torch.zeros_like(b) for _ in range(world)]
+        dist.all_gather(bg, b)
+        if rank == 0:
+            torch.save({"g": gathered, "w": wg, "b": bg}, out)
+    finally:
+        dist.destroy_process_group()
+
+
+def _single_process_reference(world):
+    import factorizer_amd as ft
+    torch.manual_seed(100)
+    model = ft.Factorizer(in_channels=2, out_channels=2, spatial_size=(8, 8, 8), encoder_depth=(1, 1),
+                          encoder_width=(8, 16), strides=(1, 2), decoder_depth=(1,),
+                          reshape=(ft.SWMatricize, {"head_dim": 8, "patch_size": 4}), act=nn.ReLU,
+                          factorize=ft.NMF, rank=1, num_iters=3, solver="hals", mlp_ratio=2, dropout=0.0)
+    grads = []
+    for rank in range(world):
+        torch.manual_seed(7 + rank)
+        x = torch.rand(2, 2, 8, 8, 8)
+        model.zero_grad()
+        model(x).square().mean().backward()
+        grads.append(torch.cat([p.grad.reshape(-1) for p in model.parameters()]))
+    return torch.stack(grads).mean(0)
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_flat_grad_sync_world2(tmp_path, overlap):
+    world = 2
+    out = str(tmp_path / "res.pt")
+    mp.spawn(_worker, args=(world, _free_port(), overlap, out), nprocs=world, join=True)
+    res = torch.load(out)
+    ref = _single_process_reference(world)
+    for r in range(world):
+        assert torch.allclose(res["g"][r], ref, rtol=1e-5, atol=1e-7)
+    assert torch.equal(res["g"][0], res["g"][1])
+    assert torch.equal(res["w"][0], res["w"][1])   # replicas stay identical after the step
+    assert torch.equal(res["b"][0], res["b"][1])   # u0/v0 buffers were broadcast

@@ -1,0 +1,337 @@
+"""-m gpu: the gfx950 kernels (through the C ABI) against the reference goldens and the CPU
+oracle.  Bit-exact for SWMatricize (pure data movement); 1e-4 (fp32) for NMF / blocks."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+import factorizer_amd as ft
+from factorizer_amd import _native
+from oracle import cpu_ref as O
+from test_oracle_golden import G1_CASES, NMF_CASES
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+class Launches:
+    """Asserts that the native library actually launched kernels inside the block."""
+
+    def __enter__(self):
+        self.n0 = _native.launch_count()
+        return self
+
+    def __exit__(self, *a):
+        torch.cuda.synchronize()
+        assert _native.launch_count() > self.n0, "native kernels were not launched"
+
+
+# ---------------------------------------------------------------- SWMatricize ---------
+@pytest.mark.parametrize("name", sorted(G1_CASES))
+def test_swm_goldens_bit_exact(golden, name):
+    g = golden("g1_swmatricize").case(name)
+    shape, kw = G1_CASES[name]
+    x = torch.arange(int(np.prod(shape)), dtype=torch.float32).reshape(shape)
+    m = ft.SWMatricize((None, *shape[1:]), **kw)
+    with Launches():
+        y = m(x.to(DEV))
+        z = m.inverse_forward(y)
+    assert torch.equal(y.cpu().to(torch.int32), g["y"])
+    nw = len(kw.get("shifts", [0, 1]))
+    if nw in (1, 2, 4):
+        assert torch.equal(z.cpu(), g["z"])
+    else:
+        assert torch.allclose(z.cpu(), g["z"], rtol=2e-7, atol=0)
+    if "yr" in g:
+        zr = m.inverse_forward(g["yr"].to(DEV)).cpu()
+        if nw in (1, 2, 4):
+            assert torch.equal(zr, g["zr"])
+        else:
+            assert torch.allclose(zr, g["zr"], rtol=3e-7, atol=1e-7)
+
+
+def test_swm_cfg2_sha256_and_roundtrip(golden):
+    """BASELINE cfg 2 size: (1,32,128^3) -> (8,4096,8,512); hash of the reference's output."""
+    g = golden("g1_swmatricize")
+    torch.manual_seed(0)
+    x = torch.rand(1, 32, 128, 128, 128)
+    m = ft.SWMatricize((None, 32, 128, 128, 128), head_dim=8, patch_size=8)
+    xd = x.to(DEV)
+    with Launches():
+        y = m(xd)
+    assert list(y.shape) == g["cfg2:shape_y"].tolist()
+    digest = hashlib.sha256(y.cpu().numpy().tobytes()).digest()
+    assert np.frombuffer(digest, dtype=np.uint8).tolist() == g["cfg2:sha256_y"].tolist()
+    z = m.inverse_forward(y)
+    assert torch.equal(z, xd)  # encode -> decode round trip, size-independent property
+
+
+SWM_RANDOM = [
+    ((2, 16, 8, 16, 32), dict(head_dim=8, patch_size=(2, 4, 8))),
+    ((1, 8, 12, 10, 6), dict(head_dim=4, patch_size=(3, 5, 2))),               # non power-of-two, VE=2
+    ((2, 8, 8, 8, 8), dict(num_heads=2, patch_size=4, shifts=[None, 1, 2, 3])),  # odd shifts, VE=1
+    ((1, 16, 16, 16, 16), dict(head_dim=8, patch_size=8, shifts=[None, 2, 4, 6])),  # production windows
+    ((3, 8, 4, 4, 4), dict(head_dim=8, grid_size=1)),                           # global patch
+    ((2, 8, 16, 16), dict(head_dim=4, patch_size=4)),                           # 2-D
+    ((1, 8, 10, 12, 10), dict(head_dim=8, patch_size=(5, 6, 5))),               # cfg-5 bottleneck shape
+]
+
+
+@pytest.mark.parametrize("shape,kw", SWM_RANDOM)
+def test_swm_vs_oracle_random(shape, kw):
+    torch.manual_seed(1)
+    x = torch.randn(shape)
+    m = ft.SWMatricize((None, *shape[1:]), **kw)
+    spatial = shape[2:]
+    okw = dict(kw)
+    if len(spatial) == 3:
+        yo = O.swm_forward(x, **okw)
+    else:  # oracle is 3-D: lift with a unit leading axis
+        yo = None
+    xd = x.to(DEV).requires_grad_(True)
+    with Launches():
+        y = m(xd)
+    ycpu = ft.SWMatricize((None, *shape[1:]), **kw)(x)  # composed path, bit-exact too
+    assert torch.equal(y.cpu(), ycpu)
+    if yo is not None:
+        assert torch.equal(y.cpu(), yo)
+    yr = torch.randn_like(ycpu)
+    z = m.inverse_forward(yr.to(DEV))
+    zc = m.inverse_forward(yr)
+    nw = m.geometry.nshift
+    if nw in (1, 2, 4):
+        assert torch.equal(z.cpu(), zc)
+    else:
+        assert torch.allclose(z.cpu(), zc, rtol=3e-7, atol=1e-7)
+    # backward of forward = un-averaged inverse; backward of inverse = forward / nshift
+    gy = torch.randn_like(ycpu)
+    (gx,) = torch.autograd.grad(y, xd, gy.to(DEV))
+    xc = x.clone().requires_grad_(True)
+    (gxc,) = torch.autograd.grad(m(xc), xc, gy)
+    assert torch.allclose(gx.cpu(), gxc, rtol=1e-6, atol=1e-6)
+    yd = yr.to(DEV).requires_grad_(True)
+    gz = torch.randn(shape)
+    (gyd,) = torch.autograd.grad(m.inverse_forward(yd), yd, gz.to(DEV))
+    ycl = yr.clone().requires_grad_(True)
+    (gyc,) = torch.autograd.grad(m.inverse_forward(ycl), ycl, gz)
+    assert torch.allclose(gyd.cpu(), gyc, rtol=1e-6, atol=1e-7)
+
+
+def test_swm_bf16_moves_bits():
+    torch.manual_seed(2)
+    x = torch.randn(2, 16, 8, 8, 16).to(torch.bfloat16)
+    m = ft.SWMatricize((None, 16, 8, 8, 16), head_dim=8, patch_size=(4, 4, 8))
+    y = m(x.to(DEV))
+    assert y.dtype == torch.bfloat16
+    assert torch.equal(y.cpu(), m(x))
+
+
+# ---------------------------------------------------------------- NMF -------------------
+@pytest.mark.parametrize("name", sorted(NMF_CASES))
+def test_nmf_goldens(golden, name):
+    g = golden("g2_nmf").case(name)
+    kw = dict(NMF_CASES[name])
+    M, N = g["x"].shape[-2:]
+    R = g["u0"].shape[1]
+    nmf = ft.NMF(size=(M, N), rank=R, init="uniform", **kw)
+    nmf.load_state_dict({"init.u0": g["u0"], "init.v0": g["v0"]})
+    nmf = nmf.to(DEV)
+    x = g["x"].to(DEV).requires_grad_(True)
+    with Launches():
+        u, v = nmf.decompose(x)
+        y = nmf(x)
+        (gx,) = torch.autograd.grad(y, x, g["gy"].to(DEV))
+    tol = dict(rtol=1e-4, atol=1e-5)
+    assert torch.allclose(u.cpu(), g["u"], **tol)
+    assert torch.allclose(v.cpu(), g["v"], **tol)
+    assert torch.allclose(y.cpu(), g["y"], **tol)
+    s = g["gx"].abs().max().item()
+    assert (gx.cpu() - g["gx"]).abs().max().item() <= 1e-4 * s + 1e-5
+    assert (u >= 0).all() and (v >= 0).all()
+
+
+@pytest.mark.parametrize("solver", ["mu", "hals"])
+@pytest.mark.parametrize("R", [1, 2, 3, 4])
+def test_nmf_8x512_vs_oracle(solver, R):
+    torch.manual_seed(10 + R)
+    x = torch.rand(37, 3, 8, 512)           # ragged count: not a multiple of waves per block
+    x[0, 0].zero_()                          # all-zero matrix (eps path)
+    x[1, 1, :, :300] = 0
+    u0, v0 = torch.rand(8, R), torch.rand(512, R)
+    gy = torch.rand_like(x)
+    nmf = ft.NMF(size=(8, 512), rank=R, num_iters=5, init="uniform", solver=solver)
+    nmf.load_state_dict({"init.u0": u0, "init.v0": v0})
+    nmf = nmf.to(DEV)
+    xd = x.to(DEV).requires_grad_(True)
+    with Launches():
+        y = nmf(xd)
+        (gx,) = torch.autograd.grad(y, xd, gy.to(DEV))
+    yo = O.nmf_forward(x, u0, v0, 5, solver)
+    gxo = O.nmf_backward(x, u0, v0, gy, 5, solver)
+    gx64 = O.nmf_backward(x.double(), u0.double(), v0.double(), gy.double(), 5, solver).float()
+    assert torch.allclose(y.cpu(), yo, rtol=1e-4, atol=1e-5)
+    kink = (gxo - gx64).abs().amax(dim=(-1, -2))          # per-matrix conditioning guard
+    err = (gx.cpu() - gx64).abs().amax(dim=(-1, -2))
+    scale = gx64.abs().amax(dim=(-1, -2))
+    assert (err <= 1e-4 * scale + 1e-5 + 30 * kink).all()
+
+
+@pytest.mark.parametrize("M,N", [(8, 150), (4, 64), (16, 256), (16, 64), (32, 128), (5, 100), (8, 64)])
+def test_nmf_masked_families_vs_oracle(M, N):
+    torch.manual_seed(M * 1000 + N)
+    for solver in ("mu", "hals"):
+        for R in (1, 2):
+            x = torch.rand(11, M, N)
+            u0, v0 = torch.rand(M, R), torch.rand(N, R)
+            gy = torch.rand_like(x)
+            nmf = ft.NMF(size=(M, N), rank=R, num_iters=4, num_grad_steps=3, init="uniform", solver=solver)
+            nmf.load_state_dict({"init.u0": u0, "init.v0": v0})
+            nmf = nmf.to(DEV)
+            xd = x.to(DEV).requires_grad_(True)
+            with Launches():
+                y = nmf(xd)
+                (gx,) = torch.autograd.grad(y, xd, gy.to(DEV))
+            yo = O.nmf_forward(x, u0, v0, 4, solver)
+            gx64 = O.nmf_backward(x.double(), u0.double(), v0.double(), gy.double(), 4, solver, 3).float()
+            gxo = O.nmf_backward(x, u0, v0, gy, 4, solver, 3)
+            assert torch.allclose(y.cpu(), yo, rtol=1e-4, atol=1e-5), (solver, R)
+            kink = (gxo - gx64).abs().max().item()
+            s = gx64.abs().max().item()
+            assert (gx.cpu() - gx64).abs().max().item() <= 2e-4 * s + 1e-5 + 30 * kink, (solver, R)
+
+
+def test_nmf_decompose_backward():
+    torch.manual_seed(5)
+    x = torch.rand(9, 8, 512)
+    for solver in ("mu", "hals"):
+        nmf = ft.NMF(size=(8, 512), rank=2, num_iters=3, init="uniform", solver=solver)
+        xc = x.clone().requires_grad_(True)
+        u, v = nmf.decompose(xc)
+        gu, gv = torch.rand_like(u), torch.rand_like(v)
+        (gxc,) = torch.autograd.grad([u, v], xc, [gu, gv])
+        nd = nmf.to(DEV)
+        xd = x.to(DEV).requires_grad_(True)
+        with Launches():
+            ud, vd = nd.decompose(xd)
+            (gxd,) = torch.autograd.grad([ud, vd], xd, [gu.to(DEV), gv.to(DEV)])
+        assert torch.allclose(ud.cpu(), u, rtol=1e-4, atol=1e-5)
+        assert torch.allclose(vd.cpu(), v, rtol=1e-4, atol=1e-5)
+        s = gxc.abs().max().item()
+        assert (gxd.cpu() - gxc).abs().max().item() <= 2e-4 * s + 1e-5
+
+
+def test_nmf_full_size_properties():
+    """Stage-0 batch of BASELINE cfg 3/4 (65 536 matrices of 8x512): size-independent
+    properties — batch-position independence (bit-exact), non-negativity, exact recovery of
+    rank-1 non-negative matrices, linearity of the backward in gy."""
+    torch.manual_seed(0)
+    nmat = 65536
+    nmf = ft.NMF(size=(8, 512), rank=1, num_iters=5, init="uniform", solver="hals").to(DEV)
+    x = torch.rand(nmat, 8, 512, device=DEV)
+    with Launches():
+        y = nmf(x)
+    assert torch.isfinite(y).all() and (y >= 0).all()
+    perm = torch.randperm(nmat, device=DEV)
+    assert torch.equal(nmf(x[perm]), y[perm])
+    a = torch.rand(1024, 8, 1, device=DEV) + 0.1
+    b = torch.rand(1024, 1, 512, device=DEV) + 0.1
+    r1 = a * b
+    assert torch.allclose(nmf(r1), r1, rtol=1e-4, atol=1e-6)
+    xs = x[:4096].clone().requires_grad_(True)
+    ys = nmf(xs)
+    g1, g2 = torch.rand_like(ys), torch.rand_like(ys)
+    (ga,) = torch.autograd.grad(ys, xs, g1, retain_graph=True)
+    (gb,) = torch.autograd.grad(ys, xs, g2, retain_graph=True)
+    (gab,) = torch.autograd.grad(ys, xs, g1 + 2 * g2)
+    s = gab.abs().max().item()
+    assert (gab - (ga + 2 * gb)).abs().max().item() <= 1e-4 * s
+
+
+def test_nmf_unsupported_shape_uses_composed_path_with_warning():
+    nmf = ft.NMF(size=(8, 1200), rank=2, num_iters=2, init="uniform", solver="hals").to(DEV)
+    x = torch.rand(3, 8, 1200, device=DEV)
+    with pytest.warns(RuntimeWarning):
+        y = nmf(x)
+    yo = O.nmf_forward(x.cpu(), nmf.init.u0.cpu(), nmf.init.v0.cpu(), 2, "hals")
+    assert torch.allclose(y.cpu(), yo, rtol=1e-4, atol=1e-5)
+
+
+# ---------------------------------------------------------------- blocks / model ---------
+BLOCK_KW = {"hals_r1": dict(rank=1, num_iters=5, solver="hals"), "mu_r2": dict(rank=2, num_iters=3, solver="mu")}
+
+
+@pytest.mark.parametrize("name", sorted(BLOCK_KW))
+def test_block_goldens(golden, name):
+    g = golden("g5_block").case(name)
+    blk = ft.FactorizerBlock(channels=16, spatial_size=(8, 8, 8), norm=ft.LayerNorm,
+                             reshape=(ft.SWMatricize, {"head_dim": 8, "patch_size": 4}), act=nn.ReLU,
+                             factorize=ft.NMF, init="uniform", mlp_ratio=2, dropout=0.0, **BLOCK_KW[name])
+    blk.load_state_dict({k[3:]: v for k, v in g.items() if k.startswith("sd:")})
+    blk = blk.to(DEV)
+    x = g["x"].to(DEV).requires_grad_(True)
+    with Launches():
+        y = blk(x)
+        names = [k for k, _ in blk.named_parameters()]
+        grads = torch.autograd.grad(y, [x] + list(blk.parameters()), g["gy"].to(DEV))
+    assert torch.allclose(y.cpu(), g["y"], rtol=1e-4, atol=1e-4)
+    assert torch.allclose(grads[0].cpu(), g["gx"], rtol=1e-3, atol=2e-4)
+    for k, gr in zip(names, grads[1:]):
+        r = g["grad:" + k]
+        assert (gr.cpu() - r).abs().max().item() <= 1e-3 * (r.abs().max().item() + 1e-6), k
+
+
+def test_model_goldens(golden):
+    from test_modules_cpu import _tiny_model
+    g = golden("g6_model")
+    model = _tiny_model().eval()
+    model.load_state_dict(g.case("sd"))
+    model = model.to(DEV)
+    x = g["x"].to(DEV).requires_grad_(True)
+    with Launches():
+        y = model(x)
+        names = [k for k, _ in model.named_parameters()]
+        grads = torch.autograd.grad(y, [x] + list(model.parameters()), g["gy"].to(DEV))
+    assert torch.allclose(y.cpu(), g["y"], rtol=1e-4, atol=1e-4)
+    assert torch.allclose(grads[0].cpu(), g["gx"], rtol=1e-3, atol=1e-4)
+    for k, gr in zip(names, grads[1:]):
+        r = g["grad:" + k]
+        assert (gr.cpu() - r).abs().max().item() <= 2e-3 * (r.abs().max().item() + 1e-6), k
+
+
+def test_block_cfg2_shape_vs_oracle_reduced():
+    """BASELINE cfg 2 block (C=32, d=8, p=8, HALS R=1 T=5) on a 32^3 volume vs the oracle."""
+    torch.manual_seed(0)
+    blk = ft.FactorizerBlock(channels=32, spatial_size=(32, 32, 32), norm=ft.LayerNorm,
+                             reshape=(ft.SWMatricize, {"head_dim": 8, "patch_size": 8}), act=nn.ReLU,
+                             factorize=ft.NMF, rank=1, num_iters=5, init="uniform", solver="hals",
+                             mlp_ratio=2, dropout=0.0)
+    sd = {k: v.clone() for k, v in blk.state_dict().items()}
+    x = torch.rand(1, 32, 32, 32, 32)
+    gy = torch.rand_like(x)
+    xo = x.clone().requires_grad_(True)
+    cfg = dict(reshape=dict(head_dim=8, patch_size=8), num_iters=5, solver="hals")
+    yo = O.factorizer_block(xo, sd, "", cfg)
+    (gxo,) = torch.autograd.grad(yo, xo, gy)
+    blk = blk.to(DEV)
+    xd = x.to(DEV).requires_grad_(True)
+    with Launches():
+        yd = blk(xd)
+        (gxd,) = torch.autograd.grad(yd, xd, gy.to(DEV))
+    assert torch.allclose(yd.cpu(), yo, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(gxd.cpu(), gxo, rtol=1e-3, atol=1e-4)
+
+
+def test_block_cfg2_full_size_runs():
+    """BASELINE cfg 2 at full size (1,32,128^3): finite outputs and gradients."""
+    torch.manual_seed(0)
+    blk = ft.FactorizerBlock(channels=32, spatial_size=(128, 128, 128), norm=ft.LayerNorm,
+                             reshape=(ft.SWMatricize, {"head_dim": 8, "patch_size": 8}), act=nn.ReLU,
+                             factorize=ft.NMF, rank=1, num_iters=5, init="uniform", solver="hals",
+                             mlp_ratio=2, dropout=0.0).to(DEV)
+    x = torch.rand(1, 32, 128, 128, 128, device=DEV, requires_grad=True)
+    with Launches():
+        y = blk(x)
+        (gx,) = torch.autograd.grad(y, x, torch.rand_like(y))
+    assert y.shape == x.shape and torch.isfinite(y).all() and torch.isfinite(gx).all()
