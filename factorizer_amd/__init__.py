@@ -10,6 +10,7 @@ from .matricize import Matricize, Reshape, SWMatricize
 from .nmf import (NMF, BCDSolver, Compose, CoordinateDescent, Initializer, MatrixFactorization,
                   MultiplicativeUpdate, RandomInit, relative_error)
 from .layers import MLP, LayerNorm, Linear, PosEmbed, PositionalEmbedding
+from .convs import Conv3d, ConvTranspose3d
 from .blocks import FactMixer, FactorizerBlock, FactorizerStage
 from .unet import (Factorizer, Same, UNet, UNetDecoder, UNetDecoderBlock, UNetEncoder,
                    UNetEncoderBlock, UNetStage)

@@ -86,3 +86,31 @@ def ptr(t):
 def shifts_array(shifts):
     flat = [int(v) for s in shifts for v in s]
     return (_i * len(flat))(*flat)
+
+
+# ---- descriptor structs of the GEMM family (include/factorizer_hip.h) -----------------------
+_fp = _c.POINTER(_c.c_float)
+
+
+class GemmDesc(_c.Structure):
+    _fields_ = [("x", _vp * 4), ("nsrc", _i), ("src_mode", _i), ("c0", _i), ("Cin", _i), ("Vin", _i64),
+                ("Di", _i), ("Hi", _i), ("Wi", _i), ("w", _vp), ("w_t", _i), ("ldw", _i), ("M", _i), ("K", _i),
+                ("bias", _vp), ("ln", _i), ("ln_g", _vp), ("ln_b", _vp), ("ln_eps", _f), ("stats_out", _vp),
+                ("bact", _i), ("bmul", _vp), ("bmul_kind", _i), ("eact", _i), ("res", _vp), ("emul", _vp), ("emul_kind", _i), ("y", _vp),
+                ("Ncol", _i64), ("Ho", _i), ("Wo", _i), ("B", _i), ("loader", _i), ("epilogue", _i)]
+
+
+class WgradDesc(_c.Structure):
+    _fields_ = [("p", _vp), ("M", _i), ("pmul", _vp), ("pmul_kind", _i), ("q", _vp * 4), ("nsrc", _i),
+                ("src_mode", _i), ("c0", _i), ("Cin", _i), ("K", _i), ("Vq", _i64), ("D", _i), ("H", _i),
+                ("W", _i), ("N", _i64), ("Ho", _i), ("Wo", _i), ("stats", _vp), ("qact", _i), ("ln_g", _vp),
+                ("ln_b", _vp), ("gw", _vp), ("gbias", _vp), ("accumulate", _i), ("B", _i), ("loader", _i)]
+
+
+_SIGS.update({
+    "fz_gemm": ([_c.POINTER(GemmDesc), _vp], _i),
+    "fz_wgrad": ([_c.POINTER(WgradDesc), _vp, _vp], _i),
+    "fz_wgrad_workspace_bytes": ([_c.POINTER(WgradDesc)], _i64),
+    "fz_ln_fwd": ([_vp] * 5 + [_i, _i, _i64, _f, _vp], _i),
+    "fz_ln_bwd": ([_vp] * 6 + [_i, _i, _i64, _vp], _i),
+})

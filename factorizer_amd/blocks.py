@@ -3,8 +3,10 @@ factorizer.py:9-122 (same constructor arguments, sub-module names and constructi
 seeds and state_dicts line up)."""
 from __future__ import annotations
 
+import torch
 from torch import nn
 
+from . import pointwise as PW
 from .layers import MLP, LayerNorm, Linear
 from .matricize import Matricize
 from .nmf import NMF
@@ -52,7 +54,35 @@ class FactorizerBlock(nn.Module):
         self.norm2 = partialize(norm)(channels)
         self.mlp = MLP(channels, ratio=mlp_ratio, dropout=dropout)
 
+    def _fusable(self, x) -> bool:
+        """Standard Swin block on a device fp32 tensor: LayerNorm / ReLU / exact GELU, no live
+        dropout — then LayerNorm, bias, ReLU, GELU and both residual adds are fused into the GEMM
+        kernels (csrc/gemm.hip) instead of running as separate full-tensor passes."""
+        f, m = self.fact, self.mlp
+        if not (x.is_cuda and x.dtype == torch.float32 and PW._vox(x) % 4 == 0 and x.shape[1] % 2 == 0):
+            return False
+        if not (isinstance(self.norm1, LayerNorm) and isinstance(self.norm2, LayerNorm)
+                and self.norm1.norm.elementwise_affine and self.norm2.norm.elementwise_affine
+                and self.norm1.norm.bias is not None and self.norm2.norm.bias is not None):
+            return False
+        if not (isinstance(f.act, nn.ReLU) and isinstance(f.in_proj, Linear) and isinstance(f.out_proj, Linear)):
+            return False
+        blk = m.block
+        if not (len(blk) == 5 and isinstance(blk[1], nn.GELU) and blk[1].approximate == "none"
+                and blk[0].linear.weight.shape[0] % 2 == 0):
+            return False
+        live = self.training and (f.dropout.p > 0 or blk[2].p > 0 or blk[4].p > 0)
+        return not live
+
     def forward(self, x):
+        if self._fusable(x):
+            f, blk = self.fact, self.mlp.block
+            n1, n2 = self.norm1.norm, self.norm2.norm
+            t = PW.ln_linear(x, n1.weight, n1.bias, n1.eps, f.in_proj.linear.weight, f.in_proj.linear.bias, "relu")
+            a = f.reshape.inverse_forward(f.factorize(f.reshape(t)))  # ReLU already applied (commutes)
+            x = PW.act_linear_res(a, f.out_proj.linear.weight, f.out_proj.linear.bias, x, "none")
+            z = PW.ln_linear(x, n2.weight, n2.bias, n2.eps, blk[0].linear.weight, blk[0].linear.bias, "none")
+            return PW.act_linear_res(z, blk[3].linear.weight, blk[3].linear.bias, x, "gelu")
         x = x + self.fact(self.norm1(x))
         x = x + self.mlp(self.norm2(x))
         return x
@@ -74,8 +104,19 @@ class FactorizerStage(nn.Module):
         for _ in range(depth):
             self.blocks.append(FactorizerBlock(out_channels, spatial_size, **subblocks))
 
+    def forward_pair(self, skip, up):
+        """forward(torch.cat([skip, up], 1)) without materialising the concatenation
+        (unet.py:128): the adapter GEMM reads its two channel groups from two pointers."""
+        if hasattr(self, "adapter") and isinstance(self.adapter, Linear):
+            out = PW.cat_linear(skip, up, self.adapter.linear.weight, self.adapter.linear.bias)
+            return self._after_adapter(out)
+        return self.forward(torch.cat([skip, up], dim=1))
+
     def forward(self, x):
         out = self.adapter(x) if hasattr(self, "adapter") else x
+        return self._after_adapter(out)
+
+    def _after_adapter(self, out):
         if not isinstance(self.pos_embed, nn.Identity):
             out = self.pos_embed(out)
         if hasattr(self, "pos_drop") and self.pos_drop.p > 0:

@@ -44,8 +44,19 @@ def needs_build() -> bool:
     return not os.path.exists(LIB) or os.path.getmtime(LIB) < _deps_mtime()
 
 
+def _hdr_mtime() -> float:
+    m = 0.0
+    for root in (CSRC, os.path.join(os.path.dirname(HERE), "include")):
+        for f in os.listdir(root):
+            if f.endswith((".h", ".inc")):
+                m = max(m, os.path.getmtime(os.path.join(root, f)))
+    return m
+
+
 def _compile(src: str) -> str:
     obj = os.path.join(OBJ, src[:-4] + ".o")
+    if os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(os.path.join(CSRC, src)), _hdr_mtime()):
+        return obj
     cmd = [_hipcc(), *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:

@@ -1,0 +1,53 @@
+"""Conv3d / ConvTranspose3d parameter containers whose forward runs the native GEMM-family
+kernels for the shapes the Factorizer U-shape uses (unet.py:53,123,231,253):
+kernel 2 / stride 2 (space-to-depth GEMM), transposed kernel 2 / stride 2 (GEMM +
+depth-to-space), kernel 3 / padding 1 (stem) and kernel 1 (head).  They subclass the torch
+modules, so initialisation and state_dict keys are those of the reference's nn.Conv3d."""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from . import composed
+from . import pointwise as PW
+
+
+def _all(v, n):
+    return tuple(v) == (n,) * len(v)
+
+
+class Conv3d(nn.Conv3d):
+    def forward(self, x):
+        ok = (x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and self.groups == 1
+              and _all(self.dilation, 1) and self.padding_mode == "zeros")
+        if ok:
+            C = self.in_channels
+            if _all(self.kernel_size, 2) and _all(self.stride, 2) and _all(self.padding, 0) \
+                    and x.shape[-1] % 4 == 0 and x.shape[-2] % 2 == 0 and x.shape[-3] % 2 == 0 \
+                    and (x.shape[2] * x.shape[3] * x.shape[4] // 8) % 4 == 0 and C % 2 == 0:
+                return PW.ConvK2S2Fn.apply(x, self.weight, self.bias)
+            if _all(self.kernel_size, 3) and _all(self.stride, 1) and _all(self.padding, 1) \
+                    and x.shape[-1] % 4 == 0 and C % 2 == 0:
+                return PW.ConvK3Fn.apply(x, self.weight, self.bias)
+            if _all(self.kernel_size, 1) and _all(self.stride, 1) and _all(self.padding, 0) and C % 2 == 0 \
+                    and (x.shape[2] * x.shape[3] * x.shape[4]) % 4 == 0:
+                return PW.LinearFn.apply(x, self.weight.reshape(self.out_channels, C, 1), self.bias)
+            composed.warn_once(f"conv3d{self.kernel_size}{self.stride}{tuple(x.shape[2:])}",
+                               f"Conv3d kernel={self.kernel_size} stride={self.stride} on {tuple(x.shape)} is "
+                               "outside the native kernel set; using ATen on device")
+        return super().forward(x)
+
+
+class ConvTranspose3d(nn.ConvTranspose3d):
+    def forward(self, x, output_size=None):
+        ok = (x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and self.groups == 1 and output_size is None
+              and _all(self.dilation, 1) and _all(self.kernel_size, 2) and _all(self.stride, 2)
+              and _all(self.padding, 0) and _all(self.output_padding, 0) and self.in_channels % 2 == 0
+              and (x.shape[2] * x.shape[3] * x.shape[4]) % 4 == 0)
+        if ok:
+            return PW.TConvK2S2Fn.apply(x, self.weight, self.bias)
+        if x.is_cuda:
+            composed.warn_once(f"tconv3d{self.kernel_size}{self.stride}{tuple(x.shape[2:])}",
+                               f"ConvTranspose3d kernel={self.kernel_size} stride={self.stride} on "
+                               f"{tuple(x.shape)} is outside the native kernel set; using ATen on device")
+        return super().forward(x, output_size)

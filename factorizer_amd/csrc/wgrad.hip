@@ -1,0 +1,336 @@
+// wgrad.hip — weight gradients of the channels-first GEMM family on the fp32 matrix cores.
+//
+//   GW[m, k] = Σ_{b, n}  P[b, m, n] · Q(In)[b, k, n]          (reduction over voxels n)
+//
+// where P is the output-side gradient (plain rows) and Q the layer's input operand, produced
+// by the same loaders as the forward (plain / space-to-depth / 3x3x3 taps) with the same
+// prologues (LayerNorm with saved statistics, GELU, window average, two-source concat).
+// This is what autograd's conv1d/conv3d weight-gradient kernels compute for
+// layers/linear.py:53-58, unet.py:53,123,231 — MIOpen's naive conv wrw kernel took 76 % of a
+// training step on MI355X (profiles/r01_p1), hence a dedicated kernel.
+//
+// Both MFMA operands need "lane = channel, k-step = voxel pair", the transpose of the
+// coalesced global layout, so every wave stages 32-voxel tiles of P and Q in its own LDS
+// region (row stride 33 → conflict-free column reads), with no workgroup barriers.  Voxel
+// ranges are split over waves and workgroups; partial sums go to a workspace and a second
+// kernel reduces them in a fixed order (bitwise reproducible, no float atomics).
+#include "fz_common.h"
+
+namespace fz {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { QL_PLAIN = 0, QL_S2D = 1, QL_K3 = 2 };
+
+struct WgradArgs {
+  const float* p;      // (B, M, Np) output-side gradient rows
+  int M;
+  const float* pmul;   // optional: P *= act'(pmul) (same shape as p)
+  int pmul_kind;
+  const float* q[4];   // input sources
+  int nsrc, src_mode, c0;
+  int Cin;             // input channels
+  int K;               // Q rows: Cin (plain), 8*Cin (s2d), 27*Cin (k3)
+  int64_t Vq;          // voxels per sample of the input tensor
+  int D, H, W;         // input spatial dims (s2d: fine grid; k3: grid)
+  int64_t N;           // reduction columns per sample (= Np): Vq (plain/k3) or Vq/8 (s2d)
+  int Ho, Wo;          // coarse grid (s2d)
+  const float* stats;  // (B, 2, Vq) mean/rstd: Q = (x - mean) * rstd   (LN prologue), or null
+  int qact;            // activation on Q
+  float* part;         // workspace: [nchunk][M][K] partial sums
+  float* part_bias;    // workspace: [nchunk][M] partial row sums of P (or null)
+  int B;
+  int tiles_per_chunk; // 32-column tiles per (workgroup, wave) unit
+};
+
+constexpr int kTile = 32;       // voxels per staged tile
+constexpr int kStride = 33;     // LDS row stride (floats)
+
+__device__ __forceinline__ float gelu_w(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_w(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  return cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+// MBP x MBQ blocks of 32x32 outputs per workgroup; 4 waves split the voxel tiles.
+template <int MBP, int MBQ, int QL>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int PR = 32 * MBP, QR = 32 * MBQ;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* Pt = lds + wave * (PR + QR) * kStride;
+  float* Qt = Pt + PR * kStride;
+  const int m0 = blockIdx.y * PR;
+  const int k0 = blockIdx.z * QR;
+  const int64_t tiles_per_sample = (a.N + kTile - 1) / kTile;
+  const int64_t total_tiles = tiles_per_sample * a.B;
+  const int64_t unit = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t t_begin = unit * a.tiles_per_chunk;
+  const int64_t t_end = min(t_begin + a.tiles_per_chunk, total_tiles);
+
+  f32x16 acc[MBP][MBQ];
+#pragma unroll
+  for (int i = 0; i < MBP; ++i)
+#pragma unroll
+    for (int jq = 0; jq < MBQ; ++jq)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][jq][r] = 0.f;
+  float psum[MBP];
+#pragma unroll
+  for (int i = 0; i < MBP; ++i) psum[i] = 0.f;
+
+  const int c = lane & 31, h = lane >> 5;
+
+  for (int64_t t = t_begin; t < t_end; ++t) {
+    const int b = (int)(t / tiles_per_sample);
+    const int64_t n0 = (t % tiles_per_sample) * kTile;
+    // ---- stage P tile: rows m0..m0+PR, columns n0..n0+31 (8 x 16-byte chunks per row) ----
+    for (int idx = lane; idx < PR * 8; idx += 64) {
+      const int r = idx >> 3, cq = idx & 7;
+      const int m = m0 + r;
+      const int64_t n = n0 + cq * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < a.M && n < a.N) {
+        const int64_t o = ((int64_t)b * a.M + m) * a.N + n;
+        v = *reinterpret_cast<const float4*>(a.p + o);
+        if (a.pmul) {
+          const float4 e = *reinterpret_cast<const float4*>(a.pmul + o);
+          if (a.pmul_kind == 2) { v.x *= gelu_grad_w(e.x); v.y *= gelu_grad_w(e.y); v.z *= gelu_grad_w(e.z); v.w *= gelu_grad_w(e.w); }
+          else { v.x = e.x > 0.f ? v.x : 0.f; v.y = e.y > 0.f ? v.y : 0.f; v.z = e.z > 0.f ? v.z : 0.f; v.w = e.w > 0.f ? v.w : 0.f; }
+        }
+      }
+      float* d = Pt + r * kStride + cq * 4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    // ---- stage Q tile ----
+    if (QL == QL_PLAIN) {
+      for (int idx = lane; idx < QR * 8; idx += 64) {
+        const int r = idx >> 3, cq = idx & 7;
+        const int k = k0 + r;
+        const int64_t n = n0 + cq * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (k < a.K && n < a.N) {
+          if (a.src_mode == 0) {
+            const float* src = (k < a.c0) ? a.q[0] + ((int64_t)b * a.c0 + k) * a.Vq
+                                          : a.q[1] + ((int64_t)b * (a.Cin - a.c0) + (k - a.c0)) * a.Vq;
+            const float4 t4 = *reinterpret_cast<const float4*>(src + n);
+            v[0] = t4.x; v[1] = t4.y; v[2] = t4.z; v[3] = t4.w;
+          } else {
+            const int64_t o = ((int64_t)b * a.Cin + k) * a.Vq + n;
+            float4 t4 = *reinterpret_cast<const float4*>(a.q[0] + o);
+            v[0] = 0.0f + t4.x; v[1] = 0.0f + t4.y; v[2] = 0.0f + t4.z; v[3] = 0.0f + t4.w;
+            for (int i = 1; i < a.nsrc; ++i) {
+              t4 = *reinterpret_cast<const float4*>(a.q[i] + o);
+              v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w;
+            }
+            const float nw = (float)a.nsrc;
+            v[0] /= nw; v[1] /= nw; v[2] /= nw; v[3] /= nw;
+          }
+          if (a.stats) {
+            const float* st = a.stats + (int64_t)b * 2 * a.Vq;
+            const float4 mu = *reinterpret_cast<const float4*>(st + n);
+            const float4 rs = *reinterpret_cast<const float4*>(st + a.Vq + n);
+            v[0] = (v[0] - mu.x) * rs.x; v[1] = (v[1] - mu.y) * rs.y;
+            v[2] = (v[2] - mu.z) * rs.z; v[3] = (v[3] - mu.w) * rs.w;
+          }
+          if (a.qact == 2) { v[0] = gelu_w(v[0]); v[1] = gelu_w(v[1]); v[2] = gelu_w(v[2]); v[3] = gelu_w(v[3]); }
+          else if (a.qact == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        }
+        float* d = Qt + r * kStride + cq * 4;
+        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+      }
+    } else if (QL == QL_S2D) {
+      // rows k = (ci, td, th, tw); one 16-byte load gives (tw0,tw1) of two coarse voxels
+      for (int idx = lane; idx < (QR / 2) * 16; idx += 64) {
+        const int rp = idx >> 4, cp = idx & 15;      // row pair (tw = 0/1), coarse column pair
+        const int k = k0 + 2 * rp;                     // tw = 0 row
+        const int64_t n = n0 + 2 * cp;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < a.K && n < a.N) {
+          const int ci = k >> 3, td = (k >> 2) & 1, th = (k >> 1) & 1;
+          const int wo = (int)(n % a.Wo);
+          const int64_t t2 = n / a.Wo;
+          const int ho = (int)(t2 % a.Ho);
+          const int dz = (int)(t2 / a.Ho);
+          const int64_t fo = ((int64_t)(2 * dz + td) * a.H + (2 * ho + th)) * a.W + 2 * wo;
+          v = *reinterpret_cast<const float4*>(a.q[0] + ((int64_t)b * a.Cin + ci) * a.Vq + fo);
+        }
+        float* d0 = Qt + (2 * rp) * kStride + 2 * cp;
+        float* d1 = d0 + kStride;
+        d0[0] = v.x; d1[0] = v.y; d0[1] = v.z; d1[1] = v.w;
+      }
+    } else {
+      // QL_K3: rows k = ci*27 + (kd*9 + kh*3 + kw); zero padding 1
+      for (int idx = lane; idx < QR * kTile; idx += 64) {
+        const int r = idx >> 5, col = idx & 31;
+        const int k = k0 + r;
+        const int64_t n = n0 + col;
+        float v = 0.f;
+        if (k < a.K && n < a.N) {
+          const int ci = k / 27, tap = k % 27;
+          const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+          const int w = (int)(n % a.W);
+          const int64_t t2 = n / a.W;
+          const int hh = (int)(t2 % a.H);
+          const int dz = (int)(t2 / a.H);
+          const int zd = dz + kd - 1, zh = hh + kh - 1, zw = w + kw - 1;
+          if (zd >= 0 && zd < a.D && zh >= 0 && zh < a.H && zw >= 0 && zw < a.W)
+            v = a.q[0][((int64_t)b * a.Cin + ci) * a.Vq + ((int64_t)zd * a.H + zh) * a.W + zw];
+        }
+        Qt[r * kStride + col] = v;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // ---- 16 K-steps of 2 voxels ----
+#pragma unroll 4
+    for (int s = 0; s < kTile / 2; ++s) {
+      float av[MBP], bv[MBQ];
+#pragma unroll
+      for (int i = 0; i < MBP; ++i) {
+        av[i] = Pt[(i * 32 + c) * kStride + 2 * s + h];
+        psum[i] += av[i];
+      }
+#pragma unroll
+      for (int jq = 0; jq < MBQ; ++jq) bv[jq] = Qt[(jq * 32 + c) * kStride + 2 * s + h];
+#pragma unroll
+      for (int i = 0; i < MBP; ++i)
+#pragma unroll
+        for (int jq = 0; jq < MBQ; ++jq)
+          acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[jq], acc[i][jq], 0, 0, 0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+
+  // ---- reduce the 4 waves through LDS, then write this workgroup's partial block ----
+  __syncthreads();
+  float* red = lds;  // [4][PR*QR] would not fit for big blocks: reduce block by block
+#pragma unroll
+  for (int i = 0; i < MBP; ++i) {
+#pragma unroll
+    for (int jq = 0; jq < MBQ; ++jq) {
+      // wave w writes its 32x32 block (1024 floats) at red + w*1024 ; layout [row][col]
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        red[wave * 1024 + row * 32 + c] = acc[i][jq][r];
+      }
+      __syncthreads();
+      for (int e = threadIdx.x; e < 1024; e += 256) {
+        const float s = (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]);
+        const int row = e >> 5, col = e & 31;
+        const int m = m0 + i * 32 + row, k = k0 + jq * 32 + col;
+        if (m < a.M && k < a.K) a.part[((int64_t)blockIdx.x * a.M + m) * a.K + k] = s;
+      }
+      __syncthreads();
+    }
+  }
+  if (a.part_bias != nullptr && blockIdx.z == 0) {
+#pragma unroll
+    for (int i = 0; i < MBP; ++i) {
+      float s = psum[i] + __shfl_xor(psum[i], 32, 64);
+      if (h == 0) red[wave * 32 + c] = s;
+      __syncthreads();
+      if (threadIdx.x < 32) {
+        const float tot = (red[threadIdx.x] + red[32 + threadIdx.x]) + (red[64 + threadIdx.x] + red[96 + threadIdx.x]);
+        const int m = m0 + i * 32 + threadIdx.x;
+        if (m < a.M) a.part_bias[(int64_t)blockIdx.x * a.M + m] = tot;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// out[e] = Σ_chunks part[chunk][e] (fixed order), with the LayerNorm affine folded in:
+//   gw[m][k] = γ_k · Σ gz·n̂  +  β_k · gb[m]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ part_bias,
+                                    int nchunk, int M, int K, const float* __restrict__ ln_g,
+                                    const float* __restrict__ ln_b, float* __restrict__ gw,
+                                    float* __restrict__ gbias, int accumulate) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t MK = (int64_t)M * K;
+  if (e < MK) {
+    float s = 0.f;
+    for (int ch = 0; ch < nchunk; ++ch) s += part[(int64_t)ch * MK + e];
+    const int m = (int)(e / K), k = (int)(e % K);
+    if (ln_g != nullptr) {
+      float gb = 0.f;
+      for (int ch = 0; ch < nchunk; ++ch) gb += part_bias[(int64_t)ch * M + m];
+      s = ln_g[k] * s + ln_b[k] * gb;
+    }
+    gw[e] = accumulate ? gw[e] + s : s;
+  }
+  if (gbias != nullptr && e < M) {
+    float gb = 0.f;
+    for (int ch = 0; ch < nchunk; ++ch) gb += part_bias[(int64_t)ch * M + e];
+    gbias[e] = accumulate ? gbias[e] + gb : gb;
+  }
+}
+
+}  // namespace fz
+
+using namespace fz;
+
+static int pick_chunks(int64_t total_tiles, int out_blocks, int* tiles_per_chunk) {
+  // aim at ~2048 (workgroup, wave) units over the whole grid, at least 1 tile each
+  int64_t units_target = 2048 / (out_blocks > 0 ? out_blocks : 1);
+  if (units_target < 4) units_target = 4;
+  int64_t tpc = (total_tiles + units_target - 1) / units_target;
+  if (tpc < 1) tpc = 1;
+  *tiles_per_chunk = (int)tpc;
+  int64_t units = (total_tiles + tpc - 1) / tpc;
+  return (int)((units + 3) / 4);  // workgroups (4 waves each)
+}
+
+extern "C" int64_t fz_wgrad_workspace_bytes(const fz_wgrad_desc* d) {
+  if (!d || d->M < 1 || d->K < 1) return -1;
+  const int PR = d->M > 32 ? 64 : 32, QR = d->K > 32 ? 64 : 32;
+  const int out_blocks = ((d->M + PR - 1) / PR) * ((d->K + QR - 1) / QR);
+  const int64_t total_tiles = ((d->N + kTile - 1) / kTile) * d->B;
+  int tpc;
+  const int nchunk = pick_chunks(total_tiles, out_blocks, &tpc);
+  return ((int64_t)nchunk * d->M * d->K + (int64_t)nchunk * d->M) * (int64_t)sizeof(float);
+}
+
+extern "C" int fz_wgrad(const fz_wgrad_desc* d, void* workspace, fz_stream_t stream) {
+  if (!d || !workspace) return fail(FZ_E_ARG, "fz_wgrad: null descriptor/workspace");
+  if (!d->p || !d->q[0] || !d->gw) return fail(FZ_E_ARG, "fz_wgrad: null pointer");
+  if (d->loader < 0 || d->loader > 2) return fail(FZ_E_ARG, "fz_wgrad: bad loader");
+  if (d->N % 4 != 0) return fail(FZ_E_UNSUPPORTED, "fz_wgrad: column count must be a multiple of 4");
+  if (d->loader == QL_S2D && ((d->Wo & 1) || d->K != 8 * d->Cin)) return fail(FZ_E_SHAPE, "fz_wgrad: s2d shape");
+  if (d->loader == QL_K3 && d->K != 27 * d->Cin) return fail(FZ_E_SHAPE, "fz_wgrad: k3 shape");
+  if (d->B == 0) return FZ_OK;
+  const int PR = d->M > 32 ? 64 : 32, QR = d->K > 32 ? 64 : 32;
+  const int gy = (d->M + PR - 1) / PR, gz = (d->K + QR - 1) / QR;
+  const int64_t total_tiles = ((d->N + kTile - 1) / kTile) * d->B;
+  int tpc;
+  const int nchunk = pick_chunks(total_tiles, gy * gz, &tpc);
+  WgradArgs a;
+  a.p = d->p; a.M = d->M; a.pmul = d->pmul; a.pmul_kind = d->pmul_kind;
+  for (int i = 0; i < 4; ++i) a.q[i] = d->q[i];
+  a.nsrc = d->nsrc; a.src_mode = d->src_mode; a.c0 = d->c0 > 0 ? d->c0 : d->Cin; a.Cin = d->Cin; a.K = d->K;
+  a.Vq = d->Vq; a.D = d->D; a.H = d->H; a.W = d->W; a.N = d->N; a.Ho = d->Ho; a.Wo = d->Wo;
+  a.stats = d->stats; a.qact = d->qact; a.B = d->B; a.tiles_per_chunk = tpc;
+  a.part = (float*)workspace;
+  a.part_bias = a.part + (int64_t)nchunk * d->M * d->K;
+  dim3 grid(nchunk, gy, gz), block(256);
+  const size_t lds = (size_t)4 * (PR + QR) * kStride * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+#define FZ_WG(MBP, MBQ, QL) hipLaunchKernelGGL((wgrad_kernel<MBP, MBQ, QL>), grid, block, lds, st, a)
+#define FZ_WG_SHAPES(QL)                                 \
+  do {                                                   \
+    if (PR == 64 && QR == 64) FZ_WG(2, 2, QL);           \
+    else if (PR == 64) FZ_WG(2, 1, QL);                  \
+    else if (QR == 64) FZ_WG(1, 2, QL);                  \
+    else FZ_WG(1, 1, QL);                                \
+  } while (0)
+  if (d->loader == QL_PLAIN) FZ_WG_SHAPES(QL_PLAIN);
+  else if (d->loader == QL_S2D) FZ_WG_SHAPES(QL_S2D);
+  else FZ_WG_SHAPES(QL_K3);
+  FZ_LAUNCH_CHECK();
+  const int64_t MK = (int64_t)d->M * d->K;
+  const int64_t nthr = MK > d->M ? MK : d->M;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, a.part,
+                     a.part_bias, nchunk, d->M, d->K, d->ln_g, d->ln_b, d->gw, d->gbias, d->accumulate);
+  FZ_LAUNCH_CHECK();
+  return FZ_OK;
+}

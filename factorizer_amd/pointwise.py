@@ -1,15 +1,371 @@
-"""Per-voxel ops on channels-first tensors (LayerNorm over C, 1×1 GEMMs, MLP).
+"""Dense per-voxel layers on channels-first tensors: LayerNorm over C, 1×1 GEMMs ("Linear"),
+the MLP, k2s2 (transposed) convolutions and the k3 stem — device paths over the fp32-MFMA GEMM
+family of libfactorizer_hip (csrc/gemm.hip, wgrad.hip, ln.hip), CPU paths composed from ATen.
 
-Round-1 state: these dispatch to composed PyTorch ops (rocBLAS/ATen on device); the fused
-gfx950 kernels (LN→GEMM, GEMM→GELU→GEMM→residual) replace them behind the same functions.
+Each autograd Function below is one fused layer of the reference block:
+  LNLinearFn      LayerNorm → Linear (+bias) → [ReLU]     norm.py:29-34 + linear.py:53-58 (+ factorizer.py:44)
+  ActLinearResFn  res + Linear([GELU](z)) + bias           mlp.py:54-60 / factorizer.py:53,75-76
+  LinearFn        plain Linear                              linear.py:53-58
+  CatLinearFn     Linear(cat([x1, x2], 1)) without the cat  unet.py:128 + factorizer.py:116
+  ConvK2S2Fn / TConvK2S2Fn / ConvK3Fn / ConvK1            unet.py:53,123,231,253
 """
 from __future__ import annotations
+
+import ctypes
 
 import torch
 import torch.nn.functional as F
 
+from . import _native as N
+from . import functional as Fn
 
+ACT = {"none": 0, "relu": 1, "gelu": 2}
+LOAD_PLAIN, LOAD_S2D, LOAD_K3 = 0, 1, 2
+EPI_PLAIN, EPI_D2S = 0, 1
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _vox(x):
+    v = 1
+    for s in x.shape[2:]:
+        v *= s
+    return v
+
+
+# ---- raw launches ---------------------------------------------------------------------------
+def _gemm(xs, w, y, *, B, Cin, Vin, M, K, Ncol, w_t=False, ldw=None, bias=None, ln=None, stats_out=None,
+          bact=0, bmul=None, bmul_kind=0, eact=0, res=None, emul=None, emul_kind=0, src_mode=0, c0=0,
+          loader=LOAD_PLAIN, epilogue=EPI_PLAIN, Di=0, Hi=0, Wi=0, Ho=0, Wo=0, name="gemm"):
+    d = N.GemmDesc()
+    for i in range(4):
+        d.x[i] = _p(xs[i]) if i < len(xs) else None
+    d.nsrc, d.src_mode, d.c0, d.Cin, d.Vin = len(xs), src_mode, c0, Cin, Vin
+    d.Di, d.Hi, d.Wi = Di, Hi, Wi
+    d.w, d.w_t, d.ldw, d.M, d.K = _p(w), int(w_t), (ldw if ldw is not None else K), M, K
+    d.bias = _p(bias)
+    if ln is not None:
+        d.ln, d.ln_g, d.ln_b, d.ln_eps = 1, _p(ln[0]), _p(ln[1]), float(ln[2])
+    d.stats_out = _p(stats_out)
+    d.bact, d.bmul, d.bmul_kind = bact, _p(bmul), bmul_kind
+    d.eact, d.res, d.emul, d.emul_kind = eact, _p(res), _p(emul), emul_kind
+    d.y, d.Ncol, d.Ho, d.Wo, d.B = _p(y), Ncol, Ho, Wo, B
+    d.loader, d.epilogue = loader, epilogue
+    x0 = xs[0]
+    nbytes = 4 * (sum(t.numel() for t in xs) + y.numel() + (res.numel() if res is not None else 0))
+    with torch.cuda.device(x0.device):
+        rc = Fn._timed(f"{name}_{Cin}->{M}", nbytes,
+                       lambda: N.lib().fz_gemm(ctypes.byref(d), N.stream_ptr(x0)))
+    N.check(rc, "fz_gemm")
+    return y
+
+
+def _wgrad(p, qs, gw, *, B, M, Cin, K, Vq, Ncols, gbias=None, pmul=None, pmul_kind=0, src_mode=0, c0=0,
+           stats=None, qact=0, ln=None, loader=0, D=0, H=0, W=0, Ho=0, Wo=0, accumulate=False, name="wgrad"):
+    d = N.WgradDesc()
+    d.p, d.M, d.pmul, d.pmul_kind = _p(p), M, _p(pmul), pmul_kind
+    for i in range(4):
+        d.q[i] = _p(qs[i]) if i < len(qs) else None
+    d.nsrc, d.src_mode, d.c0, d.Cin, d.K, d.Vq = len(qs), src_mode, c0, Cin, K, Vq
+    d.D, d.H, d.W, d.N, d.Ho, d.Wo = D, H, W, Ncols, Ho, Wo
+    d.stats, d.qact = _p(stats), qact
+    if ln is not None:
+        d.ln_g, d.ln_b = _p(ln[0]), _p(ln[1])
+    d.gw, d.gbias, d.accumulate, d.B, d.loader = _p(gw), _p(gbias), int(accumulate), B, loader
+    nb = N.lib().fz_wgrad_workspace_bytes(ctypes.byref(d))
+    if nb < 0:
+        raise N.NativeError("fz_wgrad_workspace_bytes failed")
+    ws = torch.empty(max(nb // 4, 1), dtype=torch.float32, device=p.device)
+    nbytes = 4 * (p.numel() + sum(t.numel() for t in qs))
+    with torch.cuda.device(p.device):
+        rc = Fn._timed(f"{name}_{M}x{K}", nbytes,
+                       lambda: N.lib().fz_wgrad(ctypes.byref(d), ws.data_ptr(), N.stream_ptr(p)))
+    N.check(rc, "fz_wgrad")
+    return gw
+
+
+def _native_ok(*ts):
+    t0 = ts[0]
+    return t0.is_cuda and all(t is None or (t.dtype == torch.float32) for t in ts) and _vox(t0) % 4 == 0
+
+
+# ---- LayerNorm → Linear → [ReLU] -----------------------------------------------------------
+class LNLinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, eps, w, b, act):
+        x = x.contiguous()
+        B, C = x.shape[:2]
+        V = _vox(x)
+        M = w.shape[0]
+        w2 = w.reshape(M, C)
+        y = torch.empty((B, M, *x.shape[2:]), dtype=x.dtype, device=x.device)
+        stats = torch.empty((B, 2, V), dtype=x.dtype, device=x.device)
+        _gemm([x], w2, y, B=B, Cin=C, Vin=V, M=M, K=C, Ncol=V, bias=b, ln=(ln_w, ln_b, eps), stats_out=stats,
+              eact=ACT[act], name="ln_linear")
+        ctx.save_for_backward(x, stats, ln_w, ln_b, w2, y if act == "relu" else None)
+        ctx.act, ctx.has_bias, ctx.wshape = act, b is not None, w.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, stats, ln_w, ln_b, w2, y = ctx.saved_tensors
+        gy = gy.contiguous()
+        B, C = x.shape[:2]
+        V = _vox(x)
+        M = w2.shape[0]
+        gate = y if ctx.act == "relu" else None
+        # gl = Wᵀ (gy ∘ relu'(y))
+        gl = torch.empty_like(x)
+        _gemm([gy], w2, gl, B=B, Cin=M, Vin=V, M=C, K=M, Ncol=V, w_t=True, ldw=C, bmul=gate,
+              bmul_kind=ACT["relu"], name="linear_dgrad")
+        gx = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            rc = Fn._timed(f"ln_bwd_{C}", 3 * 4 * x.numel(), lambda: N.lib().fz_ln_bwd(
+                gl.data_ptr(), x.data_ptr(), stats.data_ptr(), ln_w.data_ptr(), None, gx.data_ptr(), B, C, V,
+                N.stream_ptr(x)))
+        N.check(rc, "fz_ln_bwd")
+        # weight / bias grads: GW = (gy∘gate) · LN(x)ᵀ with the affine folded in the reduce step
+        gw = torch.empty_like(w2)
+        gb = torch.empty(M, dtype=x.dtype, device=x.device)
+        _wgrad(gy, [x], gw, B=B, M=M, Cin=C, K=C, Vq=V, Ncols=V, gbias=gb, pmul=gate, pmul_kind=ACT["relu"],
+               stats=stats, ln=(ln_w, ln_b), name="wgrad_ln_linear")
+        # LN affine grads: gγ = diag(gl · n̂ᵀ), gβ = rowsum(gl)
+        gmat = torch.empty((C, C), dtype=x.dtype, device=x.device)
+        gbeta = torch.empty(C, dtype=x.dtype, device=x.device)
+        _wgrad(gl, [x], gmat, B=B, M=C, Cin=C, K=C, Vq=V, Ncols=V, gbias=gbeta, stats=stats, name="wgrad_ln_affine")
+        ggamma = torch.diagonal(gmat).clone()
+        return gx, ggamma, gbeta, None, gw.reshape(ctx.wshape), (gb if ctx.has_bias else None), None
+
+
+# ---- res + Linear(act(z)) + bias -------------------------------------------------------------
+class ActLinearResFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, w, b, res, bact):
+        z = z.contiguous()
+        B, C = z.shape[:2]
+        V = _vox(z)
+        M = w.shape[0]
+        w2 = w.reshape(M, C)
+        if res is not None:
+            res = res.contiguous()
+        y = torch.empty((B, M, *z.shape[2:]), dtype=z.dtype, device=z.device)
+        _gemm([z], w2, y, B=B, Cin=C, Vin=V, M=M, K=C, Ncol=V, bias=b, bact=ACT[bact], res=res,
+              name="act_linear_res")
+        ctx.save_for_backward(z, w2)
+        ctx.bact, ctx.has_bias, ctx.has_res, ctx.wshape = bact, b is not None, res is not None, w.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        z, w2 = ctx.saved_tensors
+        gy = gy.contiguous()
+        B, C = z.shape[:2]
+        V = _vox(z)
+        M = w2.shape[0]
+        gz = torch.empty_like(z)
+        _gemm([gy], w2, gz, B=B, Cin=M, Vin=V, M=C, K=M, Ncol=V, w_t=True, ldw=C,
+              emul=(z if ctx.bact != "none" else None), emul_kind=ACT[ctx.bact], name="linear_dgrad")
+        gw = torch.empty_like(w2)
+        gb = torch.empty(M, dtype=z.dtype, device=z.device)
+        _wgrad(gy, [z], gw, B=B, M=M, Cin=C, K=C, Vq=V, Ncols=V, gbias=gb, qact=ACT[ctx.bact], name="wgrad_linear")
+        return gz, gw.reshape(ctx.wshape), (gb if ctx.has_bias else None), (gy if ctx.has_res else None), None
+
+
+# ---- Linear over a virtual channel concat -------------------------------------------------------
+class CatLinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x1, x2, w, b):
+        x1, x2 = x1.contiguous(), x2.contiguous()
+        B, C1 = x1.shape[:2]
+        C2 = x2.shape[1]
+        V = _vox(x1)
+        M = w.shape[0]
+        w2 = w.reshape(M, C1 + C2)
+        y = torch.empty((B, M, *x1.shape[2:]), dtype=x1.dtype, device=x1.device)
+        _gemm([x1, x2], w2, y, B=B, Cin=C1 + C2, Vin=V, M=M, K=C1 + C2, Ncol=V, bias=b, c0=C1, name="cat_linear")
+        ctx.save_for_backward(x1, x2, w2)
+        ctx.has_bias, ctx.wshape = b is not None, w.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x1, x2, w2 = ctx.saved_tensors
+        gy = gy.contiguous()
+        B, C1 = x1.shape[:2]
+        C2 = x2.shape[1]
+        V = _vox(x1)
+        M = w2.shape[0]
+        C = C1 + C2
+        g1 = torch.empty_like(x1)
+        g2 = torch.empty_like(x2)
+        _gemm([gy], w2, g1, B=B, Cin=M, Vin=V, M=C1, K=M, Ncol=V, w_t=True, ldw=C, name="linear_dgrad")
+        _gemm([gy], w2[:, C1:], g2, B=B, Cin=M, Vin=V, M=C2, K=M, Ncol=V, w_t=True, ldw=C, name="linear_dgrad")
+        gw = torch.empty_like(w2)
+        gb = torch.empty(M, dtype=gy.dtype, device=gy.device)
+        _wgrad(gy, [x1, x2], gw, B=B, M=M, Cin=C, K=C, Vq=V, Ncols=V, gbias=gb, c0=C1, name="wgrad_cat_linear")
+        return g1, g2, gw.reshape(ctx.wshape), (gb if ctx.has_bias else None)
+
+
+class LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        return ActLinearResFn.forward(ctx, x, w, b, None, "none")
+
+    @staticmethod
+    def backward(ctx, gy):
+        return ActLinearResFn.backward(ctx, gy)[:3]
+
+
+# ---- standalone LayerNorm -------------------------------------------------------------------------
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        x = x.contiguous()
+        B, C = x.shape[:2]
+        V = _vox(x)
+        y = torch.empty_like(x)
+        stats = torch.empty((B, 2, V), dtype=x.dtype, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = Fn._timed(f"ln_fwd_{C}", 2 * 4 * x.numel(), lambda: N.lib().fz_ln_fwd(
+                x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), B, C, V, eps,
+                N.stream_ptr(x)))
+        N.check(rc, "fz_ln_fwd")
+        ctx.save_for_backward(x, stats, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, stats, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        B, C = x.shape[:2]
+        V = _vox(x)
+        gx = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            rc = Fn._timed(f"ln_bwd_{C}", 3 * 4 * x.numel(), lambda: N.lib().fz_ln_bwd(
+                gy.data_ptr(), x.data_ptr(), stats.data_ptr(), w.data_ptr(), None, gx.data_ptr(), B, C, V,
+                N.stream_ptr(x)))
+        N.check(rc, "fz_ln_bwd")
+        gmat = torch.empty((C, C), dtype=x.dtype, device=x.device)
+        gbeta = torch.empty(C, dtype=x.dtype, device=x.device)
+        _wgrad(gy, [x], gmat, B=B, M=C, Cin=C, K=C, Vq=V, Ncols=V, gbias=gbeta, stats=stats, name="wgrad_ln_affine")
+        return gx, torch.diagonal(gmat).clone(), gbeta, None
+
+
+# ---- strided convolutions of the U-shape ------------------------------------------------------------
+class ConvK2S2Fn(torch.autograd.Function):
+    """Conv3d(kernel 2, stride 2): space-to-depth gather fused into the GEMM's operand loads."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = x.contiguous()
+        B, C, D, H, W = x.shape
+        O = w.shape[0]
+        Do, Ho, Wo = D // 2, H // 2, W // 2
+        y = torch.empty((B, O, Do, Ho, Wo), dtype=x.dtype, device=x.device)
+        _gemm([x], w, y, B=B, Cin=C, Vin=D * H * W, M=O, K=8 * C, Ncol=Do * Ho * Wo, bias=b, loader=LOAD_S2D,
+              Di=D, Hi=H, Wi=W, Ho=Ho, Wo=Wo, name="conv_k2s2")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        B, C, D, H, W = x.shape
+        O = w.shape[0]
+        Do, Ho, Wo = D // 2, H // 2, W // 2
+        Vc = Do * Ho * Wo
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            # rows (ci, tap), reduction over o:  A[m][k] = w[k*(8C) + m]
+            _gemm([gy], w, gx, B=B, Cin=O, Vin=Vc, M=8 * C, K=O, Ncol=Vc, w_t=True, ldw=8 * C,
+                  epilogue=EPI_D2S, Ho=Ho, Wo=Wo, name="conv_k2s2_dgrad")
+        gw = torch.empty_like(w)
+        gb = torch.empty(O, dtype=x.dtype, device=x.device)
+        _wgrad(gy, [x], gw, B=B, M=O, Cin=C, K=8 * C, Vq=D * H * W, Ncols=Vc, gbias=gb, loader=LOAD_S2D,
+               D=D, H=H, W=W, Ho=Ho, Wo=Wo, name="wgrad_conv_k2s2")
+        return gx, gw, (gb if ctx.has_bias else None)
+
+
+class TConvK2S2Fn(torch.autograd.Function):
+    """ConvTranspose3d(kernel 2, stride 2): GEMM with (o, tap) rows + depth-to-space epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = x.contiguous()
+        B, C, D, H, W = x.shape
+        O = w.shape[1]
+        y = torch.empty((B, O, 2 * D, 2 * H, 2 * W), dtype=x.dtype, device=x.device)
+        V = D * H * W
+        _gemm([x], w, y, B=B, Cin=C, Vin=V, M=8 * O, K=C, Ncol=V, w_t=True, ldw=8 * O, bias=b,
+              epilogue=EPI_D2S, Ho=H, Wo=W, name="tconv_k2s2")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        B, C, D, H, W = x.shape
+        O = w.shape[1]
+        V = D * H * W
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            # GX[ci, coarse] = Σ_{o,tap} w[ci, o, tap] · GY[o, fine]: a k2s2 "conv" of gy with w as [C][8O]
+            _gemm([gy], w, gx, B=B, Cin=O, Vin=8 * V, M=C, K=8 * O, Ncol=V, loader=LOAD_S2D,
+                  Di=2 * D, Hi=2 * H, Wi=2 * W, Ho=H, Wo=W, name="tconv_k2s2_dgrad")
+        gw = torch.empty_like(w)
+        # GW[ci][(o,tap)] = Σ X[ci][n] · GY[o][fine(n,tap)]
+        _wgrad(x, [gy], gw, B=B, M=C, Cin=O, K=8 * O, Vq=8 * V, Ncols=V, loader=LOAD_S2D, D=2 * D, H=2 * H,
+               W=2 * W, Ho=H, Wo=W, name="wgrad_tconv_k2s2")
+        gb = gy.sum(dim=(0, 2, 3, 4)) if ctx.has_bias else None
+        return gx, gw, gb
+
+
+class ConvK3Fn(torch.autograd.Function):
+    """Conv3d(kernel 3, padding 1) — the stem (C_in = 4): taps gathered by the GEMM's loader."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = x.contiguous()
+        B, C, D, H, W = x.shape
+        O = w.shape[0]
+        V = D * H * W
+        y = torch.empty((B, O, D, H, W), dtype=x.dtype, device=x.device)
+        _gemm([x], w, y, B=B, Cin=C, Vin=V, M=O, K=27 * C, Ncol=V, bias=b, loader=LOAD_K3, Di=D, Hi=H, Wi=W,
+              name="conv_k3")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        B, C, D, H, W = x.shape
+        O = w.shape[0]
+        V = D * H * W
+        gx = None
+        if ctx.needs_input_grad[0]:
+            # not on the training path (the stem's input is data); composed from ATen
+            gx = torch.nn.grad.conv3d_input(x.shape, w, gy, padding=1)
+        gw = torch.empty_like(w)
+        gb = torch.empty(O, dtype=x.dtype, device=x.device)
+        _wgrad(gy, [x], gw, B=B, M=O, Cin=C, K=27 * C, Vq=V, Ncols=V, gbias=gb, loader=LOAD_K3, D=D, H=H, W=W,
+               name="wgrad_conv_k3")
+        return gx, gw, (gb if ctx.has_bias else None)
+
+
+# ---- public dispatchers (device → native, CPU → composed ATen) ---------------------------------------
 def linear_cf(x, weight, bias=None):
+    if _native_ok(x, weight, bias) and weight.shape[1] % 2 == 0:
+        return LinearFn.apply(x, weight, bias)
     B, C = x.shape[:2]
     y = torch.matmul(weight.reshape(weight.shape[0], weight.shape[1]), x.reshape(B, C, -1))
     if bias is not None:
@@ -18,9 +374,37 @@ def linear_cf(x, weight, bias=None):
 
 
 def layernorm_cf(x, weight, bias, eps):
+    if weight is not None and bias is not None and _native_ok(x, weight, bias):
+        return LayerNormFn.apply(x, weight, bias, eps)
     y = F.layer_norm(x.movedim(1, -1), (x.shape[1],), weight, bias, eps)
     return y.movedim(-1, 1).contiguous()
 
 
 def mlp_cf(x, w1, b1, w2, b2):
+    if _native_ok(x, w1, b1, w2, b2) and w1.shape[1] % 2 == 0 and w2.shape[1] % 2 == 0:
+        z = LinearFn.apply(x, w1, b1)
+        return ActLinearResFn.apply(z, w2, b2, None, "gelu")
     return linear_cf(F.gelu(linear_cf(x, w1, b1)), w2, b2)
+
+
+def ln_linear(x, ln_w, ln_b, eps, w, b, act="none"):
+    """act(Linear(LayerNorm(x)))."""
+    if _native_ok(x, ln_w, ln_b, w, b) and w.shape[1] % 2 == 0:
+        return LNLinearFn.apply(x, ln_w, ln_b, eps, w, b, act)
+    y = linear_cf(layernorm_cf(x, ln_w, ln_b, eps), w, b)
+    return torch.relu(y) if act == "relu" else y
+
+
+def act_linear_res(z, w, b, res, act="none"):
+    """res + Linear(act(z))."""
+    if _native_ok(z, w, b, res) and w.shape[1] % 2 == 0:
+        return ActLinearResFn.apply(z, w, b, res, act)
+    y = linear_cf(F.gelu(z) if act == "gelu" else z, w, b)
+    return y if res is None else res + y
+
+
+def cat_linear(x1, x2, w, b=None):
+    """Linear(cat([x1, x2], dim=1)) without materialising the concatenation."""
+    if _native_ok(x1, x2, w, b) and x1.shape[1] % 2 == 0 and x2.shape[1] % 2 == 0:
+        return CatLinearFn.apply(x1, x2, w, b)
+    return linear_cf(torch.cat([x1, x2], dim=1), w, b)

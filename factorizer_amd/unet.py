@@ -9,6 +9,7 @@ from collections.abc import Sequence
 import torch
 from torch import nn
 
+from . import convs
 from .blocks import FactorizerStage
 from .layers import PositionalEmbedding
 from .utils import as_tuple, partialize
@@ -89,6 +90,8 @@ class UNetDecoderBlock(nn.Module):
 
     def forward(self, x1, x2):
         x1 = self.upsample(x1)
+        if hasattr(self.block, "forward_pair"):
+            return self.block.forward_pair(x2, x1)
         return self.block(torch.cat([x2, x1], dim=1))
 
 
@@ -125,8 +128,8 @@ class UNet(nn.Module):
         for s in strides:
             if math.prod(as_tuple(s)) not in (1, 2 ** spatial_dims) and as_tuple(s) != (2,):
                 raise ValueError("only strides of 1 or 2 are coherent in this U-shape (unet.py:53,123)")
-        conv = getattr(nn, f"Conv{spatial_dims}d")
-        tconv = getattr(nn, f"ConvTranspose{spatial_dims}d")
+        conv = convs.Conv3d if spatial_dims == 3 else getattr(nn, f"Conv{spatial_dims}d")
+        tconv = convs.ConvTranspose3d if spatial_dims == 3 else getattr(nn, f"ConvTranspose{spatial_dims}d")
         if stem in (None, nn.Identity):
             stem = nn.Identity
             stem_width = in_channels
@@ -180,7 +183,8 @@ class Factorizer(UNet):
                  pos_embed=PositionalEmbedding, num_deep_supr=False, **kwargs):
         nd = len(spatial_size)
         if stem is None:
-            stem = (getattr(nn, f"Conv{nd}d"), {"kernel_size": 3, "padding": 1, "bias": False})
+            stem = (convs.Conv3d if nd == 3 else getattr(nn, f"Conv{nd}d"),
+                    {"kernel_size": 3, "padding": 1, "bias": False})
         n_enc, n_dec = len(encoder_depth), len(decoder_depth)
         block = ((n_enc - 1) * [(FactorizerStage, kwargs)]
                  + [(FactorizerStage, {"pos_embed": pos_embed, **kwargs})]

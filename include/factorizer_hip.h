@@ -92,6 +92,108 @@ int fz_nmf_bwd(const float* x, const float* u0, const float* v0, const float* gy
 /* 1 if (M,N,R,T,Tgrad) is covered by the native kernels (fwd and bwd), else 0. */
 int fz_nmf_supported(int M, int N, int R, int T, int Tgrad);
 
+/* ---- channels-first GEMM family (1x1 layers, k2s2 conv / transposed conv, input grads) ----
+ * Out[m, n] = epilogue( sum_k A[m,k] * prologue(In)[k,n] ), n = voxel.  One descriptor drives
+ * every dense layer of the block and of the U-shape:
+ *   Linear (Conv1d k=1 on flatten(2))      layers/linear.py:53-58
+ *   LayerNorm over channels as a prologue  layers/norm.py:29-34
+ *   MLP Linear-GELU-Linear                 layers/mlp.py:54-60
+ *   window average of inverse_forward      factorization/operations.py:426-433 (src_mode 1)
+ *   adapter on cat([skip, up])             unet.py:128 + factorizer.py:116 (two sources, no cat)
+ *   Conv3d(k=2,s=2) downsample             unet.py:53   (loader = FZ_LOAD_S2D)
+ *   ConvTranspose3d(k=2,s=2) upsample      unet.py:123  (epilogue = FZ_EPI_D2S)
+ *   head Conv3d(k=1)                       unet.py:253
+ * and, with w_t (use the weight transposed), the input gradient of each of them.
+ */
+#define FZ_LOAD_PLAIN 0 /* In[k][n] = x[b, k, n]                                             */
+#define FZ_LOAD_S2D 1   /* In[(c,td,th,tw)][coarse n] = x[b, c, 2d+td, 2h+th, 2w+tw]         */
+#define FZ_LOAD_K3 2    /* In[(c,kd,kh,kw)][n] = x[b, c, d+kd-1, h+kh-1, w+kw-1], zero padded  */
+#define FZ_EPI_PLAIN 0  /* y[b, m, n]                                                         */
+#define FZ_EPI_D2S 1    /* rows m = (o, td,th,tw): y[b, o, 2d+td, 2h+th, 2w+tw]               */
+#define FZ_ACT_NONE 0
+#define FZ_ACT_RELU 1
+#define FZ_ACT_GELU 2 /* exact erf GELU, layers/mlp.py:56 */
+
+typedef struct fz_gemm_desc {
+  const float* x[4];   /* input source tensors (B, C_i, Vin)                                   */
+  int nsrc;            /* number of sources                                                    */
+  int src_mode;        /* 0: channel concat of x[0] (c0 ch) and x[1]; 1: average of nsrc sources */
+  int c0;              /* channels of x[0] in concat mode (0 = all)                            */
+  int Cin;             /* input channels                                                       */
+  int64_t Vin;         /* voxels per sample of the input                                       */
+  int Di, Hi, Wi;      /* input D, H, W (FZ_LOAD_S2D: fine grid; FZ_LOAD_K3)                   */
+  const float* w;      /* weights                                                              */
+  int w_t, ldw;        /* A[m][k] = w_t ? w[k*ldw + m] : w[m*ldw + k]                          */
+  int M, K;            /* output rows, reduction length (even)                                 */
+  const float* bias;   /* [M] (plain) / [M/8] (d2s) or NULL                                    */
+  int ln;              /* LayerNorm prologue over Cin                                          */
+  const float* ln_g;
+  const float* ln_b;
+  float ln_eps;
+  float* stats_out;    /* (B, 2, Vin): mean, rstd of the LN prologue, or NULL                  */
+  int bact;            /* activation applied to the input operand                              */
+  const float* bmul;   /* input operand *= act'(bmul) (same shape as the input) or NULL        */
+  int bmul_kind;
+  int eact;            /* activation applied to the result                                     */
+  const float* res;    /* residual added to the result (same shape as y) or NULL               */
+  const float* emul;   /* result *= act'(emul) (same shape as y) or NULL                       */
+  int emul_kind;
+  float* y;
+  int64_t Ncol;        /* columns per sample: Vin (plain) or coarse voxel count (s2d)          */
+  int Ho, Wo;          /* coarse H, W (s2d columns / d2s input grid)                           */
+  int B;
+  int loader, epilogue;
+} fz_gemm_desc;
+
+int fz_gemm(const fz_gemm_desc* desc, fz_stream_t stream);
+
+/* ---- weight gradients of the GEMM family ------------------------------------------------
+ * GW[m,k] = sum_{b,n} P[b,m,n] * Q(In)[b,k,n] — what autograd computes for the weights of
+ * Conv1d(k=1) (layers/linear.py:44-58), Conv3d k2s2 / ConvTranspose3d k2s2 (unet.py:53,123)
+ * and the k3 stem (factorizer.py:145-149).  Deterministic two-stage reduction; the caller
+ * passes a workspace of fz_wgrad_workspace_bytes().
+ */
+#define FZ_QL_PLAIN 0 /* Q[k][n] = in[b,k,n]                                     */
+#define FZ_QL_S2D 1   /* Q[(c,td,th,tw)][coarse n] = in[b,c,2d+td,2h+th,2w+tw]   */
+#define FZ_QL_K3 2    /* Q[(c,kd,kh,kw)][n] = in[b,c,d+kd-1,h+kh-1,w+kw-1] (zero pad) */
+
+typedef struct fz_wgrad_desc {
+  const float* p;     /* (B, M, N) output-side gradient                                      */
+  int M;
+  const float* pmul;  /* optional: P *= act'(pmul)                                           */
+  int pmul_kind;      /* FZ_ACT_RELU / FZ_ACT_GELU                                           */
+  const float* q[4];  /* input sources                                                       */
+  int nsrc, src_mode, c0;
+  int Cin;            /* input channels                                                      */
+  int K;              /* Q rows: Cin / 8*Cin / 27*Cin                                        */
+  int64_t Vq;         /* voxels per sample of the input                                      */
+  int D, H, W;        /* input grid (s2d: fine grid; k3)                                     */
+  int64_t N;          /* reduction columns per sample                                        */
+  int Ho, Wo;         /* coarse grid (s2d)                                                   */
+  const float* stats; /* (B,2,Vq) mean/rstd: Q = (in-mean)*rstd, or NULL                     */
+  int qact;           /* activation applied to Q                                             */
+  const float* ln_g;  /* with stats: gw[m][k] = ln_g[k]*acc + ln_b[k]*rowsum(P)[m]           */
+  const float* ln_b;
+  float* gw;          /* (M, K) out                                                          */
+  float* gbias;       /* (M) row sums of P, or NULL                                          */
+  int accumulate;     /* add into gw/gbias instead of overwriting                            */
+  int B;
+  int loader;
+} fz_wgrad_desc;
+
+int64_t fz_wgrad_workspace_bytes(const fz_wgrad_desc* desc);
+int fz_wgrad(const fz_wgrad_desc* desc, void* workspace, fz_stream_t stream);
+
+/* ---- channels-first LayerNorm (layers/norm.py:29-34), standalone ---------------------------
+ * fwd: y = (x-mean)*rstd*gamma + beta over C per voxel; stats (B,2,V) = (mean, rstd) optional.
+ * bwd: gx = rstd*(gl*gamma - mean_c(gl*gamma) - n*mean_c(gl*gamma*n)) [+ gadd]; the parameter
+ * gradients come from fz_wgrad (diag of P=gl, Q=normalised x; row sums).
+ */
+int fz_ln_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats, int B,
+              int C, int64_t V, float eps, fz_stream_t stream);
+int fz_ln_bwd(const float* gl, const float* x, const float* stats, const float* gamma,
+              const float* gadd, float* gx, int B, int C, int64_t V, fz_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,191 @@
+"""-m gpu: the fp32-MFMA GEMM family (csrc/gemm.hip, wgrad.hip, ln.hip) behind the layer
+Functions of factorizer_amd/pointwise.py, against ATen on CPU (the arithmetic the reference
+runs: nn.Conv1d / nn.LayerNorm / nn.Conv3d / nn.ConvTranspose3d) and the reference goldens."""
+import pytest
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+import factorizer_amd as ft
+from factorizer_amd import _native
+from factorizer_amd import pointwise as PW
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = dict(rtol=2e-4, atol=2e-4)
+
+
+def _cmp(a, b, what, rtol=2e-4):
+    s = b.abs().max().item() + 1e-6
+    err = (a.detach().cpu() - b.detach()).abs().max().item()
+    assert err <= rtol * s + 1e-5, f"{what}: err {err:.3e} scale {s:.3e}"
+
+
+def _run_both(fn_dev, fn_cpu, tensors, gy_shape_like=None):
+    """tensors: list of CPU leaf tensors (None allowed).  Returns nothing; asserts parity."""
+    cpu = [None if t is None else t.clone().requires_grad_(True) for t in tensors]
+    dev = [None if t is None else t.clone().to(DEV).requires_grad_(True) for t in tensors]
+    n0 = _native.launch_count()
+    yd = fn_dev(*dev)
+    yc = fn_cpu(*cpu)
+    _cmp(yd, yc, "forward")
+    torch.manual_seed(99)
+    gy = torch.randn_like(yc)
+    gd = torch.autograd.grad(yd, [t for t in dev if t is not None], gy.to(DEV))
+    gc = torch.autograd.grad(yc, [t for t in cpu if t is not None], gy)
+    torch.cuda.synchronize()
+    assert _native.launch_count() > n0
+    for i, (a, b) in enumerate(zip(gd, gc)):
+        _cmp(a, b, f"grad[{i}]", rtol=5e-4)
+
+
+def _lin_cpu(x, w, b=None):
+    return F.conv1d(x.flatten(2), w, b).reshape(x.shape[0], w.shape[0], *x.shape[2:])
+
+
+SHAPES = [
+    (2, 32, 32, (8, 8, 8)),
+    (1, 16, 24, (4, 4, 4)),     # rows not a multiple of 32, tiny V (tile tail)
+    (2, 64, 32, (6, 4, 4)),     # V = 96: partial wave tiles
+    (1, 32, 64, (8, 8, 16)),    # two row blocks (MB = 2)
+    (1, 32, 3, (8, 8, 8)),      # head
+    (1, 128, 128, (4, 4, 8)),   # several row blocks, K > one LDS chunk? (64 a-steps = K 128)
+    (1, 512, 256, (4, 4, 4)),   # K-chunked weights
+]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,S", SHAPES)
+@pytest.mark.parametrize("bias", [True, False])
+def test_linear(B, Cin, Cout, S, bias):
+    torch.manual_seed(0)
+    x = torch.randn(B, Cin, *S)
+    w = torch.randn(Cout, Cin, 1) / Cin ** 0.5
+    b = torch.randn(Cout) if bias else None
+    _run_both(lambda x, w, b=None: PW.linear_cf(x, w, b), _lin_cpu, [x, w, b])
+
+
+@pytest.mark.parametrize("B,Cin,Cout,S", SHAPES[:5])
+@pytest.mark.parametrize("act", ["relu", "none"])
+def test_ln_linear(B, Cin, Cout, S, act):
+    torch.manual_seed(1)
+    x = torch.randn(B, Cin, *S) * 2 + 0.5
+    g, bt = torch.rand(Cin) + 0.5, torch.randn(Cin) * 0.3
+    w = torch.randn(Cout, Cin, 1) / Cin ** 0.5
+    b = torch.randn(Cout)
+
+    def cpu(x, g, bt, w, b):
+        y = _lin_cpu(F.layer_norm(x.movedim(1, -1), (Cin,), g, bt, 1e-5).movedim(-1, 1), w, b)
+        return torch.relu(y) if act == "relu" else y
+
+    _run_both(lambda x, g, bt, w, b: PW.ln_linear(x, g, bt, 1e-5, w, b, act), cpu, [x, g, bt, w, b])
+
+
+def test_ln_linear_large_mean():
+    """single-pass variance must stay accurate when |mean| >> std"""
+    torch.manual_seed(2)
+    x = torch.randn(1, 32, 8, 8, 8) * 0.5 + 30.0
+    g, bt = torch.rand(32) + 0.5, torch.randn(32)
+    w = torch.randn(32, 32, 1) / 32 ** 0.5
+    y = PW.ln_linear(x.to(DEV), g.to(DEV), bt.to(DEV), 1e-5, w.to(DEV), None, "none")
+    yc = _lin_cpu(F.layer_norm(x.movedim(1, -1), (32,), g, bt, 1e-5).movedim(-1, 1), w)
+    _cmp(y, yc, "ln large mean", rtol=5e-4)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,S", SHAPES[:4])
+@pytest.mark.parametrize("act", ["gelu", "none"])
+@pytest.mark.parametrize("res", [True, False])
+def test_act_linear_res(B, Cin, Cout, S, act, res):
+    torch.manual_seed(3)
+    z = torch.randn(B, Cin, *S)
+    w = torch.randn(Cout, Cin, 1) / Cin ** 0.5
+    b = torch.randn(Cout)
+    r = torch.randn(B, Cout, *S) if res else None
+
+    def cpu(z, w, b, r=None):
+        y = _lin_cpu(F.gelu(z) if act == "gelu" else z, w, b)
+        return y if r is None else y + r
+
+    _run_both(lambda z, w, b, r=None: PW.act_linear_res(z, w, b, r, act), cpu, [z, w, b, r])
+
+
+def test_cat_linear():
+    torch.manual_seed(4)
+    x1, x2 = torch.randn(2, 32, 8, 8, 8), torch.randn(2, 32, 8, 8, 8)
+    w = torch.randn(32, 64, 1) / 8
+    _run_both(lambda a, b, w: PW.cat_linear(a, b, w), lambda a, b, w: _lin_cpu(torch.cat([a, b], 1), w), [x1, x2, w])
+    x1, x2 = torch.randn(1, 16, 4, 4, 4), torch.randn(1, 8, 4, 4, 4)
+    w = torch.randn(8, 24, 1) / 5
+    _run_both(lambda a, b, w: PW.cat_linear(a, b, w), lambda a, b, w: _lin_cpu(torch.cat([a, b], 1), w), [x1, x2, w])
+
+
+@pytest.mark.parametrize("C,S", [(32, (8, 8, 8)), (16, (4, 4, 4)), (512, (4, 4, 4)), (6, (2, 2, 4))])
+def test_layernorm(C, S):
+    torch.manual_seed(5)
+    x = torch.randn(2, C, *S) * 3 + 1
+    g, bt = torch.rand(C) + 0.5, torch.randn(C)
+    _run_both(lambda x, g, bt: PW.layernorm_cf(x, g, bt, 1e-5),
+              lambda x, g, bt: F.layer_norm(x.movedim(1, -1), (C,), g, bt, 1e-5).movedim(-1, 1), [x, g, bt])
+
+
+@pytest.mark.parametrize("Cin,Cout,S", [(32, 64, (8, 8, 8)), (8, 16, (8, 8, 8)), (64, 128, (4, 4, 8)),
+                                        (256, 512, (4, 4, 4)), (16, 16, (4, 6, 4))])
+def test_conv_k2s2(Cin, Cout, S):
+    torch.manual_seed(6)
+    m = nn.Conv3d(Cin, Cout, kernel_size=2, stride=2)
+    d = ft.Conv3d(Cin, Cout, kernel_size=2, stride=2)
+    d.load_state_dict(m.state_dict())
+    d = d.to(DEV)
+    x = torch.randn(2, Cin, *S)
+    _run_both(lambda x, w, b: F.conv3d(x, w, b, stride=2) if not x.is_cuda else PW.ConvK2S2Fn.apply(x, w, b),
+              lambda x, w, b: F.conv3d(x, w, b, stride=2), [x, m.weight.detach(), m.bias.detach()])
+    _cmp(d(x.to(DEV)), m(x), "module")
+
+
+@pytest.mark.parametrize("Cin,Cout,S", [(64, 32, (4, 4, 4)), (16, 8, (4, 4, 4)), (512, 256, (2, 2, 4)),
+                                        (32, 16, (2, 4, 2))])
+def test_tconv_k2s2(Cin, Cout, S):
+    torch.manual_seed(7)
+    m = nn.ConvTranspose3d(Cin, Cout, kernel_size=2, stride=2)
+    x = torch.randn(2, Cin, *S)
+    _run_both(lambda x, w, b: PW.TConvK2S2Fn.apply(x, w, b),
+              lambda x, w, b: F.conv_transpose3d(x, w, b, stride=2), [x, m.weight.detach(), m.bias.detach()])
+
+
+@pytest.mark.parametrize("Cin,Cout,S", [(4, 32, (8, 8, 8)), (4, 8, (4, 6, 8)), (2, 16, (16, 4, 4))])
+def test_conv_k3_stem(Cin, Cout, S):
+    torch.manual_seed(8)
+    w = torch.randn(Cout, Cin, 3, 3, 3) / 5
+    x = torch.randn(2, Cin, *S)
+    _run_both(lambda x, w: PW.ConvK3Fn.apply(x, w, None), lambda x, w: F.conv3d(x, w, None, padding=1), [x, w])
+
+
+@pytest.mark.parametrize("name", ["conv_k2s2", "tconv_k2s2", "conv_k3", "conv_k1", "linear", "linear_nobias",
+                                  "layernorm", "mlp"])
+def test_reference_layer_goldens(golden, name):
+    """tests/golden/g7_layers.npz: outputs of the reference's own layers."""
+    g = golden("g7_layers").case(name)
+    sd = {k[3:]: v for k, v in g.items() if k.startswith("sd:")}
+    mods = {
+        "conv_k2s2": lambda: ft.Conv3d(8, 16, kernel_size=2, stride=2),
+        "tconv_k2s2": lambda: ft.ConvTranspose3d(16, 8, kernel_size=2, stride=2),
+        "conv_k3": lambda: ft.Conv3d(4, 8, kernel_size=3, padding=1, bias=False),
+        "conv_k1": lambda: ft.Conv3d(8, 3, kernel_size=1),
+        "linear": lambda: ft.Linear(16, 24),
+        "linear_nobias": lambda: ft.Linear(16, 16, bias=False),
+        "layernorm": lambda: ft.LayerNorm(16),
+        "mlp": lambda: ft.MLP(16, ratio=2),
+    }
+    m = mods[name]()
+    m.load_state_dict(sd)
+    m = m.to(DEV)
+    x = g["x"].to(DEV).requires_grad_(True)
+    n0 = _native.launch_count()
+    y = m(x)
+    names = [k for k, _ in m.named_parameters()]
+    grads = torch.autograd.grad(y, [x] + list(m.parameters()), g["gy"].to(DEV))
+    torch.cuda.synchronize()
+    assert _native.launch_count() > n0
+    _cmp(y, g["y"], "y")
+    _cmp(grads[0], g["gx"], "gx", rtol=5e-4)
+    for k, gr in zip(names, grads[1:]):
+        _cmp(gr, g["grad:" + k], k, rtol=5e-4)
