@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   const int b = blockIdx.x / tiles_per_sample;
   const int64_t n0 = ((int64_t)(blockIdx.x % tiles_per_sample) * 4 + wave) * TN;
   const int m0 = blockIdx.y * 32 * MB;
-  const int nA = p.K / 2;  // number of A-operand steps
+  const int nA = (p.K + 1) / 2;  // number of A-operand steps (odd K: last step half-masked)
 
   // ---- per-row constants for the LN prologue: s[m] = Σ_k W[m][k]γ_k ; t[m] = Σ_k W[m][k]β_k
   if (p.ln) {
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
       c = 2 * (s / 27) + h;
       off = 0;
     }
-    if (!col_ok) {
+    if (!col_ok || c >= p.Cin) {
       v[0] = v[1] = v[2] = v[3] = 0.f;
       return;
     }
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
       const int m = m0 + mb * 32 + (l & 31);
       const int k = a_k<LOADER>(a, l >> 5);
       float wv = 0.f;
-      if (m < p.M) {
+      if (m < p.M && k < p.K) {
         wv = p.w_t ? p.w[(int64_t)k * p.ldw + m] : p.w[(int64_t)m * p.ldw + k];
         if (p.ln) wv *= p.ln_g[k];
       }
@@ -414,8 +414,10 @@ extern "C" int fz_gemm(const fz_gemm_desc* d, fz_stream_t stream) {
   if (d->bmul && (d->loader != LOAD_PLAIN || d->src_mode != 0 || d->nsrc != 1))
     return fail(FZ_E_UNSUPPORTED, "fz_gemm: bmul needs the plain single-source loader");
   if (d->epilogue != EPI_PLAIN && d->epilogue != EPI_D2S) return fail(FZ_E_ARG, "fz_gemm: bad epilogue");
-  if (d->B < 0 || d->Cin < 1 || d->M < 1 || d->K < 2 || (d->K & 1))
-    return fail(FZ_E_SHAPE, "fz_gemm: K must be even and sizes positive");
+  if (d->B < 0 || d->Cin < 1 || d->M < 1 || d->K < 1)
+    return fail(FZ_E_SHAPE, "fz_gemm: sizes must be positive");
+  if ((d->K & 1) && (d->loader != LOAD_PLAIN || d->ln))
+    return fail(FZ_E_UNSUPPORTED, "fz_gemm: odd K only with the plain loader and no LayerNorm prologue");
   if (d->Ncol % 4 != 0 && d->loader != LOAD_S2D) return fail(FZ_E_UNSUPPORTED, "fz_gemm: voxel count must be a multiple of 4");
   if (d->loader == LOAD_S2D && ((d->Wo & 1) || d->epilogue != EPI_PLAIN || d->ln || d->src_mode != 0 || d->nsrc != 1))
     return fail(FZ_E_UNSUPPORTED, "fz_gemm: space-to-depth loader needs even coarse width, plain epilogue");
