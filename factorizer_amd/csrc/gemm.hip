@@ -84,56 +84,297 @@ __device__ __forceinline__ int a_k(int a, int h) {
   return 2 * a + h;
 }
 
-constexpr int kAChunk = 64;  // A-operand steps staged in LDS at a time
+__device__ __forceinline__ float weight_at(const GemmArgs& p, int m, int k) {
+  return p.w_t ? p.w[(int64_t)k * p.ldw + m] : p.w[(int64_t)m * p.ldw + k];
+}
 
-template <int MB, int LOADER, int EPI>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
-  constexpr int NACC = (LOADER == LOAD_S2D) ? 2 : 4;  // column groups per lane
-  constexpr int TN = 32 * NACC;                         // columns per wave tile
+// ---- NACC-wide vector access (NACC = 4, 2, 1 consecutive voxels per lane) -------------------
+template <int NACC>
+__device__ __forceinline__ void vload(const float* p, float (&v)[NACC]) {
+  if (NACC == 4) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2 % NACC] = t.z; v[3 % NACC] = t.w;
+  } else if (NACC == 2) {
+    const float2 t = *reinterpret_cast<const float2*>(p);
+    v[0] = t.x; v[1 % NACC] = t.y;
+  } else {
+    v[0] = *p;
+  }
+}
+template <int NACC>
+__device__ __forceinline__ void vstore(float* p, const float (&v)[NACC]) {
+  if (NACC == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2 % NACC], v[3 % NACC]);
+  else if (NACC == 2) *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1 % NACC]);
+  else *p = v[0];
+}
+
+// ---- plain-loader fetch of NACC voxels of channel c (concat / window-average / act') ---------
+template <int NACC>
+__device__ __forceinline__ void fetch_plain(const GemmArgs& p, int b, int c, int64_t off, bool ok,
+                                            float (&v)[NACC]) {
+  if (!ok || c >= p.Cin) {
+#pragma unroll
+    for (int e = 0; e < NACC; ++e) v[e] = 0.f;
+    return;
+  }
+  if (p.src_mode == 0) {
+    const float* src = (c < p.c0) ? p.x[0] + ((int64_t)b * p.c0 + c) * p.Vin
+                                  : p.x[1] + ((int64_t)b * (p.Cin - p.c0) + (c - p.c0)) * p.Vin;
+    vload<NACC>(src + off, v);
+    if (p.bmul != nullptr) {
+      float e[NACC];
+      vload<NACC>(p.bmul + ((int64_t)b * p.Cin + c) * p.Vin + off, e);
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) v[i] *= act_grad_f(p.bmul_kind, e[i]);
+    }
+  } else {
+    const int64_t o = ((int64_t)b * p.Cin + c) * p.Vin + off;
+    float t[NACC];
+    vload<NACC>(p.x[0] + o, t);
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) v[i] = 0.0f + t[i];
+    for (int sidx = 1; sidx < p.nsrc; ++sidx) {
+      vload<NACC>(p.x[sidx] + o, t);
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) v[i] += t[i];
+    }
+    const float nw = (float)p.nsrc;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) v[i] /= nw;
+  }
+}
+
+// ---- epilogue for one 32-row block -------------------------------------------------------------
+// acc[q][r]: row (r&3)+8(r>>2)+4h of the block, column group q.  tw = per-row additive constant
+// (LayerNorm β·W term), or null.
+template <int NACC, int EPI, bool S2DCOLS>
+__device__ __forceinline__ void store_block(const GemmArgs& p, const f32x16 (&acc)[NACC], int b, int mrow0,
+                                            int64_t ncol, int h, const float* tWblk) {
+  if (EPI == EPI_PLAIN) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int m = mrow0 + rl;
+      if (m >= p.M) continue;
+      float v[NACC];
+      float add = p.bias ? p.bias[m] : 0.f;
+      if (tWblk != nullptr) add += tWblk[rl];
+#pragma unroll
+      for (int q = 0; q < NACC; ++q) v[q] = acc[q][r] + add;
+      if (p.eact) {
+#pragma unroll
+        for (int q = 0; q < NACC; ++q) v[q] = act_f(p.eact, v[q]);
+      }
+      const int64_t o = ((int64_t)b * p.M + m) * p.Ncol + ncol;
+      if (p.emul) {
+        float e[NACC];
+        vload<NACC>(p.emul + o, e);
+#pragma unroll
+        for (int q = 0; q < NACC; ++q) v[q] *= act_grad_f(p.emul_kind, e[q]);
+      }
+      if (p.res) {
+        float e[NACC];
+        vload<NACC>(p.res + o, e);
+#pragma unroll
+        for (int q = 0; q < NACC; ++q) v[q] += e[q];
+      }
+      vstore<NACC>(p.y + o, v);
+    }
+  } else {
+    // rows are (o, tap): m = o*8 + td*4 + th*2 + tw ; inside a 32-row block td = h,
+    // th = (r>>1)&1, tw = r&1, o_local = r>>2.  Columns ncol..ncol+3 are coarse voxels; the
+    // fine tensor gets 8 consecutive voxels (tw pairs) per (o, td, th).
+    const int Wf = 2 * p.Wo, Hf = 2 * p.Ho;
+    const int64_t Vf = 8 * p.Ncol;
+    const int Mo = p.M >> 3;
+#pragma unroll
+    for (int rp = 0; rp < 8; ++rp) {
+      const int r0 = 2 * rp;
+      const int o = (mrow0 >> 3) + (r0 >> 2);
+      if (o >= Mo) continue;
+      const int th = (r0 >> 1) & 1, td = h;
+      const float bs = p.bias ? p.bias[o] : 0.f;
+      float* ybase = p.y + ((int64_t)b * Mo + o) * Vf;
+      if (NACC == 4 && (p.Wo & 3) == 0) {
+        const int wo = (int)(ncol % p.Wo);
+        const int64_t t2 = ncol / p.Wo;
+        const int ho = (int)(t2 % p.Ho);
+        const int dz = (int)(t2 / p.Ho);
+        const int64_t fo = ((int64_t)(2 * dz + td) * Hf + (2 * ho + th)) * Wf + 2 * wo;
+        *reinterpret_cast<float4*>(ybase + fo) =
+            make_float4(acc[0][r0] + bs, acc[0][r0 + 1] + bs, acc[1 % NACC][r0] + bs, acc[1 % NACC][r0 + 1] + bs);
+        *reinterpret_cast<float4*>(ybase + fo + 4) =
+            make_float4(acc[2 % NACC][r0] + bs, acc[2 % NACC][r0 + 1] + bs, acc[3 % NACC][r0] + bs,
+                        acc[3 % NACC][r0 + 1] + bs);
+      } else {
+#pragma unroll
+        for (int q = 0; q < NACC; ++q) {
+          const int64_t nq = ncol + q;
+          const int wo = (int)(nq % p.Wo);
+          const int64_t t2 = nq / p.Wo;
+          const int ho = (int)(t2 % p.Ho);
+          const int dz = (int)(t2 / p.Ho);
+          const int64_t fo = ((int64_t)(2 * dz + td) * Hf + (2 * ho + th)) * Wf + 2 * wo;
+          *reinterpret_cast<float2*>(ybase + fo) = make_float2(acc[q][r0] + bs, acc[q][r0 + 1] + bs);
+        }
+      }
+    }
+  }
+}
+
+// =================================================================================================
+// Kernel A — register-resident operand, K <= 2*NSTEP (the HBM-bound layers, C <= 64).
+// Every lane issues ALL its operand loads up front (NSTEP x 16 B in flight per lane), applies the
+// prologue in registers (exact two-pass LayerNorm), then walks the RB row blocks of the
+// workgroup sequentially with one accumulator set: the input is read from HBM exactly once for
+// all output rows and 10+ KiB per wave are in flight.
+// =================================================================================================
+template <int NSTEP, int EPI>
+__global__ __launch_bounds__(256, (NSTEP <= 16 ? 3 : 2)) void gemm_resident_kernel(GemmArgs p, int RB) {
+  extern __shared__ __attribute__((aligned(16))) float lds_a[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int nA = (p.K + 1) / 2;
+  float* As = lds_a;                      // [nA][RB][64]
+  float* tW = lds_a + nA * RB * 64;       // [32*RB]
+  const int tiles_per_sample = (int)((p.Ncol + 511) / 512);
+  const int b = blockIdx.x / tiles_per_sample;
+  const int64_t n0 = ((int64_t)(blockIdx.x % tiles_per_sample) * 4 + wave) * 128;
+  const int m0 = blockIdx.y * 32 * RB;
+
+  for (int idx = threadIdx.x; idx < nA * RB * 64; idx += blockDim.x) {
+    const int l = idx & 63;
+    const int rb = (idx >> 6) % RB;
+    const int a = idx / (64 * RB);
+    const int m = m0 + rb * 32 + (l & 31);
+    const int k = 2 * a + (l >> 5);
+    float wv = 0.f;
+    if (m < p.M && k < p.K) {
+      wv = weight_at(p, m, k);
+      if (p.ln) wv *= p.ln_g[k];
+    }
+    As[idx] = wv;
+  }
+  if (p.ln) {
+    for (int r = threadIdx.x; r < 32 * RB; r += blockDim.x) {
+      const int m = m0 + r;
+      float t = 0.f;
+      if (m < p.M)
+        for (int k = 0; k < p.K; ++k) t += weight_at(p, m, k) * p.ln_b[k];
+      tW[r] = t;
+    }
+  }
+
+  const int64_t col_off = n0 + 4 * j;
+  const bool col_ok = col_off < p.Ncol;
+  float bv[NSTEP][4];
+#pragma unroll
+  for (int s = 0; s < NSTEP; ++s) fetch_plain<4>(p, b, 2 * s + h, col_off, col_ok && s < nA, bv[s]);
+
+  if (p.ln) {
+    // exact two-pass statistics over the Cin channels (this lane holds the parity-h half)
+    float mu[4], rs[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float t = 0.f;
+#pragma unroll
+      for (int s = 0; s < NSTEP; ++s) t += bv[s][e];
+      t += __shfl_xor(t, 32, 64);
+      mu[e] = t / (float)p.Cin;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float t = 0.f;
+#pragma unroll
+      for (int s = 0; s < NSTEP; ++s) {
+        const float d = (2 * s + h < p.Cin) ? bv[s][e] - mu[e] : 0.f;
+        t += d * d;
+      }
+      t += __shfl_xor(t, 32, 64);
+      rs[e] = 1.0f / sqrtf(t / (float)p.Cin + p.ln_eps);
+    }
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bv[s][e] = (2 * s + h < p.Cin) ? (bv[s][e] - mu[e]) * rs[e] : 0.f;
+    if (p.stats_out != nullptr && blockIdx.y == 0 && h == 0 && col_ok) {
+      float* so = p.stats_out + (int64_t)b * 2 * p.Vin;
+      *reinterpret_cast<float4*>(so + col_off) = make_float4(mu[0], mu[1], mu[2], mu[3]);
+      *reinterpret_cast<float4*>(so + p.Vin + col_off) = make_float4(rs[0], rs[1], rs[2], rs[3]);
+    }
+  }
+  if (p.bact) {
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bv[s][e] = act_f(p.bact, bv[s][e]);
+  }
+  __syncthreads();
+  if (!col_ok) return;
+
+  for (int rb = 0; rb < RB; ++rb) {
+    if (m0 + rb * 32 >= p.M) break;
+    f32x16 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+      if (s < nA) {
+        const float av = As[(s * RB + rb) * 64 + lane];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[s][q], acc[q], 0, 0, 0);
+      }
+    }
+    store_block<4, EPI, false>(p, acc, b, m0 + rb * 32, col_off, h, p.ln ? tW + rb * 32 : nullptr);
+  }
+}
+
+// =================================================================================================
+// Kernel B — streaming operand with a PF-deep register prefetch ring, any K, all loaders.
+// NACC = consecutive voxels per lane (4/2/1 → 128/64/32-column wave tiles): small tiles give the
+// deep, narrow stages (8^3..32^3 voxels, C = 128..512) enough workgroups to fill 256 CUs.
+// =================================================================================================
+constexpr int kAChunk = 64;  // A-operand steps staged in LDS at a time
+constexpr int kPF = 4;       // operand prefetch depth (load steps)
+
+template <int MB, int NACC, int LOADER, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgs p) {
+  constexpr int TN = 32 * NACC;
+  constexpr int NL = (LOADER == LOAD_S2D) ? 4 : NACC;  // floats fetched per load step
   __shared__ float As[kAChunk * MB * 64];
   __shared__ float sW[32 * MB];
   __shared__ float tW[32 * MB];
 
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, h = lane >> 5;
   const int tiles_per_sample = (int)((p.Ncol + TN * 4 - 1) / (TN * 4));
   const int b = blockIdx.x / tiles_per_sample;
   const int64_t n0 = ((int64_t)(blockIdx.x % tiles_per_sample) * 4 + wave) * TN;
   const int m0 = blockIdx.y * 32 * MB;
-  const int nA = (p.K + 1) / 2;  // number of A-operand steps (odd K: last step half-masked)
+  const int nA = (p.K + 1) / 2;
 
-  // ---- per-row constants for the LN prologue: s[m] = Σ_k W[m][k]γ_k ; t[m] = Σ_k W[m][k]β_k
   if (p.ln) {
     for (int r = threadIdx.x; r < 32 * MB; r += blockDim.x) {
       const int m = m0 + r;
       float s = 0.f, t = 0.f;
-      if (m < p.M) {
+      if (m < p.M)
         for (int k = 0; k < p.K; ++k) {
-          const float wv = p.w_t ? p.w[(int64_t)k * p.ldw + m] : p.w[(int64_t)m * p.ldw + k];
+          const float wv = weight_at(p, m, k);
           s += wv * p.ln_g[k];
           t += wv * p.ln_b[k];
         }
-      }
       sW[r] = s;
       tW[r] = t;
     }
   }
 
   // ---- per-lane input addressing ----
-  int64_t col_off;       // offset of this lane's first column inside a channel plane
-  bool col_ok;           // lane's columns are inside the tensor
-  int kw0 = 0, kh0 = 0, kd0 = 0;  // LOAD_K3: (w, h, d) of this lane's first voxel
-  if (LOADER == LOAD_PLAIN || LOADER == LOAD_K3) {
-    col_off = n0 + 4 * j;
-    col_ok = col_off < p.Ncol;
-    if (LOADER == LOAD_K3) {
-      const int64_t nn = col_ok ? col_off : 0;
-      kw0 = (int)(nn % p.Wi);
-      kh0 = (int)((nn / p.Wi) % p.Hi);
-      kd0 = (int)(nn / ((int64_t)p.Wi * p.Hi));
-    }
-  } else {
+  int64_t col_off;
+  bool col_ok;
+  int kw0 = 0, kh0 = 0, kd0 = 0;
+  if (LOADER == LOAD_S2D) {
     const int64_t n = n0 + 2 * j;  // coarse voxel pair (wo even)
     col_ok = n < p.Ncol;
     const int64_t nn = col_ok ? n : 0;
@@ -142,7 +383,49 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     const int ho = (int)(t2 % p.Ho);
     const int dz = (int)(t2 / p.Ho);
     col_off = ((int64_t)(2 * dz) * p.Hi + 2 * ho) * p.Wi + 2 * wo;
+  } else {
+    col_off = n0 + NACC * j;
+    col_ok = col_off < p.Ncol;
+    if (LOADER == LOAD_K3) {
+      const int64_t nn = col_ok ? col_off : 0;
+      kw0 = (int)(nn % p.Wi);
+      kh0 = (int)((nn / p.Wi) % p.Hi);
+      kd0 = (int)(nn / ((int64_t)p.Wi * p.Hi));
+    }
   }
+
+  auto fetch = [&](int s, float (&v)[NL]) {
+    if (LOADER == LOAD_PLAIN) {
+      fetch_plain<NL>(p, b, 2 * s + h, col_off, col_ok, v);
+    } else if (LOADER == LOAD_S2D) {
+      const int c = 2 * (s >> 2) + h;
+      if (!col_ok || c >= p.Cin) {
+#pragma unroll
+        for (int e = 0; e < NL; ++e) v[e] = 0.f;
+        return;
+      }
+      const int64_t off = col_off + (int64_t)((s >> 1) & 1) * p.Hi * p.Wi + (int64_t)(s & 1) * p.Wi;
+      vload<NL>(p.x[0] + ((int64_t)b * p.Cin + c) * p.Vin + off, v);
+    } else {
+      // LOAD_K3 (NL == 4): taps of the 3x3x3 stencil, zero padding
+      const int c = 2 * (s / 27) + h;
+      const int tap = s % 27;
+      const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+      const int zd = kd0 + kd - 1, zh = kh0 + kh - 1;
+#pragma unroll
+      for (int e = 0; e < NL; ++e) v[e] = 0.f;
+      if (!col_ok || c >= p.Cin || zd < 0 || zd >= p.Di || zh < 0 || zh >= p.Hi) return;
+      const float* row = p.x[0] + ((int64_t)b * p.Cin + c) * p.Vin + ((int64_t)zd * p.Hi + zh) * p.Wi;
+      const float4 t = *reinterpret_cast<const float4*>(row + kw0);
+      if (kw == 1) {
+        v[0] = t.x; v[1 % NL] = t.y; v[2 % NL] = t.z; v[3 % NL] = t.w;
+      } else if (kw == 0) {
+        v[0] = kw0 > 0 ? row[kw0 - 1] : 0.f; v[1 % NL] = t.x; v[2 % NL] = t.y; v[3 % NL] = t.z;
+      } else {
+        v[0] = t.y; v[1 % NL] = t.z; v[2 % NL] = t.w; v[3 % NL] = (kw0 + 4 < p.Wi) ? row[kw0 + 4] : 0.f;
+      }
+    }
+  };
 
   f32x16 acc[MB][NACC];
 #pragma unroll
@@ -152,75 +435,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mb][q][r] = 0.f;
 
-  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, shift[4] = {0.f, 0.f, 0.f, 0.f};
-
-  // ---- B-operand fetch for load step s (4 floats per lane) ----
-  auto fetch = [&](int s, float (&v)[4]) {
-    int c;
-    int64_t off;
-    if (LOADER == LOAD_PLAIN) {
-      c = 2 * s + h;
-      off = col_off;
-    } else if (LOADER == LOAD_S2D) {
-      c = 2 * (s >> 2) + h;
-      off = col_off + (int64_t)((s >> 1) & 1) * p.Hi * p.Wi + (int64_t)(s & 1) * p.Wi;
-    } else {
-      c = 2 * (s / 27) + h;
-      off = 0;
-    }
-    if (!col_ok || c >= p.Cin) {
-      v[0] = v[1] = v[2] = v[3] = 0.f;
-      return;
-    }
-    if (LOADER == LOAD_K3) {
-      const int tap = s % 27;
-      const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-      const int zd = kd0 + kd - 1, zh = kh0 + kh - 1;
-      v[0] = v[1] = v[2] = v[3] = 0.f;
-      if (zd < 0 || zd >= p.Di || zh < 0 || zh >= p.Hi) return;
-      const float* row = p.x[0] + ((int64_t)b * p.Cin + c) * p.Vin + ((int64_t)zd * p.Hi + zh) * p.Wi;
-      const float4 t = *reinterpret_cast<const float4*>(row + kw0);
-      if (kw == 1) {
-        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-      } else if (kw == 0) {
-        v[0] = kw0 > 0 ? row[kw0 - 1] : 0.f; v[1] = t.x; v[2] = t.y; v[3] = t.z;
-      } else {
-        v[0] = t.y; v[1] = t.z; v[2] = t.w; v[3] = (kw0 + 4 < p.Wi) ? row[kw0 + 4] : 0.f;
-      }
-      return;
-    }
-    if (p.src_mode == 0) {
-      const float* src;
-      if (c < p.c0) src = p.x[0] + ((int64_t)b * p.c0 + c) * p.Vin;
-      else src = p.x[1] + ((int64_t)b * (p.Cin - p.c0) + (c - p.c0)) * p.Vin;
-      const float4 t = *reinterpret_cast<const float4*>(src + off);
-      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-      if (p.bmul != nullptr) {
-        const float4 e = *reinterpret_cast<const float4*>(p.bmul + ((int64_t)b * p.Cin + c) * p.Vin + off);
-        v[0] *= act_grad_f(p.bmul_kind, e.x); v[1] *= act_grad_f(p.bmul_kind, e.y);
-        v[2] *= act_grad_f(p.bmul_kind, e.z); v[3] *= act_grad_f(p.bmul_kind, e.w);
-      }
-    } else {
-      const int64_t o = ((int64_t)b * p.Cin + c) * p.Vin + off;
-      float4 t = *reinterpret_cast<const float4*>(p.x[0] + o);
-      v[0] = 0.0f + t.x; v[1] = 0.0f + t.y; v[2] = 0.0f + t.z; v[3] = 0.0f + t.w;
-      for (int i = 1; i < p.nsrc; ++i) {
-        t = *reinterpret_cast<const float4*>(p.x[i] + o);
-        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-      }
-      const float nw = (float)p.nsrc;
-      v[0] /= nw; v[1] /= nw; v[2] /= nw; v[3] /= nw;
-    }
-  };
-
-  const int nload = (LOADER == LOAD_S2D) ? nA / 2 : nA;  // load steps
-  float cur[4], nxt[4];
-  fetch(0, cur);
-  if (p.ln) {
-    // shift = channel-0 value of each voxel (held by half 0 at step 0): a cheap, well-conditioned
-    // pivot for the single-pass variance
+  float s1[NACC], s2[NACC], shift[NACC];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) shift[e] = __shfl(cur[e], j, 64);
+  for (int e = 0; e < NACC; ++e) s1[e] = s2[e] = shift[e] = 0.f;
+
+  const int nload = (LOADER == LOAD_S2D) ? nA / 2 : nA;
+  float ring[kPF][NL];
+#pragma unroll
+  for (int i = 0; i < kPF; ++i) {
+    if (i < nload) fetch(i, ring[i]);
+  }
+  if (p.ln) {
+    // pivot = channel-0 value (held by half 0 in ring[0]): well-conditioned single-pass variance
+#pragma unroll
+    for (int e = 0; e < NACC; ++e) shift[e] = __shfl(ring[0][e % NL], j, 64);
   }
 
   for (int a0 = 0; a0 < nA; a0 += kAChunk) {
@@ -234,61 +462,63 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
       const int k = a_k<LOADER>(a, l >> 5);
       float wv = 0.f;
       if (m < p.M && k < p.K) {
-        wv = p.w_t ? p.w[(int64_t)k * p.ldw + m] : p.w[(int64_t)m * p.ldw + k];
+        wv = weight_at(p, m, k);
         if (p.ln) wv *= p.ln_g[k];
       }
       As[idx] = wv;
     }
     __syncthreads();
-    if (LOADER != LOAD_S2D) {
-      for (int al = 0; al < an; ++al) {
-        const int s = a0 + al;
-        if (s + 1 < nload) fetch(s + 1, nxt);
-        float bv[4];
+    constexpr int ASTEP = (LOADER == LOAD_S2D) ? 2 : 1;
+    // kAChunk is a multiple of kPF*ASTEP, so the ring slot of a step is static after unrolling
+    for (int al = 0; al < an; al += kPF * ASTEP) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float t = cur[e];
-          if (p.ln) {
-            t -= shift[e];
-            s1[e] += t;
-            s2[e] += t * t;
+      for (int u = 0; u < kPF; ++u) {
+        const int ali = al + u * ASTEP;
+        if (ali < an) {
+          const int s = (a0 + ali) / ASTEP;
+          float cur[NL];
+#pragma unroll
+          for (int e = 0; e < NL; ++e) cur[e] = ring[u][e];
+          if (s + kPF < nload) fetch(s + kPF, ring[u]);
+          if (LOADER == LOAD_S2D) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+              const float av0 = As[(ali * MB + mb) * 64 + lane];        // tw = 0
+              const float av1 = As[((ali + 1) * MB + mb) * 64 + lane];  // tw = 1
+              acc[mb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, cur[0], acc[mb][0], 0, 0, 0);
+              acc[mb][1 % NACC] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, cur[2 % NL], acc[mb][1 % NACC], 0, 0, 0);
+              acc[mb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, cur[1 % NL], acc[mb][0], 0, 0, 0);
+              acc[mb][1 % NACC] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, cur[3 % NL], acc[mb][1 % NACC], 0, 0, 0);
+            }
+          } else {
+            float bvv[NACC];
+#pragma unroll
+            for (int e = 0; e < NACC; ++e) {
+              float t = cur[e % NL];
+              if (p.ln) {
+                t -= shift[e];
+                s1[e] += t;
+                s2[e] += t * t;
+              }
+              bvv[e] = p.bact ? act_f(p.bact, t) : t;
+            }
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+              const float av = As[(ali * MB + mb) * 64 + lane];
+#pragma unroll
+              for (int q = 0; q < NACC; ++q)
+                acc[mb][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bvv[q], acc[mb][q], 0, 0, 0);
+            }
           }
-          bv[e] = p.bact ? act_f(p.bact, t) : t;
         }
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-          const float av = As[(al * MB + mb) * 64 + lane];
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            acc[mb][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[q], acc[mb][q], 0, 0, 0);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) cur[e] = nxt[e];
-      }
-    } else {
-      for (int al = 0; al < an; al += 2) {
-        const int s = (a0 + al) >> 1;
-        if (s + 1 < nload) fetch(s + 1, nxt);
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-          const float av0 = As[(al * MB + mb) * 64 + lane];        // tw = 0
-          const float av1 = As[((al + 1) * MB + mb) * 64 + lane];  // tw = 1
-          acc[mb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, cur[0], acc[mb][0], 0, 0, 0);
-          acc[mb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, cur[2], acc[mb][1], 0, 0, 0);
-          acc[mb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, cur[1], acc[mb][0], 0, 0, 0);
-          acc[mb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, cur[3], acc[mb][1], 0, 0, 0);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) cur[e] = nxt[e];
       }
     }
   }
 
-  // ---- LayerNorm statistics of this lane's 4 voxels ----
-  float mu_d[4], rstd[4];
+  float mu_d[NACC], rstd[NACC];
   if (p.ln) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < NACC; ++e) {
       const float t1 = s1[e] + __shfl_xor(s1[e], 32, 64);
       const float t2 = s2[e] + __shfl_xor(s2[e], 32, 64);
       const float inv = 1.0f / (float)p.Cin;
@@ -299,103 +529,30 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
       rstd[e] = 1.0f / sqrtf(var + p.ln_eps);
     }
     if (p.stats_out != nullptr && blockIdx.y == 0 && h == 0 && col_ok) {
-      float4 mean4 = make_float4(shift[0] + mu_d[0], shift[1] + mu_d[1], shift[2] + mu_d[2], shift[3] + mu_d[3]);
-      float4 rs4 = make_float4(rstd[0], rstd[1], rstd[2], rstd[3]);
+      float mean[NACC];
+#pragma unroll
+      for (int e = 0; e < NACC; ++e) mean[e] = shift[e] + mu_d[e];
       float* so = p.stats_out + (int64_t)b * 2 * p.Vin;
-      *reinterpret_cast<float4*>(so + col_off) = mean4;
-      *reinterpret_cast<float4*>(so + p.Vin + col_off) = rs4;
+      vstore<NACC>(so + col_off, mean);
+      vstore<NACC>(so + p.Vin + col_off, rstd);
     }
   }
-
-  // ---- epilogue ----
   if (!col_ok) return;
+  const int64_t ncol = (LOADER == LOAD_S2D) ? n0 + 2 * j : col_off;
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
+    if (p.ln) {
+      // y = rstd·(acc − μ_d·s[m]) + t[m]
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;  // row inside the 32-row block
-      const int m = m0 + mb * 32 + rl;
-      if (m >= p.M) continue;
-      float v[NACC];
+      for (int r = 0; r < 16; ++r) {
+        const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float sw = sW[mb * 32 + rl];
 #pragma unroll
-      for (int q = 0; q < NACC; ++q) v[q] = acc[mb][q][r];
-      if (p.ln) {
-        const float sw = sW[mb * 32 + rl], tw = tW[mb * 32 + rl];
-#pragma unroll
-        for (int q = 0; q < NACC; ++q) v[q] = rstd[q] * (v[q] - mu_d[q] * sw) + tw;
-      }
-      if (EPI == EPI_PLAIN) {
-        const float bs = p.bias ? p.bias[m] : 0.f;
-        const int64_t o = ((int64_t)b * p.M + m) * p.Ncol + (LOADER == LOAD_S2D ? n0 + 2 * j : n0 + 4 * j);
-#pragma unroll
-        for (int q = 0; q < NACC; ++q) v[q] += bs;
-        if (p.eact) {
-#pragma unroll
-          for (int q = 0; q < NACC; ++q) v[q] = act_f(p.eact, v[q]);
-        }
-        if (NACC == 4) {
-          if (p.emul) {
-            const float4 e4 = *reinterpret_cast<const float4*>(p.emul + o);
-            v[0] *= act_grad_f(p.emul_kind, e4.x); v[1] *= act_grad_f(p.emul_kind, e4.y);
-            v[2] *= act_grad_f(p.emul_kind, e4.z); v[3] *= act_grad_f(p.emul_kind, e4.w);
-          }
-          if (p.res) {
-            const float4 r4 = *reinterpret_cast<const float4*>(p.res + o);
-            v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
-          }
-          *reinterpret_cast<float4*>(p.y + o) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-          if (p.res) {
-            const float2 r2 = *reinterpret_cast<const float2*>(p.res + o);
-            v[0] += r2.x; v[1] += r2.y;
-          }
-          *reinterpret_cast<float2*>(p.y + o) = make_float2(v[0], v[1]);
-        }
+        for (int q = 0; q < NACC; ++q) acc[mb][q][r] = rstd[q] * (acc[mb][q][r] - mu_d[q] * sw);
       }
     }
-    if (EPI == EPI_D2S) {
-      // rows are (o, tap): m = o*8 + td*4 + th*2 + tw ; inside a 32-row block td = h,
-      // th = (r>>1)&1, tw = r&1, o_local = r>>2.  Columns 4j..4j+3 are coarse voxels; the
-      // fine tensor gets 8 consecutive voxels (tw pairs) per (o, td, th).
-      const int Wf = 2 * p.Wo, Hf = 2 * p.Ho;
-      const int64_t Vf = 8 * p.Ncol;
-      const int Mo = p.M >> 3;
-#pragma unroll
-      for (int rp = 0; rp < 8; ++rp) {
-        const int r0 = 2 * rp;  // registers r0 (tw=0), r0+1 (tw=1)
-        const int o = ((m0 + mb * 32) >> 3) + (r0 >> 2);
-        if (o >= Mo) continue;
-        const int th = (r0 >> 1) & 1, td = h;
-        const float bs = p.bias ? p.bias[o] : 0.f;
-        const int64_t n = n0 + 4 * j;
-        float* ybase = p.y + ((int64_t)b * Mo + o) * Vf;
-        if ((p.Wo & 3) == 0) {
-          const int wo = (int)(n % p.Wo);
-          const int64_t t2 = n / p.Wo;
-          const int ho = (int)(t2 % p.Ho);
-          const int dz = (int)(t2 / p.Ho);
-          const int64_t fo = ((int64_t)(2 * dz + td) * Hf + (2 * ho + th)) * Wf + 2 * wo;
-          float4 lo = make_float4(acc[mb][0][r0] + bs, acc[mb][0][r0 + 1] + bs, acc[mb][1][r0] + bs,
-                                  acc[mb][1][r0 + 1] + bs);
-          float4 hi = make_float4(acc[mb][2][r0] + bs, acc[mb][2][r0 + 1] + bs, acc[mb][3][r0] + bs,
-                                  acc[mb][3][r0 + 1] + bs);
-          *reinterpret_cast<float4*>(ybase + fo) = lo;
-          *reinterpret_cast<float4*>(ybase + fo + 4) = hi;
-        } else {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int64_t nq = n + q;
-            const int wo = (int)(nq % p.Wo);
-            const int64_t t2 = nq / p.Wo;
-            const int ho = (int)(t2 % p.Ho);
-            const int dz = (int)(t2 / p.Ho);
-            const int64_t fo = ((int64_t)(2 * dz + td) * Hf + (2 * ho + th)) * Wf + 2 * wo;
-            ybase[fo] = acc[mb][q][r0] + bs;
-            ybase[fo + 1] = acc[mb][q][r0 + 1] + bs;
-          }
-        }
-      }
-    }
+    store_block<NACC, EPI, LOADER == LOAD_S2D>(p, acc[mb], b, m0 + mb * 32, ncol, h,
+                                                p.ln ? tW + mb * 32 : nullptr);
   }
 }
 
@@ -408,16 +565,15 @@ extern "C" int fz_gemm(const fz_gemm_desc* d, fz_stream_t stream) {
   if (!d) return fail(FZ_E_ARG, "fz_gemm: null descriptor");
   if (!d->x[0] || !d->w || !d->y) return fail(FZ_E_ARG, "fz_gemm: null pointer");
   if (d->loader < LOAD_PLAIN || d->loader > LOAD_K3) return fail(FZ_E_ARG, "fz_gemm: bad loader");
+  if (d->epilogue != EPI_PLAIN && d->epilogue != EPI_D2S) return fail(FZ_E_ARG, "fz_gemm: bad epilogue");
+  if (d->B < 0 || d->Cin < 1 || d->M < 1 || d->K < 1) return fail(FZ_E_SHAPE, "fz_gemm: sizes must be positive");
+  if ((d->K & 1) && (d->loader != LOAD_PLAIN || d->ln))
+    return fail(FZ_E_UNSUPPORTED, "fz_gemm: odd K only with the plain loader and no LayerNorm prologue");
   if (d->loader == LOAD_K3 && (d->epilogue != EPI_PLAIN || d->ln || d->src_mode != 0 || d->nsrc != 1 ||
                                (d->Wi & 3) || d->K != 27 * d->Cin || (d->Cin & 1)))
     return fail(FZ_E_UNSUPPORTED, "fz_gemm: k3 loader needs W % 4 == 0, even Cin, K = 27*Cin, plain epilogue");
   if (d->bmul && (d->loader != LOAD_PLAIN || d->src_mode != 0 || d->nsrc != 1))
     return fail(FZ_E_UNSUPPORTED, "fz_gemm: bmul needs the plain single-source loader");
-  if (d->epilogue != EPI_PLAIN && d->epilogue != EPI_D2S) return fail(FZ_E_ARG, "fz_gemm: bad epilogue");
-  if (d->B < 0 || d->Cin < 1 || d->M < 1 || d->K < 1)
-    return fail(FZ_E_SHAPE, "fz_gemm: sizes must be positive");
-  if ((d->K & 1) && (d->loader != LOAD_PLAIN || d->ln))
-    return fail(FZ_E_UNSUPPORTED, "fz_gemm: odd K only with the plain loader and no LayerNorm prologue");
   if (d->Ncol % 4 != 0 && d->loader != LOAD_S2D) return fail(FZ_E_UNSUPPORTED, "fz_gemm: voxel count must be a multiple of 4");
   if (d->loader == LOAD_S2D && ((d->Wo & 1) || d->epilogue != EPI_PLAIN || d->ln || d->src_mode != 0 || d->nsrc != 1))
     return fail(FZ_E_UNSUPPORTED, "fz_gemm: space-to-depth loader needs even coarse width, plain epilogue");
@@ -427,20 +583,48 @@ extern "C" int fz_gemm(const fz_gemm_desc* d, fz_stream_t stream) {
   GemmArgs a;
   for (int i = 0; i < 4; ++i) a.x[i] = d->x[i];
   a.nsrc = d->nsrc; a.src_mode = d->src_mode; a.c0 = d->c0 > 0 ? d->c0 : d->Cin; a.Cin = d->Cin;
-  a.Vin = d->Vin; a.Di = d->Di; a.Hi = d->Hi; a.Wi = d->Wi; a.bmul = d->bmul; a.bmul_kind = d->bmul_kind; a.w = d->w; a.w_t = d->w_t; a.ldw = d->ldw; a.M = d->M; a.K = d->K;
+  a.Vin = d->Vin; a.Di = d->Di; a.Hi = d->Hi; a.Wi = d->Wi; a.bmul = d->bmul; a.bmul_kind = d->bmul_kind;
+  a.w = d->w; a.w_t = d->w_t; a.ldw = d->ldw; a.M = d->M; a.K = d->K;
   a.bias = d->bias; a.ln = d->ln; a.ln_g = d->ln_g; a.ln_b = d->ln_b; a.ln_eps = d->ln_eps;
   a.stats_out = d->stats_out; a.bact = d->bact; a.eact = d->eact; a.res = d->res; a.emul = d->emul;
   a.emul_kind = d->emul_kind; a.y = d->y; a.Ncol = d->Ncol; a.Ho = d->Ho; a.Wo = d->Wo; a.B = d->B;
-  const int TN = d->loader == LOAD_S2D ? 64 : 128;
-  const int64_t tiles = (d->Ncol + TN * 4 - 1) / (TN * 4);
-  const int MBsel = d->M > 32 ? 2 : 1;
-  dim3 grid((unsigned)(tiles * d->B), (unsigned)((d->M + 32 * MBsel - 1) / (32 * MBsel))), block(256);
   hipStream_t st = (hipStream_t)stream;
-#define FZ_GEMM(MB, L, E) hipLaunchKernelGGL((gemm_kernel<MB, L, E>), grid, block, 0, st, a)
-  if (d->loader == LOAD_PLAIN && d->epilogue == EPI_PLAIN) { if (MBsel == 2) FZ_GEMM(2, LOAD_PLAIN, EPI_PLAIN); else FZ_GEMM(1, LOAD_PLAIN, EPI_PLAIN); }
-  else if (d->loader == LOAD_PLAIN && d->epilogue == EPI_D2S) { if (MBsel == 2) FZ_GEMM(2, LOAD_PLAIN, EPI_D2S); else FZ_GEMM(1, LOAD_PLAIN, EPI_D2S); }
-  else if (d->loader == LOAD_K3) { if (MBsel == 2) FZ_GEMM(2, LOAD_K3, EPI_PLAIN); else FZ_GEMM(1, LOAD_K3, EPI_PLAIN); }
-  else { if (MBsel == 2) FZ_GEMM(2, LOAD_S2D, EPI_PLAIN); else FZ_GEMM(1, LOAD_S2D, EPI_PLAIN); }
+  const int mblocks = (d->M + 31) / 32;
+
+  // ---- Kernel A: whole operand in registers (K <= 64, plain loader) ----
+  if (d->loader == LOAD_PLAIN && d->K <= 64) {
+    const int nA = (d->K + 1) / 2;
+    int RB = mblocks < 8 ? mblocks : 8;
+    while ((size_t)(nA * RB * 64 + 32 * RB) * sizeof(float) > 65536) --RB;
+    const size_t lds = (size_t)(nA * RB * 64 + 32 * RB) * sizeof(float);
+    const int64_t tiles = (d->Ncol + 511) / 512;
+    dim3 grid((unsigned)(tiles * d->B), (unsigned)((mblocks + RB - 1) / RB)), block(256);
+#define FZ_RES(NS, E) hipLaunchKernelGGL((gemm_resident_kernel<NS, E>), grid, block, lds, st, a, RB)
+    if (nA <= 16) { if (d->epilogue == EPI_D2S) FZ_RES(16, EPI_D2S); else FZ_RES(16, EPI_PLAIN); }
+    else { if (d->epilogue == EPI_D2S) FZ_RES(32, EPI_D2S); else FZ_RES(32, EPI_PLAIN); }
+    FZ_LAUNCH_CHECK();
+    return FZ_OK;
+  }
+
+  // ---- Kernel B: streaming; pick the column-tile width so the grid fills the chip ----
+  int nacc = 4;
+  if (d->loader == LOAD_S2D) nacc = 2;
+  else if (d->loader == LOAD_PLAIN && d->epilogue == EPI_PLAIN) {
+    const int64_t cols = d->Ncol * d->B;
+    const int64_t wg4 = ((cols + 511) / 512) * ((mblocks + 1) / 2);
+    if (wg4 < 256 && d->Ncol % 4 == 0) nacc = (((cols + 255) / 256) * mblocks >= 256) ? 2 : 1;
+  }
+  const int MBsel = (mblocks >= 2 && nacc == 4) ? 2 : 1;
+  const int TN = 32 * nacc;
+  const int64_t tiles = (d->Ncol + TN * 4 - 1) / (TN * 4);
+  dim3 grid((unsigned)(tiles * d->B), (unsigned)((mblocks + MBsel - 1) / MBsel)), block(256);
+#define FZ_STR(MB, NA, L, E) hipLaunchKernelGGL((gemm_stream_kernel<MB, NA, L, E>), grid, block, 0, st, a)
+  if (d->loader == LOAD_S2D) { FZ_STR(1, 2, LOAD_S2D, EPI_PLAIN); }
+  else if (d->loader == LOAD_K3) { if (MBsel == 2) FZ_STR(2, 4, LOAD_K3, EPI_PLAIN); else FZ_STR(1, 4, LOAD_K3, EPI_PLAIN); }
+  else if (d->epilogue == EPI_D2S) { if (MBsel == 2) FZ_STR(2, 4, LOAD_PLAIN, EPI_D2S); else FZ_STR(1, 4, LOAD_PLAIN, EPI_D2S); }
+  else if (nacc == 4) { if (MBsel == 2) FZ_STR(2, 4, LOAD_PLAIN, EPI_PLAIN); else FZ_STR(1, 4, LOAD_PLAIN, EPI_PLAIN); }
+  else if (nacc == 2) FZ_STR(1, 2, LOAD_PLAIN, EPI_PLAIN);
+  else FZ_STR(1, 1, LOAD_PLAIN, EPI_PLAIN);
   FZ_LAUNCH_CHECK();
   return FZ_OK;
 }

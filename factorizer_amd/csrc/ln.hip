@@ -53,10 +53,17 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 }
 
 // gx = rstd * (gl*g - mean_c(gl*g) - n * mean_c(gl*g*n)) [+ gadd],  n = (x - mean) * rstd
+// CMAX > 0: the kernel also accumulates the affine gradients  gγ_c = Σ gl_c·n_c ,  gβ_c = Σ gl_c
+// in registers (C <= CMAX) and writes one partial row per workgroup: part[blk][2][C].
+template <int CMAX>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ gl, const float* __restrict__ x,
                                                      const float* __restrict__ stats, const float* __restrict__ g,
                                                      const float* __restrict__ gadd, float* __restrict__ gx,
-                                                     int B, int C, int64_t V) {
+                                                     float* __restrict__ part, int B, int C, int64_t V) {
+  constexpr int CA = CMAX > 0 ? CMAX : 1;
+  float ag[CA], ab[CA];
+#pragma unroll
+  for (int c = 0; c < CA; ++c) ag[c] = ab[c] = 0.f;
   const int64_t nvec = V / 4;
   const int64_t total = nvec * B;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -67,14 +74,26 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ g
     const float4 mu = *reinterpret_cast<const float4*>(sp);
     const float4 rs = *reinterpret_cast<const float4*>(sp + V);
     float4 m1 = make_float4(0.f, 0.f, 0.f, 0.f), m2 = m1;
-    for (int c = 0; c < C; ++c) {
+    auto pass1 = [&](int c, int ci) {
       const float4 t = *reinterpret_cast<const float4*>(x + base + (int64_t)c * V);
       const float4 d = *reinterpret_cast<const float4*>(gl + base + (int64_t)c * V);
       const float gc = g[c];
+      const float nx = (t.x - mu.x) * rs.x, ny = (t.y - mu.y) * rs.y, nz = (t.z - mu.z) * rs.z,
+                  nw = (t.w - mu.w) * rs.w;
       const float ax = d.x * gc, ay = d.y * gc, az = d.z * gc, aw = d.w * gc;
       m1.x += ax; m1.y += ay; m1.z += az; m1.w += aw;
-      m2.x += ax * (t.x - mu.x) * rs.x; m2.y += ay * (t.y - mu.y) * rs.y;
-      m2.z += az * (t.z - mu.z) * rs.z; m2.w += aw * (t.w - mu.w) * rs.w;
+      m2.x += ax * nx; m2.y += ay * ny; m2.z += az * nz; m2.w += aw * nw;
+      if (CMAX > 0) {
+        ag[ci] += (d.x * nx + d.y * ny) + (d.z * nz + d.w * nw);
+        ab[ci] += (d.x + d.y) + (d.z + d.w);
+      }
+    };
+    if (CMAX > 0) {
+#pragma unroll
+      for (int c = 0; c < CA; ++c)
+        if (c < C) pass1(c, c);
+    } else {
+      for (int c = 0; c < C; ++c) pass1(c, 0);
     }
     const float inv = 1.0f / (float)C;
     m1.x *= inv; m1.y *= inv; m1.z *= inv; m1.w *= inv;
@@ -95,6 +114,41 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ g
       *reinterpret_cast<float4*>(gx + base + (int64_t)c * V) = o;
     }
   }
+  if (CMAX > 0) {
+    __shared__ float red[4][2 * CA];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < CA; ++c) {
+      const float sg = wave_sum(ag[c]);
+      const float sb = wave_sum(ab[c]);
+      if (lane == 0) {
+        red[wave][c] = sg;
+        red[wave][CA + c] = sb;
+      }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * C; e += blockDim.x) {
+      const int which = e / C, c = e % C;
+      const int idx = which * CA + c;
+      part[(int64_t)blockIdx.x * 2 * C + e] = (red[0][idx] + red[1][idx]) + (red[2][idx] + red[3][idx]);
+    }
+  }
+}
+
+// out[e] = Σ_blk part[blk][e], fixed order (same scheme as wgrad's chunk reduce)
+__global__ __launch_bounds__(256) void ln_part_reduce_kernel(const float* __restrict__ part, int nblk, int n,
+                                                             float* __restrict__ out) {
+  __shared__ float red[8][33];
+  const int el = threadIdx.x & 31, gq = threadIdx.x >> 5;
+  const int e = blockIdx.x * 32 + el;
+  float s = 0.f;
+  if (e < n)
+    for (int ch = gq; ch < nblk; ch += 8) s += part[(int64_t)ch * n + e];
+  red[gq][el] = s;
+  __syncthreads();
+  if (gq == 0 && e < n)
+    out[e] = ((red[0][el] + red[1][el]) + (red[2][el] + red[3][el])) +
+             ((red[4][el] + red[5][el]) + (red[6][el] + red[7][el]));
 }
 
 }  // namespace fz
@@ -120,14 +174,36 @@ extern "C" int fz_ln_fwd(const float* x, const float* gamma, const float* beta, 
   return FZ_OK;
 }
 
+// If gparams != NULL and C <= 64 the kernel also produces the affine gradients:
+//   gparams[0..C) = gγ, gparams[C..2C) = gβ ; workspace must hold fz_ln_bwd_workspace_bytes().
+extern "C" int64_t fz_ln_bwd_workspace_bytes(int C) { return C <= 64 ? (int64_t)1024 * 2 * C * 4 : 0; }
+
 extern "C" int fz_ln_bwd(const float* gl, const float* x, const float* stats, const float* gamma,
-                         const float* gadd, float* gx, int B, int C, int64_t V, fz_stream_t stream) {
+                         const float* gadd, float* gx, float* gparams, void* workspace, int B, int C, int64_t V,
+                         fz_stream_t stream) {
   if (!gl || !x || !stats || !gamma || !gx) return fail(FZ_E_ARG, "fz_ln_bwd: null pointer");
   if (B < 0 || C < 1 || V < 1) return fail(FZ_E_SHAPE, "fz_ln_bwd: bad sizes");
   if (V % 4) return fail(FZ_E_UNSUPPORTED, "fz_ln_bwd: voxel count must be a multiple of 4");
+  if (gparams != nullptr && (C > 64 || workspace == nullptr))
+    return fail(FZ_E_UNSUPPORTED, "fz_ln_bwd: fused affine gradients need C <= 64 and a workspace");
   if (B == 0) return FZ_OK;
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(ln_grid(V / 4 * B)), dim3(256), 0, (hipStream_t)stream, gl, x, stats,
-                     gamma, gadd, gx, B, C, V);
+  hipStream_t st = (hipStream_t)stream;
+  unsigned grid = ln_grid(V / 4 * B);
+  if (gparams != nullptr) {
+    if (grid > 1024) grid = 1024;
+    float* part = (float*)workspace;
+    if (C <= 32)
+      hipLaunchKernelGGL(ln_bwd_kernel<32>, dim3(grid), dim3(256), 0, st, gl, x, stats, gamma, gadd, gx, part, B, C, V);
+    else
+      hipLaunchKernelGGL(ln_bwd_kernel<64>, dim3(grid), dim3(256), 0, st, gl, x, stats, gamma, gadd, gx, part, B, C, V);
+    FZ_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ln_part_reduce_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, st, part, (int)grid, 2 * C,
+                       gparams);
+    FZ_LAUNCH_CHECK();
+    return FZ_OK;
+  }
+  hipLaunchKernelGGL(ln_bwd_kernel<0>, dim3(grid), dim3(256), 0, st, gl, x, stats, gamma, gadd, gx, (float*)nullptr,
+                     B, C, V);
   FZ_LAUNCH_CHECK();
   return FZ_OK;
 }

@@ -160,19 +160,21 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         d0[0] = v.x; d1[0] = v.y; d0[1] = v.z; d1[1] = v.w;
       }
     } else {
-      // QL_K3: rows k = ci*27 + (kd*9 + kh*3 + kw); zero padding 1
-      for (int idx = lane; idx < QR * kTile; idx += 64) {
-        const int r = idx >> 5, col = idx & 31;
+      // QL_K3: rows k = ci*27 + (kd*9 + kh*3 + kw); zero padding 1.  Lane = (column, row parity):
+      // the voxel coordinates are decoded once per tile, the tap once per (uniform) row.
+      const int col = lane & 31;
+      const int64_t n = n0 + col;
+      const bool nok = n < a.N;
+      const int w = (int)((nok ? n : 0) % a.W);
+      const int64_t t2 = (nok ? n : 0) / a.W;
+      const int hh = (int)(t2 % a.H);
+      const int dz = (int)(t2 / a.H);
+      for (int r = lane >> 5; r < QR; r += 2) {
         const int k = k0 + r;
-        const int64_t n = n0 + col;
         float v = 0.f;
-        if (k < a.K && n < a.N) {
+        if (k < a.K && nok) {
           const int ci = k / 27, tap = k % 27;
           const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-          const int w = (int)(n % a.W);
-          const int64_t t2 = n / a.W;
-          const int hh = (int)(t2 % a.H);
-          const int dz = (int)(t2 / a.H);
           const int zd = dz + kd - 1, zh = hh + kh - 1, zw = w + kw - 1;
           if (zd >= 0 && zd < a.D && zh >= 0 && zh < a.H && zw >= 0 && zw < a.W)
             v = a.q[0][((int64_t)b * a.Cin + ci) * a.Vq + ((int64_t)zd * a.H + zh) * a.W + zw];
@@ -240,30 +242,34 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
   }
 }
 
-// out[e] = Σ_chunks part[chunk][e] (fixed order), with the LayerNorm affine folded in:
-//   gw[m][k] = γ_k · Σ gz·n̂  +  β_k · gb[m]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ part_bias,
-                                    int nchunk, int M, int K, const float* __restrict__ ln_g,
-                                    const float* __restrict__ ln_b, float* __restrict__ gw,
-                                    float* __restrict__ gbias, int accumulate) {
+// out[e] = Σ_chunks part[chunk][e] in a fixed order: 8 strided partial sums per element, combined
+// through LDS (bitwise reproducible).  32 elements per 256-thread block.
+__global__ __launch_bounds__(256) void chunk_reduce_kernel(const float* __restrict__ part, int nchunk, int64_t n,
+                                                           float* __restrict__ out, int accumulate) {
+  __shared__ float red[8][33];
+  const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int64_t e = (int64_t)blockIdx.x * 32 + el;
+  float s = 0.f;
+  if (e < n)
+    for (int ch = g; ch < nchunk; ch += 8) s += part[(int64_t)ch * n + e];
+  red[g][el] = s;
+  __syncthreads();
+  if (g == 0 && e < n) {
+    float t = ((red[0][el] + red[1][el]) + (red[2][el] + red[3][el])) +
+              ((red[4][el] + red[5][el]) + (red[6][el] + red[7][el]));
+    out[e] = accumulate ? out[e] + t : t;
+  }
+}
+
+// LayerNorm affine folded into the weight gradient: gw[m][k] = γ_k · acc[m][k] + β_k · gb[m]
+__global__ __launch_bounds__(256) void ln_fold_kernel(float* __restrict__ gw, const float* __restrict__ acc,
+                                                      const float* __restrict__ gb, const float* __restrict__ ln_g,
+                                                      const float* __restrict__ ln_b, int M, int K, int accumulate) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t MK = (int64_t)M * K;
-  if (e < MK) {
-    float s = 0.f;
-    for (int ch = 0; ch < nchunk; ++ch) s += part[(int64_t)ch * MK + e];
-    const int m = (int)(e / K), k = (int)(e % K);
-    if (ln_g != nullptr) {
-      float gb = 0.f;
-      for (int ch = 0; ch < nchunk; ++ch) gb += part_bias[(int64_t)ch * M + m];
-      s = ln_g[k] * s + ln_b[k] * gb;
-    }
-    gw[e] = accumulate ? gw[e] + s : s;
-  }
-  if (gbias != nullptr && e < M) {
-    float gb = 0.f;
-    for (int ch = 0; ch < nchunk; ++ch) gb += part_bias[(int64_t)ch * M + e];
-    gbias[e] = accumulate ? gbias[e] + gb : gb;
-  }
+  if (e >= (int64_t)M * K) return;
+  const int m = (int)(e / K), k = (int)(e % K);
+  const float v = ln_g[k] * acc[e] + ln_b[k] * gb[m];
+  gw[e] = accumulate ? gw[e] + v : v;
 }
 
 }  // namespace fz
@@ -272,8 +278,9 @@ using namespace fz;
 
 static int pick_chunks(int64_t total_tiles, int out_blocks, int* tiles_per_chunk) {
   // aim at ~2048 (workgroup, wave) units over the whole grid, at least 1 tile each
-  int64_t units_target = 2048 / (out_blocks > 0 ? out_blocks : 1);
-  if (units_target < 4) units_target = 4;
+  // ~4 workgroups per CU for latency hiding; partial-sum workspace stays modest for big outputs
+  int64_t units_target = 4096 / (out_blocks > 0 ? out_blocks : 1);
+  if (units_target < 16) units_target = 16;
   int64_t tpc = (total_tiles + units_target - 1) / units_target;
   if (tpc < 1) tpc = 1;
   *tiles_per_chunk = (int)tpc;
@@ -288,7 +295,9 @@ extern "C" int64_t fz_wgrad_workspace_bytes(const fz_wgrad_desc* d) {
   const int64_t total_tiles = ((d->N + kTile - 1) / kTile) * d->B;
   int tpc;
   const int nchunk = pick_chunks(total_tiles, out_blocks, &tpc);
-  return ((int64_t)nchunk * d->M * d->K + (int64_t)nchunk * d->M) * (int64_t)sizeof(float);
+  // partial blocks + partial row sums + (LN fold) reduced accumulator and row sums
+  return ((int64_t)nchunk * d->M * d->K + (int64_t)nchunk * d->M + (int64_t)d->M * d->K + d->M) *
+         (int64_t)sizeof(float);
 }
 
 extern "C" int fz_wgrad(const fz_wgrad_desc* d, void* workspace, fz_stream_t stream) {
@@ -328,9 +337,32 @@ extern "C" int fz_wgrad(const fz_wgrad_desc* d, void* workspace, fz_stream_t str
   else FZ_WG_SHAPES(QL_K3);
   FZ_LAUNCH_CHECK();
   const int64_t MK = (int64_t)d->M * d->K;
-  const int64_t nthr = MK > d->M ? MK : d->M;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, a.part,
-                     a.part_bias, nchunk, d->M, d->K, d->ln_g, d->ln_b, d->gw, d->gbias, d->accumulate);
+  float* acc_tmp = a.part_bias + (int64_t)nchunk * d->M;  // [M*K]
+  float* gb_tmp = acc_tmp + MK;                           // [M]
+  const bool fold = d->ln_g != nullptr;
+  if (fold || d->gbias != nullptr) {
+    float* gb_out = (d->gbias != nullptr && !d->accumulate) ? d->gbias : gb_tmp;
+    hipLaunchKernelGGL(chunk_reduce_kernel, dim3((unsigned)((d->M + 31) / 32)), dim3(256), 0, st, a.part_bias,
+                       nchunk, (int64_t)d->M, gb_out, 0);
+    FZ_LAUNCH_CHECK();
+    if (d->gbias != nullptr && d->accumulate) {
+      // accumulate mode keeps the fresh sums in gb_tmp for the fold and adds them to gbias
+      hipLaunchKernelGGL(chunk_reduce_kernel, dim3((unsigned)((d->M + 31) / 32)), dim3(256), 0, st, a.part_bias,
+                         nchunk, (int64_t)d->M, d->gbias, 1);
+      FZ_LAUNCH_CHECK();
+    }
+    if (fold) {
+      hipLaunchKernelGGL(chunk_reduce_kernel, dim3((unsigned)((MK + 31) / 32)), dim3(256), 0, st, a.part, nchunk,
+                         MK, acc_tmp, 0);
+      FZ_LAUNCH_CHECK();
+      hipLaunchKernelGGL(ln_fold_kernel, dim3((unsigned)((MK + 255) / 256)), dim3(256), 0, st, d->gw, acc_tmp,
+                         gb_out, d->ln_g, d->ln_b, d->M, d->K, d->accumulate);
+      FZ_LAUNCH_CHECK();
+      return FZ_OK;
+    }
+  }
+  hipLaunchKernelGGL(chunk_reduce_kernel, dim3((unsigned)((MK + 31) / 32)), dim3(256), 0, st, a.part, nchunk, MK,
+                     d->gw, d->accumulate);
   FZ_LAUNCH_CHECK();
   return FZ_OK;
 }

@@ -86,6 +86,29 @@ def _wgrad(p, qs, gw, *, B, M, Cin, K, Vq, Ncols, gbias=None, pmul=None, pmul_ki
     return gw
 
 
+def _ln_backward(gl, x, stats, ln_w):
+    """LayerNorm backward: (gx, gγ, gβ).  C <= 64: one pass produces all three; larger C (the
+    small deep stages): gx from the elementwise kernel, gγ/gβ as diag / row sums of a wgrad."""
+    B, C = x.shape[:2]
+    V = _vox(x)
+    gx = torch.empty_like(x)
+    fused = C <= 64
+    gpar = torch.empty(2 * C, dtype=x.dtype, device=x.device) if fused else None
+    ws = torch.empty(max(N.lib().fz_ln_bwd_workspace_bytes(C) // 4, 1), dtype=x.dtype, device=x.device) \
+        if fused else None
+    with torch.cuda.device(x.device):
+        rc = Fn._timed(f"ln_bwd_{C}", 3 * 4 * x.numel(), lambda: N.lib().fz_ln_bwd(
+            gl.data_ptr(), x.data_ptr(), stats.data_ptr(), ln_w.data_ptr(), None, gx.data_ptr(), _p(gpar), _p(ws),
+            B, C, V, N.stream_ptr(x)))
+    N.check(rc, "fz_ln_bwd")
+    if fused:
+        return gx, gpar[:C], gpar[C:]
+    gmat = torch.empty((C, C), dtype=x.dtype, device=x.device)
+    gbeta = torch.empty(C, dtype=x.dtype, device=x.device)
+    _wgrad(gl, [x], gmat, B=B, M=C, Cin=C, K=C, Vq=V, Ncols=V, gbias=gbeta, stats=stats, name="wgrad_ln_affine")
+    return gx, torch.diagonal(gmat).clone(), gbeta
+
+
 def _native_ok(*ts):
     t0 = ts[0]
     return t0.is_cuda and all(t is None or (t.dtype == torch.float32) for t in ts) and _vox(t0) % 4 == 0
@@ -120,22 +143,12 @@ class LNLinearFn(torch.autograd.Function):
         gl = torch.empty_like(x)
         _gemm([gy], w2, gl, B=B, Cin=M, Vin=V, M=C, K=M, Ncol=V, w_t=True, ldw=C, bmul=gate,
               bmul_kind=ACT["relu"], name="linear_dgrad")
-        gx = torch.empty_like(x)
-        with torch.cuda.device(x.device):
-            rc = Fn._timed(f"ln_bwd_{C}", 3 * 4 * x.numel(), lambda: N.lib().fz_ln_bwd(
-                gl.data_ptr(), x.data_ptr(), stats.data_ptr(), ln_w.data_ptr(), None, gx.data_ptr(), B, C, V,
-                N.stream_ptr(x)))
-        N.check(rc, "fz_ln_bwd")
+        gx, ggamma, gbeta = _ln_backward(gl, x, stats, ln_w)
         # weight / bias grads: GW = (gy∘gate) · LN(x)ᵀ with the affine folded in the reduce step
         gw = torch.empty_like(w2)
         gb = torch.empty(M, dtype=x.dtype, device=x.device)
         _wgrad(gy, [x], gw, B=B, M=M, Cin=C, K=C, Vq=V, Ncols=V, gbias=gb, pmul=gate, pmul_kind=ACT["relu"],
                stats=stats, ln=(ln_w, ln_b), name="wgrad_ln_linear")
-        # LN affine grads: gγ = diag(gl · n̂ᵀ), gβ = rowsum(gl)
-        gmat = torch.empty((C, C), dtype=x.dtype, device=x.device)
-        gbeta = torch.empty(C, dtype=x.dtype, device=x.device)
-        _wgrad(gl, [x], gmat, B=B, M=C, Cin=C, K=C, Vq=V, Ncols=V, gbias=gbeta, stats=stats, name="wgrad_ln_affine")
-        ggamma = torch.diagonal(gmat).clone()
         return gx, ggamma, gbeta, None, gw.reshape(ctx.wshape), (gb if ctx.has_bias else None), None
 
 
@@ -241,16 +254,8 @@ class LayerNormFn(torch.autograd.Function):
         gy = gy.contiguous()
         B, C = x.shape[:2]
         V = _vox(x)
-        gx = torch.empty_like(x)
-        with torch.cuda.device(x.device):
-            rc = Fn._timed(f"ln_bwd_{C}", 3 * 4 * x.numel(), lambda: N.lib().fz_ln_bwd(
-                gy.data_ptr(), x.data_ptr(), stats.data_ptr(), w.data_ptr(), None, gx.data_ptr(), B, C, V,
-                N.stream_ptr(x)))
-        N.check(rc, "fz_ln_bwd")
-        gmat = torch.empty((C, C), dtype=x.dtype, device=x.device)
-        gbeta = torch.empty(C, dtype=x.dtype, device=x.device)
-        _wgrad(gy, [x], gmat, B=B, M=C, Cin=C, K=C, Vq=V, Ncols=V, gbias=gbeta, stats=stats, name="wgrad_ln_affine")
-        return gx, torch.diagonal(gmat).clone(), gbeta, None
+        gx, ggamma, gbeta = _ln_backward(gy, x, stats, w)
+        return gx, ggamma, gbeta, None
 
 
 # ---- strided convolutions of the U-shape ------------------------------------------------------------

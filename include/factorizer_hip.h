@@ -187,12 +187,16 @@ int fz_wgrad(const fz_wgrad_desc* desc, void* workspace, fz_stream_t stream);
 /* ---- channels-first LayerNorm (layers/norm.py:29-34), standalone ---------------------------
  * fwd: y = (x-mean)*rstd*gamma + beta over C per voxel; stats (B,2,V) = (mean, rstd) optional.
  * bwd: gx = rstd*(gl*gamma - mean_c(gl*gamma) - n*mean_c(gl*gamma*n)) [+ gadd]; the parameter
- * gradients come from fz_wgrad (diag of P=gl, Q=normalised x; row sums).
+ * gradients come from the same pass (C <= 64) or from fz_wgrad (diag of P=gl, Q=normalised x).
  */
 int fz_ln_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats, int B,
               int C, int64_t V, float eps, fz_stream_t stream);
+/* gparams (optional, C <= 64): [gamma grad (C) | beta grad (C)] computed in the same pass;
+ * needs a workspace of fz_ln_bwd_workspace_bytes(C). */
+int64_t fz_ln_bwd_workspace_bytes(int C);
 int fz_ln_bwd(const float* gl, const float* x, const float* stats, const float* gamma,
-              const float* gadd, float* gx, int B, int C, int64_t V, fz_stream_t stream);
+              const float* gadd, float* gx, float* gparams, void* workspace, int B, int C, int64_t V,
+              fz_stream_t stream);
 
 #ifdef __cplusplus
 }
