@@ -310,8 +310,9 @@ __global__ __launch_bounds__(256, (NSTEP <= 16 ? 3 : 2)) void gemm_resident_kern
       for (int e = 0; e < 4; ++e) bv[s][e] = act_f(p.bact, bv[s][e]);
   }
   __syncthreads();
-  if (!col_ok) return;
 
+  // NOTE: every lane must stay active through the MFMAs (the A operand lives in all 64 lanes);
+  // lanes whose columns fall outside the tensor only skip the stores.
   for (int rb = 0; rb < RB; ++rb) {
     if (m0 + rb * 32 >= p.M) break;
     f32x16 acc[4];
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(256, (NSTEP <= 16 ? 3 : 2)) void gemm_resident_kern
         for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[s][q], acc[q], 0, 0, 0);
       }
     }
-    store_block<4, EPI, false>(p, acc, b, m0 + rb * 32, col_off, h, p.ln ? tW + rb * 32 : nullptr);
+    if (col_ok) store_block<4, EPI, false>(p, acc, b, m0 + rb * 32, col_off, h, p.ln ? tW + rb * 32 : nullptr);
   }
 }
 
