@@ -235,6 +235,42 @@ def relative_error(x, y, eps=EPS):
     return num / den
 
 
+def hals_gate_margin(x, u0, v0, num_iters=5, eps=EPS):
+    """Test helper: per matrix, the smallest |pre-activation| of any HALS ReLU gate relative
+    to its leading term a/b, over all iterations (float64).  The gradient of HALS is
+    discontinuous where a pre-activation crosses 0 (ReLU gate [w > 0] of SURVEY.md
+    Appendix A): a matrix whose margin is within fp32 rounding (≲1e-6) has no well-defined
+    fp32 gradient, and parity tests exclude it."""
+    x = x.double()
+    lead = x.shape[:-2]
+    u = u0.double().expand(*lead, *u0.shape)
+    v = v0.double().expand(*lead, *v0.shape)
+    R = u0.shape[1]
+    margin = torch.full(lead, float("inf"), dtype=torch.float64)
+
+    def half(z, w, s):
+        nonlocal margin
+        a = z @ s
+        b = s.mT @ s
+        cols = [w[..., r] for r in range(R)]
+        for r in range(R):
+            acc = torch.zeros_like(cols[0])
+            for j in range(R):
+                if j != r:
+                    acc = acc + cols[j] * b[..., j, r].unsqueeze(-1)
+            den = b[..., r, r].unsqueeze(-1) + eps
+            q = (a[..., r] - acc + eps) / den
+            ref = (a[..., r].abs() + acc.abs()) / den + 1e-300
+            margin = torch.minimum(margin, (q.abs() / ref).amin(-1))
+            cols[r] = torch.relu(q)
+        return torch.stack(cols, dim=-1)
+
+    for _ in range(num_iters):
+        u = half(x, u, v)
+        v = half(x.mT, v, u)
+    return margin
+
+
 # ---- hand-derived backward (SURVEY.md Appendix A), used to validate the HIP backward ----
 def _half_bwd_mu(z, w, s, w_new, gw_new, eps):
     a = z @ s
