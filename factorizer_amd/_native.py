@@ -108,6 +108,9 @@ class WgradDesc(_c.Structure):
 
 
 _SIGS.update({
+    "fz_nmf_cf_supported": ([_i] * 11, _i),
+    "fz_nmf_cf_fwd": ([_vp] * 4 + [_i] * 5 + [_c.POINTER(_i)] + [_i] * 5 + [_f, _vp], _i),
+    "fz_nmf_cf_bwd": ([_vp] * 5 + [_i] * 5 + [_c.POINTER(_i)] + [_i] * 7 + [_f, _vp], _i),
     "fz_gemm": ([_c.POINTER(GemmDesc), _vp], _i),
     "fz_wgrad": ([_c.POINTER(WgradDesc), _vp, _vp], _i),
     "fz_wgrad_workspace_bytes": ([_c.POINTER(WgradDesc)], _i64),

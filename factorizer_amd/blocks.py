@@ -6,10 +6,11 @@ from __future__ import annotations
 import torch
 from torch import nn
 
+from . import functional as Fn
 from . import pointwise as PW
 from .layers import MLP, LayerNorm, Linear
-from .matricize import Matricize
-from .nmf import NMF
+from .matricize import Matricize, SWMatricize
+from .nmf import NMF, MatrixFactorization, RandomInit
 from .utils import partialize
 
 
@@ -74,12 +75,37 @@ class FactorizerBlock(nn.Module):
         live = self.training and (f.dropout.p > 0 or blk[2].p > 0 or blk[4].p > 0)
         return not live
 
+    def _core_cfg(self):
+        """(grad steps, solver id) if matricize→NMF→inverse can run as the fused channels-first
+        kernels (SWMatricize head_dim 8 / patch 8³, native MU/HALS, rank ≤ 2), else None."""
+        f = self.fact
+        mf = f.factorize
+        if not (isinstance(f.reshape, SWMatricize) and isinstance(mf, MatrixFactorization)):
+            return None
+        sid = getattr(mf.solver, "native_id", None)
+        if sid is None or not isinstance(mf.init, RandomInit) or mf.solver.factor != (0, 1) or mf.verbose:
+            return None
+        G = min(max(mf.num_grad_steps, 0), mf.num_iters)
+        if tuple(mf.size) != (8, 512) or not Fn.nmf_cf_supported(f.reshape.geometry, mf.rank, mf.num_iters, G):
+            return None
+        return G, sid
+
     def forward(self, x):
         if self._fusable(x):
             f, blk = self.fact, self.mlp.block
             n1, n2 = self.norm1.norm, self.norm2.norm
-            t = PW.ln_linear(x, n1.weight, n1.bias, n1.eps, f.in_proj.linear.weight, f.in_proj.linear.bias, "relu")
-            a = f.reshape.inverse_forward(f.factorize(f.reshape(t)))  # ReLU already applied (commutes)
+            core = self._core_cfg()
+            if core is not None:
+                # matricize → NMF → inverse as one kernel per window on the channels-first tensor
+                t = PW.ln_linear(x, n1.weight, n1.bias, n1.eps, f.in_proj.linear.weight, f.in_proj.linear.bias,
+                                 "relu_out")
+                mf = f.factorize
+                a = Fn.FactCoreFn.apply(t, mf.init.u0, mf.init.v0, f.reshape.geometry, mf.num_iters, core[0],
+                                        core[1], mf.solver.eps, True)
+            else:
+                t = PW.ln_linear(x, n1.weight, n1.bias, n1.eps, f.in_proj.linear.weight, f.in_proj.linear.bias,
+                                 "relu")
+                a = f.reshape.inverse_forward(f.factorize(f.reshape(t)))  # ReLU already applied (commutes)
             x = PW.act_linear_res(a, f.out_proj.linear.weight, f.out_proj.linear.bias, x, "none")
             z = PW.ln_linear(x, n2.weight, n2.bias, n2.eps, blk[0].linear.weight, blk[0].linear.bias, "none")
             return PW.act_linear_res(z, blk[3].linear.weight, blk[3].linear.bias, x, "gelu")

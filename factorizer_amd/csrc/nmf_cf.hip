@@ -1,0 +1,245 @@
+// nmf_cf.hip — FactMixer core on channels-first tensors: shifted-window matricize → NMF →
+// inverse matricize in ONE kernel per window (hot shape: head_dim 8, patch 8x8x8).
+//
+// Replaces the chain SWMatricize.forward → NMF.forward → SWMatricize.inverse_forward
+// (factorizer/factorizer.py:41-50; operations.py:417-434; matrix_factorization.py:514-546):
+// the (W·B·h, G, 8, 512) matricized tensors are never materialised.  A wave gathers its 8x512
+// matrix straight from t (B, C, D, H, W) with the window's cyclic shift, runs the per-wave NMF
+// program of nmf_core.h with X in registers, and scatters u vᵀ back to the same voxels of the
+// averaged output a:  window 0 stores (0 + z_0), window w>0 adds z_w, the last window divides by
+// the number of windows — the reference's ((0.0 + z_0) + z_1 + …) / W order (operations.py:426-433).
+// Windows are separate launches on one stream, so the accumulation is deterministic.
+//
+// Lane map: lane l = (p0 & 3 = l>>4, p1 = (l>>1)&7, half = l&1); for every channel dd and
+// p0-group jp the lane moves one 16-byte vector = voxels p2 = 4·half..4·half+3 of patch row
+// (p0 = 4·jp + (l>>4), p1).  Column index of local element (jp, e): n = (p0·8 + p1)·8 + 4·half + e.
+#include "fz_common.h"
+#include "nmf_core.h"
+
+namespace fz {
+
+struct CfGeom {
+  int B, C, D, H, W;   // channels-first tensor
+  int h;               // heads (C / 8)
+  int G0, G1, G2;      // patch grid (D/8, H/8, W/8)
+  int s0, s1, s2;      // this window's shift, normalised to [0, S)
+  int accumulate;      // add to the existing output (windows > 0)
+  int divisor;         // > 1: divide the result by it (last window, forward)
+  float gscale_div;    // backward: gY = gather(ga) / gscale_div
+};
+
+struct CfWave {
+  using F = float;
+  int lane;
+  __device__ __forceinline__ int col(int j) const {
+    const int jp = j >> 2, e = j & 3;
+    return (((jp * 4 + (lane >> 4)) * 8 + ((lane >> 1) & 7)) * 8) + (lane & 1) * 4 + e;
+  }
+  __device__ __forceinline__ float sum(float v) const { return wave_sum(v); }
+  __device__ __forceinline__ void st_priv(float* base, int idx, float v) const { base[idx * 64 + lane] = v; }
+  __device__ __forceinline__ float ld_priv(const float* base, int idx) const { return base[idx * 64 + lane]; }
+  __device__ __forceinline__ void st_uni(float* base, int idx, float v) const {
+    if (lane == 0) base[idx] = v;
+  }
+  __device__ __forceinline__ float ld_uni(const float* base, int idx) const { return base[idx]; }
+  __device__ __forceinline__ float ld_uni_global(const float* p, int idx) const { return p[idx]; }
+  __device__ __forceinline__ float ld_v0(const float* v0, int j, int r, int R) const { return v0[col(j) * R + r]; }
+  __device__ __forceinline__ float keep_col(int, float v) const { return v; }
+  __device__ __forceinline__ void fence() const { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+};
+
+// element offsets (inside one channel plane) of this lane's two vectors, and the plane base
+struct CfAddr {
+  int64_t base;     // (b*C + hh*8) * V
+  int64_t off[2];   // jp = 0, 1
+  int64_t V;
+};
+
+__device__ __forceinline__ bool cf_decode(const CfGeom& q, int64_t mat, int lane, CfAddr& a) {
+  const int g2 = (int)(mat % q.G2);
+  int64_t t = mat / q.G2;
+  const int g1 = (int)(t % q.G1); t /= q.G1;
+  const int g0 = (int)(t % q.G0); t /= q.G0;
+  const int hh = (int)(t % q.h);
+  const int b = (int)(t / q.h);
+  const int p1 = (lane >> 1) & 7, half = lane & 1;
+  int z1 = g1 * 8 + p1 - q.s1; if (z1 < 0) z1 += q.H;
+  int z2 = g2 * 8 + half * 4 - q.s2; if (z2 < 0) z2 += q.W;
+  a.V = (int64_t)q.D * q.H * q.W;
+  a.base = ((int64_t)b * q.C + (int64_t)hh * 8) * a.V;
+#pragma unroll
+  for (int jp = 0; jp < 2; ++jp) {
+    int z0 = g0 * 8 + jp * 4 + (lane >> 4) - q.s0; if (z0 < 0) z0 += q.D;
+    a.off[jp] = ((int64_t)z0 * q.H + z1) * q.W + z2;
+  }
+  return true;
+}
+
+__device__ __forceinline__ void cf_load(const float* __restrict__ t, const CfAddr& a, float (&x)[8][8]) {
+#pragma unroll
+  for (int dd = 0; dd < 8; ++dd)
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+      const float4 v = *reinterpret_cast<const float4*>(t + a.base + dd * a.V + a.off[jp]);
+      x[dd][jp * 4 + 0] = v.x; x[dd][jp * 4 + 1] = v.y; x[dd][jp * 4 + 2] = v.z; x[dd][jp * 4 + 3] = v.w;
+    }
+}
+
+template <int R, int SOLVER>
+__global__ __launch_bounds__(256) void nmf_cf_fwd_kernel(const float* __restrict__ t, const float* __restrict__ u0,
+                                                         const float* __restrict__ v0, float* __restrict__ out,
+                                                         CfGeom q, int64_t nmat, int T, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t mat = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (mat >= nmat) return;
+  CfWave w{lane};
+  CfAddr a;
+  cf_decode(q, mat, lane, a);
+  float x[8][8], u[8][R], v[8][R];
+  cf_load(t, a, x);
+  nmf_forward_wave<8, 8, R, SOLVER>(w, u0, v0, x, u, v, 8, T, eps);
+  const float dv = (float)q.divisor;
+#pragma unroll
+  for (int dd = 0; dd < 8; ++dd)
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+      float* p = out + a.base + dd * a.V + a.off[jp];
+      float4 o;
+      if (q.accumulate) {
+        o = *reinterpret_cast<const float4*>(p);
+        o.x += x[dd][jp * 4 + 0]; o.y += x[dd][jp * 4 + 1]; o.z += x[dd][jp * 4 + 2]; o.w += x[dd][jp * 4 + 3];
+      } else {
+        o = make_float4(0.0f + x[dd][jp * 4 + 0], 0.0f + x[dd][jp * 4 + 1], 0.0f + x[dd][jp * 4 + 2],
+                        0.0f + x[dd][jp * 4 + 3]);
+      }
+      if (q.divisor > 1) { o.x /= dv; o.y /= dv; o.z /= dv; o.w /= dv; }
+      *reinterpret_cast<float4*>(p) = o;
+    }
+}
+
+// backward: gY = gather_w(ga) / W ; gt (+)= [t > 0] ∘ scatter_w(gX)
+template <int R, int SOLVER>
+__global__ __launch_bounds__(256, 2) void nmf_cf_bwd_kernel(const float* __restrict__ t, const float* __restrict__ u0,
+                                                            const float* __restrict__ v0,
+                                                            const float* __restrict__ ga, float* __restrict__ gt,
+                                                            CfGeom q, int64_t nmat, int T, int G, float eps,
+                                                            int relu_gate) {
+  extern __shared__ __attribute__((aligned(16))) float fz_lds_cf[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t mat = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+  if (mat >= nmat) return;
+  CfWave w{lane};
+  CfAddr a;
+  cf_decode(q, mat, lane, a);
+  Hist<8, 8, R> h;
+  h.carve(fz_lds_cf + wave * Hist<8, 8, R>::floats(G), G);
+  float x[8][8], g[8][8];
+  cf_load(t, a, x);
+  cf_load(ga, a, g);
+  const float dv = q.gscale_div;
+  if (dv != 1.0f) {
+#pragma unroll
+    for (int dd = 0; dd < 8; ++dd)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[dd][j] = g[dd][j] / dv;
+  }
+  nmf_backward_wave<8, 8, R, SOLVER>(w, u0, v0, x, g, h, 8, T, G, eps, nullptr, nullptr);
+#pragma unroll
+  for (int dd = 0; dd < 8; ++dd)
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+      float* p = gt + a.base + dd * a.V + a.off[jp];
+      float r[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float gv = g[dd][jp * 4 + e];
+        r[e] = (!relu_gate || x[dd][jp * 4 + e] > 0.f) ? gv : 0.f;
+      }
+      if (q.accumulate) {
+        const float4 o = *reinterpret_cast<const float4*>(p);
+        r[0] += o.x; r[1] += o.y; r[2] += o.z; r[3] += o.w;
+      }
+      *reinterpret_cast<float4*>(p) = make_float4(r[0], r[1], r[2], r[3]);
+    }
+}
+
+static int cf_geom(CfGeom& q, int B, int C, int D, int H, int W, const int* shift, int accumulate, int divisor) {
+  if (B < 0 || C < 8 || (C % 8) || D < 8 || H < 8 || W < 8 || (D % 8) || (H % 8) || (W % 8))
+    return fail(FZ_E_SHAPE, "fz_nmf_cf: needs C % 8 == 0 and spatial dims multiples of 8");
+  if (!shift) return fail(FZ_E_ARG, "fz_nmf_cf: shift is null");
+  q.B = B; q.C = C; q.D = D; q.H = H; q.W = W; q.h = C / 8; q.G0 = D / 8; q.G1 = H / 8; q.G2 = W / 8;
+  int s[3];
+  const int S[3] = {D, H, W};
+  for (int i = 0; i < 3; ++i) { s[i] = shift[i] % S[i]; if (s[i] < 0) s[i] += S[i]; }
+  if (s[2] % 4) return fail(FZ_E_UNSUPPORTED, "fz_nmf_cf: W-axis shift must be a multiple of 4");
+  q.s0 = s[0]; q.s1 = s[1]; q.s2 = s[2];
+  q.accumulate = accumulate; q.divisor = divisor; q.gscale_div = 1.0f;
+  return FZ_OK;
+}
+
+}  // namespace fz
+
+using namespace fz;
+
+extern "C" int fz_nmf_cf_supported(int C, int D, int H, int W, int d, int pd, int ph, int pw, int R, int T, int Tgrad) {
+  if (d != 8 || pd != 8 || ph != 8 || pw != 8 || (C % 8) || (D % 8) || (H % 8) || (W % 8)) return 0;
+  if (R < 1 || R > 2 || T < 0) return 0;
+  const int G = Tgrad < 0 ? 0 : (Tgrad > T ? T : Tgrad);
+  const int per_wave = ((G + 1) * R * 8 * 64 + (G + 1) * 8 * R + G * (8 * R + R * R)) * 4;
+  return per_wave <= 160 * 1024 ? 1 : 0;
+}
+
+extern "C" int fz_nmf_cf_fwd(const float* t, const float* u0, const float* v0, float* out, int B, int C, int D,
+                             int H, int W, const int* shift, int accumulate, int divisor, int R, int T,
+                             int solver, float eps, fz_stream_t stream) {
+  CfGeom q;
+  int rc = cf_geom(q, B, C, D, H, W, shift, accumulate, divisor);
+  if (rc != FZ_OK) return rc;
+  if (!t || !u0 || !v0 || !out) return fail(FZ_E_ARG, "fz_nmf_cf_fwd: null pointer");
+  if (R < 1 || R > 2) return fail(FZ_E_UNSUPPORTED, "fz_nmf_cf_fwd: rank 1..2");
+  if (solver != FZ_SOLVER_MU && solver != FZ_SOLVER_HALS) return fail(FZ_E_ARG, "fz_nmf_cf_fwd: bad solver");
+  if (B == 0) return FZ_OK;
+  const int64_t nmat = (int64_t)B * q.h * q.G0 * q.G1 * q.G2;
+  dim3 grid((unsigned)((nmat + 3) / 4)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define FZ_CF_FWD(RR, SS) hipLaunchKernelGGL((nmf_cf_fwd_kernel<RR, SS>), grid, block, 0, st, t, u0, v0, out, q, nmat, T, eps)
+  if (R == 1) { if (solver == FZ_SOLVER_MU) FZ_CF_FWD(1, SOLVER_MU); else FZ_CF_FWD(1, SOLVER_HALS); }
+  else { if (solver == FZ_SOLVER_MU) FZ_CF_FWD(2, SOLVER_MU); else FZ_CF_FWD(2, SOLVER_HALS); }
+  FZ_LAUNCH_CHECK();
+  return FZ_OK;
+}
+
+extern "C" int fz_nmf_cf_bwd(const float* t, const float* u0, const float* v0, const float* ga, float* gt, int B,
+                             int C, int D, int H, int W, const int* shift, int accumulate, int nshift,
+                             int relu_gate, int R, int T, int Tgrad, int solver, float eps, fz_stream_t stream) {
+  CfGeom q;
+  int rc = cf_geom(q, B, C, D, H, W, shift, accumulate, 1);
+  if (rc != FZ_OK) return rc;
+  if (!t || !u0 || !v0 || !ga || !gt) return fail(FZ_E_ARG, "fz_nmf_cf_bwd: null pointer");
+  if (R < 1 || R > 2) return fail(FZ_E_UNSUPPORTED, "fz_nmf_cf_bwd: rank 1..2");
+  if (solver != FZ_SOLVER_MU && solver != FZ_SOLVER_HALS) return fail(FZ_E_ARG, "fz_nmf_cf_bwd: bad solver");
+  if (B == 0) return FZ_OK;
+  q.gscale_div = (float)(nshift > 1 ? nshift : 1);
+  const int G = Tgrad < 0 ? 0 : (Tgrad > T ? T : Tgrad);
+  const int64_t nmat = (int64_t)B * q.h * q.G0 * q.G1 * q.G2;
+  const int per_wave = (R == 1 ? Hist<8, 8, 1>::floats(G) : Hist<8, 8, 2>::floats(G)) * (int)sizeof(float);
+  if (per_wave > 160 * 1024) return fail(FZ_E_UNSUPPORTED, "fz_nmf_cf_bwd: history exceeds LDS");
+  int wpb = 65536 / per_wave;
+  if (wpb > 4) wpb = 4;
+  if (wpb < 1) wpb = 1;
+  const int lds = per_wave * wpb;
+  dim3 grid((unsigned)((nmat + wpb - 1) / wpb)), block(64 * wpb);
+  hipStream_t st = (hipStream_t)stream;
+#define FZ_CF_BWD(RR, SS)                                                                                 \
+  do {                                                                                                    \
+    auto kern = nmf_cf_bwd_kernel<RR, SS>;                                                                \
+    if (lds > 65536)                                                                                      \
+      FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                  \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));                    \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, t, u0, v0, ga, gt, q, nmat, T, G, eps, relu_gate);     \
+  } while (0)
+  if (R == 1) { if (solver == FZ_SOLVER_MU) FZ_CF_BWD(1, SOLVER_MU); else FZ_CF_BWD(1, SOLVER_HALS); }
+  else { if (solver == FZ_SOLVER_MU) FZ_CF_BWD(2, SOLVER_MU); else FZ_CF_BWD(2, SOLVER_HALS); }
+  FZ_LAUNCH_CHECK();
+  return FZ_OK;
+}

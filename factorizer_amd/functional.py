@@ -243,3 +243,57 @@ def nmf(x, u0, v0, T, G, solver, eps=1e-16):
 
 def nmf_decompose(x, u0, v0, T, G, solver, eps=1e-16):
     return NMFDecomposeFn.apply(x, u0, v0, T, G, solver, eps)
+
+
+# ---- fused FactMixer core on channels-first tensors ------------------------------------------
+def nmf_cf_supported(geo: Geometry, R, T, G) -> bool:
+    if len(geo.spatial) != 3 or any(s[2] % 4 for s in geo.shifts):
+        return False
+    return bool(N.lib().fz_nmf_cf_supported(geo.C, *geo.spatial, geo.d, *geo.patch, int(R), int(T), int(G)))
+
+
+class FactCoreFn(torch.autograd.Function):
+    """a = SWMatricize⁻¹(NMF(SWMatricize(t))) for t >= 0 already activated (factorizer.py:41-50)
+    without materialising the matricized tensors (csrc/nmf_cf.hip).  `relu_gate`: the caller's
+    t is relu(z); the backward then returns the gradient w.r.t. z (gated by [t > 0])."""
+
+    @staticmethod
+    def forward(ctx, t, u0, v0, geo, T, G, solver, eps, relu_gate):
+        t = t.contiguous()
+        u0, v0 = u0.contiguous(), v0.contiguous()
+        B = t.shape[0]
+        out = torch.empty_like(t)
+        R = u0.shape[1]
+        nb = 2 * 4 * t.numel()
+        with _dev_guard(t):
+            for w, s in enumerate(geo.shifts):
+                arr = (N._i * 3)(*s)
+                rc = _timed("nmf_cf_fwd", nb + (4 * t.numel() if w else 0), lambda: N.lib().fz_nmf_cf_fwd(
+                    t.data_ptr(), u0.data_ptr(), v0.data_ptr(), out.data_ptr(), B, geo.C, *geo.spatial, arr,
+                    int(w > 0), geo.nshift if w == geo.nshift - 1 else 1, R, T, N.SOLVER_ID[solver], eps,
+                    N.stream_ptr(t)))
+                N.check(rc, "fz_nmf_cf_fwd")
+        ctx.save_for_backward(t, u0, v0)
+        ctx.cfg = (geo, T, G, solver, eps, relu_gate)
+        return out
+
+    @staticmethod
+    def backward(ctx, ga):
+        t, u0, v0 = ctx.saved_tensors
+        geo, T, G, solver, eps, relu_gate = ctx.cfg
+        if G <= 0:
+            return (torch.zeros_like(t),) + (None,) * 8
+        ga = ga.contiguous()
+        gt = torch.empty_like(t)
+        B = t.shape[0]
+        R = u0.shape[1]
+        nb = 3 * 4 * t.numel()
+        with _dev_guard(t):
+            for w, s in enumerate(geo.shifts):
+                arr = (N._i * 3)(*s)
+                rc = _timed("nmf_cf_bwd", nb + (4 * t.numel() if w else 0), lambda: N.lib().fz_nmf_cf_bwd(
+                    t.data_ptr(), u0.data_ptr(), v0.data_ptr(), ga.data_ptr(), gt.data_ptr(), B, geo.C,
+                    *geo.spatial, arr, int(w > 0), geo.nshift, int(relu_gate), R, T, G, N.SOLVER_ID[solver], eps,
+                    N.stream_ptr(t)))
+                N.check(rc, "fz_nmf_cf_bwd")
+        return (gt,) + (None,) * 8

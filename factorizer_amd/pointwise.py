@@ -126,7 +126,7 @@ class LNLinearFn(torch.autograd.Function):
         y = torch.empty((B, M, *x.shape[2:]), dtype=x.dtype, device=x.device)
         stats = torch.empty((B, 2, V), dtype=x.dtype, device=x.device)
         _gemm([x], w2, y, B=B, Cin=C, Vin=V, M=M, K=C, Ncol=V, bias=b, ln=(ln_w, ln_b, eps), stats_out=stats,
-              eact=ACT[act], name="ln_linear")
+              eact=ACT["relu" if act == "relu_out" else act], name="ln_linear")
         ctx.save_for_backward(x, stats, ln_w, ln_b, w2, y if act == "relu" else None)
         ctx.act, ctx.has_bias, ctx.wshape = act, b is not None, w.shape
         return y
@@ -393,11 +393,12 @@ def mlp_cf(x, w1, b1, w2, b2):
 
 
 def ln_linear(x, ln_w, ln_b, eps, w, b, act="none"):
-    """act(Linear(LayerNorm(x)))."""
+    """act(Linear(LayerNorm(x))).  act: "none" | "relu" | "relu_out" (ReLU applied, but the
+    incoming gradient is already gated by the consumer — FactCoreFn — so backward skips it)."""
     if _native_ok(x, ln_w, ln_b, w, b) and w.shape[1] % 2 == 0:
         return LNLinearFn.apply(x, ln_w, ln_b, eps, w, b, act)
     y = linear_cf(layernorm_cf(x, ln_w, ln_b, eps), w, b)
-    return torch.relu(y) if act == "relu" else y
+    return torch.relu(y) if act != "none" else y
 
 
 def act_linear_res(z, w, b, res, act="none"):

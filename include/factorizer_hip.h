@@ -92,6 +92,25 @@ int fz_nmf_bwd(const float* x, const float* u0, const float* v0, const float* gy
 /* 1 if (M,N,R,T,Tgrad) is covered by the native kernels (fwd and bwd), else 0. */
 int fz_nmf_supported(int M, int N, int R, int T, int Tgrad);
 
+/* ---- FactMixer core on channels-first tensors (hot shape: head_dim 8, patch 8x8x8) -----------
+ * One launch per shift window performs SWMatricize.forward → NMF.forward →
+ * SWMatricize.inverse_forward (factorizer.py:41-50; operations.py:417-434;
+ * matrix_factorization.py:514-546) without materialising the matricized tensors:
+ *   fwd: out = ((0 + z_0) + z_1 + ...) / nshift, z_w = scatter_w(NMF(gather_w(t)));
+ *        call once per window in order with accumulate = (w > 0), divisor = nshift on the last
+ *        window (1 otherwise).
+ *   bwd: gt (+)= [t > 0 if relu_gate] * scatter_w(dNMF(gather_w(t); gather_w(ga) / nshift));
+ *        call once per window with accumulate = (w > 0).
+ * t, out, ga, gt: (B, C, D, H, W) fp32; shift: HOST pointer to 3 ints (W-axis shift % 4 == 0).
+ */
+int fz_nmf_cf_supported(int C, int D, int H, int W, int d, int pd, int ph, int pw, int R, int T, int Tgrad);
+int fz_nmf_cf_fwd(const float* t, const float* u0, const float* v0, float* out, int B, int C, int D,
+                  int H, int W, const int* shift, int accumulate, int divisor, int R, int T,
+                  int solver, float eps, fz_stream_t stream);
+int fz_nmf_cf_bwd(const float* t, const float* u0, const float* v0, const float* ga, float* gt, int B,
+                  int C, int D, int H, int W, const int* shift, int accumulate, int nshift,
+                  int relu_gate, int R, int T, int Tgrad, int solver, float eps, fz_stream_t stream);
+
 /* ---- channels-first GEMM family (1x1 layers, k2s2 conv / transposed conv, input grads) ----
  * Out[m, n] = epilogue( sum_k A[m,k] * prologue(In)[k,n] ), n = voxel.  One descriptor drives
  * every dense layer of the block and of the U-shape:

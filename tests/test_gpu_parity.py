@@ -341,3 +341,36 @@ def test_block_cfg2_full_size_runs():
         y = blk(x)
         (gx,) = torch.autograd.grad(y, x, torch.rand_like(y))
     assert y.shape == x.shape and torch.isfinite(y).all() and torch.isfinite(gx).all()
+
+
+# ---------------------------------------------------------------- fused FactMixer core -----
+@pytest.mark.parametrize("shifts", [None, [None, 4, (4, 0, 4), (0, 4, 0)], [None]])
+@pytest.mark.parametrize("solver,R", [("hals", 1), ("mu", 2), ("hals", 2)])
+def test_fact_core_fused_vs_modular(shifts, solver, R):
+    """csrc/nmf_cf.hip (gather → NMF → scatter/average per window) against the modular chain
+    SWMatricize → NMF → inverse (itself checked against the reference goldens)."""
+    from factorizer_amd import functional as Fn
+    torch.manual_seed(11)
+    C, S = 16, (16, 8, 24)
+    m = ft.SWMatricize((None, C, *S), head_dim=8, patch_size=8, shifts=shifts)
+    nmf = ft.NMF(size=(8, 512), rank=R, num_iters=4, num_grad_steps=3, init="uniform", solver=solver).to(DEV)
+    t = torch.rand(2, C, *S, device=DEV)
+    t[0, :8, :8, :8, :8] = 0
+    G = 3
+    assert Fn.nmf_cf_supported(m.geometry, R, 4, G)
+    t1 = t.clone().requires_grad_(True)
+    t2 = t.clone().requires_grad_(True)
+    with Launches():
+        a1 = Fn.FactCoreFn.apply(t1, nmf.init.u0, nmf.init.v0, m.geometry, 4, G, solver, 1e-16, False)
+    a2 = m.inverse_forward(nmf(m(t2)))
+    assert torch.allclose(a1, a2, rtol=1e-5, atol=1e-6)
+    ga = torch.rand_like(a1)
+    (g1,) = torch.autograd.grad(a1, t1, ga)
+    (g2,) = torch.autograd.grad(a2, t2, ga)
+    s = g2.abs().max().item()
+    assert (g1 - g2).abs().max().item() <= 2e-4 * s + 1e-6
+    # relu_gate = True gates the gradient by [t > 0]
+    t3 = t.clone().requires_grad_(True)
+    a3 = Fn.FactCoreFn.apply(t3, nmf.init.u0, nmf.init.v0, m.geometry, 4, G, solver, 1e-16, True)
+    (g3,) = torch.autograd.grad(a3, t3, ga)
+    assert torch.allclose(g3, g1 * (t > 0), rtol=0, atol=0)
