@@ -108,40 +108,29 @@ __device__ __forceinline__ void vstore(float* p, const float (&v)[NACC]) {
   else *p = v[0];
 }
 
-// ---- plain-loader fetch of NACC voxels of channel c (concat / window-average / act') ---------
-template <int NACC>
+// ---- plain-loader fetch of NACC voxels of channel c -------------------------------------------
+// BRANCH-FREE on purpose: hipcc wraps a conditional load in s_cbranch + s_waitcnt vmcnt(0), which
+// serialises every load of the prefetch ring.  Out-of-range lanes/channels read a clamped (valid)
+// address and are zeroed with a select; the two-source concat picks its pointer with a select.
+template <int NACC, bool BMUL>
 __device__ __forceinline__ void fetch_plain(const GemmArgs& p, int b, int c, int64_t off, bool ok,
                                             float (&v)[NACC]) {
-  if (!ok || c >= p.Cin) {
+  const bool cok = ok && c < p.Cin;
+  const int cc = c < p.Cin ? c : p.Cin - 1;
+  const bool first = cc < p.c0;
+  const float* base = first ? p.x[0] : p.x[1];
+  const int cs = first ? p.c0 : p.Cin - p.c0;
+  const int ci = first ? cc : cc - p.c0;
+  const int64_t o = ((int64_t)b * cs + ci) * p.Vin + (ok ? off : 0);
+  vload<NACC>(base + o, v);
+  if (BMUL) {  // ReLU gate of the consumer's forward output (bmul_kind == ACT_RELU)
+    float e[NACC];
+    vload<NACC>(p.bmul + ((int64_t)b * p.Cin + cc) * p.Vin + (ok ? off : 0), e);
 #pragma unroll
-    for (int e = 0; e < NACC; ++e) v[e] = 0.f;
-    return;
+    for (int i = 0; i < NACC; ++i) v[i] = e[i] > 0.f ? v[i] : 0.f;
   }
-  if (p.src_mode == 0) {
-    const float* src = (c < p.c0) ? p.x[0] + ((int64_t)b * p.c0 + c) * p.Vin
-                                  : p.x[1] + ((int64_t)b * (p.Cin - p.c0) + (c - p.c0)) * p.Vin;
-    vload<NACC>(src + off, v);
-    if (p.bmul != nullptr) {
-      float e[NACC];
-      vload<NACC>(p.bmul + ((int64_t)b * p.Cin + c) * p.Vin + off, e);
 #pragma unroll
-      for (int i = 0; i < NACC; ++i) v[i] *= act_grad_f(p.bmul_kind, e[i]);
-    }
-  } else {
-    const int64_t o = ((int64_t)b * p.Cin + c) * p.Vin + off;
-    float t[NACC];
-    vload<NACC>(p.x[0] + o, t);
-#pragma unroll
-    for (int i = 0; i < NACC; ++i) v[i] = 0.0f + t[i];
-    for (int sidx = 1; sidx < p.nsrc; ++sidx) {
-      vload<NACC>(p.x[sidx] + o, t);
-#pragma unroll
-      for (int i = 0; i < NACC; ++i) v[i] += t[i];
-    }
-    const float nw = (float)p.nsrc;
-#pragma unroll
-    for (int i = 0; i < NACC; ++i) v[i] /= nw;
-  }
+  for (int i = 0; i < NACC; ++i) v[i] = cok ? v[i] : 0.f;
 }
 
 // ---- epilogue for one 32-row block -------------------------------------------------------------
@@ -229,7 +218,7 @@ __device__ __forceinline__ void store_block(const GemmArgs& p, const f32x16 (&ac
 // workgroup sequentially with one accumulator set: the input is read from HBM exactly once for
 // all output rows and 10+ KiB per wave are in flight.
 // =================================================================================================
-template <int NSTEP, int EPI>
+template <int NSTEP, int EPI, bool BMUL>
 __global__ __launch_bounds__(256, (NSTEP <= 16 ? 3 : 2)) void gemm_resident_kernel(GemmArgs p, int RB) {
   extern __shared__ __attribute__((aligned(16))) float lds_a[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -242,18 +231,30 @@ __global__ __launch_bounds__(256, (NSTEP <= 16 ? 3 : 2)) void gemm_resident_kern
   const int64_t n0 = ((int64_t)(blockIdx.x % tiles_per_sample) * 4 + wave) * 128;
   const int m0 = blockIdx.y * 32 * RB;
 
-  for (int idx = threadIdx.x; idx < nA * RB * 64; idx += blockDim.x) {
-    const int l = idx & 63;
-    const int rb = (idx >> 6) % RB;
-    const int a = idx / (64 * RB);
-    const int m = m0 + rb * 32 + (l & 31);
-    const int k = 2 * a + (l >> 5);
-    float wv = 0.f;
-    if (m < p.M && k < p.K) {
-      wv = weight_at(p, m, k);
-      if (p.ln) wv *= p.ln_g[k];
+  // batched fill (8 independent loads per thread before the LDS stores)
+  for (int base = threadIdx.x; base < nA * RB * 64; base += blockDim.x * 8) {
+    float tmp[8];
+#pragma unroll
+    for (int uu = 0; uu < 8; ++uu) {
+      const int idx = base + uu * blockDim.x;
+      const bool in = idx < nA * RB * 64;
+      const int ii = in ? idx : 0;
+      const int l = ii & 63;
+      const int rb = (ii >> 6) % RB;
+      const int a = ii / (64 * RB);
+      const int m = m0 + rb * 32 + (l & 31);
+      const int k = 2 * a + (l >> 5);
+      const bool ok = in && m < p.M && k < p.K;
+      const int mc = m < p.M ? m : p.M - 1, kc = k < p.K ? k : p.K - 1;
+      float wv = weight_at(p, mc, kc);
+      if (p.ln) wv *= p.ln_g[kc];
+      tmp[uu] = ok ? wv : 0.f;
     }
-    As[idx] = wv;
+#pragma unroll
+    for (int uu = 0; uu < 8; ++uu) {
+      const int idx = base + uu * blockDim.x;
+      if (idx < nA * RB * 64) As[idx] = tmp[uu];
+    }
   }
   if (p.ln) {
     for (int r = threadIdx.x; r < 32 * RB; r += blockDim.x) {
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(256, (NSTEP <= 16 ? 3 : 2)) void gemm_resident_kern
   const bool col_ok = col_off < p.Ncol;
   float bv[NSTEP][4];
 #pragma unroll
-  for (int s = 0; s < NSTEP; ++s) fetch_plain<4>(p, b, 2 * s + h, col_off, col_ok && s < nA, bv[s]);
+  for (int s = 0; s < NSTEP; ++s) fetch_plain<4, BMUL>(p, b, 2 * s + h, col_off, col_ok, bv[s]);
 
   if (p.ln) {
     // exact two-pass statistics over the Cin channels (this lane holds the parity-h half)
@@ -303,11 +304,16 @@ __global__ __launch_bounds__(256, (NSTEP <= 16 ? 3 : 2)) void gemm_resident_kern
       *reinterpret_cast<float4*>(so + p.Vin + col_off) = make_float4(rs[0], rs[1], rs[2], rs[3]);
     }
   }
-  if (p.bact) {
+  if (p.bact == ACT_GELU) {
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) bv[s][e] = act_f(p.bact, bv[s][e]);
+      for (int e = 0; e < 4; ++e) bv[s][e] = gelu_f(bv[s][e]);
+  } else if (p.bact == ACT_RELU) {
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bv[s][e] = bv[s][e] > 0.f ? bv[s][e] : 0.f;
   }
   __syncthreads();
 
@@ -338,12 +344,14 @@ __global__ __launch_bounds__(256, (NSTEP <= 16 ? 3 : 2)) void gemm_resident_kern
 // deep, narrow stages (8^3..32^3 voxels, C = 128..512) enough workgroups to fill 256 CUs.
 // =================================================================================================
 constexpr int kAChunk = 64;  // A-operand steps staged in LDS at a time
-constexpr int kPF = 4;       // operand prefetch depth (load steps)
 
-template <int MB, int NACC, int LOADER, int EPI>
+template <int MB, int NACC, int LOADER, int EPI, bool BMUL>
 __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgs p) {
   constexpr int TN = 32 * NACC;
   constexpr int NL = (LOADER == LOAD_S2D) ? 4 : NACC;  // floats fetched per load step
+  // operand prefetch depth (load steps): narrow tiles are latency-bound (L2 round trip ≈ 500-900
+  // cycles vs 64·NACC MFMA cycles per step), so they keep more loads in flight
+  constexpr int kPF = (NL == 4) ? 8 : 16;
   __shared__ float As[kAChunk * MB * 64];
   __shared__ float sW[32 * MB];
   __shared__ float tW[32 * MB];
@@ -397,34 +405,36 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgs p) {
 
   auto fetch = [&](int s, float (&v)[NL]) {
     if (LOADER == LOAD_PLAIN) {
-      fetch_plain<NL>(p, b, 2 * s + h, col_off, col_ok, v);
+      fetch_plain<NL, BMUL>(p, b, 2 * s + h, col_off, col_ok, v);
     } else if (LOADER == LOAD_S2D) {
       const int c = 2 * (s >> 2) + h;
-      if (!col_ok || c >= p.Cin) {
+      const bool ok = col_ok && c < p.Cin;
+      const int cc = c < p.Cin ? c : p.Cin - 1;
+      const int64_t off = (col_ok ? col_off : 0) + (int64_t)((s >> 1) & 1) * p.Hi * p.Wi + (int64_t)(s & 1) * p.Wi;
+      vload<NL>(p.x[0] + ((int64_t)b * p.Cin + cc) * p.Vin + off, v);
 #pragma unroll
-        for (int e = 0; e < NL; ++e) v[e] = 0.f;
-        return;
-      }
-      const int64_t off = col_off + (int64_t)((s >> 1) & 1) * p.Hi * p.Wi + (int64_t)(s & 1) * p.Wi;
-      vload<NL>(p.x[0] + ((int64_t)b * p.Cin + c) * p.Vin + off, v);
+      for (int e = 0; e < NL; ++e) v[e] = ok ? v[e] : 0.f;
     } else {
-      // LOAD_K3 (NL == 4): taps of the 3x3x3 stencil, zero padding
+      // LOAD_K3 (NL == 4): taps of the 3x3x3 stencil, zero padding — clamped addresses + selects
       const int c = 2 * (s / 27) + h;
       const int tap = s % 27;
       const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
       const int zd = kd0 + kd - 1, zh = kh0 + kh - 1;
-#pragma unroll
-      for (int e = 0; e < NL; ++e) v[e] = 0.f;
-      if (!col_ok || c >= p.Cin || zd < 0 || zd >= p.Di || zh < 0 || zh >= p.Hi) return;
-      const float* row = p.x[0] + ((int64_t)b * p.Cin + c) * p.Vin + ((int64_t)zd * p.Hi + zh) * p.Wi;
+      const bool ok = col_ok && c < p.Cin && zd >= 0 && zd < p.Di && zh >= 0 && zh < p.Hi;
+      const int cc = c < p.Cin ? c : p.Cin - 1;
+      const int zdc = zd < 0 ? 0 : (zd >= p.Di ? p.Di - 1 : zd);
+      const int zhc = zh < 0 ? 0 : (zh >= p.Hi ? p.Hi - 1 : zh);
+      const float* row = p.x[0] + ((int64_t)b * p.Cin + cc) * p.Vin + ((int64_t)zdc * p.Hi + zhc) * p.Wi;
       const float4 t = *reinterpret_cast<const float4*>(row + kw0);
-      if (kw == 1) {
-        v[0] = t.x; v[1 % NL] = t.y; v[2 % NL] = t.z; v[3 % NL] = t.w;
-      } else if (kw == 0) {
-        v[0] = kw0 > 0 ? row[kw0 - 1] : 0.f; v[1 % NL] = t.x; v[2 % NL] = t.y; v[3 % NL] = t.z;
-      } else {
-        v[0] = t.y; v[1 % NL] = t.z; v[2 % NL] = t.w; v[3 % NL] = (kw0 + 4 < p.Wi) ? row[kw0 + 4] : 0.f;
-      }
+      const float lft = row[kw0 > 0 ? kw0 - 1 : 0];
+      const float rgt = row[kw0 + 4 < p.Wi ? kw0 + 4 : kw0];
+      const float l0 = kw0 > 0 ? lft : 0.f;
+      const float r0 = kw0 + 4 < p.Wi ? rgt : 0.f;
+      float o0, o1, o2, o3;
+      if (kw == 1) { o0 = t.x; o1 = t.y; o2 = t.z; o3 = t.w; }
+      else if (kw == 0) { o0 = l0; o1 = t.x; o2 = t.y; o3 = t.z; }
+      else { o0 = t.y; o1 = t.z; o2 = t.w; o3 = r0; }
+      v[0] = ok ? o0 : 0.f; v[1 % NL] = ok ? o1 : 0.f; v[2 % NL] = ok ? o2 : 0.f; v[3 % NL] = ok ? o3 : 0.f;
     }
   };
 
@@ -442,10 +452,9 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgs p) {
 
   const int nload = (LOADER == LOAD_S2D) ? nA / 2 : nA;
   float ring[kPF][NL];
+  // unconditional, clamped prefetch: a load inside a branch costs an s_waitcnt vmcnt(0)
 #pragma unroll
-  for (int i = 0; i < kPF; ++i) {
-    if (i < nload) fetch(i, ring[i]);
-  }
+  for (int i = 0; i < kPF; ++i) fetch(i < nload ? i : nload - 1, ring[i]);
   if (p.ln) {
     // pivot = channel-0 value (held by half 0 in ring[0]): well-conditioned single-pass variance
 #pragma unroll
@@ -455,18 +464,32 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgs p) {
   for (int a0 = 0; a0 < nA; a0 += kAChunk) {
     const int an = min(kAChunk, nA - a0);
     __syncthreads();
-    for (int idx = threadIdx.x; idx < an * MB * 64; idx += blockDim.x) {
-      const int l = idx & 63;
-      const int mb = (idx >> 6) % MB;
-      const int a = a0 + idx / (64 * MB);
-      const int m = m0 + mb * 32 + (l & 31);
-      const int k = a_k<LOADER>(a, l >> 5);
-      float wv = 0.f;
-      if (m < p.M && k < p.K) {
-        wv = weight_at(p, m, k);
-        if (p.ln) wv *= p.ln_g[k];
+    // batched fill: issue 8 independent weight loads per thread before the LDS stores, so the
+    // (L2-resident) weight fetch latency overlaps instead of serialising load→store pairs
+    for (int base = threadIdx.x; base < an * MB * 64; base += blockDim.x * 8) {
+      float tmp[8];
+#pragma unroll
+      for (int uu = 0; uu < 8; ++uu) {
+        const int idx = base + uu * blockDim.x;
+        float wv = 0.f;
+        if (idx < an * MB * 64) {
+          const int l = idx & 63;
+          const int mb = (idx >> 6) % MB;
+          const int a = a0 + idx / (64 * MB);
+          const int m = m0 + mb * 32 + (l & 31);
+          const int k = a_k<LOADER>(a, l >> 5);
+          if (m < p.M && k < p.K) {
+            wv = weight_at(p, m, k);
+            if (p.ln) wv *= p.ln_g[k];
+          }
+        }
+        tmp[uu] = wv;
       }
-      As[idx] = wv;
+#pragma unroll
+      for (int uu = 0; uu < 8; ++uu) {
+        const int idx = base + uu * blockDim.x;
+        if (idx < an * MB * 64) As[idx] = tmp[uu];
+      }
     }
     __syncthreads();
     constexpr int ASTEP = (LOADER == LOAD_S2D) ? 2 : 1;
@@ -475,12 +498,15 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgs p) {
 #pragma unroll
       for (int u = 0; u < kPF; ++u) {
         const int ali = al + u * ASTEP;
-        if (ali < an) {
-          const int s = (a0 + ali) / ASTEP;
-          float cur[NL];
+        const int s = (a0 + ali) / ASTEP;
+        float cur[NL];
 #pragma unroll
-          for (int e = 0; e < NL; ++e) cur[e] = ring[u][e];
-          if (s + kPF < nload) fetch(s + kPF, ring[u]);
+        for (int e = 0; e < NL; ++e) cur[e] = ring[u][e];
+        {
+          const int sn = s + kPF;
+          fetch(sn < nload ? sn : nload - 1, ring[u]);  // tail: harmless re-read of the last step
+        }
+        if (ali < an) {
           if (LOADER == LOAD_S2D) {
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
@@ -501,7 +527,14 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgs p) {
                 s1[e] += t;
                 s2[e] += t * t;
               }
-              bvv[e] = p.bact ? act_f(p.bact, t) : t;
+              bvv[e] = t;
+            }
+            if (p.bact == ACT_GELU) {
+#pragma unroll
+              for (int e = 0; e < NACC; ++e) bvv[e] = gelu_f(bvv[e]);
+            } else if (p.bact == ACT_RELU) {
+#pragma unroll
+              for (int e = 0; e < NACC; ++e) bvv[e] = bvv[e] > 0.f ? bvv[e] : 0.f;
             }
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
@@ -579,7 +612,9 @@ extern "C" int fz_gemm(const fz_gemm_desc* d, fz_stream_t stream) {
   if (d->loader == LOAD_S2D && ((d->Wo & 1) || d->epilogue != EPI_PLAIN || d->ln || d->src_mode != 0 || d->nsrc != 1))
     return fail(FZ_E_UNSUPPORTED, "fz_gemm: space-to-depth loader needs even coarse width, plain epilogue");
   if (d->epilogue == EPI_D2S && (d->M % 8 != 0)) return fail(FZ_E_SHAPE, "fz_gemm: depth-to-space rows must be 8*C");
-  if (d->nsrc < 1 || d->nsrc > 4) return fail(FZ_E_ARG, "fz_gemm: 1..4 sources");
+  if (d->nsrc < 1 || d->nsrc > 2 || d->src_mode != 0)
+    return fail(FZ_E_UNSUPPORTED, "fz_gemm: one source, or two sources concatenated along channels");
+  if (d->bmul && d->bmul_kind != ACT_RELU) return fail(FZ_E_UNSUPPORTED, "fz_gemm: bmul supports the ReLU gate");
   if (d->B == 0) return FZ_OK;
   GemmArgs a;
   for (int i = 0; i < 4; ++i) a.x[i] = d->x[i];
@@ -600,32 +635,54 @@ extern "C" int fz_gemm(const fz_gemm_desc* d, fz_stream_t stream) {
     const size_t lds = (size_t)(nA * RB * 64 + 32 * RB) * sizeof(float);
     const int64_t tiles = (d->Ncol + 511) / 512;
     dim3 grid((unsigned)(tiles * d->B), (unsigned)((mblocks + RB - 1) / RB)), block(256);
-#define FZ_RES(NS, E) hipLaunchKernelGGL((gemm_resident_kernel<NS, E>), grid, block, lds, st, a, RB)
-    if (nA <= 16) { if (d->epilogue == EPI_D2S) FZ_RES(16, EPI_D2S); else FZ_RES(16, EPI_PLAIN); }
-    else { if (d->epilogue == EPI_D2S) FZ_RES(32, EPI_D2S); else FZ_RES(32, EPI_PLAIN); }
+#define FZ_RES(NS, E, BM) hipLaunchKernelGGL((gemm_resident_kernel<NS, E, BM>), grid, block, lds, st, a, RB)
+    if (d->epilogue == EPI_D2S) {
+      if (d->bmul) return fail(FZ_E_UNSUPPORTED, "fz_gemm: bmul with depth-to-space epilogue");
+      if (nA <= 16) FZ_RES(16, EPI_D2S, false); else FZ_RES(32, EPI_D2S, false);
+    } else if (d->bmul) {
+      if (nA <= 16) FZ_RES(16, EPI_PLAIN, true); else FZ_RES(32, EPI_PLAIN, true);
+    } else {
+      if (nA <= 16) FZ_RES(16, EPI_PLAIN, false); else FZ_RES(32, EPI_PLAIN, false);
+    }
     FZ_LAUNCH_CHECK();
     return FZ_OK;
   }
 
   // ---- Kernel B: streaming; pick the column-tile width so the grid fills the chip ----
-  int nacc = 4;
-  if (d->loader == LOAD_S2D) nacc = 2;
-  else if (d->loader == LOAD_PLAIN && d->epilogue == EPI_PLAIN) {
-    const int64_t cols = d->Ncol * d->B;
-    const int64_t wg4 = ((cols + 511) / 512) * ((mblocks + 1) / 2);
-    if (wg4 < 256 && d->Ncol % 4 == 0) nacc = (((cols + 255) / 256) * mblocks >= 256) ? 2 : 1;
+  // aim at >= ~3 workgroups per CU: prefer wide tiles and 2 row blocks per workgroup (fewer
+  // re-reads of the input) but fall back to narrower tiles / single row blocks on small grids
+  int nacc = 4, MBsel = mblocks >= 2 ? 2 : 1;
+  if (d->loader == LOAD_S2D) { nacc = 2; MBsel = 1; }
+  else {
+    const bool narrow_ok = d->loader == LOAD_PLAIN && d->epilogue == EPI_PLAIN;
+    auto wgs = [&](int na, int mb) {
+      const int64_t t = (d->Ncol + 32 * na * 4 - 1) / (32 * na * 4);
+      return t * d->B * ((mblocks + mb - 1) / mb);
+    };
+    if (wgs(nacc, MBsel) < 768 && MBsel == 2) MBsel = 1;
+    if (narrow_ok) {
+      if (wgs(nacc, MBsel) < 768) nacc = 2;
+      if (wgs(nacc, MBsel) < 768) nacc = 1;
+    }
   }
-  const int MBsel = (mblocks >= 2 && nacc == 4) ? 2 : 1;
   const int TN = 32 * nacc;
   const int64_t tiles = (d->Ncol + TN * 4 - 1) / (TN * 4);
   dim3 grid((unsigned)(tiles * d->B), (unsigned)((mblocks + MBsel - 1) / MBsel)), block(256);
-#define FZ_STR(MB, NA, L, E) hipLaunchKernelGGL((gemm_stream_kernel<MB, NA, L, E>), grid, block, 0, st, a)
-  if (d->loader == LOAD_S2D) { FZ_STR(1, 2, LOAD_S2D, EPI_PLAIN); }
-  else if (d->loader == LOAD_K3) { if (MBsel == 2) FZ_STR(2, 4, LOAD_K3, EPI_PLAIN); else FZ_STR(1, 4, LOAD_K3, EPI_PLAIN); }
-  else if (d->epilogue == EPI_D2S) { if (MBsel == 2) FZ_STR(2, 4, LOAD_PLAIN, EPI_D2S); else FZ_STR(1, 4, LOAD_PLAIN, EPI_D2S); }
-  else if (nacc == 4) { if (MBsel == 2) FZ_STR(2, 4, LOAD_PLAIN, EPI_PLAIN); else FZ_STR(1, 4, LOAD_PLAIN, EPI_PLAIN); }
-  else if (nacc == 2) FZ_STR(1, 2, LOAD_PLAIN, EPI_PLAIN);
-  else FZ_STR(1, 1, LOAD_PLAIN, EPI_PLAIN);
+#define FZ_STR(MB, NA, L, E, BM) hipLaunchKernelGGL((gemm_stream_kernel<MB, NA, L, E, BM>), grid, block, 0, st, a)
+  if (d->loader == LOAD_S2D) { FZ_STR(1, 2, LOAD_S2D, EPI_PLAIN, false); }
+  else if (d->loader == LOAD_K3) { if (MBsel == 2) FZ_STR(2, 4, LOAD_K3, EPI_PLAIN, false); else FZ_STR(1, 4, LOAD_K3, EPI_PLAIN, false); }
+  else if (d->epilogue == EPI_D2S) {
+    if (d->bmul) return fail(FZ_E_UNSUPPORTED, "fz_gemm: bmul with depth-to-space epilogue");
+    if (MBsel == 2) FZ_STR(2, 4, LOAD_PLAIN, EPI_D2S, false); else FZ_STR(1, 4, LOAD_PLAIN, EPI_D2S, false);
+  } else if (d->bmul) {
+    if (nacc == 4) { if (MBsel == 2) FZ_STR(2, 4, LOAD_PLAIN, EPI_PLAIN, true); else FZ_STR(1, 4, LOAD_PLAIN, EPI_PLAIN, true); }
+    else if (nacc == 2) FZ_STR(1, 2, LOAD_PLAIN, EPI_PLAIN, true);
+    else FZ_STR(1, 1, LOAD_PLAIN, EPI_PLAIN, true);
+  } else {
+    if (nacc == 4) { if (MBsel == 2) FZ_STR(2, 4, LOAD_PLAIN, EPI_PLAIN, false); else FZ_STR(1, 4, LOAD_PLAIN, EPI_PLAIN, false); }
+    else if (nacc == 2) FZ_STR(1, 2, LOAD_PLAIN, EPI_PLAIN, false);
+    else FZ_STR(1, 1, LOAD_PLAIN, EPI_PLAIN, false);
+  }
   FZ_LAUNCH_CHECK();
   return FZ_OK;
 }
