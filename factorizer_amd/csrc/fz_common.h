@@ -36,6 +36,17 @@ inline int fail(int code, const char* msg) {
   } while (0)
 
 #if defined(__HIPCC__)
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7): branch-free, 1 rcp + 1 exp + 5 fma —
+// the libm erff costs ~4x more VALU and carries a branch per element.  Used for the exact-erf
+// GELU of the MLP (layers/mlp.py:56); the 1e-4 parity budget dwarfs its error.
+__device__ __forceinline__ float fast_erf(float x) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float r = 1.0f - poly * __expf(-ax * ax);
+  return x < 0.f ? -r : r;
+}
+
 // ---- wave64 all-lanes sum on the DPP network (no LDS traffic) ----------------------------
 // xor-1, xor-2 (quad_perm), half-mirror, mirror give every lane its 16-lane row total;
 // row_bcast15/31 fold the four rows into lane 63; readlane makes it a scalar.

@@ -46,9 +46,9 @@ struct WgradArgs {
 constexpr int kTile = 32;       // voxels per staged tile
 constexpr int kStride = 33;     // LDS row stride (floats)
 
-__device__ __forceinline__ float gelu_w(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_w(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_grad_w(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float cdf = 0.5f * (1.0f + fast_erf(x * 0.70710678118654752f));
   return cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }
 
@@ -81,85 +81,112 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 
   const int c = lane & 31, h = lane >> 5;
 
+  // Staging is BRANCH-FREE (clamped addresses + selects) so that the global loads of a tile are
+  // issued back to back; for the plain loaders the next tile's loads are issued BEFORE the MFMA
+  // loop of the current tile and land in registers while the matrix cores run.
+  constexpr int NP = PR * 8 / 64;  // 16-byte chunks per lane for the P tile
+  constexpr int NQ = QR * 8 / 64;  // ... for a plain Q tile
+  const int cq = lane & 7;          // column chunk of this lane (same for every chunk it stages)
+  const int r0 = lane >> 3;         // first row of this lane; chunk i covers row r0 + 8*i
+  float4 pv[NP], qv[NQ], mu4, rs4;
+
+  auto issue_loads = [&](int64_t t) {
+    const int b = (int)(t / tiles_per_sample);
+    const int64_t n = (t % tiles_per_sample) * kTile + cq * 4;
+    const int64_t nc = n < a.N ? n : 0;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int m = m0 + r0 + 8 * i;
+      const int mc = m < a.M ? m : a.M - 1;
+      pv[i] = *reinterpret_cast<const float4*>(a.p + ((int64_t)b * a.M + mc) * a.N + nc);
+    }
+    if (QL == QL_PLAIN) {
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
+        const int k = k0 + r0 + 8 * i;
+        const int kc = k < a.K ? k : a.K - 1;
+        const bool first = kc < a.c0;
+        const float* base = first ? a.q[0] : a.q[1];
+        const int cs = first ? a.c0 : a.Cin - a.c0;
+        const int ci = first ? kc : kc - a.c0;
+        qv[i] = *reinterpret_cast<const float4*>(base + ((int64_t)b * cs + ci) * a.Vq + nc);
+      }
+      const float* st = (a.stats ? a.stats : a.q[0]) + (a.stats ? (int64_t)b * 2 * a.Vq : 0);
+      mu4 = *reinterpret_cast<const float4*>(st + nc);
+      rs4 = *reinterpret_cast<const float4*>(st + (a.stats ? a.Vq : 0) + nc);
+    }
+  };
+
+  auto commit_tiles = [&](int64_t t) {
+    const int64_t n = (t % tiles_per_sample) * kTile + cq * 4;
+    const bool nok = n < a.N;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int r = r0 + 8 * i;
+      const bool ok = nok && (m0 + r) < a.M;
+      float* d = Pt + r * kStride + cq * 4;
+      d[0] = ok ? pv[i].x : 0.f; d[1] = ok ? pv[i].y : 0.f; d[2] = ok ? pv[i].z : 0.f; d[3] = ok ? pv[i].w : 0.f;
+    }
+    if (QL == QL_PLAIN) {
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
+        const int r = r0 + 8 * i;
+        const bool ok = nok && (k0 + r) < a.K;
+        float v[4] = {qv[i].x, qv[i].y, qv[i].z, qv[i].w};
+        if (a.stats) {
+          v[0] = (v[0] - mu4.x) * rs4.x; v[1] = (v[1] - mu4.y) * rs4.y;
+          v[2] = (v[2] - mu4.z) * rs4.z; v[3] = (v[3] - mu4.w) * rs4.w;
+        }
+        if (a.qact == 2) { v[0] = gelu_w(v[0]); v[1] = gelu_w(v[1]); v[2] = gelu_w(v[2]); v[3] = gelu_w(v[3]); }
+        else if (a.qact == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        float* d = Qt + r * kStride + cq * 4;
+        d[0] = ok ? v[0] : 0.f; d[1] = ok ? v[1] : 0.f; d[2] = ok ? v[2] : 0.f; d[3] = ok ? v[3] : 0.f;
+      }
+    }
+  };
+
+  if (t_begin < t_end) issue_loads(t_begin);
   for (int64_t t = t_begin; t < t_end; ++t) {
     const int b = (int)(t / tiles_per_sample);
     const int64_t n0 = (t % tiles_per_sample) * kTile;
-    // ---- stage P tile: rows m0..m0+PR, columns n0..n0+31 (8 x 16-byte chunks per row) ----
-    for (int idx = lane; idx < PR * 8; idx += 64) {
-      const int r = idx >> 3, cq = idx & 7;
-      const int m = m0 + r;
+    // ---- P (and plain Q) tiles: registers -> LDS ----
+    if (a.pmul) {
+      // ReLU / GELU' gate of the output-side gradient (modular path only)
       const int64_t n = n0 + cq * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < a.M && n < a.N) {
-        const int64_t o = ((int64_t)b * a.M + m) * a.N + n;
-        v = *reinterpret_cast<const float4*>(a.p + o);
-        if (a.pmul) {
-          const float4 e = *reinterpret_cast<const float4*>(a.pmul + o);
-          if (a.pmul_kind == 2) { v.x *= gelu_grad_w(e.x); v.y *= gelu_grad_w(e.y); v.z *= gelu_grad_w(e.z); v.w *= gelu_grad_w(e.w); }
-          else { v.x = e.x > 0.f ? v.x : 0.f; v.y = e.y > 0.f ? v.y : 0.f; v.z = e.z > 0.f ? v.z : 0.f; v.w = e.w > 0.f ? v.w : 0.f; }
-        }
+      const int64_t nc = n < a.N ? n : 0;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int m = m0 + r0 + 8 * i;
+        const int mc = m < a.M ? m : a.M - 1;
+        const float4 e = *reinterpret_cast<const float4*>(a.pmul + ((int64_t)b * a.M + mc) * a.N + nc);
+        if (a.pmul_kind == 2) { pv[i].x *= gelu_grad_w(e.x); pv[i].y *= gelu_grad_w(e.y); pv[i].z *= gelu_grad_w(e.z); pv[i].w *= gelu_grad_w(e.w); }
+        else { pv[i].x = e.x > 0.f ? pv[i].x : 0.f; pv[i].y = e.y > 0.f ? pv[i].y : 0.f; pv[i].z = e.z > 0.f ? pv[i].z : 0.f; pv[i].w = e.w > 0.f ? pv[i].w : 0.f; }
       }
-      float* d = Pt + r * kStride + cq * 4;
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
-    // ---- stage Q tile ----
-    if (QL == QL_PLAIN) {
-      for (int idx = lane; idx < QR * 8; idx += 64) {
-        const int r = idx >> 3, cq = idx & 7;
-        const int k = k0 + r;
-        const int64_t n = n0 + cq * 4;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (k < a.K && n < a.N) {
-          if (a.src_mode == 0) {
-            const float* src = (k < a.c0) ? a.q[0] + ((int64_t)b * a.c0 + k) * a.Vq
-                                          : a.q[1] + ((int64_t)b * (a.Cin - a.c0) + (k - a.c0)) * a.Vq;
-            const float4 t4 = *reinterpret_cast<const float4*>(src + n);
-            v[0] = t4.x; v[1] = t4.y; v[2] = t4.z; v[3] = t4.w;
-          } else {
-            const int64_t o = ((int64_t)b * a.Cin + k) * a.Vq + n;
-            float4 t4 = *reinterpret_cast<const float4*>(a.q[0] + o);
-            v[0] = 0.0f + t4.x; v[1] = 0.0f + t4.y; v[2] = 0.0f + t4.z; v[3] = 0.0f + t4.w;
-            for (int i = 1; i < a.nsrc; ++i) {
-              t4 = *reinterpret_cast<const float4*>(a.q[i] + o);
-              v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w;
-            }
-            const float nw = (float)a.nsrc;
-            v[0] /= nw; v[1] /= nw; v[2] /= nw; v[3] /= nw;
-          }
-          if (a.stats) {
-            const float* st = a.stats + (int64_t)b * 2 * a.Vq;
-            const float4 mu = *reinterpret_cast<const float4*>(st + n);
-            const float4 rs = *reinterpret_cast<const float4*>(st + a.Vq + n);
-            v[0] = (v[0] - mu.x) * rs.x; v[1] = (v[1] - mu.y) * rs.y;
-            v[2] = (v[2] - mu.z) * rs.z; v[3] = (v[3] - mu.w) * rs.w;
-          }
-          if (a.qact == 2) { v[0] = gelu_w(v[0]); v[1] = gelu_w(v[1]); v[2] = gelu_w(v[2]); v[3] = gelu_w(v[3]); }
-          else if (a.qact == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-        }
-        float* d = Qt + r * kStride + cq * 4;
-        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
-      }
-    } else if (QL == QL_S2D) {
+    commit_tiles(t);
+    if (QL == QL_S2D) {
       // rows k = (ci, td, th, tw); one 16-byte load gives (tw0,tw1) of two coarse voxels
-      for (int idx = lane; idx < (QR / 2) * 16; idx += 64) {
+#pragma unroll
+      for (int i = 0; i < (QR / 2) * 16 / 64; ++i) {
+        const int idx = lane + 64 * i;
         const int rp = idx >> 4, cp = idx & 15;      // row pair (tw = 0/1), coarse column pair
         const int k = k0 + 2 * rp;                     // tw = 0 row
         const int64_t n = n0 + 2 * cp;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < a.K && n < a.N) {
-          const int ci = k >> 3, td = (k >> 2) & 1, th = (k >> 1) & 1;
-          const int wo = (int)(n % a.Wo);
-          const int64_t t2 = n / a.Wo;
-          const int ho = (int)(t2 % a.Ho);
-          const int dz = (int)(t2 / a.Ho);
-          const int64_t fo = ((int64_t)(2 * dz + td) * a.H + (2 * ho + th)) * a.W + 2 * wo;
-          v = *reinterpret_cast<const float4*>(a.q[0] + ((int64_t)b * a.Cin + ci) * a.Vq + fo);
-        }
+        const bool ok = k < a.K && n < a.N;
+        const int kc = k < a.K ? k : 0;
+        const int64_t nn = n < a.N ? n : 0;
+        const int ci = kc >> 3, td = (kc >> 2) & 1, th = (kc >> 1) & 1;
+        const int wo = (int)(nn % a.Wo);
+        const int64_t t2 = nn / a.Wo;
+        const int ho = (int)(t2 % a.Ho);
+        const int dz = (int)(t2 / a.Ho);
+        const int64_t fo = ((int64_t)(2 * dz + td) * a.H + (2 * ho + th)) * a.W + 2 * wo;
+        const float4 v = *reinterpret_cast<const float4*>(a.q[0] + ((int64_t)b * a.Cin + ci) * a.Vq + fo);
         float* d0 = Qt + (2 * rp) * kStride + 2 * cp;
         float* d1 = d0 + kStride;
-        d0[0] = v.x; d1[0] = v.y; d0[1] = v.z; d1[1] = v.w;
+        d0[0] = ok ? v.x : 0.f; d1[0] = ok ? v.y : 0.f; d0[1] = ok ? v.z : 0.f; d1[1] = ok ? v.w : 0.f;
       }
-    } else {
+    } else if (QL == QL_K3) {
       // QL_K3: rows k = ci*27 + (kd*9 + kh*3 + kw); zero padding 1.  Lane = (column, row parity):
       // the voxel coordinates are decoded once per tile, the tap once per (uniform) row.
       const int col = lane & 31;
@@ -169,19 +196,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
       const int64_t t2 = (nok ? n : 0) / a.W;
       const int hh = (int)(t2 % a.H);
       const int dz = (int)(t2 / a.H);
+#pragma unroll 8
       for (int r = lane >> 5; r < QR; r += 2) {
         const int k = k0 + r;
-        float v = 0.f;
-        if (k < a.K && nok) {
-          const int ci = k / 27, tap = k % 27;
-          const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-          const int zd = dz + kd - 1, zh = hh + kh - 1, zw = w + kw - 1;
-          if (zd >= 0 && zd < a.D && zh >= 0 && zh < a.H && zw >= 0 && zw < a.W)
-            v = a.q[0][((int64_t)b * a.Cin + ci) * a.Vq + ((int64_t)zd * a.H + zh) * a.W + zw];
-        }
-        Qt[r * kStride + col] = v;
+        const int kc = k < a.K ? k : 0;
+        const int ci = kc / 27, tap = kc % 27;
+        const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+        const int zd = dz + kd - 1, zh = hh + kh - 1, zw = w + kw - 1;
+        const bool ok = nok && k < a.K && zd >= 0 && zd < a.D && zh >= 0 && zh < a.H && zw >= 0 && zw < a.W;
+        const int zdc = min(max(zd, 0), a.D - 1), zhc = min(max(zh, 0), a.H - 1), zwc = min(max(zw, 0), a.W - 1);
+        const float v = a.q[0][((int64_t)b * a.Cin + ci) * a.Vq + ((int64_t)zdc * a.H + zhc) * a.W + zwc];
+        Qt[r * kStride + col] = ok ? v : 0.f;
       }
     }
+    if (t + 1 < t_end) issue_loads(t + 1);  // in flight during the MFMA loop below
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     // ---- 16 K-steps of 2 voxels ----
 #pragma unroll 4
