@@ -75,6 +75,15 @@ class FactorizerBlock(nn.Module):
         live = self.training and (f.dropout.p > 0 or blk[2].p > 0 or blk[4].p > 0)
         return not live
 
+    def _modular_native_cfg(self, x) -> bool:
+        """matricize / NMF / inverse all covered by the native modular kernels (any patch size)."""
+        f = self.fact
+        mf = f.factorize
+        if not (isinstance(f.reshape, SWMatricize) and isinstance(mf, MatrixFactorization)):
+            return False
+        t_like = x.new_empty((1, *f.reshape.output_size[1:]))
+        return mf._native_solver(t_like) is not None and len(f.reshape.geometry.spatial) <= 3
+
     def _core_cfg(self):
         """(grad steps, solver id) if matricize→NMF→inverse can run as the fused channels-first
         kernels (SWMatricize head_dim 8 / patch 8³, native MU/HALS, rank ≤ 2), else None."""
@@ -95,17 +104,23 @@ class FactorizerBlock(nn.Module):
             f, blk = self.fact, self.mlp.block
             n1, n2 = self.norm1.norm, self.norm2.norm
             core = self._core_cfg()
-            if core is not None:
-                # matricize → NMF → inverse as one kernel per window on the channels-first tensor
-                t = PW.ln_linear(x, n1.weight, n1.bias, n1.eps, f.in_proj.linear.weight, f.in_proj.linear.bias,
-                                 "relu_out")
-                mf = f.factorize
-                a = Fn.FactCoreFn.apply(t, mf.init.u0, mf.init.v0, f.reshape.geometry, mf.num_iters, core[0],
-                                        core[1], mf.solver.eps, True)
-            else:
-                t = PW.ln_linear(x, n1.weight, n1.bias, n1.eps, f.in_proj.linear.weight, f.in_proj.linear.bias,
-                                 "relu")
-                a = f.reshape.inverse_forward(f.factorize(f.reshape(t)))  # ReLU already applied (commutes)
+            mf = f.factorize
+            nat = core is not None or self._modular_native_cfg(x)
+            if nat and f.in_proj.linear.bias is None and blk[0].linear.bias is not None \
+                    and blk[3].linear.bias is not None and f.out_proj.linear.bias is not None:
+                if core is not None:
+                    G, sid = core
+                else:
+                    G, sid = min(max(mf.num_grad_steps, 0), mf.num_iters), mf.solver.native_id
+                cfg = dict(geo=f.reshape.geometry, T=mf.num_iters, G=G, solver=sid, nmf_eps=mf.solver.eps,
+                           eps1=n1.eps, eps2=n2.eps, core=core is not None)
+                return PW.FactorizerBlockFn.apply(
+                    x, n1.weight, n1.bias, f.in_proj.linear.weight, mf.init.u0, mf.init.v0,
+                    f.out_proj.linear.weight, f.out_proj.linear.bias, n2.weight, n2.bias,
+                    blk[0].linear.weight, blk[0].linear.bias, blk[3].linear.weight, blk[3].linear.bias, cfg)
+            # per-layer fused path (composed NMF, unusual bias layout, ...)
+            t = PW.ln_linear(x, n1.weight, n1.bias, n1.eps, f.in_proj.linear.weight, f.in_proj.linear.bias, "relu")
+            a = f.reshape.inverse_forward(f.factorize(f.reshape(t)))  # ReLU already applied (commutes)
             x = PW.act_linear_res(a, f.out_proj.linear.weight, f.out_proj.linear.bias, x, "none")
             z = PW.ln_linear(x, n2.weight, n2.bias, n2.eps, blk[0].linear.weight, blk[0].linear.bias, "none")
             return PW.act_linear_res(z, blk[3].linear.weight, blk[3].linear.bias, x, "gelu")

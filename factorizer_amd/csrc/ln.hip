@@ -135,6 +135,59 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ g
   }
 }
 
+// Channel-parallel backward for wide, short tensors (C > 64: the 8^3..32^3 stages): one
+// workgroup per 4-voxel quad, threads stride over channels, block reduction of the two means.
+__global__ __launch_bounds__(256) void ln_bwd_cpar_kernel(const float* __restrict__ gl, const float* __restrict__ x,
+                                                          const float* __restrict__ stats,
+                                                          const float* __restrict__ g, const float* __restrict__ gadd,
+                                                          float* __restrict__ gx, int B, int C, int64_t V) {
+  __shared__ float red[4][8];
+  const int64_t nvec = V / 4;
+  const int64_t i = blockIdx.x;
+  const int b = (int)(i / nvec);
+  const int64_t v = (i % nvec) * 4;
+  const int64_t base = (int64_t)b * C * V + v;
+  const float* sp = stats + (int64_t)b * 2 * V + v;
+  const float4 mu = *reinterpret_cast<const float4*>(sp);
+  const float4 rs = *reinterpret_cast<const float4*>(sp + V);
+  float m[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float4 t = *reinterpret_cast<const float4*>(x + base + (int64_t)c * V);
+    const float4 d = *reinterpret_cast<const float4*>(gl + base + (int64_t)c * V);
+    const float gc = g[c];
+    const float ax = d.x * gc, ay = d.y * gc, az = d.z * gc, aw = d.w * gc;
+    m[0] += ax; m[1] += ay; m[2] += az; m[3] += aw;
+    m[4] += ax * (t.x - mu.x) * rs.x; m[5] += ay * (t.y - mu.y) * rs.y;
+    m[6] += az * (t.z - mu.z) * rs.z; m[7] += aw * (t.w - mu.w) * rs.w;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float sres = wave_sum(m[e]);
+    if (lane == 0) red[wave][e] = sres;
+  }
+  __syncthreads();
+  const float inv = 1.0f / (float)C;
+  float mm[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) mm[e] = ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])) * inv;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float4 t = *reinterpret_cast<const float4*>(x + base + (int64_t)c * V);
+    const float4 d = *reinterpret_cast<const float4*>(gl + base + (int64_t)c * V);
+    const float gc = g[c];
+    float4 o;
+    o.x = rs.x * (d.x * gc - mm[0] - (t.x - mu.x) * rs.x * mm[4]);
+    o.y = rs.y * (d.y * gc - mm[1] - (t.y - mu.y) * rs.y * mm[5]);
+    o.z = rs.z * (d.z * gc - mm[2] - (t.z - mu.z) * rs.z * mm[6]);
+    o.w = rs.w * (d.w * gc - mm[3] - (t.w - mu.w) * rs.w * mm[7]);
+    if (gadd != nullptr) {
+      const float4 r = *reinterpret_cast<const float4*>(gadd + base + (int64_t)c * V);
+      o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+    }
+    *reinterpret_cast<float4*>(gx + base + (int64_t)c * V) = o;
+  }
+}
+
 // out[e] = Σ_blk part[blk][e], fixed order (same scheme as wgrad's chunk reduce)
 __global__ __launch_bounds__(256) void ln_part_reduce_kernel(const float* __restrict__ part, int nblk, int n,
                                                              float* __restrict__ out) {
@@ -202,8 +255,13 @@ extern "C" int fz_ln_bwd(const float* gl, const float* x, const float* stats, co
     FZ_LAUNCH_CHECK();
     return FZ_OK;
   }
-  hipLaunchKernelGGL(ln_bwd_kernel<0>, dim3(grid), dim3(256), 0, st, gl, x, stats, gamma, gadd, gx, (float*)nullptr,
-                     B, C, V);
+  if (C > 64 && (V / 4) * B <= 65536) {
+    hipLaunchKernelGGL(ln_bwd_cpar_kernel, dim3((unsigned)((V / 4) * B)), dim3(256), 0, st, gl, x, stats, gamma, gadd,
+                       gx, B, C, V);
+  } else {
+    hipLaunchKernelGGL(ln_bwd_kernel<0>, dim3(grid), dim3(256), 0, st, gl, x, stats, gamma, gadd, gx,
+                       (float*)nullptr, B, C, V);
+  }
   FZ_LAUNCH_CHECK();
   return FZ_OK;
 }

@@ -86,7 +86,7 @@ def _wgrad(p, qs, gw, *, B, M, Cin, K, Vq, Ncols, gbias=None, pmul=None, pmul_ki
     return gw
 
 
-def _ln_backward(gl, x, stats, ln_w):
+def _ln_backward(gl, x, stats, ln_w, gadd=None):
     """LayerNorm backward: (gx, gγ, gβ).  C <= 64: one pass produces all three; larger C (the
     small deep stages): gx from the elementwise kernel, gγ/gβ as diag / row sums of a wgrad."""
     B, C = x.shape[:2]
@@ -98,7 +98,7 @@ def _ln_backward(gl, x, stats, ln_w):
         if fused else None
     with torch.cuda.device(x.device):
         rc = Fn._timed(f"ln_bwd_{C}", 3 * 4 * x.numel(), lambda: N.lib().fz_ln_bwd(
-            gl.data_ptr(), x.data_ptr(), stats.data_ptr(), ln_w.data_ptr(), None, gx.data_ptr(), _p(gpar), _p(ws),
+            gl.data_ptr(), x.data_ptr(), stats.data_ptr(), ln_w.data_ptr(), _p(gadd), gx.data_ptr(), _p(gpar), _p(ws),
             B, C, V, N.stream_ptr(x)))
     N.check(rc, "fz_ln_bwd")
     if fused:
@@ -414,3 +414,120 @@ def cat_linear(x1, x2, w, b=None):
     if _native_ok(x1, x2, w, b) and x1.shape[1] % 2 == 0 and x2.shape[1] % 2 == 0:
         return CatLinearFn.apply(x1, x2, w, b)
     return linear_cf(torch.cat([x1, x2], dim=1), w, b)
+
+
+# ---- whole FactorizerBlock as ONE autograd node ------------------------------------------------------
+class FactorizerBlockFn(torch.autograd.Function):
+    """x → x + out_proj(core(relu(in_proj(LN1(x))))) → (+ MLP(LN2(·)))  (factorizer.py:74-77) with a
+    hand-chained backward: both residual-gradient additions are fused into the LayerNorm-backward
+    kernels (`gadd`), nothing but the tensors listed in `save_for_backward` survives the forward.
+
+    core = matricize → NMF → inverse: the fused channels-first kernels (csrc/nmf_cf.hip) when
+    `cfg["core"]`, else the native modular chain swm_fwd → nmf → swm_inv."""
+
+    @staticmethod
+    def forward(ctx, x, n1w, n1b, win, u0, v0, wout, bout, n2w, n2b, w1, b1, w2, b2, cfg):
+        x = x.contiguous()
+        B, C = x.shape[:2]
+        V = _vox(x)
+        sp = x.shape[2:]
+        geo, T, G, solver, neps = cfg["geo"], cfg["T"], cfg["G"], cfg["solver"], cfg["nmf_eps"]
+        win2, wout2 = win.reshape(C, C), wout.reshape(C, C)
+        Hd = w1.shape[0]
+        w12, w22 = w1.reshape(Hd, C), w2.reshape(C, Hd)
+        u0c, v0c = u0.contiguous(), v0.contiguous()
+        new = lambda ch: torch.empty((B, ch, *sp), dtype=x.dtype, device=x.device)  # noqa: E731
+        # 1. t = relu(in_proj(LN1(x)))
+        t = new(C)
+        st1 = torch.empty((B, 2, V), dtype=x.dtype, device=x.device)
+        _gemm([x], win2, t, B=B, Cin=C, Vin=V, M=C, K=C, Ncol=V, ln=(n1w, n1b, cfg["eps1"]), stats_out=st1,
+              eact=ACT["relu"], name="ln_linear")
+        # 2. a = inverse(NMF(matricize(t)))
+        m = None
+        if cfg["core"]:
+            a = Fn.FactCoreFn.forward(_Ctx(), t, u0c, v0c, geo, T, G, solver, neps, True)
+        else:
+            m = Fn._swm_fwd_raw(t, geo)
+            ym, _, _ = Fn._nmf_fwd_raw(m, u0c, v0c, T, solver, neps)
+            a = Fn._swm_inv_raw(ym, geo, average=True)
+            del ym
+        # 3. x1 = x + out_proj(a)
+        x1 = new(C)
+        _gemm([a], wout2, x1, B=B, Cin=C, Vin=V, M=C, K=C, Ncol=V, bias=bout, res=x, name="act_linear_res")
+        # 4. z1 = fc1(LN2(x1)) ; x2 = x1 + fc2(gelu(z1))
+        z1 = new(Hd)
+        st2 = torch.empty((B, 2, V), dtype=x.dtype, device=x.device)
+        _gemm([x1], w12, z1, B=B, Cin=C, Vin=V, M=Hd, K=C, Ncol=V, bias=b1, ln=(n2w, n2b, cfg["eps2"]),
+              stats_out=st2, name="ln_linear")
+        x2 = new(C)
+        _gemm([z1], w22, x2, B=B, Cin=Hd, Vin=V, M=C, K=Hd, Ncol=V, bias=b2, bact=ACT["gelu"], res=x1,
+              name="act_linear_res")
+        ctx.save_for_backward(x, st1, t, a, x1, st2, z1, m, n1w, n1b, win2, u0c, v0c, wout2, n2w, n2b, w12, w22)
+        ctx.cfg = cfg
+        ctx.shapes = (win.shape, wout.shape, w1.shape, w2.shape)
+        return x2
+
+    @staticmethod
+    def backward(ctx, g2):
+        x, st1, t, a, x1, st2, z1, m, n1w, n1b, win2, u0c, v0c, wout2, n2w, n2b, w12, w22 = ctx.saved_tensors
+        cfg = ctx.cfg
+        g2 = g2.contiguous()
+        B, C = x.shape[:2]
+        V = _vox(x)
+        Hd = w12.shape[0]
+        dev, dt = x.device, x.dtype
+        geo, T, G, solver, neps = cfg["geo"], cfg["T"], cfg["G"], cfg["solver"], cfg["nmf_eps"]
+        # --- MLP ---
+        gz1 = torch.empty_like(z1)
+        _gemm([g2], w22, gz1, B=B, Cin=C, Vin=V, M=Hd, K=C, Ncol=V, w_t=True, ldw=Hd, emul=z1,
+              emul_kind=ACT["gelu"], name="linear_dgrad")
+        gw2 = torch.empty_like(w22)
+        gb2 = torch.empty(C, dtype=dt, device=dev)
+        _wgrad(g2, [z1], gw2, B=B, M=C, Cin=Hd, K=Hd, Vq=V, Ncols=V, gbias=gb2, qact=ACT["gelu"], name="wgrad_linear")
+        gl2 = torch.empty_like(x1)
+        _gemm([gz1], w12, gl2, B=B, Cin=Hd, Vin=V, M=C, K=Hd, Ncol=V, w_t=True, ldw=C, name="linear_dgrad")
+        gx1, gg2, gbt2 = _ln_backward(gl2, x1, st2, n2w, gadd=g2)      # + residual path of the MLP
+        gw1 = torch.empty_like(w12)
+        gb1 = torch.empty(Hd, dtype=dt, device=dev)
+        _wgrad(gz1, [x1], gw1, B=B, M=Hd, Cin=C, K=C, Vq=V, Ncols=V, gbias=gb1, stats=st2, ln=(n2w, n2b),
+               name="wgrad_ln_linear")
+        del gz1, gl2
+        # --- out_proj ---
+        ga = torch.empty_like(a)
+        _gemm([gx1], wout2, ga, B=B, Cin=C, Vin=V, M=C, K=C, Ncol=V, w_t=True, ldw=C, name="linear_dgrad")
+        gwo = torch.empty_like(wout2)
+        gbo = torch.empty(C, dtype=dt, device=dev)
+        _wgrad(gx1, [a], gwo, B=B, M=C, Cin=C, K=C, Vq=V, Ncols=V, gbias=gbo, name="wgrad_linear")
+        # --- core (gradient arrives gated by [t > 0]) ---
+        if G <= 0:
+            gt = torch.zeros_like(t)
+        elif cfg["core"]:
+            c2 = _Ctx()
+            c2.saved_tensors = (t, u0c, v0c)
+            c2.cfg = (geo, T, G, solver, neps, True)
+            gt = Fn.FactCoreFn.backward(c2, ga)[0]
+        else:
+            gym = Fn._swm_fwd_raw(ga, geo, div=geo.nshift)
+            gm = Fn._nmf_bwd_raw(m, u0c, v0c, gym, None, None, T, G, solver, neps)
+            del gym
+            gt = Fn._swm_inv_raw(gm, geo, average=False, gate=m)
+            del gm
+        del ga
+        # --- in_proj + LN1 ---
+        gl1 = torch.empty_like(x)
+        _gemm([gt], win2, gl1, B=B, Cin=C, Vin=V, M=C, K=C, Ncol=V, w_t=True, ldw=C, name="linear_dgrad")
+        gx, gg1, gbt1 = _ln_backward(gl1, x, st1, n1w, gadd=gx1)        # + residual path of the mixer
+        gwi = torch.empty_like(win2)
+        _wgrad(gt, [x], gwi, B=B, M=C, Cin=C, K=C, Vq=V, Ncols=V, stats=st1, ln=(n1w, n1b), name="wgrad_ln_linear")
+        s_in, s_out, s_1, s_2 = ctx.shapes
+        return (gx, gg1, gbt1, gwi.reshape(s_in), None, None, gwo.reshape(s_out), gbo, gg2, gbt2,
+                gw1.reshape(s_1), gb1, gw2.reshape(s_2), gb2, None)
+
+
+class _Ctx:
+    """Minimal stand-in for an autograd ctx when a Function's forward/backward is called directly."""
+
+    saved_tensors = ()
+
+    def save_for_backward(self, *ts):
+        self.saved_tensors = ts
