@@ -97,7 +97,8 @@ class GemmDesc(_c.Structure):
                 ("Di", _i), ("Hi", _i), ("Wi", _i), ("w", _vp), ("w_t", _i), ("ldw", _i), ("M", _i), ("K", _i),
                 ("bias", _vp), ("ln", _i), ("ln_g", _vp), ("ln_b", _vp), ("ln_eps", _f), ("stats_out", _vp),
                 ("bact", _i), ("bmul", _vp), ("bmul_kind", _i), ("eact", _i), ("res", _vp), ("emul", _vp), ("emul_kind", _i), ("y", _vp),
-                ("Ncol", _i64), ("Ho", _i), ("Wo", _i), ("B", _i), ("loader", _i), ("epilogue", _i)]
+                ("Ncol", _i64), ("Ho", _i), ("Wo", _i), ("B", _i), ("loader", _i), ("epilogue", _i), ("lnb_x", _vp), ("lnb_stats", _vp), ("lnb_g", _vp),
+                ("lnb_gadd", _vp), ("lnb_part", _vp)]
 
 
 class WgradDesc(_c.Structure):
@@ -112,6 +113,8 @@ _SIGS.update({
     "fz_nmf_cf_fwd": ([_vp] * 4 + [_i] * 5 + [_c.POINTER(_i)] + [_i] * 5 + [_f, _vp], _i),
     "fz_nmf_cf_bwd": ([_vp] * 5 + [_i] * 5 + [_c.POINTER(_i)] + [_i] * 7 + [_f, _vp], _i),
     "fz_gemm": ([_c.POINTER(GemmDesc), _vp], _i),
+    "fz_gemm_lnbwd_partials": ([_c.POINTER(GemmDesc)], _i64),
+    "fz_reduce_rows": ([_vp, _i64, _i, _vp, _vp], _i),
     "fz_wgrad": ([_c.POINTER(WgradDesc), _vp, _vp], _i),
     "fz_wgrad_workspace_bytes": ([_c.POINTER(WgradDesc)], _i64),
     "fz_ln_fwd": ([_vp] * 5 + [_i, _i, _i64, _f, _vp], _i),

@@ -26,7 +26,7 @@ namespace fz {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 enum { LOAD_PLAIN = 0, LOAD_S2D = 1, LOAD_K3 = 2 };
-enum { EPI_PLAIN = 0, EPI_D2S = 1 };
+enum { EPI_PLAIN = 0, EPI_D2S = 1, EPI_LNBWD = 2 };
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
 
 struct GemmArgs {
@@ -57,6 +57,13 @@ struct GemmArgs {
   int64_t Ncol;        // columns per sample (= Vin for LOAD_PLAIN, coarse voxels for LOAD_S2D)
   int Ho, Wo;          // coarse H, W (LOAD_S2D columns / EPI_D2S input grid)
   int B;
+  // EPI_LNBWD (M == 32): the result is gl = dL/d(LN output); the epilogue applies the LayerNorm
+  // backward in registers: y = rstd*(gl*g - mean_c(gl*g) - n*mean_c(gl*g*n)) + lnb_gadd
+  const float* lnb_x;      // (B, 32, V) LayerNorm input
+  const float* lnb_stats;  // (B, 2, V) mean, rstd
+  const float* lnb_g;      // (32) gamma
+  const float* lnb_gadd;   // (B, 32, V) gradient added to the result, or null
+  float* lnb_part;         // [gridDim.x][64] per-workgroup partial (gγ | gβ) sums
 };
 
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f)); }
@@ -211,6 +218,93 @@ __device__ __forceinline__ void store_block(const GemmArgs& p, const f32x16 (&ac
   }
 }
 
+// ---- LayerNorm-backward epilogue (M == 32, one row block) ------------------------------------------
+// acc[q][r] = gl[row (r,h)][voxel 4j+q].  Everything stays in registers: the channel means are
+// sums over the 16 registers + the other lane half; the affine gradients are reduced over the
+// 32 lanes of each half on the DPP network, then over the 4 waves through LDS.
+__device__ __forceinline__ float half_sum32(float v) {
+  v += dpp_take<0xB1, 0xf>(v);   // xor 1
+  v += dpp_take<0x4E, 0xf>(v);   // xor 2
+  v += dpp_take<0x141, 0xf>(v);  // row_half_mirror
+  v += dpp_take<0x140, 0xf>(v);  // row_mirror  -> 16-lane row totals in every lane
+  v += dpp_take<0x142, 0xa>(v);  // row_bcast15: rows 1,3 += rows 0,2  -> lanes 16-31 / 48-63 hold the half totals
+  return v;
+}
+
+__device__ __forceinline__ void lnbwd_block(const GemmArgs& p, const f32x16 (&acc)[4], int b, int64_t ncol,
+                                            bool col_ok, int lane, int wave, float* red /* [4][64] */) {
+  const int h = lane >> 5;
+  const int64_t nc = col_ok ? ncol : 0;
+  const float* sp = p.lnb_stats + (int64_t)b * 2 * p.Ncol;
+  const float4 mu4 = *reinterpret_cast<const float4*>(sp + nc);
+  const float4 rs4 = *reinterpret_cast<const float4*>(sp + p.Ncol + nc);
+  const float mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, rs[4] = {rs4.x, rs4.y, rs4.z, rs4.w};
+  __builtin_amdgcn_sched_barrier(0);  // do not hoist the x loads above the MFMA loop (operand regs still live)
+  float xs[16][4];  // LayerNorm input rows of this lane (the only big live array besides acc)
+  float m1[4] = {0.f, 0.f, 0.f, 0.f}, m2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+    const float4 xv = *reinterpret_cast<const float4*>(p.lnb_x + ((int64_t)b * 32 + row) * p.Ncol + nc);
+    xs[r][0] = xv.x; xs[r][1] = xv.y; xs[r][2] = xv.z; xs[r][3] = xv.w;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+    const float gc = p.lnb_g[row];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float av = acc[q][r] * gc;
+      m1[q] += av;
+      m2[q] += av * ((xs[r][q] - mu[q]) * rs[q]);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep rows from interleaving (register pressure)
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    m1[q] = (m1[q] + __shfl_xor(m1[q], 32, 64)) * (1.0f / 32.0f);
+    m2[q] = (m2[q] + __shfl_xor(m2[q], 32, 64)) * (1.0f / 32.0f);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+    const int64_t o = ((int64_t)b * 32 + row) * p.Ncol + nc;
+    const float gc = p.lnb_g[row];
+    float v[4], nhr[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      nhr[q] = (xs[r][q] - mu[q]) * rs[q];
+      v[q] = rs[q] * (acc[q][r] * gc - m1[q] - nhr[q] * m2[q]);
+    }
+    if (p.lnb_gadd != nullptr) {
+      const float4 e = *reinterpret_cast<const float4*>(p.lnb_gadd + o);
+      v[0] += e.x; v[1] += e.y; v[2] += e.z; v[3] += e.w;
+    }
+    if (col_ok) *reinterpret_cast<float4*>(p.y + o) = make_float4(v[0], v[1], v[2], v[3]);
+    // affine-gradient partials of this row over the wave's 128 voxels
+    float sg = 0.f, sb = 0.f;
+    if (col_ok) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        sg += acc[q][r] * nhr[q];
+        sb += acc[q][r];
+      }
+    }
+    sg = half_sum32(sg);
+    sb = half_sum32(sb);
+    if ((lane & 31) == 31) {
+      red[wave * 64 + row] = sg;
+      red[wave * 64 + 32 + row] = sb;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int e = threadIdx.x;
+    p.lnb_part[(int64_t)blockIdx.x * 64 + e] = (red[e] + red[64 + e]) + (red[128 + e] + red[192 + e]);
+  }
+}
+
 // =================================================================================================
 // Kernel A — register-resident operand, K <= 2*NSTEP (the HBM-bound layers, C <= 64).
 // Every lane issues ALL its operand loads up front (NSTEP x 16 B in flight per lane), applies the
@@ -219,7 +313,7 @@ __device__ __forceinline__ void store_block(const GemmArgs& p, const f32x16 (&ac
 // all output rows and 10+ KiB per wave are in flight.
 // =================================================================================================
 template <int NSTEP, int EPI, bool BMUL>
-__global__ __launch_bounds__(256, (NSTEP <= 16 ? 3 : 2)) void gemm_resident_kernel(GemmArgs p, int RB) {
+__global__ __launch_bounds__(256, ((NSTEP <= 16 && EPI != EPI_LNBWD) ? 3 : 2)) void gemm_resident_kernel(GemmArgs p, int RB) {
   extern __shared__ __attribute__((aligned(16))) float lds_a[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, h = lane >> 5;
@@ -319,8 +413,12 @@ __global__ __launch_bounds__(256, (NSTEP <= 16 ? 3 : 2)) void gemm_resident_kern
 
   // NOTE: every lane must stay active through the MFMAs (the A operand lives in all 64 lanes);
   // lanes whose columns fall outside the tensor only skip the stores.
-  for (int rb = 0; rb < RB; ++rb) {
-    if (m0 + rb * 32 >= p.M) break;
+  // EPI_LNBWD is host-checked to M == 32 and K == 2*NSTEP: one row block, no tail guards — this
+  // keeps the register allocation of the (register-heavy) fused epilogue free of dead paths
+  constexpr bool kExact = (EPI == EPI_LNBWD);
+  const int RBn = kExact ? 1 : RB;
+  for (int rb = 0; rb < RBn; ++rb) {
+    if (!kExact && m0 + rb * 32 >= p.M) break;
     f32x16 acc[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -328,13 +426,17 @@ __global__ __launch_bounds__(256, (NSTEP <= 16 ? 3 : 2)) void gemm_resident_kern
       for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) {
-      if (s < nA) {
-        const float av = As[(s * RB + rb) * 64 + lane];
+      if (kExact || s < nA) {
+        const float av = As[(s * RBn + rb) * 64 + lane];
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[s][q], acc[q], 0, 0, 0);
       }
     }
-    if (col_ok) store_block<4, EPI, false>(p, acc, b, m0 + rb * 32, col_off, h, p.ln ? tW + rb * 32 : nullptr);
+    if (EPI == EPI_LNBWD) {
+      lnbwd_block(p, acc, b, col_off, col_ok, lane, wave, tW + 32 * RB);
+    } else {
+      if (col_ok) store_block<4, (EPI == EPI_LNBWD ? EPI_PLAIN : EPI), false>(p, acc, b, m0 + rb * 32, col_off, h, p.ln ? tW + rb * 32 : nullptr);
+    }
   }
 }
 
@@ -599,7 +701,10 @@ extern "C" int fz_gemm(const fz_gemm_desc* d, fz_stream_t stream) {
   if (!d) return fail(FZ_E_ARG, "fz_gemm: null descriptor");
   if (!d->x[0] || !d->w || !d->y) return fail(FZ_E_ARG, "fz_gemm: null pointer");
   if (d->loader < LOAD_PLAIN || d->loader > LOAD_K3) return fail(FZ_E_ARG, "fz_gemm: bad loader");
-  if (d->epilogue != EPI_PLAIN && d->epilogue != EPI_D2S) return fail(FZ_E_ARG, "fz_gemm: bad epilogue");
+  if (d->epilogue < EPI_PLAIN || d->epilogue > EPI_LNBWD) return fail(FZ_E_ARG, "fz_gemm: bad epilogue");
+  if (d->epilogue == EPI_LNBWD && (d->M != 32 || (d->K != 32 && d->K != 64) || d->loader != LOAD_PLAIN || !d->lnb_x || !d->lnb_stats ||
+                                   !d->lnb_g || !d->lnb_part || d->bias || d->res || d->emul || d->eact || d->ln))
+    return fail(FZ_E_UNSUPPORTED, "fz_gemm: LayerNorm-backward epilogue needs M == 32, K <= 64, plain loader");
   if (d->B < 0 || d->Cin < 1 || d->M < 1 || d->K < 1) return fail(FZ_E_SHAPE, "fz_gemm: sizes must be positive");
   if ((d->K & 1) && (d->loader != LOAD_PLAIN || d->ln))
     return fail(FZ_E_UNSUPPORTED, "fz_gemm: odd K only with the plain loader and no LayerNorm prologue");
@@ -624,6 +729,7 @@ extern "C" int fz_gemm(const fz_gemm_desc* d, fz_stream_t stream) {
   a.bias = d->bias; a.ln = d->ln; a.ln_g = d->ln_g; a.ln_b = d->ln_b; a.ln_eps = d->ln_eps;
   a.stats_out = d->stats_out; a.bact = d->bact; a.eact = d->eact; a.res = d->res; a.emul = d->emul;
   a.emul_kind = d->emul_kind; a.y = d->y; a.Ncol = d->Ncol; a.Ho = d->Ho; a.Wo = d->Wo; a.B = d->B;
+  a.lnb_x = d->lnb_x; a.lnb_stats = d->lnb_stats; a.lnb_g = d->lnb_g; a.lnb_gadd = d->lnb_gadd; a.lnb_part = d->lnb_part;
   hipStream_t st = (hipStream_t)stream;
   const int mblocks = (d->M + 31) / 32;
 
@@ -632,11 +738,14 @@ extern "C" int fz_gemm(const fz_gemm_desc* d, fz_stream_t stream) {
     const int nA = (d->K + 1) / 2;
     int RB = mblocks < 8 ? mblocks : 8;
     while ((size_t)(nA * RB * 64 + 32 * RB) * sizeof(float) > 65536) --RB;
-    const size_t lds = (size_t)(nA * RB * 64 + 32 * RB) * sizeof(float);
+    const size_t lds = (size_t)(nA * RB * 64 + 32 * RB + (d->epilogue == EPI_LNBWD ? 256 : 0)) * sizeof(float);
     const int64_t tiles = (d->Ncol + 511) / 512;
     dim3 grid((unsigned)(tiles * d->B), (unsigned)((mblocks + RB - 1) / RB)), block(256);
 #define FZ_RES(NS, E, BM) hipLaunchKernelGGL((gemm_resident_kernel<NS, E, BM>), grid, block, lds, st, a, RB)
-    if (d->epilogue == EPI_D2S) {
+    if (d->epilogue == EPI_LNBWD) {
+      if (d->bmul) return fail(FZ_E_UNSUPPORTED, "fz_gemm: bmul with LayerNorm-backward epilogue");
+      if (nA <= 16) FZ_RES(16, EPI_LNBWD, false); else FZ_RES(32, EPI_LNBWD, false);
+    } else if (d->epilogue == EPI_D2S) {
       if (d->bmul) return fail(FZ_E_UNSUPPORTED, "fz_gemm: bmul with depth-to-space epilogue");
       if (nA <= 16) FZ_RES(16, EPI_D2S, false); else FZ_RES(32, EPI_D2S, false);
     } else if (d->bmul) {
@@ -685,4 +794,9 @@ extern "C" int fz_gemm(const fz_gemm_desc* d, fz_stream_t stream) {
   }
   FZ_LAUNCH_CHECK();
   return FZ_OK;
+}
+
+extern "C" int64_t fz_gemm_lnbwd_partials(const fz_gemm_desc* d) {
+  if (!d) return -1;
+  return ((d->Ncol + 511) / 512) * d->B;  // one row per workgroup of the resident kernel
 }

@@ -265,3 +265,11 @@ extern "C" int fz_ln_bwd(const float* gl, const float* x, const float* stats, co
   FZ_LAUNCH_CHECK();
   return FZ_OK;
 }
+
+extern "C" int fz_reduce_rows(const float* part, int64_t rows, int n, float* out, fz_stream_t stream) {
+  if (!part || !out || rows < 1 || n < 1 || rows > 0x7fffffff) return fail(FZ_E_ARG, "fz_reduce_rows: bad arguments");
+  hipLaunchKernelGGL(ln_part_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, (hipStream_t)stream, part, (int)rows, n,
+                     out);
+  FZ_LAUNCH_CHECK();
+  return FZ_OK;
+}

@@ -13,6 +13,8 @@
 // Lane map: lane l = (p0 & 3 = l>>4, p1 = (l>>1)&7, half = l&1); for every channel dd and
 // p0-group jp the lane moves one 16-byte vector = voxels p2 = 4·half..4·half+3 of patch row
 // (p0 = 4·jp + (l>>4), p1).  Column index of local element (jp, e): n = (p0·8 + p1)·8 + 4·half + e.
+#include <cstdlib>
+
 #include "fz_common.h"
 #include "nmf_core.h"
 
@@ -85,12 +87,21 @@ __device__ __forceinline__ void cf_load(const float* __restrict__ t, const CfAdd
     }
 }
 
+// logical workgroup id: optionally remapped so that consecutive workgroups (patch neighbours
+// along W, then H) run on the same XCD and share its L2 (blocks are dealt round-robin over 8 XCDs)
+__device__ __forceinline__ int64_t cf_logical_block(int xcd_remap) {
+  const int64_t bid = blockIdx.x, nb = gridDim.x;
+  if (!xcd_remap || nb < 16) return bid;
+  const int64_t q = nb / 8, r = nb % 8, xcd = bid % 8, i = bid / 8;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+}
+
 template <int R, int SOLVER>
-__global__ __launch_bounds__(256) void nmf_cf_fwd_kernel(const float* __restrict__ t, const float* __restrict__ u0,
-                                                         const float* __restrict__ v0, float* __restrict__ out,
-                                                         CfGeom q, int64_t nmat, int T, float eps) {
+__global__ __launch_bounds__(1024) void nmf_cf_fwd_kernel(const float* __restrict__ t, const float* __restrict__ u0,
+                                                          const float* __restrict__ v0, float* __restrict__ out,
+                                                          CfGeom q, int64_t nmat, int T, float eps, int xcd_remap) {
   const int lane = threadIdx.x & 63;
-  const int64_t mat = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t mat = cf_logical_block(xcd_remap) * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (mat >= nmat) return;
   CfWave w{lane};
   CfAddr a;
@@ -119,14 +130,14 @@ __global__ __launch_bounds__(256) void nmf_cf_fwd_kernel(const float* __restrict
 
 // backward: gY = gather_w(ga) / W ; gt (+)= [t > 0] ∘ scatter_w(gX)
 template <int R, int SOLVER>
-__global__ __launch_bounds__(256, 2) void nmf_cf_bwd_kernel(const float* __restrict__ t, const float* __restrict__ u0,
+__global__ __launch_bounds__(512, 2) void nmf_cf_bwd_kernel(const float* __restrict__ t, const float* __restrict__ u0,
                                                             const float* __restrict__ v0,
                                                             const float* __restrict__ ga, float* __restrict__ gt,
                                                             CfGeom q, int64_t nmat, int T, int G, float eps,
-                                                            int relu_gate) {
+                                                            int relu_gate, int xcd_remap) {
   extern __shared__ __attribute__((aligned(16))) float fz_lds_cf[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t mat = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+  const int64_t mat = cf_logical_block(xcd_remap) * (blockDim.x >> 6) + wave;
   if (mat >= nmat) return;
   CfWave w{lane};
   CfAddr a;
@@ -200,9 +211,17 @@ extern "C" int fz_nmf_cf_fwd(const float* t, const float* u0, const float* v0, f
   if (solver != FZ_SOLVER_MU && solver != FZ_SOLVER_HALS) return fail(FZ_E_ARG, "fz_nmf_cf_fwd: bad solver");
   if (B == 0) return FZ_OK;
   const int64_t nmat = (int64_t)B * q.h * q.G0 * q.G1 * q.G2;
-  dim3 grid((unsigned)((nmat + 3) / 4)), block(256);
+  // measured on MI355X (tools/debug/cf_probe.py): a workgroup = one full row of patches along W
+  // (up to 16 waves) consumes whole 128-B lines inside one CU: 0.856 -> 0.725 ms at stage 0
+  int wpb = 16;
+  { const char* e = getenv("FZ_CF_WPB"); if (e) wpb = atoi(e); }
+  if (wpb > q.G2) wpb = q.G2;
+  if (wpb < 1) wpb = 1;
+  int xr = 1;
+  { const char* e = getenv("FZ_CF_XCD"); if (e) xr = atoi(e); }
+  dim3 grid((unsigned)((nmat + wpb - 1) / wpb)), block(64 * wpb);
   hipStream_t st = (hipStream_t)stream;
-#define FZ_CF_FWD(RR, SS) hipLaunchKernelGGL((nmf_cf_fwd_kernel<RR, SS>), grid, block, 0, st, t, u0, v0, out, q, nmat, T, eps)
+#define FZ_CF_FWD(RR, SS) hipLaunchKernelGGL((nmf_cf_fwd_kernel<RR, SS>), grid, block, 0, st, t, u0, v0, out, q, nmat, T, eps, xr)
   if (R == 1) { if (solver == FZ_SOLVER_MU) FZ_CF_FWD(1, SOLVER_MU); else FZ_CF_FWD(1, SOLVER_HALS); }
   else { if (solver == FZ_SOLVER_MU) FZ_CF_FWD(2, SOLVER_MU); else FZ_CF_FWD(2, SOLVER_HALS); }
   FZ_LAUNCH_CHECK();
@@ -226,7 +245,12 @@ extern "C" int fz_nmf_cf_bwd(const float* t, const float* u0, const float* v0, c
   if (per_wave > 160 * 1024) return fail(FZ_E_UNSUPPORTED, "fz_nmf_cf_bwd: history exceeds LDS");
   int wpb = 65536 / per_wave;
   if (wpb > 4) wpb = 4;
+  { const char* e = getenv("FZ_CF_WPB_BWD"); if (e) { wpb = atoi(e); if (wpb * per_wave > 160 * 1024) wpb = 160 * 1024 / per_wave; } }
+  if (wpb > 8) wpb = 8;
   if (wpb < 1) wpb = 1;
+  // patch neighbours on the same XCD share its L2 (shifted windows straddle lines): 1.31 -> 1.17 ms
+  int xr = 1;
+  { const char* e = getenv("FZ_CF_XCD"); if (e) xr = atoi(e); }
   const int lds = per_wave * wpb;
   dim3 grid((unsigned)((nmat + wpb - 1) / wpb)), block(64 * wpb);
   hipStream_t st = (hipStream_t)stream;
@@ -236,7 +260,7 @@ extern "C" int fz_nmf_cf_bwd(const float* t, const float* u0, const float* v0, c
     if (lds > 65536)                                                                                      \
       FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                  \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));                    \
-    hipLaunchKernelGGL(kern, grid, block, lds, st, t, u0, v0, ga, gt, q, nmat, T, G, eps, relu_gate);     \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, t, u0, v0, ga, gt, q, nmat, T, G, eps, relu_gate, xr);     \
   } while (0)
   if (R == 1) { if (solver == FZ_SOLVER_MU) FZ_CF_BWD(1, SOLVER_MU); else FZ_CF_BWD(1, SOLVER_HALS); }
   else { if (solver == FZ_SOLVER_MU) FZ_CF_BWD(2, SOLVER_MU); else FZ_CF_BWD(2, SOLVER_HALS); }

@@ -109,6 +109,37 @@ def _ln_backward(gl, x, stats, ln_w, gadd=None):
     return gx, torch.diagonal(gmat).clone(), gbeta
 
 
+def _dgrad_lnbwd(gz, w2, x, stats, ln_w, gadd):
+    """gx = LayerNormBackward(W2ᵀ·gz; x, stats, γ) + gadd and (gγ, gβ), in ONE kernel when the
+    LayerNorm width is 32 (csrc/gemm.hip EPI_LNBWD: gl never leaves the accumulators)."""
+    B, C = x.shape[:2]
+    V = _vox(x)
+    Mz = gz.shape[1]
+    if C != 32 or Mz > 64 or Mz % 2:
+        gl = torch.empty_like(x)
+        _gemm([gz], w2, gl, B=B, Cin=Mz, Vin=V, M=C, K=Mz, Ncol=V, w_t=True, ldw=C, name="linear_dgrad")
+        return _ln_backward(gl, x, stats, ln_w, gadd=gadd)
+    gx = torch.empty_like(x)
+    d = N.GemmDesc()
+    d.x[0] = gz.data_ptr()
+    d.nsrc, d.src_mode, d.c0, d.Cin, d.Vin = 1, 0, 0, Mz, V
+    d.w, d.w_t, d.ldw, d.M, d.K = w2.data_ptr(), 1, C, C, Mz
+    d.y, d.Ncol, d.B = gx.data_ptr(), V, B
+    d.loader, d.epilogue = LOAD_PLAIN, 2
+    d.lnb_x, d.lnb_stats, d.lnb_g, d.lnb_gadd = x.data_ptr(), stats.data_ptr(), ln_w.data_ptr(), _p(gadd)
+    rows = N.lib().fz_gemm_lnbwd_partials(ctypes.byref(d))
+    part = torch.empty((rows, 64), dtype=x.dtype, device=x.device)
+    d.lnb_part = part.data_ptr()
+    gpar = torch.empty(64, dtype=x.dtype, device=x.device)
+    nbytes = 4 * (gz.numel() + 2 * x.numel() + (gadd.numel() if gadd is not None else 0))
+    with torch.cuda.device(x.device):
+        rc = Fn._timed(f"dgrad_lnbwd_{Mz}->{C}", nbytes, lambda: N.lib().fz_gemm(ctypes.byref(d), N.stream_ptr(x)))
+        N.check(rc, "fz_gemm")
+        rc = N.lib().fz_reduce_rows(part.data_ptr(), rows, 64, gpar.data_ptr(), N.stream_ptr(x))
+        N.check(rc, "fz_reduce_rows")
+    return gx, gpar[:32], gpar[32:]
+
+
 def _native_ok(*ts):
     t0 = ts[0]
     return t0.is_cuda and all(t is None or (t.dtype == torch.float32) for t in ts) and _vox(t0) % 4 == 0
@@ -484,14 +515,12 @@ class FactorizerBlockFn(torch.autograd.Function):
         gw2 = torch.empty_like(w22)
         gb2 = torch.empty(C, dtype=dt, device=dev)
         _wgrad(g2, [z1], gw2, B=B, M=C, Cin=Hd, K=Hd, Vq=V, Ncols=V, gbias=gb2, qact=ACT["gelu"], name="wgrad_linear")
-        gl2 = torch.empty_like(x1)
-        _gemm([gz1], w12, gl2, B=B, Cin=Hd, Vin=V, M=C, K=Hd, Ncol=V, w_t=True, ldw=C, name="linear_dgrad")
-        gx1, gg2, gbt2 = _ln_backward(gl2, x1, st2, n2w, gadd=g2)      # + residual path of the MLP
+        gx1, gg2, gbt2 = _dgrad_lnbwd(gz1, w12, x1, st2, n2w, g2)      # + residual path of the MLP
         gw1 = torch.empty_like(w12)
         gb1 = torch.empty(Hd, dtype=dt, device=dev)
         _wgrad(gz1, [x1], gw1, B=B, M=Hd, Cin=C, K=C, Vq=V, Ncols=V, gbias=gb1, stats=st2, ln=(n2w, n2b),
                name="wgrad_ln_linear")
-        del gz1, gl2
+        del gz1
         # --- out_proj ---
         ga = torch.empty_like(a)
         _gemm([gx1], wout2, ga, B=B, Cin=C, Vin=V, M=C, K=C, Ncol=V, w_t=True, ldw=C, name="linear_dgrad")
@@ -514,9 +543,7 @@ class FactorizerBlockFn(torch.autograd.Function):
             del gm
         del ga
         # --- in_proj + LN1 ---
-        gl1 = torch.empty_like(x)
-        _gemm([gt], win2, gl1, B=B, Cin=C, Vin=V, M=C, K=C, Ncol=V, w_t=True, ldw=C, name="linear_dgrad")
-        gx, gg1, gbt1 = _ln_backward(gl1, x, st1, n1w, gadd=gx1)        # + residual path of the mixer
+        gx, gg1, gbt1 = _dgrad_lnbwd(gt, win2, x, st1, n1w, gx1)        # + residual path of the mixer
         gwi = torch.empty_like(win2)
         _wgrad(gt, [x], gwi, B=B, M=C, Cin=C, K=C, Vq=V, Ncols=V, stats=st1, ln=(n1w, n1b), name="wgrad_ln_linear")
         s_in, s_out, s_1, s_2 = ctx.shapes

@@ -129,6 +129,7 @@ int fz_nmf_cf_bwd(const float* t, const float* u0, const float* v0, const float*
 #define FZ_LOAD_K3 2    /* In[(c,kd,kh,kw)][n] = x[b, c, d+kd-1, h+kh-1, w+kw-1], zero padded  */
 #define FZ_EPI_PLAIN 0  /* y[b, m, n]                                                         */
 #define FZ_EPI_D2S 1    /* rows m = (o, td,th,tw): y[b, o, 2d+td, 2h+th, 2w+tw]               */
+#define FZ_EPI_LNBWD 2  /* M == 32: result = dL/d(LayerNorm out); y = LayerNorm backward of it  */
 #define FZ_ACT_NONE 0
 #define FZ_ACT_RELU 1
 #define FZ_ACT_GELU 2 /* exact erf GELU, layers/mlp.py:56 */
@@ -162,7 +163,20 @@ typedef struct fz_gemm_desc {
   int Ho, Wo;          /* coarse H, W (s2d columns / d2s input grid)                           */
   int B;
   int loader, epilogue;
+  /* FZ_EPI_LNBWD: LayerNorm input x (B,32,V), saved stats (B,2,V), gamma (32), optional gradient
+   * added to the result, and a partial buffer of fz_gemm_lnbwd_partials(desc) x 64 floats that
+   * receives per-workgroup (dgamma | dbeta) sums (reduce over rows in order). */
+  const float* lnb_x;
+  const float* lnb_stats;
+  const float* lnb_g;
+  const float* lnb_gadd;
+  float* lnb_part;
 } fz_gemm_desc;
+
+/* number of 64-float partial rows fz_gemm writes to lnb_part for this descriptor */
+int64_t fz_gemm_lnbwd_partials(const fz_gemm_desc* desc);
+/* out[e] = sum over rows of part[row][e], fixed order (rows x n floats) */
+int fz_reduce_rows(const float* part, int64_t rows, int n, float* out, fz_stream_t stream);
 
 int fz_gemm(const fz_gemm_desc* desc, fz_stream_t stream);
 
