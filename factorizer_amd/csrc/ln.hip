@@ -135,23 +135,32 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ g
   }
 }
 
-// Channel-parallel backward for wide, short tensors (C > 64: the 8^3..32^3 stages): one
-// workgroup per 4-voxel quad, threads stride over channels, block reduction of the two means.
-__global__ __launch_bounds__(256) void ln_bwd_cpar_kernel(const float* __restrict__ gl, const float* __restrict__ x,
-                                                          const float* __restrict__ stats,
-                                                          const float* __restrict__ g, const float* __restrict__ gadd,
-                                                          float* __restrict__ gx, int B, int C, int64_t V) {
-  __shared__ float red[4][8];
+// Backward for wide tensors (C > 64: the 8^3..32^3 stages).  Lanes = consecutive 4-voxel quads
+// (16-byte accesses stay coalesced: 1 KiB per channel row per wave), the NW waves of a workgroup
+// split the channels; the two per-voxel means are combined through LDS.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void ln_bwd_split_kernel(const float* __restrict__ gl, const float* __restrict__ x,
+                                                               const float* __restrict__ stats,
+                                                               const float* __restrict__ g,
+                                                               const float* __restrict__ gadd, float* __restrict__ gx,
+                                                               int B, int C, int64_t V) {
+  __shared__ float red[NW][8][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t nvec = V / 4;
-  const int64_t i = blockIdx.x;
-  const int b = (int)(i / nvec);
-  const int64_t v = (i % nvec) * 4;
+  const int64_t total = nvec * B;
+  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+  const bool ok = i < total;
+  const int64_t ii = ok ? i : 0;
+  const int b = (int)(ii / nvec);
+  const int64_t v = (ii % nvec) * 4;
   const int64_t base = (int64_t)b * C * V + v;
   const float* sp = stats + (int64_t)b * 2 * V + v;
   const float4 mu = *reinterpret_cast<const float4*>(sp);
   const float4 rs = *reinterpret_cast<const float4*>(sp + V);
+  const int cs = (C + NW - 1) / NW;
+  const int c0 = wave * cs, c1 = min(C, c0 + cs);
   float m[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+  for (int c = c0; c < c1; ++c) {
     const float4 t = *reinterpret_cast<const float4*>(x + base + (int64_t)c * V);
     const float4 d = *reinterpret_cast<const float4*>(gl + base + (int64_t)c * V);
     const float gc = g[c];
@@ -160,18 +169,20 @@ __global__ __launch_bounds__(256) void ln_bwd_cpar_kernel(const float* __restric
     m[4] += ax * (t.x - mu.x) * rs.x; m[5] += ay * (t.y - mu.y) * rs.y;
     m[6] += az * (t.z - mu.z) * rs.z; m[7] += aw * (t.w - mu.w) * rs.w;
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const float sres = wave_sum(m[e]);
-    if (lane == 0) red[wave][e] = sres;
-  }
+  for (int e = 0; e < 8; ++e) red[wave][e][lane] = m[e];
   __syncthreads();
   const float inv = 1.0f / (float)C;
   float mm[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) mm[e] = ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])) * inv;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+  for (int e = 0; e < 8; ++e) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t += red[w][e][lane];
+    mm[e] = t * inv;
+  }
+  if (!ok) return;
+  for (int c = c0; c < c1; ++c) {
     const float4 t = *reinterpret_cast<const float4*>(x + base + (int64_t)c * V);
     const float4 d = *reinterpret_cast<const float4*>(gl + base + (int64_t)c * V);
     const float gc = g[c];
@@ -255,9 +266,13 @@ extern "C" int fz_ln_bwd(const float* gl, const float* x, const float* stats, co
     FZ_LAUNCH_CHECK();
     return FZ_OK;
   }
-  if (C > 64 && (V / 4) * B <= 65536) {
-    hipLaunchKernelGGL(ln_bwd_cpar_kernel, dim3((unsigned)((V / 4) * B)), dim3(256), 0, st, gl, x, stats, gamma, gadd,
-                       gx, B, C, V);
+  if (C > 64) {
+    const int64_t quads = (V / 4) * B;
+    const unsigned gq = (unsigned)((quads + 63) / 64);
+    if (C >= 256)
+      hipLaunchKernelGGL(ln_bwd_split_kernel<16>, dim3(gq), dim3(1024), 0, st, gl, x, stats, gamma, gadd, gx, B, C, V);
+    else
+      hipLaunchKernelGGL(ln_bwd_split_kernel<8>, dim3(gq), dim3(512), 0, st, gl, x, stats, gamma, gadd, gx, B, C, V);
   } else {
     hipLaunchKernelGGL(ln_bwd_kernel<0>, dim3(grid), dim3(256), 0, st, gl, x, stats, gamma, gadd, gx,
                        (float*)nullptr, B, C, V);

@@ -270,21 +270,30 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
   }
 }
 
-// out[e] = Σ_chunks part[chunk][e] in a fixed order: 8 strided partial sums per element, combined
-// through LDS (bitwise reproducible).  32 elements per 256-thread block.
+// out[e] = Σ_chunks part[chunk][e] in a fixed order: 32 strided partial sums per element (8
+// elements per 256-thread block), combined by a fixed tree through LDS — bitwise reproducible.
 __global__ __launch_bounds__(256) void chunk_reduce_kernel(const float* __restrict__ part, int nchunk, int64_t n,
                                                            float* __restrict__ out, int accumulate) {
-  __shared__ float red[8][33];
-  const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
-  const int64_t e = (int64_t)blockIdx.x * 32 + el;
-  float s = 0.f;
-  if (e < n)
-    for (int ch = g; ch < nchunk; ch += 8) s += part[(int64_t)ch * n + e];
-  red[g][el] = s;
+  __shared__ float red[32][9];
+  const int el = threadIdx.x & 7, g = threadIdx.x >> 3;
+  const int64_t e = (int64_t)blockIdx.x * 8 + el;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (e < n) {
+    int ch = g;
+    for (; ch + 96 < nchunk; ch += 128) {  // 4 independent loads in flight
+      s0 += part[(int64_t)ch * n + e];
+      s1 += part[(int64_t)(ch + 32) * n + e];
+      s2 += part[(int64_t)(ch + 64) * n + e];
+      s3 += part[(int64_t)(ch + 96) * n + e];
+    }
+    for (; ch < nchunk; ch += 32) s0 += part[(int64_t)ch * n + e];
+  }
+  red[g][el] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (g == 0 && e < n) {
-    float t = ((red[0][el] + red[1][el]) + (red[2][el] + red[3][el])) +
-              ((red[4][el] + red[5][el]) + (red[6][el] + red[7][el]));
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) t += red[i][el];
     out[e] = accumulate ? out[e] + t : t;
   }
 }
@@ -370,17 +379,17 @@ extern "C" int fz_wgrad(const fz_wgrad_desc* d, void* workspace, fz_stream_t str
   const bool fold = d->ln_g != nullptr;
   if (fold || d->gbias != nullptr) {
     float* gb_out = (d->gbias != nullptr && !d->accumulate) ? d->gbias : gb_tmp;
-    hipLaunchKernelGGL(chunk_reduce_kernel, dim3((unsigned)((d->M + 31) / 32)), dim3(256), 0, st, a.part_bias,
+    hipLaunchKernelGGL(chunk_reduce_kernel, dim3((unsigned)((d->M + 7) / 8)), dim3(256), 0, st, a.part_bias,
                        nchunk, (int64_t)d->M, gb_out, 0);
     FZ_LAUNCH_CHECK();
     if (d->gbias != nullptr && d->accumulate) {
       // accumulate mode keeps the fresh sums in gb_tmp for the fold and adds them to gbias
-      hipLaunchKernelGGL(chunk_reduce_kernel, dim3((unsigned)((d->M + 31) / 32)), dim3(256), 0, st, a.part_bias,
+      hipLaunchKernelGGL(chunk_reduce_kernel, dim3((unsigned)((d->M + 7) / 8)), dim3(256), 0, st, a.part_bias,
                          nchunk, (int64_t)d->M, d->gbias, 1);
       FZ_LAUNCH_CHECK();
     }
     if (fold) {
-      hipLaunchKernelGGL(chunk_reduce_kernel, dim3((unsigned)((MK + 31) / 32)), dim3(256), 0, st, a.part, nchunk,
+      hipLaunchKernelGGL(chunk_reduce_kernel, dim3((unsigned)((MK + 7) / 8)), dim3(256), 0, st, a.part, nchunk,
                          MK, acc_tmp, 0);
       FZ_LAUNCH_CHECK();
       hipLaunchKernelGGL(ln_fold_kernel, dim3((unsigned)((MK + 255) / 256)), dim3(256), 0, st, d->gw, acc_tmp,
@@ -389,7 +398,7 @@ extern "C" int fz_wgrad(const fz_wgrad_desc* d, void* workspace, fz_stream_t str
       return FZ_OK;
     }
   }
-  hipLaunchKernelGGL(chunk_reduce_kernel, dim3((unsigned)((MK + 31) / 32)), dim3(256), 0, st, a.part, nchunk, MK,
+  hipLaunchKernelGGL(chunk_reduce_kernel, dim3((unsigned)((MK + 7) / 8)), dim3(256), 0, st, a.part, nchunk, MK,
                      d->gw, d->accumulate);
   FZ_LAUNCH_CHECK();
   return FZ_OK;
