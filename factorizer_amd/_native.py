@@ -114,7 +114,7 @@ _SIGS.update({
     "fz_nmf_cf_bwd": ([_vp] * 5 + [_i] * 5 + [_c.POINTER(_i)] + [_i] * 7 + [_f, _vp], _i),
     "fz_gemm": ([_c.POINTER(GemmDesc), _vp], _i),
     "fz_gemm_lnbwd_partials": ([_c.POINTER(GemmDesc)], _i64),
-    "fz_reduce_rows": ([_vp, _i64, _i, _vp, _vp], _i),
+    "fz_reduce_rows": ([_vp, _i64, _i, _vp, _vp, _vp], _i),
     "fz_wgrad": ([_c.POINTER(WgradDesc), _vp, _vp], _i),
     "fz_wgrad_workspace_bytes": ([_c.POINTER(WgradDesc)], _i64),
     "fz_ln_fwd": ([_vp] * 5 + [_i, _i, _i64, _f, _vp], _i),

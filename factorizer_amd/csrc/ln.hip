@@ -199,20 +199,23 @@ __global__ __launch_bounds__(64 * NW) void ln_bwd_split_kernel(const float* __re
   }
 }
 
-// out[e] = Σ_blk part[blk][e], fixed order (same scheme as wgrad's chunk reduce)
-__global__ __launch_bounds__(256) void ln_part_reduce_kernel(const float* __restrict__ part, int nblk, int n,
-                                                             float* __restrict__ out) {
+// out[grp][e] = Σ_{row in group grp} part[row][e], fixed order.  Rows are split into `groups`
+// contiguous slices (blockIdx.y); 32 outputs per block, 8 strided partial sums per output.
+__global__ __launch_bounds__(256) void ln_part_reduce_kernel(const float* __restrict__ part, int nrows, int n,
+                                                             int rows_per_group, float* __restrict__ out) {
   __shared__ float red[8][33];
   const int el = threadIdx.x & 31, gq = threadIdx.x >> 5;
   const int e = blockIdx.x * 32 + el;
+  const int r0 = blockIdx.y * rows_per_group;
+  const int r1 = min(nrows, r0 + rows_per_group);
   float s = 0.f;
   if (e < n)
-    for (int ch = gq; ch < nblk; ch += 8) s += part[(int64_t)ch * n + e];
+    for (int ch = r0 + gq; ch < r1; ch += 8) s += part[(int64_t)ch * n + e];
   red[gq][el] = s;
   __syncthreads();
   if (gq == 0 && e < n)
-    out[e] = ((red[0][el] + red[1][el]) + (red[2][el] + red[3][el])) +
-             ((red[4][el] + red[5][el]) + (red[6][el] + red[7][el]));
+    out[(int64_t)blockIdx.y * n + e] = ((red[0][el] + red[1][el]) + (red[2][el] + red[3][el])) +
+                                       ((red[4][el] + red[5][el]) + (red[6][el] + red[7][el]));
 }
 
 }  // namespace fz
@@ -261,8 +264,8 @@ extern "C" int fz_ln_bwd(const float* gl, const float* x, const float* stats, co
     else
       hipLaunchKernelGGL(ln_bwd_kernel<64>, dim3(grid), dim3(256), 0, st, gl, x, stats, gamma, gadd, gx, part, B, C, V);
     FZ_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ln_part_reduce_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, st, part, (int)grid, 2 * C,
-                       gparams);
+    hipLaunchKernelGGL(ln_part_reduce_kernel, dim3((2 * C + 31) / 32, 1), dim3(256), 0, st, part, (int)grid, 2 * C,
+                       (int)grid, gparams);
     FZ_LAUNCH_CHECK();
     return FZ_OK;
   }
@@ -281,10 +284,22 @@ extern "C" int fz_ln_bwd(const float* gl, const float* x, const float* stats, co
   return FZ_OK;
 }
 
-extern "C" int fz_reduce_rows(const float* part, int64_t rows, int n, float* out, fz_stream_t stream) {
+// Two-stage when there are many rows: `tmp` (64 x n floats, may be NULL for rows <= 512) holds the
+// per-slice sums of stage 1.
+extern "C" int fz_reduce_rows(const float* part, int64_t rows, int n, float* out, float* tmp, fz_stream_t stream) {
   if (!part || !out || rows < 1 || n < 1 || rows > 0x7fffffff) return fail(FZ_E_ARG, "fz_reduce_rows: bad arguments");
-  hipLaunchKernelGGL(ln_part_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, (hipStream_t)stream, part, (int)rows, n,
-                     out);
+  hipStream_t st = (hipStream_t)stream;
+  if (rows <= 512 || tmp == nullptr) {
+    hipLaunchKernelGGL(ln_part_reduce_kernel, dim3((n + 31) / 32, 1), dim3(256), 0, st, part, (int)rows, n, (int)rows,
+                       out);
+    FZ_LAUNCH_CHECK();
+    return FZ_OK;
+  }
+  const int groups = 64;
+  const int rpg = (int)((rows + groups - 1) / groups);
+  hipLaunchKernelGGL(ln_part_reduce_kernel, dim3((n + 31) / 32, groups), dim3(256), 0, st, part, (int)rows, n, rpg, tmp);
+  FZ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ln_part_reduce_kernel, dim3((n + 31) / 32, 1), dim3(256), 0, st, tmp, groups, n, groups, out);
   FZ_LAUNCH_CHECK();
   return FZ_OK;
 }

@@ -131,11 +131,12 @@ def _dgrad_lnbwd(gz, w2, x, stats, ln_w, gadd):
     part = torch.empty((rows, 64), dtype=x.dtype, device=x.device)
     d.lnb_part = part.data_ptr()
     gpar = torch.empty(64, dtype=x.dtype, device=x.device)
+    tmp = torch.empty((64, 64), dtype=x.dtype, device=x.device)
     nbytes = 4 * (gz.numel() + 2 * x.numel() + (gadd.numel() if gadd is not None else 0))
     with torch.cuda.device(x.device):
         rc = Fn._timed(f"dgrad_lnbwd_{Mz}->{C}", nbytes, lambda: N.lib().fz_gemm(ctypes.byref(d), N.stream_ptr(x)))
         N.check(rc, "fz_gemm")
-        rc = N.lib().fz_reduce_rows(part.data_ptr(), rows, 64, gpar.data_ptr(), N.stream_ptr(x))
+        rc = N.lib().fz_reduce_rows(part.data_ptr(), rows, 64, gpar.data_ptr(), tmp.data_ptr(), N.stream_ptr(x))
         N.check(rc, "fz_reduce_rows")
     return gx, gpar[:32], gpar[32:]
 

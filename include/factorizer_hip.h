@@ -175,8 +175,9 @@ typedef struct fz_gemm_desc {
 
 /* number of 64-float partial rows fz_gemm writes to lnb_part for this descriptor */
 int64_t fz_gemm_lnbwd_partials(const fz_gemm_desc* desc);
-/* out[e] = sum over rows of part[row][e], fixed order (rows x n floats) */
-int fz_reduce_rows(const float* part, int64_t rows, int n, float* out, fz_stream_t stream);
+/* out[e] = sum over rows of part[row][e], fixed order (rows x n floats); tmp: 64 x n floats of
+ * scratch for the two-stage path (rows > 512), may be NULL */
+int fz_reduce_rows(const float* part, int64_t rows, int n, float* out, float* tmp, fz_stream_t stream);
 
 int fz_gemm(const fz_gemm_desc* desc, fz_stream_t stream);
 
