@@ -19,6 +19,8 @@
 // Weights (the A operand) are staged once per workgroup in LDS in operand order.
 // The accumulator tile has its row in (register, h) and its column in j, so the epilogue
 // stores 16-byte vectors (4 voxels) per register: 512 B contiguous per output row.
+#include <cstdlib>
+
 #include "fz_common.h"
 
 namespace fz {
@@ -758,8 +760,9 @@ extern "C" int fz_gemm(const fz_gemm_desc* d, fz_stream_t stream) {
   }
 
   // ---- Kernel B: streaming; pick the column-tile width so the grid fills the chip ----
-  // aim at >= ~3 workgroups per CU: prefer wide tiles and 2 row blocks per workgroup (fewer
-  // re-reads of the input) but fall back to narrower tiles / single row blocks on small grids
+  // tile choice from a sweep on MI355X (tools/debug/gemm_probe3.py, FZ_GEMM_CFG): take the widest
+  // column tile that still gives >= 256 workgroups (one per CU); two row blocks per workgroup only
+  // when that still leaves >= 512 workgroups
   int nacc = 4, MBsel = mblocks >= 2 ? 2 : 1;
   if (d->loader == LOAD_S2D) { nacc = 2; MBsel = 1; }
   else {
@@ -768,10 +771,12 @@ extern "C" int fz_gemm(const fz_gemm_desc* d, fz_stream_t stream) {
       const int64_t t = (d->Ncol + 32 * na * 4 - 1) / (32 * na * 4);
       return t * d->B * ((mblocks + mb - 1) / mb);
     };
-    if (wgs(nacc, MBsel) < 768 && MBsel == 2) MBsel = 1;
+    if (wgs(nacc, MBsel) < 512 && MBsel == 2) MBsel = 1;
     if (narrow_ok) {
-      if (wgs(nacc, MBsel) < 768) nacc = 2;
-      if (wgs(nacc, MBsel) < 768) nacc = 1;
+      if (wgs(nacc, MBsel) < 256) nacc = 2;
+      if (wgs(nacc, MBsel) < 256) nacc = 1;
+      const char* e = getenv("FZ_GEMM_CFG");  // diagnostics: "<nacc><mb>", e.g. 42
+      if (e && e[0] && e[1]) { nacc = e[0] - '0'; MBsel = e[1] - '0'; if (MBsel == 2 && (nacc != 4 || mblocks < 2)) MBsel = 1; }
     }
   }
   const int TN = 32 * nacc;
