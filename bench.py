@@ -159,7 +159,8 @@ def main():
                     "avg_launch_ms": round(avg_ms, 4), "launches": a["calls"],
                     "algorithmic_bytes_per_launch": a["bytes"] // a["calls"],
                     "share_of_step": round(a["ms"] / (elapsed * 1e3), 4),
-                    "native_kernels_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in agg.items()}}
+                    "native_kernels_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in agg.items()},
+                    "native_kernels_GBps": {k: round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 0) for k, v in agg.items()}}
         out = {
             "metric": "volumes/sec fwd+bwd, Swin Factorizer 128^3",
             "value": round(world * B * args.steps / elapsed, 4),

@@ -117,6 +117,8 @@ _SIGS.update({
     "fz_reduce_rows": ([_vp, _i64, _i, _vp, _vp, _vp], _i),
     "fz_wgrad": ([_c.POINTER(WgradDesc), _vp, _vp], _i),
     "fz_wgrad_workspace_bytes": ([_c.POINTER(WgradDesc)], _i64),
+    "fz_rowsum_chunks": ([_i64], _i),
+    "fz_rowsum": ([_vp, _vp, _vp, _i, _i, _i64, _vp], _i),
     "fz_ln_fwd": ([_vp] * 5 + [_i, _i, _i64, _f, _vp], _i),
     "fz_ln_bwd": ([_vp] * 8 + [_i, _i, _i64, _vp], _i),
     "fz_ln_bwd_workspace_bytes": ([_i], _i64),

@@ -218,6 +218,26 @@ __global__ __launch_bounds__(256) void ln_part_reduce_kernel(const float* __rest
                                        ((red[4][el] + red[5][el]) + (red[6][el] + red[7][el]));
 }
 
+// per-channel sums over batch and voxels (bias gradient of the transposed conv, unet.py:123):
+// part[(b*nchunk + chunk)][c] = Σ_{v in chunk} x[b, c, v]
+__global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ x, float* __restrict__ part, int C,
+                                                     int64_t V, int nchunk) {
+  __shared__ float red[4];
+  const int c = blockIdx.x, chunk = blockIdx.y, b = blockIdx.z;
+  const int64_t per = ((V / 4 + nchunk - 1) / nchunk) * 4;
+  const int64_t v0 = chunk * per, v1 = min(V, v0 + per);
+  const float* xp = x + ((int64_t)b * C + c) * V;
+  float s = 0.f;
+  for (int64_t v = v0 + threadIdx.x * 4; v < v1; v += 1024) {
+    const float4 t = *reinterpret_cast<const float4*>(xp + v);
+    s += (t.x + t.y) + (t.z + t.w);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[((int64_t)b * nchunk + chunk) * C + c] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 }  // namespace fz
 
 using namespace fz;
@@ -300,6 +320,27 @@ extern "C" int fz_reduce_rows(const float* part, int64_t rows, int n, float* out
   hipLaunchKernelGGL(ln_part_reduce_kernel, dim3((n + 31) / 32, groups), dim3(256), 0, st, part, (int)rows, n, rpg, tmp);
   FZ_LAUNCH_CHECK();
   hipLaunchKernelGGL(ln_part_reduce_kernel, dim3((n + 31) / 32, 1), dim3(256), 0, st, tmp, groups, n, groups, out);
+  FZ_LAUNCH_CHECK();
+  return FZ_OK;
+}
+
+// out[c] = Σ_{b,v} x[b,c,v]; part: workspace of B*nchunk*C floats with nchunk = fz_rowsum_chunks(V)
+extern "C" int fz_rowsum_chunks(int64_t V) {
+  int64_t n = V / 16384;
+  if (n < 1) n = 1;
+  if (n > 64) n = 64;
+  return (int)n;
+}
+
+extern "C" int fz_rowsum(const float* x, float* part, float* out, int B, int C, int64_t V, fz_stream_t stream) {
+  if (!x || !part || !out) return fail(FZ_E_ARG, "fz_rowsum: null pointer");
+  if (B < 1 || C < 1 || V < 4 || (V % 4)) return fail(FZ_E_SHAPE, "fz_rowsum: bad sizes");
+  const int nchunk = fz_rowsum_chunks(V);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(rowsum_kernel, dim3(C, nchunk, B), dim3(256), 0, st, x, part, C, V, nchunk);
+  FZ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ln_part_reduce_kernel, dim3((C + 31) / 32, 1), dim3(256), 0, st, part, B * nchunk, C, B * nchunk,
+                     out);
   FZ_LAUNCH_CHECK();
   return FZ_OK;
 }

@@ -34,9 +34,10 @@ class FlatGradSync:
         per = (total + num_buckets - 1) // max(num_buckets, 1)
         self.buckets, off, cur, cur_n = [], 0, [], 0
         start = 0
+        self.views = {}
         for p in order:
             n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
+            self.views[p] = self.flat[off:off + n].view_as(p)
             cur.append(p)
             off += n
             cur_n += n
@@ -69,12 +70,23 @@ class FlatGradSync:
 
     def _launch(self, bi):
         b = self.buckets[bi]
+        # pack the bucket's gradients into the flat buffer with one multi-tensor copy (autograd
+        # produced them as separate tensors: assigning, not accumulating, costs no kernel)
+        ps = [p for p in b["params"] if p.grad is not None]
+        if ps:
+            torch._foreach_copy_([self.views[p] for p in ps], [p.grad for p in ps])
+        missing = [p for p in b["params"] if p.grad is None]
+        for p in missing:
+            self.views[p].zero_()
         work = dist.all_reduce(self.flat[b["lo"]:b["hi"]], op=dist.ReduceOp.SUM, group=self.group,
                                async_op=True)
         self._pending.append(work)
 
     def zero_grad(self):
-        self.flat.zero_()
+        """Gradients are dropped (set to None), so the backward pass ASSIGNS fresh tensors instead of
+        launching one accumulate kernel per parameter."""
+        for p in self.params:
+            p.grad = None
         self._ready = [0] * len(self.buckets)
 
     def finish(self):
@@ -88,4 +100,6 @@ class FlatGradSync:
             w.wait()
         self._pending = []
         self.flat.div_(self.world)
+        for p in self.params:  # the optimizer reads the averaged gradients through the flat views
+            p.grad = self.views[p]
         self._ready = [0] * len(self.buckets)

@@ -361,7 +361,14 @@ class TConvK2S2Fn(torch.autograd.Function):
         # GW[ci][(o,tap)] = Σ X[ci][n] · GY[o][fine(n,tap)]
         _wgrad(x, [gy], gw, B=B, M=C, Cin=O, K=8 * O, Vq=8 * V, Ncols=V, loader=LOAD_S2D, D=2 * D, H=2 * H,
                W=2 * W, Ho=H, Wo=W, name="wgrad_tconv_k2s2")
-        gb = gy.sum(dim=(0, 2, 3, 4)) if ctx.has_bias else None
+        gb = None
+        if ctx.has_bias:
+            Vf = 8 * V
+            gb = torch.empty(O, dtype=x.dtype, device=x.device)
+            part = torch.empty(B * N.lib().fz_rowsum_chunks(Vf) * O, dtype=x.dtype, device=x.device)
+            with torch.cuda.device(x.device):
+                rc = N.lib().fz_rowsum(gy.data_ptr(), part.data_ptr(), gb.data_ptr(), B, O, Vf, N.stream_ptr(x))
+            N.check(rc, "fz_rowsum")
         return gx, gw, gb
 
 

@@ -232,6 +232,11 @@ int fz_ln_bwd(const float* gl, const float* x, const float* stats, const float* 
               const float* gadd, float* gx, float* gparams, void* workspace, int B, int C, int64_t V,
               fz_stream_t stream);
 
+/* out[c] = sum over batch and voxels of x[b,c,v] (bias gradient of ConvTranspose3d, unet.py:123);
+ * part: workspace of B * fz_rowsum_chunks(V) * C floats. */
+int fz_rowsum_chunks(int64_t V);
+int fz_rowsum(const float* x, float* part, float* out, int B, int C, int64_t V, fz_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
