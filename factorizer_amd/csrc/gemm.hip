@@ -59,6 +59,7 @@ struct GemmArgs {
   int64_t Ncol;        // columns per sample (= Vin for LOAD_PLAIN, coarse voxels for LOAD_S2D)
   int Ho, Wo;          // coarse H, W (LOAD_S2D columns / EPI_D2S input grid)
   int B;
+  int tile_map;        // workgroup -> column-tile order: 0 linear, 1 XCD-contiguous, 2 scattered
   // EPI_LNBWD (M == 32): the result is gl = dL/d(LN output); the epilogue applies the LayerNorm
   // backward in registers: y = rstd*(gl*g - mean_c(gl*g) - n*mean_c(gl*g*n)) + lnb_gadd
   const float* lnb_x;      // (B, 32, V) LayerNorm input
@@ -323,8 +324,16 @@ __global__ __launch_bounds__(256, ((NSTEP <= 16 && EPI != EPI_LNBWD) ? 3 : 2)) v
   float* As = lds_a;                      // [nA][RB][64]
   float* tW = lds_a + nA * RB * 64;       // [32*RB]
   const int tiles_per_sample = (int)((p.Ncol + 511) / 512);
-  const int b = blockIdx.x / tiles_per_sample;
-  const int64_t n0 = ((int64_t)(blockIdx.x % tiles_per_sample) * 4 + wave) * 128;
+  int bid = blockIdx.x;
+  if (p.tile_map == 1) {         // XCD-contiguous: each XCD walks its own eighth of the tiles
+    const int nb = gridDim.x, q8 = nb / 8, r8 = nb % 8, xcd = bid % 8, i8 = bid / 8;
+    if (nb >= 16) bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + i8;
+  } else if (p.tile_map == 2) {  // scattered: odd-multiplier permutation of a power-of-two grid
+    const int nb = gridDim.x;
+    if ((nb & (nb - 1)) == 0) bid = (int)(((unsigned)bid * 40503u) & (unsigned)(nb - 1));
+  }
+  const int b = bid / tiles_per_sample;
+  const int64_t n0 = ((int64_t)(bid % tiles_per_sample) * 4 + wave) * 128;
   const int m0 = blockIdx.y * 32 * RB;
 
   // batched fill (8 independent loads per thread before the LDS stores)
@@ -731,12 +740,18 @@ extern "C" int fz_gemm(const fz_gemm_desc* d, fz_stream_t stream) {
   a.bias = d->bias; a.ln = d->ln; a.ln_g = d->ln_g; a.ln_b = d->ln_b; a.ln_eps = d->ln_eps;
   a.stats_out = d->stats_out; a.bact = d->bact; a.eact = d->eact; a.res = d->res; a.emul = d->emul;
   a.emul_kind = d->emul_kind; a.y = d->y; a.Ncol = d->Ncol; a.Ho = d->Ho; a.Wo = d->Wo; a.B = d->B;
+  { const char* e = getenv("FZ_GEMM_TILEMAP"); a.tile_map = e ? atoi(e) : 1; }
   a.lnb_x = d->lnb_x; a.lnb_stats = d->lnb_stats; a.lnb_g = d->lnb_g; a.lnb_gadd = d->lnb_gadd; a.lnb_part = d->lnb_part;
   hipStream_t st = (hipStream_t)stream;
   const int mblocks = (d->M + 31) / 32;
 
   // ---- Kernel A: whole operand in registers (K <= 64, plain loader) ----
-  if (d->loader == LOAD_PLAIN && d->K <= 64) {
+  // measured (tools/debug/gemm_probe5.py): the register-resident kernel wins for K <= 32, the
+  // streaming ring for K = 64 (4.4 vs 3.3 TB/s at 64->32, 128^3)
+  int res_maxk = 32;
+  { const char* e = getenv("FZ_GEMM_RESMAXK"); if (e) res_maxk = atoi(e); }
+  if (d->epilogue == EPI_LNBWD) res_maxk = 64;
+  if (d->loader == LOAD_PLAIN && d->K <= res_maxk) {
     const int nA = (d->K + 1) / 2;
     int RB = mblocks < 8 ? mblocks : 8;
     while ((size_t)(nA * RB * 64 + 32 * RB) * sizeof(float) > 65536) --RB;
