@@ -1,0 +1,297 @@
+// conv3.hip — the stem: Conv3d(kernel 3, padding 1, stride 1, bias optional) forward and
+// weight gradient as direct implicit-GEMM kernels on the fp32 matrix cores.
+// Replaces nn.Conv3d(in, 32, k=3, p=1, bias=False) of the Factorizer stem
+// (factorizer/factorizer.py:145-149 → unet.py:231,261): C_in = 4 is far too thin for an im2col
+// GEMM (K = 108), and MIOpen's fallback was the single most expensive kernel of a training step
+// (profiles/r01_p1).
+//
+// Forward: one wave = 32 output channels x 128 consecutive voxels (4 per lane, W % 4 == 0).
+// The 27 taps are unrolled at compile time; for every (channel pair, kd, kh) the lane loads ONE
+// aligned 16-byte vector plus its two neighbours and derives the kw = 0,1,2 operands from them in
+// registers (3 K-steps per load group), all addresses clamped and masked branch-free.
+//
+// Weight gradient: one wave stages, per 32-voxel tile along W, the 32 gY rows and the 9 (kd,kh)
+// halo rows of every input channel (34 floats each) in LDS; the 27·C_in shifted operands are then
+// LDS reads at lane-dependent offsets, so the input is fetched 9x (L1/L2 hits) instead of 27x and
+// gY exactly once.  Partial sums per workgroup, deterministic reduction (wgrad.hip's reducer).
+#include "fz_common.h"
+
+namespace fz {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct Conv3Args {
+  const float* x;     // (B, Cin, D, H, W)
+  const float* w;     // (M, Cin, 3, 3, 3)
+  const float* bias;  // (M) or null
+  float* y;           // (B, M, D, H, W)
+  int B, Cin, M, D, H, W;
+};
+
+// ---------------------------------------------------------------------------------------------
+template <int MB>
+__global__ __launch_bounds__(256, 2) void conv3_fwd_kernel(Conv3Args p) {
+  extern __shared__ __attribute__((aligned(16))) float As[];  // [Cin/2 * 27][MB][64]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int64_t V = (int64_t)p.D * p.H * p.W;
+  const int tiles_per_sample = (int)((V + 511) / 512);
+  const int b = blockIdx.x / tiles_per_sample;
+  const int64_t n0 = ((int64_t)(blockIdx.x % tiles_per_sample) * 4 + wave) * 128;
+  const int m0 = blockIdx.y * 32 * MB;
+  const int ncp = p.Cin / 2;
+  const int nA = ncp * 27;
+
+  for (int base = threadIdx.x; base < nA * MB * 64; base += blockDim.x * 8) {
+    float tmp[8];
+#pragma unroll
+    for (int uu = 0; uu < 8; ++uu) {
+      const int idx = base + uu * blockDim.x;
+      const bool in = idx < nA * MB * 64;
+      const int ii = in ? idx : 0;
+      const int l = ii & 63, mb = (ii >> 6) % MB, a = ii / (64 * MB);
+      const int m = m0 + mb * 32 + (l & 31);
+      const int c = 2 * (a / 27) + (l >> 5), tap = a % 27;
+      const int mc = m < p.M ? m : p.M - 1;
+      const float wv = p.w[((int64_t)mc * p.Cin + c) * 27 + tap];
+      tmp[uu] = (in && m < p.M) ? wv : 0.f;
+    }
+#pragma unroll
+    for (int uu = 0; uu < 8; ++uu) {
+      const int idx = base + uu * blockDim.x;
+      if (idx < nA * MB * 64) As[idx] = tmp[uu];
+    }
+  }
+  __syncthreads();
+
+  const int64_t col = n0 + 4 * j;
+  const bool col_ok = col < V;
+  const int64_t cc = col_ok ? col : 0;
+  const int w0 = (int)(cc % p.W);
+  const int h0 = (int)((cc / p.W) % p.H);
+  const int d0 = (int)(cc / ((int64_t)p.W * p.H));
+  const bool lok = w0 > 0, rok = w0 + 4 < p.W;
+
+  f32x16 acc[MB][4];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][q][r] = 0.f;
+
+  for (int cp = 0; cp < ncp; ++cp) {
+    const float* plane = p.x + ((int64_t)b * p.Cin + 2 * cp + h) * V;
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) {
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int zd = d0 + kd - 1, zh = h0 + kh - 1;
+        const bool ok = col_ok && zd >= 0 && zd < p.D && zh >= 0 && zh < p.H;
+        const int zdc = zd < 0 ? 0 : (zd >= p.D ? p.D - 1 : zd);
+        const int zhc = zh < 0 ? 0 : (zh >= p.H ? p.H - 1 : zh);
+        const float* row = plane + ((int64_t)zdc * p.H + zhc) * p.W;
+        const float4 t = *reinterpret_cast<const float4*>(row + w0);
+        const float lf = row[lok ? w0 - 1 : w0];
+        const float rt = row[rok ? w0 + 4 : w0];
+        const float c0 = ok ? t.x : 0.f, c1 = ok ? t.y : 0.f, c2 = ok ? t.z : 0.f, c3 = ok ? t.w : 0.f;
+        const float l0 = (ok && lok) ? lf : 0.f, r0 = (ok && rok) ? rt : 0.f;
+        const float bv[3][4] = {{l0, c0, c1, c2}, {c0, c1, c2, c3}, {c1, c2, c3, r0}};
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int a = cp * 27 + (kd * 3 + kh) * 3 + kw;
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) {
+            const float av = As[(a * MB + mb) * 64 + lane];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              acc[mb][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[kw][q], acc[mb][q], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  if (!col_ok) return;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (m >= p.M) continue;
+      const float bs = p.bias ? p.bias[m] : 0.f;
+      *reinterpret_cast<float4*>(p.y + ((int64_t)b * p.M + m) * V + col) =
+          make_float4(acc[mb][0][r] + bs, acc[mb][1][r] + bs, acc[mb][2][r] + bs, acc[mb][3][r] + bs);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient: GW[m][(ci, kd, kh, kw)] = Σ_{b,v} gY[b,m,v] · x[b,ci,v + off(kd,kh,kw)]
+struct Conv3WgradArgs {
+  const float* gy;  // (B, M, D, H, W)
+  const float* x;   // (B, Cin, D, H, W)
+  float* part;      // [nchunk][M][27*Cin]
+  float* part_bias; // [nchunk][M]
+  int B, Cin, M, D, H, W;
+  int tiles_per_unit;
+};
+
+constexpr int kXs = 36;  // halo row stride (34 used)
+
+template <int KB>  // KB = number of 32-column blocks covering 27*Cin (4 for Cin = 4)
+__global__ __launch_bounds__(256) void conv3_wgrad_kernel(Conv3WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nrow = a.Cin * 9;                      // halo rows per tile
+  const int per_wave = 32 * 33 + nrow * kXs;
+  float* Pt = lds + wave * per_wave;               // [32][33] gY tile
+  float* Xs = Pt + 32 * 33;                        // [Cin*9][36] halo rows (index 0 = w0-1)
+  const int K = 27 * a.Cin;
+  const int m0 = blockIdx.y * 32;
+  const int64_t V = (int64_t)a.D * a.H * a.W;
+  const int64_t tiles_per_sample = V / 32;         // W % 32 == 0: a tile never crosses a row
+  const int64_t total = tiles_per_sample * a.B;
+  const int64_t unit = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t t_begin = unit * a.tiles_per_unit, t_end = min(t_begin + a.tiles_per_unit, total);
+  const int c = lane & 31, h = lane >> 5;
+
+  // per-lane operand offsets inside Xs for each column block: column k = jb*32 + c
+  int xoff[KB];
+#pragma unroll
+  for (int jb = 0; jb < KB; ++jb) {
+    const int k = jb * 32 + c;
+    const int kc = k < K ? k : 0;
+    const int ci = kc / 27, tap = kc % 27;
+    xoff[jb] = (ci * 9 + tap / 3) * kXs + (tap % 3);  // row (ci,kd,kh), shift kw
+  }
+  f32x16 acc[KB];
+#pragma unroll
+  for (int jb = 0; jb < KB; ++jb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[jb][r] = 0.f;
+  float psum = 0.f;
+
+  for (int64_t t = t_begin; t < t_end; ++t) {
+    const int b = (int)(t / tiles_per_sample);
+    const int64_t n0 = (t % tiles_per_sample) * 32;
+    const int w0 = (int)(n0 % a.W);
+    const int h0 = (int)((n0 / a.W) % a.H);
+    const int d0 = (int)(n0 / ((int64_t)a.W * a.H));
+    // gY tile: 32 rows x 8 chunks of 16 bytes = 4 chunks per lane
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = (lane >> 3) + 8 * i, cq = lane & 7;
+      const int m = m0 + r;
+      const int mc = m < a.M ? m : a.M - 1;
+      const float4 v = *reinterpret_cast<const float4*>(a.gy + ((int64_t)b * a.M + mc) * V + n0 + cq * 4);
+      const bool ok = m < a.M;
+      float* d = Pt + r * 33 + cq * 4;
+      d[0] = ok ? v.x : 0.f; d[1] = ok ? v.y : 0.f; d[2] = ok ? v.z : 0.f; d[3] = ok ? v.w : 0.f;
+    }
+    // halo rows: nrow x 34 floats (w0-1 .. w0+32), zero padded
+    for (int idx = lane; idx < nrow * 34; idx += 64) {
+      const int rr = idx / 34, e = idx % 34;
+      const int ci = rr / 9, kd = (rr % 9) / 3, kh = rr % 3;
+      const int zd = d0 + kd - 1, zh = h0 + kh - 1, zw = w0 + e - 1;
+      const bool ok = zd >= 0 && zd < a.D && zh >= 0 && zh < a.H && zw >= 0 && zw < a.W;
+      const int zdc = min(max(zd, 0), a.D - 1), zhc = min(max(zh, 0), a.H - 1), zwc = min(max(zw, 0), a.W - 1);
+      const float v = a.x[((int64_t)b * a.Cin + ci) * V + ((int64_t)zdc * a.H + zhc) * a.W + zwc];
+      Xs[rr * kXs + e] = ok ? v : 0.f;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll 4
+    for (int s = 0; s < 16; ++s) {
+      const float av = Pt[c * 33 + 2 * s + h];
+      psum += av;
+#pragma unroll
+      for (int jb = 0; jb < KB; ++jb) {
+        const float bv = Xs[xoff[jb] + 2 * s + h];
+        acc[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[jb], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+
+  // reduce the 4 waves, write the workgroup's partial block
+  __syncthreads();
+  float* red = lds;
+#pragma unroll
+  for (int jb = 0; jb < KB; ++jb) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+      red[wave * 1024 + row * 32 + c] = acc[jb][r];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 1024; e += 256) {
+      const float sres = (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]);
+      const int m = m0 + (e >> 5), k = jb * 32 + (e & 31);
+      if (m < a.M && k < K) a.part[((int64_t)blockIdx.x * a.M + m) * K + k] = sres;
+    }
+    __syncthreads();
+  }
+  {
+    const float sres = psum + __shfl_xor(psum, 32, 64);
+    if (h == 0) red[wave * 32 + c] = sres;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+      const int m = m0 + threadIdx.x;
+      if (m < a.M)
+        a.part_bias[(int64_t)blockIdx.x * a.M + m] =
+            (red[threadIdx.x] + red[32 + threadIdx.x]) + (red[64 + threadIdx.x] + red[96 + threadIdx.x]);
+    }
+  }
+}
+
+}  // namespace fz
+
+using namespace fz;
+
+extern "C" int fz_conv3_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int M, int D,
+                            int H, int W, fz_stream_t stream) {
+  if (!x || !w || !y) return fail(FZ_E_ARG, "fz_conv3_fwd: null pointer");
+  if (B < 0 || Cin < 2 || (Cin & 1) || M < 1 || D < 1 || H < 1 || W < 4 || (W & 3))
+    return fail(FZ_E_UNSUPPORTED, "fz_conv3_fwd: needs even C_in and W % 4 == 0");
+  if (B == 0) return FZ_OK;
+  Conv3Args p{x, w, bias, y, B, Cin, M, D, H, W};
+  const int64_t V = (int64_t)D * H * W;
+  const int mblocks = (M + 31) / 32;
+  const int MB = mblocks >= 2 ? 2 : 1;
+  const size_t lds = (size_t)(Cin / 2) * 27 * MB * 64 * sizeof(float);
+  if (lds > 65536) return fail(FZ_E_UNSUPPORTED, "fz_conv3_fwd: C_in too large for the stem kernel");
+  dim3 grid((unsigned)(((V + 511) / 512) * B), (unsigned)((mblocks + MB - 1) / MB)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (MB == 2) hipLaunchKernelGGL(conv3_fwd_kernel<2>, grid, block, lds, st, p);
+  else hipLaunchKernelGGL(conv3_fwd_kernel<1>, grid, block, lds, st, p);
+  FZ_LAUNCH_CHECK();
+  return FZ_OK;
+}
+
+static int conv3_units(int64_t total_tiles, int* tiles_per_unit) {
+  int64_t units_target = 4096;
+  int64_t tpu = (total_tiles + units_target - 1) / units_target;
+  if (tpu < 1) tpu = 1;
+  *tiles_per_unit = (int)tpu;
+  const int64_t units = (total_tiles + tpu - 1) / tpu;
+  return (int)((units + 3) / 4);
+}
+
+// workspace floats: nchunk*(M*K + M);  nchunk = fz_conv3_wgrad_chunks(...)
+extern "C" int fz_conv3_wgrad_chunks(int B, int D, int H, int W) {
+  int tpu;
+  return conv3_units(((int64_t)D * H * W / 32) * B, &tpu);
+}
+
+extern "C" int fz_conv3_wgrad_partials(const float* gy, const float* x, float* part, float* part_bias, int B, int Cin,
+                                       int M, int D, int H, int W, fz_stream_t stream) {
+  if (!gy || !x || !part || !part_bias) return fail(FZ_E_ARG, "fz_conv3_wgrad: null pointer");
+  if (B < 1 || Cin < 1 || M < 1 || (W % 32) || 27 * Cin > 128)
+    return fail(FZ_E_UNSUPPORTED, "fz_conv3_wgrad: needs W % 32 == 0 and 27*C_in <= 128");
+  Conv3WgradArgs a{gy, x, part, part_bias, B, Cin, M, D, H, W, 1};
+  const int nchunk = conv3_units(((int64_t)D * H * W / 32) * B, &a.tiles_per_unit);
+  const size_t lds = (size_t)4 * (32 * 33 + Cin * 9 * kXs) * sizeof(float);
+  const size_t lds_red = 4096 * sizeof(float);
+  dim3 grid(nchunk, (M + 31) / 32), block(256);
+  hipLaunchKernelGGL(conv3_wgrad_kernel<4>, grid, block, lds > lds_red ? lds : lds_red, (hipStream_t)stream, a);
+  FZ_LAUNCH_CHECK();
+  return FZ_OK;
+}

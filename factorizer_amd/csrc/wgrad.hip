@@ -403,3 +403,14 @@ extern "C" int fz_wgrad(const fz_wgrad_desc* d, void* workspace, fz_stream_t str
   FZ_LAUNCH_CHECK();
   return FZ_OK;
 }
+
+// out[e] (+)= Σ_chunks part[chunk][e], fixed order — exposed for kernels that produce their own
+// per-workgroup partial sums (conv3.hip).
+extern "C" int fz_chunk_reduce(const float* part, int nchunk, int64_t n, float* out, int accumulate,
+                               fz_stream_t stream) {
+  if (!part || !out || nchunk < 1 || n < 1) return fail(FZ_E_ARG, "fz_chunk_reduce: bad arguments");
+  hipLaunchKernelGGL(chunk_reduce_kernel, dim3((unsigned)((n + 7) / 8)), dim3(256), 0, (hipStream_t)stream, part,
+                     nchunk, n, out, accumulate);
+  FZ_LAUNCH_CHECK();
+  return FZ_OK;
+}

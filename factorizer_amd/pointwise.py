@@ -373,7 +373,8 @@ class TConvK2S2Fn(torch.autograd.Function):
 
 
 class ConvK3Fn(torch.autograd.Function):
-    """Conv3d(kernel 3, padding 1) — the stem (C_in = 4): taps gathered by the GEMM's loader."""
+    """Conv3d(kernel 3, padding 1) — the stem (C_in = 4): direct implicit-GEMM kernels
+    (csrc/conv3.hip); shapes outside them use the generic tap loaders of the GEMM family."""
 
     @staticmethod
     def forward(ctx, x, w, b):
@@ -382,8 +383,14 @@ class ConvK3Fn(torch.autograd.Function):
         O = w.shape[0]
         V = D * H * W
         y = torch.empty((B, O, D, H, W), dtype=x.dtype, device=x.device)
-        _gemm([x], w, y, B=B, Cin=C, Vin=V, M=O, K=27 * C, Ncol=V, bias=b, loader=LOAD_K3, Di=D, Hi=H, Wi=W,
-              name="conv_k3")
+        if C * 27 * 64 * 4 <= 65536:
+            with torch.cuda.device(x.device):
+                rc = Fn._timed(f"conv_k3_{C}->{O}", 4 * (x.numel() + y.numel()), lambda: N.lib().fz_conv3_fwd(
+                    x.data_ptr(), w.data_ptr(), _p(b), y.data_ptr(), B, C, O, D, H, W, N.stream_ptr(x)))
+            N.check(rc, "fz_conv3_fwd")
+        else:
+            _gemm([x], w, y, B=B, Cin=C, Vin=V, M=O, K=27 * C, Ncol=V, bias=b, loader=LOAD_K3, Di=D, Hi=H, Wi=W,
+                  name="conv_k3")
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
         return y
@@ -401,8 +408,28 @@ class ConvK3Fn(torch.autograd.Function):
             gx = torch.nn.grad.conv3d_input(x.shape, w, gy, padding=1)
         gw = torch.empty_like(w)
         gb = torch.empty(O, dtype=x.dtype, device=x.device)
-        _wgrad(gy, [x], gw, B=B, M=O, Cin=C, K=27 * C, Vq=V, Ncols=V, gbias=gb, loader=LOAD_K3, D=D, H=H, W=W,
-               name="wgrad_conv_k3")
+        if W % 32 == 0 and 27 * C <= 128:
+            lib = N.lib()
+            nchunk = lib.fz_conv3_wgrad_chunks(B, D, H, W)
+            K = 27 * C
+            part = torch.empty(nchunk * O * K, dtype=x.dtype, device=x.device)
+            pbias = torch.empty(nchunk * O, dtype=x.dtype, device=x.device)
+            with torch.cuda.device(x.device):
+                st = N.stream_ptr(x)
+
+                def run():
+                    rc = lib.fz_conv3_wgrad_partials(gy.data_ptr(), x.data_ptr(), part.data_ptr(), pbias.data_ptr(),
+                                                     B, C, O, D, H, W, st)
+                    if rc == 0:
+                        rc = lib.fz_chunk_reduce(part.data_ptr(), nchunk, O * K, gw.data_ptr(), 0, st)
+                    if rc == 0:
+                        rc = lib.fz_chunk_reduce(pbias.data_ptr(), nchunk, O, gb.data_ptr(), 0, st)
+                    return rc
+                rc = Fn._timed(f"wgrad_conv_k3_{O}x{K}", 4 * (x.numel() + gy.numel()), run)
+            N.check(rc, "fz_conv3_wgrad")
+        else:
+            _wgrad(gy, [x], gw, B=B, M=O, Cin=C, K=27 * C, Vq=V, Ncols=V, gbias=gb, loader=LOAD_K3, D=D, H=H, W=W,
+                   name="wgrad_conv_k3")
         return gx, gw, (gb if ctx.has_bias else None)
 
 

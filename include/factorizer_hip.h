@@ -232,6 +232,18 @@ int fz_ln_bwd(const float* gl, const float* x, const float* stats, const float* 
               const float* gadd, float* gx, float* gparams, void* workspace, int B, int C, int64_t V,
               fz_stream_t stream);
 
+/* ---- stem: Conv3d(kernel 3, padding 1) (factorizer/factorizer.py:145-149 → unet.py:231,261) ----
+ * fwd: y = conv3d(x, w) [+ bias]; needs even C_in, W % 4 == 0.
+ * wgrad: per-workgroup partial sums part[nchunk][M][27*C_in], part_bias[nchunk][M]
+ * (nchunk = fz_conv3_wgrad_chunks), reduced in a fixed order by fz_chunk_reduce; needs
+ * W % 32 == 0 and 27*C_in <= 128. */
+int fz_conv3_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int M, int D,
+                 int H, int W, fz_stream_t stream);
+int fz_conv3_wgrad_chunks(int B, int D, int H, int W);
+int fz_conv3_wgrad_partials(const float* gy, const float* x, float* part, float* part_bias, int B, int Cin,
+                            int M, int D, int H, int W, fz_stream_t stream);
+int fz_chunk_reduce(const float* part, int nchunk, int64_t n, float* out, int accumulate, fz_stream_t stream);
+
 /* out[c] = sum over batch and voxels of x[b,c,v] (bias gradient of ConvTranspose3d, unet.py:123);
  * part: workspace of B * fz_rowsum_chunks(V) * C floats. */
 int fz_rowsum_chunks(int64_t V);

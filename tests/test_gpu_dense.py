@@ -189,3 +189,13 @@ def test_reference_layer_goldens(golden, name):
     _cmp(grads[0], g["gx"], "gx", rtol=5e-4)
     for k, gr in zip(names, grads[1:]):
         _cmp(gr, g["grad:" + k], k, rtol=5e-4)
+
+
+@pytest.mark.parametrize("Cin,Cout,S", [(4, 32, (8, 8, 32)), (4, 32, (4, 6, 64)), (2, 48, (8, 4, 32)), (4, 8, (3, 5, 32))])
+def test_conv_k3_stem_direct_wgrad(Cin, Cout, S):
+    """W % 32 == 0: the LDS-halo weight-gradient kernel of csrc/conv3.hip."""
+    torch.manual_seed(18)
+    w = torch.randn(Cout, Cin, 3, 3, 3) / 5
+    b = torch.randn(Cout)
+    x = torch.randn(2, Cin, *S)
+    _run_both(lambda x, w, b: PW.ConvK3Fn.apply(x, w, b), lambda x, w, b: F.conv3d(x, w, b, padding=1), [x, w, b])
