@@ -36,6 +36,21 @@ from factorizer_amd.parallel import FlatGradSync  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
+# HBM traffic per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+# passes of this same command, FETCH_SIZE doubled per the gfx950 correction of
+# MI355X_MICROARCH.md §HBM; tools/pmc_traffic.py → profiles/r01_pmc_traffic.json).  Counters cannot
+# be read from inside the benchmark, so the committed summary of the profiled run is quoted.
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+PMC_KERNEL = {"nmf_cf_bwd": "fz::nmf_cf_bwd_kernel<1, 1>", "nmf_cf_fwd": "fz::nmf_cf_fwd_kernel<1, 1>"}
+
+
+def pmc_traffic(timer_name):
+    try:
+        d = json.load(open(PMC_TRAFFIC))
+        return d[PMC_KERNEL[timer_name]]["traffic_bytes"]
+    except Exception:
+        return None
+
 MODEL_KW = dict(in_channels=4, out_channels=3, spatial_size=(128, 128, 128),
                 encoder_depth=(1, 1, 1, 1, 1), encoder_width=(32, 64, 128, 256, 512),
                 strides=(1, 2, 2, 2, 2), decoder_depth=(1, 1, 1, 1), norm=ft.LayerNorm,
@@ -155,7 +170,7 @@ def main():
             avg_ms = a["ms"] / a["calls"]
             gbs = a["bytes"] / a["calls"] / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(name),
                     "avg_launch_ms": round(avg_ms, 4), "launches": a["calls"],
                     "algorithmic_bytes_per_launch": a["bytes"] // a["calls"],
                     "share_of_step": round(a["ms"] / (elapsed * 1e3), 4),
