@@ -29,6 +29,13 @@ namespace fz {
 constexpr int SOLVER_MU = 0;
 constexpr int SOLVER_HALS = 1;
 
+// reciprocal: v_rcp_f32 on device (1 ulp) instead of the ~10-instruction IEEE division sequence —
+// the HALS/MU ratios need 1e-4 parity, not correct rounding, and the backward kernel is VALU-bound
+#if defined(__HIP_DEVICE_COMPILE__)
+FZ_HD float fz_rcp(float v) { return __builtin_amdgcn_rcpf(v); }
+#else
+FZ_HD float fz_rcp(float v) { return 1.0f / v; }
+#endif
 FZ_HD float fz_relu(float v) { return v > 0.f ? v : 0.f; }
 // gate(w, g) = g where w > 0 else 0  (ReLU mask taken from the forward value)
 FZ_HD float fz_gate(float w, float g) { return w > 0.f ? g : 0.f; }
@@ -36,22 +43,29 @@ FZ_HD float fz_gate(float w, float g) { return w > 0.f ? g : 0.f; }
 // ---- one half-step on K independent rows of a factor:  w' = update(w; a, b) ------------
 template <int K, int R, int SOLVER, class F>
 FZ_HD void update_rows(F (&w)[K][R], const F (&a)[K][R], const F (&b)[R][R], float eps) {
+  if (SOLVER == SOLVER_MU) {
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    if (SOLVER == SOLVER_MU) {
+    for (int k = 0; k < K; ++k) {
       F nw[R];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         F dn = w[k][0] * b[0][r];
 #pragma unroll
         for (int q = 1; q < R; ++q) dn = dn + w[k][q] * b[q][r];
-        nw[r] = (w[k][r] * a[k][r] + eps) / (dn + eps);
+        nw[r] = (w[k][r] * a[k][r] + eps) * fz_rcp(dn + eps);
       }
 #pragma unroll
       for (int r = 0; r < R; ++r) w[k][r] = nw[r];
-    } else {
+    }
+  } else {
+    // the denominators b[r][r] + eps are shared by all K rows: one reciprocal per column
+    F inv[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) inv[r] = fz_rcp(b[r][r] + eps);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
       if (R == 1) {
-        w[k][0] = fz_relu((a[k][0] + eps) / (b[0][0] + eps));
+        w[k][0] = fz_relu((a[k][0] + eps) * inv[0]);
       } else {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -64,7 +78,7 @@ FZ_HD void update_rows(F (&w)[K][R], const F (&a)[K][R], const F (&b)[R][R], flo
             s = first ? t : s + t;
             first = false;
           }
-          w[k][r] = fz_relu((a[k][r] - s + eps) / (b[r][r] + eps));
+          w[k][r] = fz_relu((a[k][r] - s + eps) * inv[r]);
         }
       }
     }
@@ -85,9 +99,9 @@ FZ_HD void half_bwd_row(const F (&wold)[R], const F (&wnew)[R], const F (&a)[R],
       F dn = wold[0] * b[0][r];
 #pragma unroll
       for (int q = 1; q < R; ++q) dn = dn + wold[q] * b[q][r];
-      dn = dn + eps;
-      gn[r] = gwn[r] / dn;
-      gdn[r] = F(0.f) - gwn[r] * wnew[r] / dn;
+      const F idn = fz_rcp(dn + eps);
+      gn[r] = gwn[r] * idn;
+      gdn[r] = F(0.f) - gwn[r] * wnew[r] * idn;
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -104,10 +118,10 @@ FZ_HD void half_bwd_row(const F (&wold)[R], const F (&wnew)[R], const F (&a)[R],
     for (int r = 0; r < R; ++r) gwo[r] = F(0.f);
 #pragma unroll
     for (int r = R - 1; r >= 0; --r) {
-      F den = b[r][r] + eps;
+      const F iden = fz_rcp(b[r][r] + eps);
       F gq = fz_gate(wnew[r], gwn[r]);
-      F gnum = gq / den;
-      gb[r][r] = gb[r][r] - (gq * wnew[r]) / den;
+      F gnum = gq * iden;
+      gb[r][r] = gb[r][r] - (gq * wnew[r]) * iden;
       ga[r] = gnum;
 #pragma unroll
       for (int q = 0; q < R; ++q) {

@@ -19,6 +19,7 @@ struct V64 {
 BINOP(+) BINOP(-) BINOP(*) BINOP(/)
 
 namespace fz {
+inline V64 fz_rcp(const V64& v) { V64 r; for (int i = 0; i < 64; ++i) r.a[i] = 1.0f / v.a[i]; return r; }
 inline V64 fz_relu(const V64& v) { V64 r; for (int i = 0; i < 64; ++i) r.a[i] = v.a[i] > 0.f ? v.a[i] : 0.f; return r; }
 inline V64 fz_gate(const V64& w, const V64& g) { V64 r; for (int i = 0; i < 64; ++i) r.a[i] = w.a[i] > 0.f ? g.a[i] : 0.f; return r; }
 }  // namespace fz
