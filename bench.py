@@ -117,11 +117,19 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks "
                          f"(WORLD_SIZE={world})")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs a GPU")
+    dev_index = local_rank % ndev  # one process per GPU; the modulo only matters for the 1-GPU gloo self-test
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("FZ_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     torch.manual_seed(0)
     model = ft.Factorizer(**MODEL_KW).to(dev).train()
