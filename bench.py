@@ -59,17 +59,6 @@ MODEL_KW = dict(in_channels=4, out_channels=3, spatial_size=(128, 128, 128),
                 dropout=0.1)
 
 
-def dice_bce_loss(logits, target, smooth=1e-5):
-    """BCEWithLogits + soft Dice (sigmoid, squared denominators): the form of the bundle's
-    DiceCELoss(sigmoid=True, squared_pred=True) (train.yaml:67-70); timing only."""
-    p = torch.sigmoid(logits)
-    dims = tuple(range(2, logits.ndim))
-    inter = (p * target).sum(dims)
-    den = (p * p).sum(dims) + (target * target).sum(dims)
-    dice = 1.0 - (2.0 * inter + smooth) / (den + smooth)
-    return dice.mean() + nn.functional.binary_cross_entropy_with_logits(logits, target)
-
-
 def cpu_baseline_sample():
     """CPU oracle (a port of the reference's CPU path) on a bounded sample of the same workload:
     BASELINE configs[1] — one stage-0 FactorizerBlock (C=32, head_dim 8, patch 8, HALS R=1 T=5)
@@ -143,7 +132,7 @@ def main():
 
     def step():
         sync.zero_grad()
-        loss = dice_bce_loss(model(x), target)
+        loss = ft.dice_bce_loss(model(x), target)
         loss.backward()
         sync.finish()
         opt.step()

@@ -12,6 +12,7 @@ from .nmf import (NMF, BCDSolver, Compose, CoordinateDescent, Initializer, Matri
 from .layers import MLP, LayerNorm, Linear, PosEmbed, PositionalEmbedding
 from .convs import Conv3d, ConvTranspose3d
 from .blocks import FactMixer, FactorizerBlock, FactorizerStage
+from .losses import dice_bce_loss
 from .unet import (Factorizer, Same, UNet, UNetDecoder, UNetDecoderBlock, UNetEncoder,
                    UNetEncoderBlock, UNetStage)
 

@@ -121,6 +121,9 @@ _SIGS.update({
     "fz_conv3_wgrad_chunks": ([_i] * 4, _i),
     "fz_conv3_wgrad_partials": ([_vp] * 4 + [_i] * 6 + [_vp], _i),
     "fz_chunk_reduce": ([_vp, _i, _i64, _vp, _i, _vp], _i),
+    "fz_dice_bce_chunks": ([_i64], _i),
+    "fz_dice_bce_sums": ([_vp, _vp, _vp, _i, _i64, _vp], _i),
+    "fz_dice_bce_grad": ([_vp, _vp, _vp, _vp, _i, _i64, _f, _f, _vp, _vp], _i),
     "fz_rowsum_chunks": ([_i64], _i),
     "fz_rowsum": ([_vp, _vp, _vp, _i, _i, _i64, _vp], _i),
     "fz_ln_fwd": ([_vp] * 5 + [_i, _i, _i64, _f, _vp], _i),

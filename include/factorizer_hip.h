@@ -249,6 +249,15 @@ int fz_chunk_reduce(const float* part, int nchunk, int64_t n, float* out, int ac
 int fz_rowsum_chunks(int64_t V);
 int fz_rowsum(const float* x, float* part, float* out, int B, int C, int64_t V, fz_stream_t stream);
 
+/* ---- fused soft-Dice + BCE-with-logits loss (training step; the form of the bundle's
+ * DiceCELoss(sigmoid=True, squared_pred=True), model_zoo/factorizer_brats23/configs/train.yaml:67-70).
+ * sums: part (planes, fz_dice_bce_chunks(V), 4) = {sum p*t, sum p^2, sum t^2, sum bce} per (b,c) plane.
+ * grad: gz = gscale * (cd * dDice/dz + cb * dBCE/dz) with coef (planes,2) = {2*inter+s, den+s}. */
+int fz_dice_bce_chunks(int64_t V);
+int fz_dice_bce_sums(const float* z, const float* t, float* part, int planes, int64_t V, fz_stream_t stream);
+int fz_dice_bce_grad(const float* z, const float* t, const float* coef, float* gz, int planes, int64_t V,
+                     float cd, float cb, const float* gscale, fz_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -199,3 +199,21 @@ def test_conv_k3_stem_direct_wgrad(Cin, Cout, S):
     b = torch.randn(Cout)
     x = torch.randn(2, Cin, *S)
     _run_both(lambda x, w, b: PW.ConvK3Fn.apply(x, w, b), lambda x, w, b: F.conv3d(x, w, b, padding=1), [x, w, b])
+
+
+def test_dice_bce_loss_fused():
+    """csrc/loss.hip against the composed ATen form (and the oracle's restatement)."""
+    from oracle import cpu_ref as O
+    torch.manual_seed(21)
+    z = torch.randn(2, 3, 8, 8, 16) * 3
+    t = (torch.rand(2, 3, 8, 8, 16) > 0.5).float()
+    zc = z.clone().requires_grad_(True)
+    lc = O.dice_bce_loss(zc, t)
+    (gc,) = torch.autograd.grad(lc * 1.7, zc)
+    zd = z.to(DEV).requires_grad_(True)
+    n0 = _native.launch_count()
+    ld = ft.dice_bce_loss(zd, t.to(DEV))
+    (gd,) = torch.autograd.grad(ld * 1.7, zd)
+    assert _native.launch_count() > n0
+    assert abs(ld.item() - lc.item()) <= 1e-5 * abs(lc.item()) + 1e-6
+    _cmp(gd, gc, "dloss/dlogits", rtol=1e-4)
