@@ -374,3 +374,83 @@ def test_fact_core_fused_vs_modular(shifts, solver, R):
     a3 = Fn.FactCoreFn.apply(t3, nmf.init.u0, nmf.init.v0, m.geometry, 4, G, solver, 1e-16, True)
     (g3,) = torch.autograd.grad(a3, t3, ga)
     assert torch.allclose(g3, g1 * (t > 0), rtol=0, atol=0)
+
+
+# ---------------------------------------------------------------- other BASELINE / §8f configs ------
+def _block_vs_oracle(C, S, reshape_kw, nmf_kw, mlp_ratio=2, B=1, tol=1e-4):
+    torch.manual_seed(0)
+    blk = ft.FactorizerBlock(channels=C, spatial_size=S, norm=ft.LayerNorm, reshape=(ft.SWMatricize, reshape_kw),
+                             act=nn.ReLU, factorize=ft.NMF, init="uniform", mlp_ratio=mlp_ratio, dropout=0.0,
+                             **nmf_kw)
+    sd = {k: v.clone() for k, v in blk.state_dict().items()}
+    x = torch.rand(B, C, *S)
+    gy = torch.rand_like(x)
+    xo = x.clone().requires_grad_(True)
+    cfg = dict(reshape=reshape_kw, num_iters=nmf_kw.get("num_iters", 5), solver=nmf_kw.get("solver", "hals"))
+    yo = O.factorizer_block(xo, sd, "", cfg)
+    (gxo,) = torch.autograd.grad(yo, xo, gy)
+    blk = blk.to(DEV)
+    xd = x.to(DEV).requires_grad_(True)
+    with Launches():
+        yd = blk(xd)
+        (gxd,) = torch.autograd.grad(yd, xd, gy.to(DEV))
+    assert torch.allclose(yd.cpu(), yo, rtol=tol, atol=tol)
+    s = gxo.abs().max().item()
+    assert (gxd.cpu() - gxo).abs().max().item() <= 10 * tol * s + tol
+
+
+def test_block_production_four_shift_windows():
+    """the BraTS bundle's windows [None, 2, 4, 6] and mlp_ratio 4
+    (model_zoo/factorizer_brats23/configs/train.yaml:50-54,62)."""
+    _block_vs_oracle(32, (16, 16, 16), dict(head_dim=8, patch_size=8, shifts=[None, 2, 4, 6]),
+                     dict(rank=1, num_iters=5, solver="hals"), mlp_ratio=4)
+
+
+def test_block_cfg5_shape_rank2_t10():
+    """BASELINE cfg 5 stress shape at reduced extent: anisotropic patch (5,6,5) (p = 8 is invalid for
+    160x192x160, SURVEY headline 5), rank 2, 10 iterations — the masked 8x150 NMF family."""
+    _block_vs_oracle(16, (10, 12, 20), dict(head_dim=8, patch_size=(5, 6, 5)),
+                     dict(rank=2, num_iters=10, solver="hals"), tol=2e-4)
+
+
+def test_block_mu_rank2_fused_core():
+    _block_vs_oracle(16, (16, 16, 16), dict(head_dim=8, patch_size=8), dict(rank=2, num_iters=3, solver="mu"))
+
+
+def test_block_training_dropout_runs():
+    """README block with dropout 0.1 in training mode (factorizer.py:69,72): modular path, finite."""
+    torch.manual_seed(0)
+    blk = ft.FactorizerBlock(channels=16, spatial_size=(16, 16, 16), norm=ft.LayerNorm,
+                             reshape=(ft.SWMatricize, {"head_dim": 8, "patch_size": 8}), act=nn.ReLU,
+                             factorize=ft.NMF, rank=1, num_iters=5, init="uniform", solver="hals", mlp_ratio=2,
+                             dropout=0.1).to(DEV).train()
+    x = torch.rand(2, 16, 16, 16, 16, device=DEV, requires_grad=True)
+    with Launches():
+        y = blk(x)
+        y.sum().backward()
+    assert torch.isfinite(y).all() and torch.isfinite(x.grad).all()
+    blk.eval()
+    y1, y2 = blk(x), blk(x)
+    assert torch.equal(y1, y2)
+
+
+def test_readme_model_full_size_train_step():
+    """BASELINE cfg 3/4: README Swin Factorizer (in 4, out 3, 128^3, widths 32-512) forward, backward
+    and one optimizer step at B = 1; outputs / gradients finite, replicas deterministic."""
+    torch.manual_seed(0)
+    model = ft.Factorizer(in_channels=4, out_channels=3, spatial_size=(128, 128, 128), norm=ft.LayerNorm,
+                          reshape=(ft.SWMatricize, {"head_dim": 8, "patch_size": 8}), act=nn.ReLU,
+                          factorize=ft.NMF, rank=1, num_iters=5, init="uniform", solver="hals", mlp_ratio=2,
+                          dropout=0.1).to(DEV).eval()
+    x = torch.rand(1, 4, 128, 128, 128, device=DEV)
+    t = (torch.rand(1, 3, 128, 128, 128, device=DEV) > 0.5).float()
+    with Launches():
+        y = model(x)
+        loss = ft.dice_bce_loss(y, t)
+        loss.backward()
+    assert y.shape == (1, 3, 128, 128, 128) and torch.isfinite(y).all() and torch.isfinite(loss)
+    for n, p in model.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), n
+    with torch.no_grad():
+        y2 = model(x)
+    assert torch.equal(y, y2)  # deterministic kernels (no float atomics)
