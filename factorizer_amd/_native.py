@@ -129,4 +129,5 @@ _SIGS.update({
     "fz_ln_fwd": ([_vp] * 5 + [_i, _i, _i64, _f, _vp], _i),
     "fz_ln_bwd": ([_vp] * 8 + [_i, _i, _i64, _vp], _i),
     "fz_ln_bwd_workspace_bytes": ([_i], _i64),
+    "fz_ln_bwd_workspace_bytes2": ([_i, _i, _i64], _i64),
 })

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(64 * NW) void ln_bwd_split_kernel(const float* __re
                                                                const float* __restrict__ stats,
                                                                const float* __restrict__ g,
                                                                const float* __restrict__ gadd, float* __restrict__ gx,
-                                                               int B, int C, int64_t V) {
+                                                               float* __restrict__ part, int B, int C, int64_t V) {
   __shared__ float red[NW][8][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t nvec = V / 4;
@@ -164,10 +164,19 @@ __global__ __launch_bounds__(64 * NW) void ln_bwd_split_kernel(const float* __re
     const float4 t = *reinterpret_cast<const float4*>(x + base + (int64_t)c * V);
     const float4 d = *reinterpret_cast<const float4*>(gl + base + (int64_t)c * V);
     const float gc = g[c];
+    const float nx = (t.x - mu.x) * rs.x, ny = (t.y - mu.y) * rs.y, nz = (t.z - mu.z) * rs.z, nw = (t.w - mu.w) * rs.w;
     const float ax = d.x * gc, ay = d.y * gc, az = d.z * gc, aw = d.w * gc;
     m[0] += ax; m[1] += ay; m[2] += az; m[3] += aw;
-    m[4] += ax * (t.x - mu.x) * rs.x; m[5] += ay * (t.y - mu.y) * rs.y;
-    m[6] += az * (t.z - mu.z) * rs.z; m[7] += aw * (t.w - mu.w) * rs.w;
+    m[4] += ax * nx; m[5] += ay * ny; m[6] += az * nz; m[7] += aw * nw;
+    if (part != nullptr) {
+      // affine gradients of channel c over this workgroup's 64 quads: part[blk][c | C + c]
+      const float sg = wave_sum(ok ? (d.x * nx + d.y * ny) + (d.z * nz + d.w * nw) : 0.f);
+      const float sb = wave_sum(ok ? (d.x + d.y) + (d.z + d.w) : 0.f);
+      if (lane == 0) {
+        part[(int64_t)blockIdx.x * 2 * C + c] = sg;
+        part[(int64_t)blockIdx.x * 2 * C + C + c] = sb;
+      }
+    }
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) red[wave][e][lane] = m[e];
@@ -242,6 +251,8 @@ __global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ x
 
 using namespace fz;
 
+extern "C" int fz_reduce_rows(const float* part, int64_t rows, int n, float* out, float* tmp, fz_stream_t stream);
+
 static unsigned ln_grid(int64_t total) {
   int64_t blocks = (total + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
@@ -263,7 +274,13 @@ extern "C" int fz_ln_fwd(const float* x, const float* gamma, const float* beta, 
 
 // If gparams != NULL and C <= 64 the kernel also produces the affine gradients:
 //   gparams[0..C) = gγ, gparams[C..2C) = gβ ; workspace must hold fz_ln_bwd_workspace_bytes().
-extern "C" int64_t fz_ln_bwd_workspace_bytes(int C) { return C <= 64 ? (int64_t)1024 * 2 * C * 4 : 0; }
+// workspace: per-workgroup partial rows (C <= 64: <= 1024 rows; wider: one row per 64 quads) + 64
+// rows of scratch for the two-stage reduce
+extern "C" int64_t fz_ln_bwd_workspace_bytes2(int B, int C, int64_t V) {
+  const int64_t rows = C <= 64 ? 1024 : ((V / 4) * B + 63) / 64;
+  return (rows + 64) * 2 * C * 4;
+}
+extern "C" int64_t fz_ln_bwd_workspace_bytes(int C) { return C <= 64 ? (int64_t)(1024 + 64) * 2 * C * 4 : 0; }
 
 extern "C" int fz_ln_bwd(const float* gl, const float* x, const float* stats, const float* gamma,
                          const float* gadd, float* gx, float* gparams, void* workspace, int B, int C, int64_t V,
@@ -271,12 +288,12 @@ extern "C" int fz_ln_bwd(const float* gl, const float* x, const float* stats, co
   if (!gl || !x || !stats || !gamma || !gx) return fail(FZ_E_ARG, "fz_ln_bwd: null pointer");
   if (B < 0 || C < 1 || V < 1) return fail(FZ_E_SHAPE, "fz_ln_bwd: bad sizes");
   if (V % 4) return fail(FZ_E_UNSUPPORTED, "fz_ln_bwd: voxel count must be a multiple of 4");
-  if (gparams != nullptr && (C > 64 || workspace == nullptr))
-    return fail(FZ_E_UNSUPPORTED, "fz_ln_bwd: fused affine gradients need C <= 64 and a workspace");
+  if (gparams != nullptr && workspace == nullptr)
+    return fail(FZ_E_ARG, "fz_ln_bwd: fused affine gradients need a workspace (fz_ln_bwd_workspace_bytes2)");
   if (B == 0) return FZ_OK;
   hipStream_t st = (hipStream_t)stream;
   unsigned grid = ln_grid(V / 4 * B);
-  if (gparams != nullptr) {
+  if (gparams != nullptr && C <= 64) {
     if (grid > 1024) grid = 1024;
     float* part = (float*)workspace;
     if (C <= 32)
@@ -292,10 +309,17 @@ extern "C" int fz_ln_bwd(const float* gl, const float* x, const float* stats, co
   if (C > 64) {
     const int64_t quads = (V / 4) * B;
     const unsigned gq = (unsigned)((quads + 63) / 64);
+    float* part = gparams ? (float*)workspace : nullptr;
     if (C >= 256)
-      hipLaunchKernelGGL(ln_bwd_split_kernel<16>, dim3(gq), dim3(1024), 0, st, gl, x, stats, gamma, gadd, gx, B, C, V);
+      hipLaunchKernelGGL(ln_bwd_split_kernel<16>, dim3(gq), dim3(1024), 0, st, gl, x, stats, gamma, gadd, gx, part, B, C, V);
     else
-      hipLaunchKernelGGL(ln_bwd_split_kernel<8>, dim3(gq), dim3(512), 0, st, gl, x, stats, gamma, gadd, gx, B, C, V);
+      hipLaunchKernelGGL(ln_bwd_split_kernel<8>, dim3(gq), dim3(512), 0, st, gl, x, stats, gamma, gadd, gx, part, B, C, V);
+    FZ_LAUNCH_CHECK();
+    if (gparams) {
+      float* tmp = part + (int64_t)gq * 2 * C;
+      return fz_reduce_rows(part, gq, 2 * C, gparams, tmp, stream);
+    }
+    return FZ_OK;
   } else {
     hipLaunchKernelGGL(ln_bwd_kernel<0>, dim3(grid), dim3(256), 0, st, gl, x, stats, gamma, gadd, gx,
                        (float*)nullptr, B, C, V);

@@ -87,26 +87,19 @@ def _wgrad(p, qs, gw, *, B, M, Cin, K, Vq, Ncols, gbias=None, pmul=None, pmul_ki
 
 
 def _ln_backward(gl, x, stats, ln_w, gadd=None):
-    """LayerNorm backward: (gx, gγ, gβ).  C <= 64: one pass produces all three; larger C (the
-    small deep stages): gx from the elementwise kernel, gγ/gβ as diag / row sums of a wgrad."""
+    """LayerNorm backward: (gx, gγ, gβ) in one pass (csrc/ln.hip; the affine gradients are
+    accumulated per workgroup and reduced in a fixed order)."""
     B, C = x.shape[:2]
     V = _vox(x)
     gx = torch.empty_like(x)
-    fused = C <= 64
-    gpar = torch.empty(2 * C, dtype=x.dtype, device=x.device) if fused else None
-    ws = torch.empty(max(N.lib().fz_ln_bwd_workspace_bytes(C) // 4, 1), dtype=x.dtype, device=x.device) \
-        if fused else None
+    gpar = torch.empty(2 * C, dtype=x.dtype, device=x.device)
+    ws = torch.empty(max(N.lib().fz_ln_bwd_workspace_bytes2(B, C, V) // 4, 1), dtype=x.dtype, device=x.device)
     with torch.cuda.device(x.device):
         rc = Fn._timed(f"ln_bwd_{C}", 3 * 4 * x.numel(), lambda: N.lib().fz_ln_bwd(
             gl.data_ptr(), x.data_ptr(), stats.data_ptr(), ln_w.data_ptr(), _p(gadd), gx.data_ptr(), _p(gpar), _p(ws),
             B, C, V, N.stream_ptr(x)))
     N.check(rc, "fz_ln_bwd")
-    if fused:
-        return gx, gpar[:C], gpar[C:]
-    gmat = torch.empty((C, C), dtype=x.dtype, device=x.device)
-    gbeta = torch.empty(C, dtype=x.dtype, device=x.device)
-    _wgrad(gl, [x], gmat, B=B, M=C, Cin=C, K=C, Vq=V, Ncols=V, gbias=gbeta, stats=stats, name="wgrad_ln_affine")
-    return gx, torch.diagonal(gmat).clone(), gbeta
+    return gx, gpar[:C], gpar[C:]
 
 
 def _dgrad_lnbwd(gz, w2, x, stats, ln_w, gadd):

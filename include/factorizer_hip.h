@@ -225,9 +225,10 @@ int fz_wgrad(const fz_wgrad_desc* desc, void* workspace, fz_stream_t stream);
  */
 int fz_ln_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats, int B,
               int C, int64_t V, float eps, fz_stream_t stream);
-/* gparams (optional, C <= 64): [gamma grad (C) | beta grad (C)] computed in the same pass;
- * needs a workspace of fz_ln_bwd_workspace_bytes(C). */
-int64_t fz_ln_bwd_workspace_bytes(int C);
+/* gparams (optional): [gamma grad (C) | beta grad (C)] computed in the same pass; needs a
+ * workspace of fz_ln_bwd_workspace_bytes2(B, C, V). */
+int64_t fz_ln_bwd_workspace_bytes(int C);                        /* C <= 64 */
+int64_t fz_ln_bwd_workspace_bytes2(int B, int C, int64_t V);     /* any C   */
 int fz_ln_bwd(const float* gl, const float* x, const float* stats, const float* gamma,
               const float* gadd, float* gx, float* gparams, void* workspace, int B, int C, int64_t V,
               fz_stream_t stream);
