@@ -13,7 +13,7 @@ from .layers import MLP, LayerNorm, Linear, PosEmbed, PositionalEmbedding
 from .convs import Conv3d, ConvTranspose3d
 from .blocks import FactMixer, FactorizerBlock, FactorizerStage
 from .losses import dice_bce_loss
-from .unet import (Factorizer, Same, UNet, UNetDecoder, UNetDecoderBlock, UNetEncoder,
+from .ushape import (Factorizer, Same, UNet, UNetDecoder, UNetDecoderBlock, UNetEncoder,
                    UNetEncoderBlock, UNetStage)
 
 __version__ = "0.1.0"

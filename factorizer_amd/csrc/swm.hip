@@ -182,6 +182,79 @@ __global__ __launch_bounds__(256) void swm_inv_kernel(const float* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// forward, x-centric: every element of x is read ONCE and stored to its position in each of the
+// nshift windows (the index math of the inverse kernel with loads and stores swapped), so the
+// HBM traffic equals the algorithmic (1 + nshift)·B·C·V·s.  fp32, 16/8/4-byte vectors.
+// ------------------------------------------------------------------------------------------
+template <int VE, bool RELU, bool DIV>
+__global__ __launch_bounds__(256) void swm_fwd_x_kernel(const float* __restrict__ x, float* __restrict__ y, SwmGeom q,
+                                                        float divisor) {
+  struct alignas(VE * 4) Vf { float e[VE]; };
+  int bid = blockIdx.x;
+  const int g1 = bid % q.G1; bid /= q.G1;
+  const int g0 = bid % q.G0; bid /= q.G0;
+  const int hh = bid % q.h;
+  const int b = bid / q.h;
+  const int CP = q.p2 / VE;
+  const int P = q.p0 * q.p1 * q.p2;
+  const int64_t HW = (int64_t)q.H * q.W;
+  const int64_t V3 = (int64_t)q.D * HW;
+  const int G = q.G0 * q.G1 * q.G2;
+  const int64_t xbase = ((int64_t)b * q.C + (int64_t)hh * q.d) * V3;
+  const int64_t wstride = (int64_t)q.B * q.h * G * q.d * P;
+  const int64_t ybh = ((int64_t)b * q.h + hh) * G * q.d * P;
+  const int items = q.G2 * q.p1 * CP;
+  for (int f = threadIdx.x; f < items; f += blockDim.x) {
+    const int p2c = f % CP;
+    const int t = f / CP;
+    const int p1i = t % q.p1;
+    const int g2 = t / q.p1;
+    const int zh = g1 * q.p1 + p1i;
+    const int zw = g2 * q.p2 + p2c * VE;
+    const int64_t xoff = (int64_t)zh * q.W + zw;
+    int64_t yoff[kMaxShifts];
+#pragma unroll
+    for (int w = 0; w < kMaxShifts; ++w) {
+      if (w < q.nshift) {
+        int ch = zh + q.s[w][1]; if (ch >= q.H) ch -= q.H;
+        int cw = zw + q.s[w][2]; if (cw >= q.W) cw -= q.W;
+        const int g1s = ch / q.p1, p1s = ch % q.p1;
+        const int g2s = cw / q.p2, p2s = cw % q.p2;
+        yoff[w] = w * wstride + ybh + ((int64_t)g1s * q.G2 + g2s) * q.d * P + (p1s * q.p2 + p2s);
+      }
+    }
+    for (int p0i = 0; p0i < q.p0; ++p0i) {
+      const int zd = g0 * q.p0 + p0i;
+      int64_t yrow[kMaxShifts];
+#pragma unroll
+      for (int w = 0; w < kMaxShifts; ++w) {
+        if (w < q.nshift) {
+          int cd = zd + q.s[w][0]; if (cd >= q.D) cd -= q.D;
+          const int g0s = cd / q.p0, p0s = cd % q.p0;
+          yrow[w] = yoff[w] + (int64_t)g0s * q.G1 * q.G2 * q.d * P + (int64_t)p0s * q.p1 * q.p2;
+        }
+      }
+      for (int dd = 0; dd < q.d; ++dd) {
+        Vf v = *reinterpret_cast<const Vf*>(x + xbase + (int64_t)dd * V3 + (int64_t)zd * HW + xoff);
+        if (RELU || DIV) {
+#pragma unroll
+          for (int e = 0; e < VE; ++e) {
+            float a = v.e[e];
+            if (RELU) a = relu_f(a);
+            if (DIV) a = a / divisor;
+            v.e[e] = a;
+          }
+        }
+#pragma unroll
+        for (int w = 0; w < kMaxShifts; ++w) {
+          if (w < q.nshift) *reinterpret_cast<Vf*>(y + yrow[w] + (int64_t)dd * P) = v;
+        }
+      }
+    }
+  }
+}
+
 static int make_geom(SwmGeom& q, int B, int C, int D, int H, int W, int d, int pd, int ph, int pw,
                      int nshift, const int* shifts, const char* who) {
   if (B < 0 || C < 1 || D < 1 || H < 1 || W < 1 || d < 1 || pd < 1 || ph < 1 || pw < 1)
@@ -240,6 +313,24 @@ extern "C" int fz_swm_fwd(const void* x, void* y, int B, int C, int D, int H, in
   hipLaunchKernelGGL((swm_fwd_kernel<ES, VB, RR, DD>), grid, block, 0, st, (const char*)x, (char*)y, q, fdiv)
   if (elem_bytes == 4) {
     const int ve = pick_ve(q, 4);
+    {
+      // x-centric single-read kernel (one workgroup per unshifted pencil)
+      const int64_t nb2 = (int64_t)B * q.h * q.G0 * q.G1;
+      dim3 grid2((unsigned)nb2);
+#define FZ_FWX(VE, RR, DD) hipLaunchKernelGGL((swm_fwd_x_kernel<VE, RR, DD>), grid2, block, 0, st, (const float*)x, (float*)y, q, fdiv)
+#define FZ_FWX4(VE)                                  \
+  do {                                               \
+    if (R && Dv) FZ_FWX(VE, true, true);             \
+    else if (R) FZ_FWX(VE, true, false);             \
+    else if (Dv) FZ_FWX(VE, false, true);            \
+    else FZ_FWX(VE, false, false);                   \
+  } while (0)
+      if (ve == 4) FZ_FWX4(4);
+      else if (ve == 2) FZ_FWX4(2);
+      else FZ_FWX4(1);
+      FZ_LAUNCH_CHECK();
+      return FZ_OK;
+    }
 #define FZ_FWD4(VB)                                  \
   do {                                               \
     if (R && Dv) FZ_FWD(4, VB, true, true);          \

@@ -1,0 +1,223 @@
+"""U-shaped encoder/decoder shell and the ``Factorizer`` model.
+
+Host mirror of the reference's generic ``UNet`` family (factorizer/unet.py:11-276) and of
+``Factorizer(UNet)`` (factorizer/factorizer.py:125-171): same constructor arguments, sub-module
+names (``stem``, ``encoder.blocks.i.{downsample,block}``, ``decoder.blocks.j.{upsample,block}``,
+``head`` / ``heads``) and parameter-creation order, so seeds and checkpoints line up.  Unlike the
+reference, which threads ``spatial_size`` through a mutated kwargs dict, the per-stage geometry is
+resolved once, up front (`_plan`), and handed to each stage explicitly.
+"""
+from __future__ import annotations
+
+import math
+from collections.abc import Sequence
+
+import torch
+from torch import nn
+
+from . import convs
+from .blocks import FactorizerStage
+from .layers import PositionalEmbedding
+from .utils import as_tuple, partialize
+
+
+def _scale(size, factor, down: bool):
+    """Spatial size after one stage: ``d // s`` going down, ``d * s`` going up; non-sequences
+    (``spatial_size=None``) pass through untouched."""
+    if not isinstance(size, Sequence):
+        return size
+    return tuple(d // factor for d in size) if down else tuple(d * factor for d in size)
+
+
+def _plan(spatial_size, strides, n_dec):
+    """Per-stage spatial sizes: encoder stage i sees the input divided by strides[0..i]; decoder
+    stage j multiplies back by the reversed strides (unet.py:80-83, 149-152)."""
+    enc, cur = [], spatial_size
+    for s in strides:
+        cur = _scale(cur, s, True)
+        enc.append(cur)
+    dec = []
+    for s in list(strides)[::-1][:n_dec]:
+        cur = _scale(cur, s, False)
+        dec.append(cur)
+    return enc, dec
+
+
+class Same:
+    """``Same(spec)[i]`` is ``spec`` for every i — one block spec shared by all stages."""
+
+    def __init__(self, block):
+        self.block = block
+
+    def __getitem__(self, index):
+        return self.block
+
+
+class UNetStage(nn.Module):
+    """`depth` copies of a block; the first one changes the channel count."""
+
+    def __init__(self, in_channels, out_channels, depth=1, block=None, **kwargs):
+        super().__init__()
+        if block is None:
+            raise ValueError("UNetStage needs a `block` (the reference's CNN DoubleConv default is outside "
+                             "this build's scope)")
+        make = partialize(block)
+        layers = [make(in_channels, out_channels, **kwargs)]
+        layers += [make(out_channels, out_channels, **kwargs) for _ in range(depth - 1)]
+        self.blocks = nn.Sequential(*layers)
+
+    def forward(self, x):
+        return self.blocks(x)
+
+
+class UNetEncoderBlock(nn.Module):
+    """Optional kernel-2 / stride-2 down-convolution, then the stage."""
+
+    def __init__(self, in_channels, out_channels, depth=1, stride=2,
+                 downsample=(convs.Conv3d, {"kernel_size": 2}), block=UNetStage, **kwargs):
+        super().__init__()
+        keep_resolution = math.prod(as_tuple(stride)) == 1
+        down = nn.Identity if keep_resolution else partialize(downsample)
+        # the reference always builds the down-conv with stride 2 (unet.py:53)
+        self.downsample = down(in_channels, out_channels, stride=2)
+        self.block = partialize(block)(out_channels, out_channels, depth=depth, **kwargs)
+
+    def forward(self, x):
+        return self.block(self.downsample(x))
+
+
+class UNetEncoder(nn.Module):
+    def __init__(self, in_channels, out_channels=(32, 64, 128, 256, 512), depth=(1, 1, 1, 1, 1),
+                 strides=(1, 2, 2, 2, 2), downsample=None, block=None, spatial_size=None, **kwargs):
+        super().__init__()
+        sizes, _ = _plan(spatial_size, strides[:len(out_channels)], 0)
+        widths = (in_channels, *out_channels)
+        self.in_spatial_size = spatial_size
+        self.out_spatial_size = sizes[-1] if sizes else spatial_size
+        self.blocks = nn.ModuleList(
+            UNetEncoderBlock(widths[i], widths[i + 1], depth[i], strides[i], downsample, block[i],
+                             spatial_size=sizes[i], **kwargs)
+            for i in range(len(out_channels)))
+
+    def forward(self, x):
+        feats = []
+        for stage in self.blocks:
+            x = stage(x)
+            feats.append(x)
+        return feats
+
+
+class UNetDecoderBlock(nn.Module):
+    """Transposed kernel-2 up-convolution, skip connection, stage (unet.py:107-130).  When the stage
+    can read the two halves of the concatenation through separate pointers (FactorizerStage) the
+    ``torch.cat`` is never materialised."""
+
+    def __init__(self, in_channels, out_channels, depth=1, stride=2,
+                 upsample=(convs.ConvTranspose3d, {"kernel_size": 2}), block=UNetStage, **kwargs):
+        super().__init__()
+        self.upsample = partialize(upsample)(in_channels, out_channels, stride=stride)
+        self.block = partialize(block)(2 * out_channels, out_channels, depth=depth, **kwargs)
+
+    def forward(self, deep, skip):
+        up = self.upsample(deep)
+        pair = getattr(self.block, "forward_pair", None)
+        if pair is not None:
+            return pair(skip, up)
+        return self.block(torch.cat([skip, up], dim=1))
+
+
+class UNetDecoder(nn.Module):
+    def __init__(self, in_channels=(512, 256, 128, 64, 32), depth=(1, 1, 1, 1), strides=(2, 2, 2, 2),
+                 upsample=None, block=None, spatial_size=None, **kwargs):
+        super().__init__()
+        n = len(in_channels) - 1
+        sizes, cur = [], spatial_size
+        for j in range(n):
+            cur = _scale(cur, strides[j], False)
+            sizes.append(cur)
+        self.in_spatial_size = spatial_size
+        self.out_spatial_size = sizes[-1] if sizes else spatial_size
+        self.blocks = nn.ModuleList(
+            UNetDecoderBlock(in_channels[j], in_channels[j + 1], depth[j], strides[j], upsample, block[j],
+                             spatial_size=sizes[j], **kwargs)
+            for j in range(n))
+
+    def forward(self, feats):
+        """feats: encoder outputs, shallow → deep.  Returns the list with every level below the
+        bottleneck replaced by its decoded version (index 0 = full resolution)."""
+        feats = list(feats)
+        level = len(feats) - 1
+        for stage in self.blocks:
+            feats[level - 1] = stage(feats[level], feats[level - 1])
+            level -= 1
+        return feats
+
+
+class UNet(nn.Module):
+    """stem → encoder → decoder → head(s)."""
+
+    def __init__(self, in_channels, out_channels, spatial_dims=3, spatial_size=None,
+                 encoder_depth=(1, 1, 1, 1, 1), encoder_width=(32, 64, 128, 256, 512),
+                 strides=(1, 2, 2, 2, 2), decoder_depth=(1, 1, 1, 1), stem=None, downsample=None,
+                 block=None, upsample=None, head=None, num_deep_supr=False, **kwargs):
+        super().__init__()
+        if block is None:
+            raise ValueError("UNet needs a `block` spec per stage (Factorizer supplies FactorizerStage)")
+        self.spatial_dims = spatial_dims
+        self.spatial_size = spatial_size
+        n_enc, n_dec = len(encoder_depth), len(decoder_depth)
+        if spatial_dims == 3:
+            conv, tconv = convs.Conv3d, convs.ConvTranspose3d
+        else:
+            conv, tconv = getattr(nn, f"Conv{spatial_dims}d"), getattr(nn, f"ConvTranspose{spatial_dims}d")
+        downsample = downsample or (conv, {"kernel_size": 2})
+        upsample = upsample or (tconv, {"kernel_size": 2})
+        head = head or (conv, {"kernel_size": 1})
+        has_stem = stem not in (None, nn.Identity)
+        stem_width = encoder_width[0] if has_stem else in_channels
+
+        # creation order = reference order: stem, encoder, decoder, head(s)
+        self.stem = partialize(stem)(in_channels, stem_width) if has_stem else nn.Identity()
+        self.encoder = UNetEncoder(stem_width, encoder_width, encoder_depth, strides, downsample,
+                                   [block[i] for i in range(n_enc)], spatial_size=spatial_size, **kwargs)
+        self.decoder = UNetDecoder(encoder_width[::-1], decoder_depth, strides[::-1][:n_dec], upsample,
+                                   [block[n_enc + j] for j in range(n_dec)],
+                                   spatial_size=self.encoder.out_spatial_size, **kwargs)
+        make_head = partialize(head)
+        if num_deep_supr in (False, None):
+            self.num_deep_supr = False
+            self.head = make_head(encoder_width[0], out_channels)
+        else:
+            # reference quirk kept: True → attribute 3, but range(True) builds ONE head (unet.py:255-258)
+            self.num_deep_supr = 3 if num_deep_supr is True else num_deep_supr
+            self.heads = nn.ModuleList(make_head(encoder_width[j], out_channels) for j in range(num_deep_supr))
+
+    def forward_features(self, x):
+        return self.decoder(self.encoder(self.stem(x)))
+
+    def forward(self, x):
+        feats = self.forward_features(x)
+        if self.num_deep_supr:
+            return [h(feats[j]) for j, h in enumerate(self.heads)]
+        return self.head(feats[0])
+
+
+class Factorizer(UNet):
+    """U-shaped segmentation network whose every stage is a FactorizerStage; only the bottleneck
+    stage carries the positional embedding (factorizer.py:125-171)."""
+
+    def __init__(self, in_channels, out_channels, spatial_size, encoder_depth=(1, 1, 1, 1, 1),
+                 encoder_width=(32, 64, 128, 256, 512), strides=(1, 2, 2, 2, 2),
+                 decoder_depth=(1, 1, 1, 1), stem=None, downsample=None, upsample=None, head=None,
+                 pos_embed=PositionalEmbedding, num_deep_supr=False, **kwargs):
+        nd = len(spatial_size)
+        if stem is None:
+            conv = convs.Conv3d if nd == 3 else getattr(nn, f"Conv{nd}d")
+            stem = (conv, {"kernel_size": 3, "padding": 1, "bias": False})
+        plain = (FactorizerStage, kwargs)
+        bottleneck = (FactorizerStage, {"pos_embed": pos_embed, **kwargs})
+        stages = [plain] * (len(encoder_depth) - 1) + [bottleneck] + [plain] * len(decoder_depth)
+        super().__init__(in_channels, out_channels, spatial_dims=nd, spatial_size=spatial_size,
+                         encoder_depth=encoder_depth, encoder_width=encoder_width, strides=strides,
+                         decoder_depth=decoder_depth, stem=stem, downsample=downsample, block=stages,
+                         upsample=upsample, head=head, num_deep_supr=num_deep_supr)
