@@ -1,0 +1,93 @@
+"""Timings of the other BASELINE.json configs on one MI355X; bench.py is cfg 3/4.
+
+  cfg 1  ft.NMF(size=(8,512), rank=2, num_iters=5, solver='mu') on CPU, x=(1,8,512)      [µs]
+  cfg 2  FactorizerBlock(C=32, 128^3, d=8, p=8, HALS R1 T5) fwd / bwd, B in {1,2}          [ms]
+  cfg 3  README Swin Factorizer, eval forward, B=2                                          [volumes/s]
+Prints one JSON line per measurement.
+"""
+import json
+import os
+import sys
+import time
+
+import torch
+from torch import nn
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import factorizer_amd as ft  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def gpu_time(fn, iters, warm):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def cfg1():
+    torch.set_num_threads(min(8, os.cpu_count() or 1))  # tiny op: more threads only add overhead
+    torch.manual_seed(0)
+    nmf = ft.NMF(size=(8, 512), rank=2, num_iters=5, init="uniform", solver="mu")
+    x = torch.rand(1, 8, 512)
+    with torch.no_grad():
+        for _ in range(20):
+            nmf(x)
+        t0 = time.perf_counter()
+        for _ in range(200):
+            nmf(x)
+        us = (time.perf_counter() - t0) / 200 * 1e6
+    print(json.dumps({"config": "cfg1 NMF(8x512,R2,T5,mu) CPU forward, batch 1", "us": round(us, 1)}))
+    xd = x.to(DEV)
+    nd = nmf.to(DEV)
+    with torch.no_grad():
+        ms = gpu_time(lambda: nd(xd), 200, 20)
+    print(json.dumps({"config": "cfg1 same on MI355X (one wave; launch-bound)", "us": round(ms * 1e3, 1)}))
+
+
+def cfg2():
+    torch.manual_seed(0)
+    blk = ft.FactorizerBlock(channels=32, spatial_size=(128, 128, 128), norm=ft.LayerNorm,
+                             reshape=(ft.SWMatricize, {"head_dim": 8, "patch_size": 8}), act=nn.ReLU,
+                             factorize=ft.NMF, rank=1, num_iters=5, init="uniform", solver="hals",
+                             mlp_ratio=2, dropout=0.0).to(DEV)
+    for B in (1, 2):
+        torch.manual_seed(0)
+        x = torch.rand(B, 32, 128, 128, 128, device=DEV, requires_grad=True)
+        torch.manual_seed(1)
+        g = torch.rand(B, 32, 128, 128, 128, device=DEV)
+        with torch.no_grad():
+            fwd = gpu_time(lambda: blk(x), 50, 10)
+
+        def fb():
+            y = blk(x)
+            torch.autograd.grad(y, [x] + list(blk.parameters()), g)
+        both = gpu_time(fb, 50, 10)
+        print(json.dumps({"config": f"cfg2 FactorizerBlock C=32 128^3 B={B}", "fwd_ms": round(fwd, 3),
+                          "fwd_bwd_ms": round(both, 3), "volumes_per_s_fwd_bwd": round(B / both * 1e3, 1)}))
+
+
+def cfg3():
+    torch.manual_seed(0)
+    model = ft.Factorizer(in_channels=4, out_channels=3, spatial_size=(128, 128, 128), norm=ft.LayerNorm,
+                          reshape=(ft.SWMatricize, {"head_dim": 8, "patch_size": 8}), act=nn.ReLU,
+                          factorize=ft.NMF, rank=1, num_iters=5, init="uniform", solver="hals", mlp_ratio=2,
+                          dropout=0.1).to(DEV).eval()
+    x = torch.rand(2, 4, 128, 128, 128, device=DEV)
+    with torch.no_grad():
+        ms = gpu_time(lambda: model(x), 30, 5)
+    print(json.dumps({"config": "cfg3 README Swin Factorizer eval forward B=2", "ms": round(ms, 3),
+                      "volumes_per_s": round(2 / ms * 1e3, 1)}))
+
+
+if __name__ == "__main__":
+    cfg1()
+    cfg2()
+    cfg3()
