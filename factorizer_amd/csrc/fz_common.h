@@ -41,7 +41,7 @@ inline int fail(int code, const char* msg) {
 // GELU of the MLP (layers/mlp.py:56); the 1e-4 parity budget dwarfs its error.
 __device__ __forceinline__ float fast_erf(float x) {
   const float ax = fabsf(x);
-  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);  // 1 ulp; IEEE division is ~10 VALU ops
   const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
   const float r = 1.0f - poly * __expf(-ax * ax);
   return x < 0.f ? -r : r;

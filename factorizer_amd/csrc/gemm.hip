@@ -59,6 +59,7 @@ struct GemmArgs {
   int64_t Ncol;        // columns per sample (= Vin for LOAD_PLAIN, coarse voxels for LOAD_S2D)
   int Ho, Wo;          // coarse H, W (LOAD_S2D columns / EPI_D2S input grid)
   int B;
+  int dbg;             // diagnostics (FZ_GEMM_DBG): 3 = skip the weight staging
   int tile_map;        // workgroup -> column-tile order: 0 linear, 1 XCD-contiguous, 2 scattered
   // EPI_LNBWD (M == 32): the result is gl = dL/d(LN output); the epilogue applies the LayerNorm
   // backward in registers: y = rstd*(gl*g - mean_c(gl*g) - n*mean_c(gl*g*n)) + lnb_gadd
@@ -141,6 +142,30 @@ __device__ __forceinline__ void fetch_plain(const GemmArgs& p, int b, int c, int
   }
 #pragma unroll
   for (int i = 0; i < NACC; ++i) v[i] = cok ? v[i] : 0.f;
+}
+
+// Streaming-kernel variant: NO select on the loaded values (a select right behind the load makes the
+// scheduler wait for the load it just issued).  The consumer masks / gates when the ring slot is
+// used, PF steps later.  With BMUL the gate operand rides in the upper half of the slot.
+template <int NL, bool BMUL>
+__device__ __forceinline__ void fetch_plain_raw(const GemmArgs& p, int b, int c, int64_t off, bool ok,
+                                                float (&v)[BMUL ? 2 * NL : NL]) {
+  const int cc = c < p.Cin ? c : p.Cin - 1;
+  const bool first = cc < p.c0;
+  const float* base = first ? p.x[0] : p.x[1];
+  const int cs = first ? p.c0 : p.Cin - p.c0;
+  const int ci = first ? cc : cc - p.c0;
+  const int64_t oo = ok ? off : 0;
+  float a[NL];
+  vload<NL>(base + ((int64_t)b * cs + ci) * p.Vin + oo, a);
+#pragma unroll
+  for (int i = 0; i < NL; ++i) v[i] = a[i];
+  if (BMUL) {
+    float e[NL];
+    vload<NL>(p.bmul + ((int64_t)b * p.Cin + cc) * p.Vin + oo, e);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) v[NL + i] = e[i];
+  }
 }
 
 // ---- epilogue for one 32-row block -------------------------------------------------------------
@@ -337,7 +362,7 @@ __global__ __launch_bounds__(256, ((NSTEP <= 16 && EPI != EPI_LNBWD) ? 3 : 2)) v
   const int m0 = blockIdx.y * 32 * RB;
 
   // batched fill (8 independent loads per thread before the LDS stores)
-  for (int base = threadIdx.x; base < nA * RB * 64; base += blockDim.x * 8) {
+  for (int base = threadIdx.x; base < (p.dbg == 3 ? 0 : nA * RB * 64); base += blockDim.x * 8) {
     float tmp[8];
 #pragma unroll
     for (int uu = 0; uu < 8; ++uu) {
@@ -458,7 +483,11 @@ __global__ __launch_bounds__(256, ((NSTEP <= 16 && EPI != EPI_LNBWD) ? 3 : 2)) v
 // =================================================================================================
 constexpr int kAChunk = 64;  // A-operand steps staged in LDS at a time
 
-template <int MB, int NACC, int LOADER, int EPI, bool BMUL>
+// PRO = compile-time prologue: a runtime branch inside the K loop splits every step into its own
+// basic block (ds_read → wait → MFMA serialised), so the variants are separate instantiations.
+enum { PRO_NONE = 0, PRO_LN = 1, PRO_GELU = 2, PRO_BMUL = 3 };
+
+template <int MB, int NACC, int LOADER, int EPI, int PRO>
 __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgs p) {
   constexpr int TN = 32 * NACC;
   constexpr int NL = (LOADER == LOAD_S2D) ? 4 : NACC;  // floats fetched per load step
@@ -477,7 +506,7 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgs p) {
   const int m0 = blockIdx.y * 32 * MB;
   const int nA = (p.K + 1) / 2;
 
-  if (p.ln) {
+  if (PRO == PRO_LN) {
     for (int r = threadIdx.x; r < 32 * MB; r += blockDim.x) {
       const int m = m0 + r;
       float s = 0.f, t = 0.f;
@@ -516,10 +545,11 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgs p) {
     }
   }
 
-  auto fetch = [&](int s, float (&v)[NL]) {
-    if (LOADER == LOAD_PLAIN) {
-      fetch_plain<NL, BMUL>(p, b, 2 * s + h, col_off, col_ok, v);
-    } else if (LOADER == LOAD_S2D) {
+  constexpr int NR = (PRO == PRO_BMUL) ? 2 * NL : NL;  // ring slot: operand (+ gate operand)
+  auto fetch = [&](int s, float (&v)[NR]) {
+    if constexpr (LOADER == LOAD_PLAIN) {
+      fetch_plain_raw<NL, PRO == PRO_BMUL>(p, b, 2 * s + h, col_off, col_ok, v);
+    } else if constexpr (LOADER == LOAD_S2D) {
       const int c = 2 * (s >> 2) + h;
       const bool ok = col_ok && c < p.Cin;
       const int cc = c < p.Cin ? c : p.Cin - 1;
@@ -564,11 +594,11 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgs p) {
   for (int e = 0; e < NACC; ++e) s1[e] = s2[e] = shift[e] = 0.f;
 
   const int nload = (LOADER == LOAD_S2D) ? nA / 2 : nA;
-  float ring[kPF][NL];
+  float ring[kPF][NR];
   // unconditional, clamped prefetch: a load inside a branch costs an s_waitcnt vmcnt(0)
 #pragma unroll
   for (int i = 0; i < kPF; ++i) fetch(i < nload ? i : nload - 1, ring[i]);
-  if (p.ln) {
+  if (PRO == PRO_LN) {
     // pivot = channel-0 value (held by half 0 in ring[0]): well-conditioned single-pass variance
 #pragma unroll
     for (int e = 0; e < NACC; ++e) shift[e] = __shfl(ring[0][e % NL], j, 64);
@@ -579,7 +609,12 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgs p) {
     __syncthreads();
     // batched fill: issue 8 independent weight loads per thread before the LDS stores, so the
     // (L2-resident) weight fetch latency overlaps instead of serialising load→store pairs
-    for (int base = threadIdx.x; base < an * MB * 64; base += blockDim.x * 8) {
+    // steps are processed in groups of kPF*ASTEP with NO per-step guard (a guard turns every K-step
+    // into its own basic block: ds_read → s_waitcnt lgkmcnt(0) → MFMA, fully serialised); the tail
+    // of the last group gets zero weights instead
+    constexpr int kGroup = kPF * ((LOADER == LOAD_S2D) ? 2 : 1);
+    const int an_pad = ((an + kGroup - 1) / kGroup) * kGroup;
+    for (int base = threadIdx.x; base < (p.dbg == 3 ? 0 : an_pad * MB * 64); base += blockDim.x * 8) {
       float tmp[8];
 #pragma unroll
       for (int uu = 0; uu < 8; ++uu) {
@@ -593,7 +628,7 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgs p) {
           const int k = a_k<LOADER>(a, l >> 5);
           if (m < p.M && k < p.K) {
             wv = weight_at(p, m, k);
-            if (p.ln) wv *= p.ln_g[k];
+            if (PRO == PRO_LN) wv *= p.ln_g[k];
           }
         }
         tmp[uu] = wv;
@@ -601,25 +636,25 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgs p) {
 #pragma unroll
       for (int uu = 0; uu < 8; ++uu) {
         const int idx = base + uu * blockDim.x;
-        if (idx < an * MB * 64) As[idx] = tmp[uu];
+        if (idx < an_pad * MB * 64) As[idx] = tmp[uu];
       }
     }
     __syncthreads();
     constexpr int ASTEP = (LOADER == LOAD_S2D) ? 2 : 1;
     // kAChunk is a multiple of kPF*ASTEP, so the ring slot of a step is static after unrolling
-    for (int al = 0; al < an; al += kPF * ASTEP) {
+    for (int al = 0; al < an_pad; al += kPF * ASTEP) {
 #pragma unroll
       for (int u = 0; u < kPF; ++u) {
         const int ali = al + u * ASTEP;
         const int s = (a0 + ali) / ASTEP;
-        float cur[NL];
+        float cur[NR];
 #pragma unroll
-        for (int e = 0; e < NL; ++e) cur[e] = ring[u][e];
+        for (int e = 0; e < NR; ++e) cur[e] = ring[u][e];
         {
           const int sn = s + kPF;
           fetch(sn < nload ? sn : nload - 1, ring[u]);  // tail: harmless re-read of the last step
         }
-        if (ali < an) {
+        {
           if (LOADER == LOAD_S2D) {
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
@@ -632,22 +667,26 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgs p) {
             }
           } else {
             float bvv[NACC];
+            // deferred masking of the raw ring slot: lanes past the last column and the odd-K pad
+            // channel contribute zero (their clamped re-reads are finite; weights of the pad are 0)
+            const bool cok = col_ok && (2 * s + h) < p.Cin;
 #pragma unroll
             for (int e = 0; e < NACC; ++e) {
               float t = cur[e % NL];
-              if (p.ln) {
+              if (LOADER == LOAD_PLAIN) {
+                if (PRO == PRO_BMUL) t = cur[(NL + e) % NR] > 0.f ? t : 0.f;
+                t = cok ? t : 0.f;
+              }
+              if (PRO == PRO_LN) {
                 t -= shift[e];
                 s1[e] += t;
                 s2[e] += t * t;
               }
               bvv[e] = t;
             }
-            if (p.bact == ACT_GELU) {
+            if (PRO == PRO_GELU) {
 #pragma unroll
               for (int e = 0; e < NACC; ++e) bvv[e] = gelu_f(bvv[e]);
-            } else if (p.bact == ACT_RELU) {
-#pragma unroll
-              for (int e = 0; e < NACC; ++e) bvv[e] = bvv[e] > 0.f ? bvv[e] : 0.f;
             }
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
@@ -663,7 +702,7 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgs p) {
   }
 
   float mu_d[NACC], rstd[NACC];
-  if (p.ln) {
+  if (PRO == PRO_LN) {
 #pragma unroll
     for (int e = 0; e < NACC; ++e) {
       const float t1 = s1[e] + __shfl_xor(s1[e], 32, 64);
@@ -688,7 +727,7 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgs p) {
   const int64_t ncol = (LOADER == LOAD_S2D) ? n0 + 2 * j : col_off;
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
-    if (p.ln) {
+    if (PRO == PRO_LN) {
       // y = rstd·(acc − μ_d·s[m]) + t[m]
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -699,7 +738,7 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgs p) {
       }
     }
     store_block<NACC, EPI, LOADER == LOAD_S2D>(p, acc[mb], b, m0 + mb * 32, ncol, h,
-                                                p.ln ? tW + mb * 32 : nullptr);
+                                                PRO == PRO_LN ? tW + mb * 32 : nullptr);
   }
 }
 
@@ -740,6 +779,7 @@ extern "C" int fz_gemm(const fz_gemm_desc* d, fz_stream_t stream) {
   a.bias = d->bias; a.ln = d->ln; a.ln_g = d->ln_g; a.ln_b = d->ln_b; a.ln_eps = d->ln_eps;
   a.stats_out = d->stats_out; a.bact = d->bact; a.eact = d->eact; a.res = d->res; a.emul = d->emul;
   a.emul_kind = d->emul_kind; a.y = d->y; a.Ncol = d->Ncol; a.Ho = d->Ho; a.Wo = d->Wo; a.B = d->B;
+  { const char* e = getenv("FZ_GEMM_DBG"); a.dbg = e ? atoi(e) : 0; }
   { const char* e = getenv("FZ_GEMM_TILEMAP"); a.tile_map = e ? atoi(e) : 1; }
   a.lnb_x = d->lnb_x; a.lnb_stats = d->lnb_stats; a.lnb_g = d->lnb_g; a.lnb_gadd = d->lnb_gadd; a.lnb_part = d->lnb_part;
   hipStream_t st = (hipStream_t)stream;
@@ -797,20 +837,27 @@ extern "C" int fz_gemm(const fz_gemm_desc* d, fz_stream_t stream) {
   const int TN = 32 * nacc;
   const int64_t tiles = (d->Ncol + TN * 4 - 1) / (TN * 4);
   dim3 grid((unsigned)(tiles * d->B), (unsigned)((mblocks + MBsel - 1) / MBsel)), block(256);
-#define FZ_STR(MB, NA, L, E, BM) hipLaunchKernelGGL((gemm_stream_kernel<MB, NA, L, E, BM>), grid, block, 0, st, a)
-  if (d->loader == LOAD_S2D) { FZ_STR(1, 2, LOAD_S2D, EPI_PLAIN, false); }
-  else if (d->loader == LOAD_K3) { if (MBsel == 2) FZ_STR(2, 4, LOAD_K3, EPI_PLAIN, false); else FZ_STR(1, 4, LOAD_K3, EPI_PLAIN, false); }
+#define FZ_STR(MB, NA, L, E, PR) hipLaunchKernelGGL((gemm_stream_kernel<MB, NA, L, E, PR>), grid, block, 0, st, a)
+  if (d->bact == ACT_RELU) return fail(FZ_E_UNSUPPORTED, "fz_gemm: ReLU input prologue is not compiled (streaming)");
+  const int pro = d->ln ? PRO_LN : (d->bact == ACT_GELU ? PRO_GELU : (d->bmul ? PRO_BMUL : PRO_NONE));
+  if ((d->ln != 0) + (d->bact != 0) + (d->bmul != nullptr) > 1)
+    return fail(FZ_E_UNSUPPORTED, "fz_gemm: at most one input prologue (LayerNorm / GELU / gate)");
+  if (d->loader == LOAD_S2D) { FZ_STR(1, 2, LOAD_S2D, EPI_PLAIN, PRO_NONE); }
+  else if (d->loader == LOAD_K3) { if (MBsel == 2) FZ_STR(2, 4, LOAD_K3, EPI_PLAIN, PRO_NONE); else FZ_STR(1, 4, LOAD_K3, EPI_PLAIN, PRO_NONE); }
   else if (d->epilogue == EPI_D2S) {
-    if (d->bmul) return fail(FZ_E_UNSUPPORTED, "fz_gemm: bmul with depth-to-space epilogue");
-    if (MBsel == 2) FZ_STR(2, 4, LOAD_PLAIN, EPI_D2S, false); else FZ_STR(1, 4, LOAD_PLAIN, EPI_D2S, false);
-  } else if (d->bmul) {
-    if (nacc == 4) { if (MBsel == 2) FZ_STR(2, 4, LOAD_PLAIN, EPI_PLAIN, true); else FZ_STR(1, 4, LOAD_PLAIN, EPI_PLAIN, true); }
-    else if (nacc == 2) FZ_STR(1, 2, LOAD_PLAIN, EPI_PLAIN, true);
-    else FZ_STR(1, 1, LOAD_PLAIN, EPI_PLAIN, true);
+    if (pro != PRO_NONE) return fail(FZ_E_UNSUPPORTED, "fz_gemm: prologue with depth-to-space epilogue");
+    if (MBsel == 2) FZ_STR(2, 4, LOAD_PLAIN, EPI_D2S, PRO_NONE); else FZ_STR(1, 4, LOAD_PLAIN, EPI_D2S, PRO_NONE);
   } else {
-    if (nacc == 4) { if (MBsel == 2) FZ_STR(2, 4, LOAD_PLAIN, EPI_PLAIN, false); else FZ_STR(1, 4, LOAD_PLAIN, EPI_PLAIN, false); }
-    else if (nacc == 2) FZ_STR(1, 2, LOAD_PLAIN, EPI_PLAIN, false);
-    else FZ_STR(1, 1, LOAD_PLAIN, EPI_PLAIN, false);
+#define FZ_STR_SHAPES(PR)                                                                                   \
+  do {                                                                                                      \
+    if (nacc == 4) { if (MBsel == 2) FZ_STR(2, 4, LOAD_PLAIN, EPI_PLAIN, PR); else FZ_STR(1, 4, LOAD_PLAIN, EPI_PLAIN, PR); } \
+    else if (nacc == 2) FZ_STR(1, 2, LOAD_PLAIN, EPI_PLAIN, PR);                                            \
+    else FZ_STR(1, 1, LOAD_PLAIN, EPI_PLAIN, PR);                                                           \
+  } while (0)
+    if (pro == PRO_LN) FZ_STR_SHAPES(PRO_LN);
+    else if (pro == PRO_GELU) FZ_STR_SHAPES(PRO_GELU);
+    else if (pro == PRO_BMUL) FZ_STR_SHAPES(PRO_BMUL);
+    else FZ_STR_SHAPES(PRO_NONE);
   }
   FZ_LAUNCH_CHECK();
   return FZ_OK;
