@@ -58,12 +58,12 @@ struct CfAddr {
 };
 
 __device__ __forceinline__ bool cf_decode(const CfGeom& q, int64_t mat, int lane, CfAddr& a) {
-  const int g2 = (int)(mat % q.G2);
-  int64_t t = mat / q.G2;
-  const int g1 = (int)(t % q.G1); t /= q.G1;
-  const int g0 = (int)(t % q.G0); t /= q.G0;
-  const int hh = (int)(t % q.h);
-  const int b = (int)(t / q.h);
+  unsigned t = (unsigned)mat;  // the host rejects > 2^31 matrices
+  const int g2 = (int)(t % (unsigned)q.G2); t /= (unsigned)q.G2;
+  const int g1 = (int)(t % (unsigned)q.G1); t /= (unsigned)q.G1;
+  const int g0 = (int)(t % (unsigned)q.G0); t /= (unsigned)q.G0;
+  const int hh = (int)(t % (unsigned)q.h);
+  const int b = (int)(t / (unsigned)q.h);
   const int p1 = (lane >> 1) & 7, half = lane & 1;
   int z1 = g1 * 8 + p1 - q.s1; if (z1 < 0) z1 += q.H;
   int z2 = g2 * 8 + half * 4 - q.s2; if (z2 < 0) z2 += q.W;
@@ -85,6 +85,37 @@ __device__ __forceinline__ void cf_load(const float* __restrict__ t, const CfAdd
       const float4 v = *reinterpret_cast<const float4*>(t + a.base + dd * a.V + a.off[jp]);
       x[dd][jp * 4 + 0] = v.x; x[dd][jp * 4 + 1] = v.y; x[dd][jp * 4 + 2] = v.z; x[dd][jp * 4 + 3] = v.w;
     }
+}
+
+// x / dv for the window average.  A power-of-two divisor (2 or 4 windows — the usual case) is an
+// exact scaling, so the multiply is bit-identical to the division and 10x cheaper (IEEE fp32
+// division is ~11 VALU instructions); other divisors keep the true division.
+__device__ __forceinline__ bool cf_pow2(float dv) { return (__float_as_uint(dv) & 0x007fffffu) == 0u && dv > 0.f; }
+
+__device__ __forceinline__ void cf_divide(float (&g)[8][8], float dv) {
+  if (dv == 1.0f) return;
+  if (cf_pow2(dv)) {
+    const float inv = 1.0f / dv;
+#pragma unroll
+    for (int dd = 0; dd < 8; ++dd)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[dd][j] = g[dd][j] * inv;
+  } else {
+#pragma unroll
+    for (int dd = 0; dd < 8; ++dd)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[dd][j] = g[dd][j] / dv;
+  }
+}
+
+__device__ __forceinline__ float4 cf_divide4(float4 o, float dv, bool pow2) {
+  if (pow2) {
+    const float inv = 1.0f / dv;
+    o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv;
+  } else {
+    o.x /= dv; o.y /= dv; o.z /= dv; o.w /= dv;
+  }
+  return o;
 }
 
 // logical workgroup id: optionally remapped so that consecutive workgroups (patch neighbours
@@ -110,6 +141,7 @@ __global__ __launch_bounds__(1024) void nmf_cf_fwd_kernel(const float* __restric
   cf_load(t, a, x);
   nmf_forward_wave<8, 8, R, SOLVER>(w, u0, v0, x, u, v, 8, T, eps);
   const float dv = (float)q.divisor;
+  const bool dv_pow2 = cf_pow2(dv);
 #pragma unroll
   for (int dd = 0; dd < 8; ++dd)
 #pragma unroll
@@ -123,9 +155,149 @@ __global__ __launch_bounds__(1024) void nmf_cf_fwd_kernel(const float* __restric
         o = make_float4(0.0f + x[dd][jp * 4 + 0], 0.0f + x[dd][jp * 4 + 1], 0.0f + x[dd][jp * 4 + 2],
                         0.0f + x[dd][jp * 4 + 3]);
       }
-      if (q.divisor > 1) { o.x /= dv; o.y /= dv; o.z /= dv; o.w /= dv; }
+      if (q.divisor > 1) o = cf_divide4(o, dv, dv_pow2);
       *reinterpret_cast<float4*>(p) = o;
     }
+}
+
+// ---- line-coalesced variant -----------------------------------------------------------------------
+// A workgroup owns WPB patches that are neighbours along W, i.e. for every (channel, p0, p1) one
+// contiguous run of WPB·8 floats.  Global memory is touched only with the COALESCED map
+//   thread → (row = (p0, p1), 16-byte chunk of the run)      [whole 128-B lines per request]
+// and the patch-owner map of CfWave is reached through an LDS exchange, two channels per stage
+// (the 64 data registers are reused in place).  The direct kernel above touches 32 lines per load
+// instruction and uses 32 B of each; this one touches 1/4 as many, fully.
+template <int WPB>
+struct CfTile {
+  static constexpr int LW = WPB * 8 + 8;  // padded row: owner reads (row stride 8 banks·…) stay conflict-free
+  static constexpr int NT = WPB * 64;
+  static constexpr int CHUNKS = WPB * 2;  // 16-byte chunks per row
+  static constexpr int STAGE_FLOATS = 2 * 64 * LW;
+};
+
+template <int WPB>
+__device__ __forceinline__ void cf_tile_decode(const CfGeom& q, int64_t blk, int tid, int64_t& base, int64_t& V,
+                                               int64_t (&off)[2], int (&lidx)[2]) {
+  using TL = CfTile<WPB>;
+  // 32-bit index arithmetic (the host rejects > 2^31 matrices): 64-bit div/mod is ~100 instructions each
+  const unsigned ngrp = (unsigned)(q.G2 / WPB);
+  unsigned t = (unsigned)blk;
+  const int gq = (int)(t % ngrp); t /= ngrp;
+  const int g1 = (int)(t % (unsigned)q.G1); t /= (unsigned)q.G1;
+  const int g0 = (int)(t % (unsigned)q.G0); t /= (unsigned)q.G0;
+  const int hh = (int)(t % (unsigned)q.h);
+  const int b = (int)(t / (unsigned)q.h);
+  V = (int64_t)q.D * q.H * q.W;
+  base = ((int64_t)b * q.C + (int64_t)hh * 8) * V;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int idx = tid + k * TL::NT;
+    const int row = idx / TL::CHUNKS, chunk = idx % TL::CHUNKS;
+    int z0 = g0 * 8 + (row >> 3) - q.s0; if (z0 < 0) z0 += q.D;
+    int z1 = g1 * 8 + (row & 7) - q.s1; if (z1 < 0) z1 += q.H;
+    int z2 = gq * WPB * 8 + chunk * 4 - q.s2; if (z2 < 0) z2 += q.W;
+    off[k] = ((int64_t)z0 * q.H + z1) * q.W + z2;
+    lidx[k] = row * TL::LW + chunk * 4;
+  }
+}
+
+// owner-side LDS index of local vector jp of this lane (patch = wave)
+template <int WPB>
+__device__ __forceinline__ int cf_owner_lidx(int lane, int wave, int jp) {
+  return ((jp * 4 + (lane >> 4)) * 8 + ((lane >> 1) & 7)) * CfTile<WPB>::LW + wave * 8 + (lane & 1) * 4;
+}
+
+// exchange the 64 data registers from the coalesced map to the patch-owner map, in place
+template <int WPB>
+__device__ __forceinline__ void cf_to_owner(float* S, const int (&lidx)[2], int own0, int own1, float (&x)[8][8]) {
+  using TL = CfTile<WPB>;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        *reinterpret_cast<float4*>(S + c * 64 * TL::LW + lidx[k]) =
+            make_float4(x[2 * s + c][k * 4 + 0], x[2 * s + c][k * 4 + 1], x[2 * s + c][k * 4 + 2], x[2 * s + c][k * 4 + 3]);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const float4 a0 = *reinterpret_cast<const float4*>(S + c * 64 * TL::LW + own0);
+      const float4 a1 = *reinterpret_cast<const float4*>(S + c * 64 * TL::LW + own1);
+      x[2 * s + c][0] = a0.x; x[2 * s + c][1] = a0.y; x[2 * s + c][2] = a0.z; x[2 * s + c][3] = a0.w;
+      x[2 * s + c][4] = a1.x; x[2 * s + c][5] = a1.y; x[2 * s + c][6] = a1.z; x[2 * s + c][7] = a1.w;
+    }
+    __syncthreads();
+  }
+}
+
+template <int R, int SOLVER, int WPB>
+__global__ __launch_bounds__(WPB * 64, WPB == 8 ? 2 : 1) void nmf_cf_fwd_tile_kernel(const float* __restrict__ t,
+                                                                   const float* __restrict__ u0,
+                                                                   const float* __restrict__ v0,
+                                                                   float* __restrict__ out, CfGeom q, int T, float eps,
+                                                                   int xcd_remap) {
+  using TL = CfTile<WPB>;
+  extern __shared__ __attribute__((aligned(16))) float fz_lds_tile[];
+  float* S = fz_lds_tile;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int64_t base, V, off[2];
+  int lidx[2];
+  cf_tile_decode<WPB>(q, cf_logical_block(xcd_remap), tid, base, V, off, lidx);
+  const int own0 = cf_owner_lidx<WPB>(lane, wave, 0), own1 = cf_owner_lidx<WPB>(lane, wave, 1);
+
+  float x[8][8];
+#pragma unroll
+  for (int dd = 0; dd < 8; ++dd)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float4 v = *reinterpret_cast<const float4*>(t + base + dd * V + off[k]);
+      x[dd][k * 4 + 0] = v.x; x[dd][k * 4 + 1] = v.y; x[dd][k * 4 + 2] = v.z; x[dd][k * 4 + 3] = v.w;
+    }
+  cf_to_owner<WPB>(S, lidx, own0, own1, x);
+
+  CfWave w{lane};
+  float u[8][R], v[8][R];
+  nmf_forward_wave<8, 8, R, SOLVER>(w, u0, v0, x, u, v, 8, T, eps);
+
+  // owner → coalesced, then the (read-modify-)write of the running window average; all loads of
+  // the running sum are issued at once (one exposed round trip)
+  const float dv = (float)q.divisor;
+  const bool dv_pow2 = cf_pow2(dv);
+  float4 old[8][2];
+  if (q.accumulate) {
+#pragma unroll
+    for (int dd = 0; dd < 8; ++dd)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) old[dd][k] = *reinterpret_cast<const float4*>(out + base + dd * V + off[k]);
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      *reinterpret_cast<float4*>(S + c * 64 * TL::LW + own0) =
+          make_float4(x[2 * s + c][0], x[2 * s + c][1], x[2 * s + c][2], x[2 * s + c][3]);
+      *reinterpret_cast<float4*>(S + c * 64 * TL::LW + own1) =
+          make_float4(x[2 * s + c][4], x[2 * s + c][5], x[2 * s + c][6], x[2 * s + c][7]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const float4 z = *reinterpret_cast<const float4*>(S + c * 64 * TL::LW + lidx[k]);
+        float4 o;
+        if (q.accumulate) {
+          o = old[2 * s + c][k];
+          o.x += z.x; o.y += z.y; o.z += z.z; o.w += z.w;
+        } else {
+          o = make_float4(0.0f + z.x, 0.0f + z.y, 0.0f + z.z, 0.0f + z.w);
+        }
+        if (q.divisor > 1) o = cf_divide4(o, dv, dv_pow2);
+        *reinterpret_cast<float4*>(out + base + (2 * s + c) * V + off[k]) = o;
+      }
+    __syncthreads();
+  }
 }
 
 // backward: gY = gather_w(ga) / W ; gt (+)= [t > 0] ∘ scatter_w(gX)
@@ -147,13 +319,7 @@ __global__ __launch_bounds__(512, 2) void nmf_cf_bwd_kernel(const float* __restr
   float x[8][8], g[8][8];
   cf_load(t, a, x);
   cf_load(ga, a, g);
-  const float dv = q.gscale_div;
-  if (dv != 1.0f) {
-#pragma unroll
-    for (int dd = 0; dd < 8; ++dd)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) g[dd][j] = g[dd][j] / dv;
-  }
+  cf_divide(g, q.gscale_div);
   nmf_backward_wave<8, 8, R, SOLVER>(w, u0, v0, x, g, h, 8, T, G, eps, nullptr, nullptr);
 #pragma unroll
   for (int dd = 0; dd < 8; ++dd)
@@ -172,6 +338,84 @@ __global__ __launch_bounds__(512, 2) void nmf_cf_bwd_kernel(const float* __restr
       }
       *reinterpret_cast<float4*>(p) = make_float4(r[0], r[1], r[2], r[3]);
     }
+}
+
+// line-coalesced backward: same exchange for t and for the incoming gradient, ReLU gate applied on
+// the owner side before the exchange back, read-modify-write of gt with the coalesced map
+template <int R, int SOLVER, int WPB>
+__global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : 1) void nmf_cf_bwd_tile_kernel(
+    const float* __restrict__ t, const float* __restrict__ u0, const float* __restrict__ v0,
+    const float* __restrict__ ga, float* __restrict__ gt, CfGeom q, int T, int G, float eps, int relu_gate,
+    int xcd_remap) {
+  using TL = CfTile<WPB>;
+  extern __shared__ __attribute__((aligned(16))) float fz_lds_cf[];
+  float* S = fz_lds_cf;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int64_t base, V, off[2];
+  int lidx[2];
+  cf_tile_decode<WPB>(q, cf_logical_block(xcd_remap), tid, base, V, off, lidx);
+  const int own0 = cf_owner_lidx<WPB>(lane, wave, 0), own1 = cf_owner_lidx<WPB>(lane, wave, 1);
+  Hist<8, 8, R> h;
+  h.carve(fz_lds_cf + TL::STAGE_FLOATS + wave * Hist<8, 8, R>::floats(G), G);
+
+  float x[8][8], g[8][8];
+#pragma unroll
+  for (int dd = 0; dd < 8; ++dd)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float4 v = *reinterpret_cast<const float4*>(t + base + dd * V + off[k]);
+      x[dd][k * 4 + 0] = v.x; x[dd][k * 4 + 1] = v.y; x[dd][k * 4 + 2] = v.z; x[dd][k * 4 + 3] = v.w;
+    }
+#pragma unroll
+  for (int dd = 0; dd < 8; ++dd)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float4 v = *reinterpret_cast<const float4*>(ga + base + dd * V + off[k]);
+      g[dd][k * 4 + 0] = v.x; g[dd][k * 4 + 1] = v.y; g[dd][k * 4 + 2] = v.z; g[dd][k * 4 + 3] = v.w;
+    }
+  cf_to_owner<WPB>(S, lidx, own0, own1, x);
+  cf_to_owner<WPB>(S, lidx, own0, own1, g);
+  cf_divide(g, q.gscale_div);
+  CfWave w{lane};
+  nmf_backward_wave<8, 8, R, SOLVER>(w, u0, v0, x, g, h, 8, T, G, eps, nullptr, nullptr);
+
+  // gate first (frees x), then ALL loads of the running sum at once: one exposed round trip, not four
+  if (relu_gate) {
+#pragma unroll
+    for (int dd = 0; dd < 8; ++dd)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[dd][e] = x[dd][e] > 0.f ? g[dd][e] : 0.f;
+  }
+  float4 old[8][2];
+  if (q.accumulate) {
+#pragma unroll
+    for (int dd = 0; dd < 8; ++dd)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) old[dd][k] = *reinterpret_cast<const float4*>(gt + base + dd * V + off[k]);
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      *reinterpret_cast<float4*>(S + c * 64 * TL::LW + own0) =
+          make_float4(g[2 * s + c][0], g[2 * s + c][1], g[2 * s + c][2], g[2 * s + c][3]);
+      *reinterpret_cast<float4*>(S + c * 64 * TL::LW + own1) =
+          make_float4(g[2 * s + c][4], g[2 * s + c][5], g[2 * s + c][6], g[2 * s + c][7]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        float4 z = *reinterpret_cast<const float4*>(S + c * 64 * TL::LW + lidx[k]);
+        if (q.accumulate) {
+          const float4 o = old[2 * s + c][k];
+          z.x += o.x; z.y += o.y; z.z += o.z; z.w += o.w;
+        }
+        *reinterpret_cast<float4*>(gt + base + (2 * s + c) * V + off[k]) = z;
+      }
+    __syncthreads();
+  }
 }
 
 static int cf_geom(CfGeom& q, int B, int C, int D, int H, int W, const int* shift, int accumulate, int divisor) {
@@ -211,6 +455,7 @@ extern "C" int fz_nmf_cf_fwd(const float* t, const float* u0, const float* v0, f
   if (solver != FZ_SOLVER_MU && solver != FZ_SOLVER_HALS) return fail(FZ_E_ARG, "fz_nmf_cf_fwd: bad solver");
   if (B == 0) return FZ_OK;
   const int64_t nmat = (int64_t)B * q.h * q.G0 * q.G1 * q.G2;
+  if (nmat >= (int64_t)1 << 31) return fail(FZ_E_UNSUPPORTED, "fz_nmf_cf: more than 2^31 matrices");
   // measured on MI355X (tools/debug/cf_probe.py): a workgroup = one full row of patches along W
   // (up to 16 waves) consumes whole 128-B lines inside one CU: 0.856 -> 0.725 ms at stage 0
   int wpb = 16;
@@ -219,8 +464,30 @@ extern "C" int fz_nmf_cf_fwd(const float* t, const float* u0, const float* v0, f
   if (wpb < 1) wpb = 1;
   int xr = 1;
   { const char* e = getenv("FZ_CF_XCD"); if (e) xr = atoi(e); }
-  dim3 grid((unsigned)((nmat + wpb - 1) / wpb)), block(64 * wpb);
   hipStream_t st = (hipStream_t)stream;
+  int tile = 1;
+  { const char* e = getenv("FZ_CF_TILE"); if (e) tile = atoi(e); }
+  if (tile && (q.G2 % 8) == 0) {
+    // line-coalesced kernel: WPB patches along W per workgroup
+    // 8 patches per workgroup, two workgroups per CU out of phase: 0.524 ms vs 0.554 (16) vs 0.747 (direct)
+    const int twpb = (tile == 16 && (q.G2 % 16) == 0) ? 16 : 8;
+    const unsigned nblk = (unsigned)(nmat / twpb);
+#define FZ_CF_TILE(RR, SS, WW)                                                                              \
+  do {                                                                                                      \
+    auto kern = nmf_cf_fwd_tile_kernel<RR, SS, WW>;                                                         \
+    const int lds = CfTile<WW>::STAGE_FLOATS * (int)sizeof(float);                                          \
+    if (lds > 65536)                                                                                        \
+      FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                    \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));                      \
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(64 * WW), lds, st, t, u0, v0, out, q, T, eps, xr);            \
+  } while (0)
+#define FZ_CF_TILE_W(RR, SS) do { if (twpb == 16) FZ_CF_TILE(RR, SS, 16); else FZ_CF_TILE(RR, SS, 8); } while (0)
+    if (R == 1) { if (solver == FZ_SOLVER_MU) FZ_CF_TILE_W(1, SOLVER_MU); else FZ_CF_TILE_W(1, SOLVER_HALS); }
+    else { if (solver == FZ_SOLVER_MU) FZ_CF_TILE_W(2, SOLVER_MU); else FZ_CF_TILE_W(2, SOLVER_HALS); }
+    FZ_LAUNCH_CHECK();
+    return FZ_OK;
+  }
+  dim3 grid((unsigned)((nmat + wpb - 1) / wpb)), block(64 * wpb);
 #define FZ_CF_FWD(RR, SS) hipLaunchKernelGGL((nmf_cf_fwd_kernel<RR, SS>), grid, block, 0, st, t, u0, v0, out, q, nmat, T, eps, xr)
   if (R == 1) { if (solver == FZ_SOLVER_MU) FZ_CF_FWD(1, SOLVER_MU); else FZ_CF_FWD(1, SOLVER_HALS); }
   else { if (solver == FZ_SOLVER_MU) FZ_CF_FWD(2, SOLVER_MU); else FZ_CF_FWD(2, SOLVER_HALS); }
@@ -241,6 +508,7 @@ extern "C" int fz_nmf_cf_bwd(const float* t, const float* u0, const float* v0, c
   q.gscale_div = (float)(nshift > 1 ? nshift : 1);
   const int G = Tgrad < 0 ? 0 : (Tgrad > T ? T : Tgrad);
   const int64_t nmat = (int64_t)B * q.h * q.G0 * q.G1 * q.G2;
+  if (nmat >= (int64_t)1 << 31) return fail(FZ_E_UNSUPPORTED, "fz_nmf_cf: more than 2^31 matrices");
   const int per_wave = (R == 1 ? Hist<8, 8, 1>::floats(G) : Hist<8, 8, 2>::floats(G)) * (int)sizeof(float);
   if (per_wave > 160 * 1024) return fail(FZ_E_UNSUPPORTED, "fz_nmf_cf_bwd: history exceeds LDS");
   int wpb = 65536 / per_wave;
@@ -251,9 +519,35 @@ extern "C" int fz_nmf_cf_bwd(const float* t, const float* u0, const float* v0, c
   // patch neighbours on the same XCD share its L2 (shifted windows straddle lines): 1.31 -> 1.17 ms
   int xr = 1;
   { const char* e = getenv("FZ_CF_XCD"); if (e) xr = atoi(e); }
+  hipStream_t st = (hipStream_t)stream;
+  int tile = 1;
+  { const char* e = getenv("FZ_CF_TILE_BWD"); if (e) tile = atoi(e); }
+  if (tile && (q.G2 % 4) == 0) {
+    int twpb = (tile == 8 && (q.G2 % 8) == 0) ? 8 : 4;
+    int tlds = (twpb == 8 ? CfTile<8>::STAGE_FLOATS : CfTile<4>::STAGE_FLOATS) * (int)sizeof(float) + per_wave * twpb;
+    if (twpb == 8 && tlds > 160 * 1024) {
+      twpb = 4;
+      tlds = CfTile<4>::STAGE_FLOATS * (int)sizeof(float) + per_wave * 4;
+    }
+    if (tlds <= 160 * 1024) {
+      const unsigned nblk = (unsigned)(nmat / twpb);
+#define FZ_CF_BWD_TILE(RR, SS, WW)                                                                          \
+  do {                                                                                                      \
+    auto kern = nmf_cf_bwd_tile_kernel<RR, SS, WW>;                                                         \
+    if (tlds > 65536)                                                                                       \
+      FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                    \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, tlds));                     \
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(64 * WW), tlds, st, t, u0, v0, ga, gt, q, T, G, eps, relu_gate, xr); \
+  } while (0)
+#define FZ_CF_BWD_TILE_W(RR, SS) do { if (twpb == 8) FZ_CF_BWD_TILE(RR, SS, 8); else FZ_CF_BWD_TILE(RR, SS, 4); } while (0)
+      if (R == 1) { if (solver == FZ_SOLVER_MU) FZ_CF_BWD_TILE_W(1, SOLVER_MU); else FZ_CF_BWD_TILE_W(1, SOLVER_HALS); }
+      else { if (solver == FZ_SOLVER_MU) FZ_CF_BWD_TILE_W(2, SOLVER_MU); else FZ_CF_BWD_TILE_W(2, SOLVER_HALS); }
+      FZ_LAUNCH_CHECK();
+      return FZ_OK;
+    }
+  }
   const int lds = per_wave * wpb;
   dim3 grid((unsigned)((nmat + wpb - 1) / wpb)), block(64 * wpb);
-  hipStream_t st = (hipStream_t)stream;
 #define FZ_CF_BWD(RR, SS)                                                                                 \
   do {                                                                                                    \
     auto kern = nmf_cf_bwd_kernel<RR, SS>;                                                                \
