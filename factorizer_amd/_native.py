@@ -101,6 +101,12 @@ class GemmDesc(_c.Structure):
                 ("lnb_gadd", _vp), ("lnb_part", _vp)]
 
 
+class MlpDesc(_c.Structure):
+    _fields_ = [("mode", _i), ("inp", _vp), ("w1", _vp), ("w2", _vp), ("b1", _vp), ("b2", _vp), ("ln_g", _vp),
+                ("ln_b", _vp), ("ln_eps", _f), ("stats", _vp), ("z1", _vp), ("gz1", _vp), ("x1", _vp), ("out", _vp),
+                ("part", _vp), ("B", _i), ("C", _i), ("H", _i), ("V", _i64)]
+
+
 class WgradDesc(_c.Structure):
     _fields_ = [("p", _vp), ("M", _i), ("pmul", _vp), ("pmul_kind", _i), ("q", _vp * 4), ("nsrc", _i),
                 ("src_mode", _i), ("c0", _i), ("Cin", _i), ("K", _i), ("Vq", _i64), ("D", _i), ("H", _i),
@@ -115,6 +121,9 @@ _SIGS.update({
     "fz_gemm": ([_c.POINTER(GemmDesc), _vp], _i),
     "fz_gemm_lnbwd_partials": ([_c.POINTER(GemmDesc)], _i64),
     "fz_reduce_rows": ([_vp, _i64, _i, _vp, _vp, _vp], _i),
+    "fz_mlp_supported": ([_i, _i, _i64], _i),
+    "fz_mlp_partials": ([_i, _i64], _i64),
+    "fz_mlp_chain": ([_c.POINTER(MlpDesc), _vp], _i),
     "fz_wgrad": ([_c.POINTER(WgradDesc), _vp, _vp], _i),
     "fz_wgrad_workspace_bytes": ([_c.POINTER(WgradDesc)], _i64),
     "fz_conv3_fwd": ([_vp] * 4 + [_i] * 6 + [_vp], _i),

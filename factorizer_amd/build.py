@@ -18,6 +18,10 @@ LIB = os.path.join(HERE, "libfactorizer_hip.so")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-comment",
          "-ffp-contract=fast"]
+# gemm.hip: the SLP vectorizer pairs accumulator elements of DIFFERENT MFMA tiles for v_pk_* math,
+# which needs register-to-register copies of whole accumulator tiles (adjacent VGPRs hold the same
+# column group, not the same row) — +64..128 VGPRs and scratch spills in the fused epilogues.
+PER_FILE_FLAGS = {"gemm.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:
@@ -57,7 +61,7 @@ def _compile(src: str) -> str:
     obj = os.path.join(OBJ, src[:-4] + ".o")
     if os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(os.path.join(CSRC, src)), _hdr_mtime()):
         return obj
-    cmd = [_hipcc(), *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+    cmd = [_hipcc(), *FLAGS, *PER_FILE_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-4000:]}")

@@ -259,61 +259,82 @@ __device__ __forceinline__ float half_sum32(float v) {
   return v;
 }
 
-__device__ __forceinline__ void lnbwd_block(const GemmArgs& p, const f32x16 (&acc)[4], int b, int64_t ncol,
-                                            bool col_ok, int lane, int wave, float* red /* [4][64] */) {
+template <int NACC, bool GADD>
+__device__ __forceinline__ void lnbwd_block(const GemmArgs& p, const f32x16 (&acc)[NACC], int b, int64_t ncol,
+                                            bool col_ok, int lane, int wave, float* red /* [4][64] */,
+                                            int64_t part_row, const float* g_lds /* gamma[32] in LDS */) {
   const int h = lane >> 5;
   const int64_t nc = col_ok ? ncol : 0;
+  // row = rbase(r) + 4h: the row part of every address is wave-uniform (scalar base) and ONE
+  // 32-bit per-lane offset serves the 16 rows (global_load saddr + voffset; the host bounds Ncol so
+  // that 20*Ncol bytes fit) — per-row 64-bit lane addresses cost a VGPR pair per load in flight
+  const unsigned lane_off = (unsigned)(4 * h) * (unsigned)p.Ncol + (unsigned)nc;
+  const int64_t sample = (int64_t)b * 32 * p.Ncol;
   const float* sp = p.lnb_stats + (int64_t)b * 2 * p.Ncol;
-  const float4 mu4 = *reinterpret_cast<const float4*>(sp + nc);
-  const float4 rs4 = *reinterpret_cast<const float4*>(sp + p.Ncol + nc);
-  const float mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, rs[4] = {rs4.x, rs4.y, rs4.z, rs4.w};
+  float mu[NACC], rs[NACC];
+  vload<NACC>(sp + nc, mu);
+  vload<NACC>(sp + p.Ncol + nc, rs);
   __builtin_amdgcn_sched_barrier(0);  // do not hoist the x loads above the MFMA loop (operand regs still live)
-  float xs[16][4];  // LayerNorm input rows of this lane (the only big live array besides acc)
-  float m1[4] = {0.f, 0.f, 0.f, 0.f}, m2[4] = {0.f, 0.f, 0.f, 0.f};
+  float xs[16][NACC];  // LayerNorm input rows of this lane (the only big live array besides acc)
+  float m1[NACC], m2[NACC];
+#pragma unroll
+  for (int q = 0; q < NACC; ++q) m1[q] = m2[q] = 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-    const float4 xv = *reinterpret_cast<const float4*>(p.lnb_x + ((int64_t)b * 32 + row) * p.Ncol + nc);
-    xs[r][0] = xv.x; xs[r][1] = xv.y; xs[r][2] = xv.z; xs[r][3] = xv.w;
+    const int rbase = (r & 3) + 8 * (r >> 2);
+    vload<NACC>(p.lnb_x + sample + (int64_t)rbase * p.Ncol + lane_off, xs[r]);
+  }
+  // the added gradient is fetched here, unconditionally and all rows at once: a load behind a
+  // runtime `if` inside the row loop compiles to load → s_waitcnt vmcnt(0) per row (16 exposed
+  // round trips per tile)
+  float ga[GADD ? 16 : 1][NACC];
+  if (GADD) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rbase = (r & 3) + 8 * (r >> 2);
+      vload<NACC>(p.lnb_gadd + sample + (int64_t)rbase * p.Ncol + lane_off, ga[GADD ? r : 0]);
+    }
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-    const float gc = p.lnb_g[row];
+    const float gc = g_lds[row];  // (a global load here is a dependent L2 round trip per row)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NACC; ++q) {
       const float av = acc[q][r] * gc;
+      xs[r][q] = (xs[r][q] - mu[q]) * rs[q];  // normalised input, reused below
       m1[q] += av;
-      m2[q] += av * ((xs[r][q] - mu[q]) * rs[q]);
+      m2[q] += av * xs[r][q];
     }
     __builtin_amdgcn_sched_barrier(0);  // keep rows from interleaving (register pressure)
   }
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < NACC; ++q) {
     m1[q] = (m1[q] + __shfl_xor(m1[q], 32, 64)) * (1.0f / 32.0f);
     m2[q] = (m2[q] + __shfl_xor(m2[q], 32, 64)) * (1.0f / 32.0f);
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-    const int64_t o = ((int64_t)b * 32 + row) * p.Ncol + nc;
-    const float gc = p.lnb_g[row];
-    float v[4], nhr[4];
+    const int rbase = (r & 3) + 8 * (r >> 2);
+    const int row = rbase + 4 * h;
+    const int64_t so = sample + (int64_t)rbase * p.Ncol;  // uniform
+    const float gc = g_lds[row];  // (a global load here is a dependent L2 round trip per row)
+    float v[NACC], nhr[NACC];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      nhr[q] = (xs[r][q] - mu[q]) * rs[q];
+    for (int q = 0; q < NACC; ++q) {
+      nhr[q] = xs[r][q];
       v[q] = rs[q] * (acc[q][r] * gc - m1[q] - nhr[q] * m2[q]);
     }
-    if (p.lnb_gadd != nullptr) {
-      const float4 e = *reinterpret_cast<const float4*>(p.lnb_gadd + o);
-      v[0] += e.x; v[1] += e.y; v[2] += e.z; v[3] += e.w;
+    if (GADD) {
+#pragma unroll
+      for (int q = 0; q < NACC; ++q) v[q] += ga[GADD ? r : 0][q];
     }
-    if (col_ok) *reinterpret_cast<float4*>(p.y + o) = make_float4(v[0], v[1], v[2], v[3]);
-    // affine-gradient partials of this row over the wave's 128 voxels
+    if (col_ok) vstore<NACC>(p.y + so + lane_off, v);
+    // affine-gradient partials of this row over the wave's 32*NACC voxels
     float sg = 0.f, sb = 0.f;
     if (col_ok) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < NACC; ++q) {
         sg += acc[q][r] * nhr[q];
         sb += acc[q][r];
       }
@@ -329,7 +350,7 @@ __device__ __forceinline__ void lnbwd_block(const GemmArgs& p, const f32x16 (&ac
   __syncthreads();
   if (threadIdx.x < 64) {
     const int e = threadIdx.x;
-    p.lnb_part[(int64_t)blockIdx.x * 64 + e] = (red[e] + red[64 + e]) + (red[128 + e] + red[192 + e]);
+    p.lnb_part[part_row * 64 + e] = (red[e] + red[64 + e]) + (red[128 + e] + red[192 + e]);
   }
 }
 
@@ -340,7 +361,7 @@ __device__ __forceinline__ void lnbwd_block(const GemmArgs& p, const f32x16 (&ac
 // workgroup sequentially with one accumulator set: the input is read from HBM exactly once for
 // all output rows and 10+ KiB per wave are in flight.
 // =================================================================================================
-template <int NSTEP, int EPI, bool BMUL>
+template <int NSTEP, int EPI, bool BMUL, bool GADD = false>
 __global__ __launch_bounds__(256, ((NSTEP <= 16 && EPI != EPI_LNBWD) ? 3 : 2)) void gemm_resident_kernel(GemmArgs p, int RB) {
   extern __shared__ __attribute__((aligned(16))) float lds_a[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -394,6 +415,10 @@ __global__ __launch_bounds__(256, ((NSTEP <= 16 && EPI != EPI_LNBWD) ? 3 : 2)) v
         for (int k = 0; k < p.K; ++k) t += weight_at(p, m, k) * p.ln_b[k];
       tW[r] = t;
     }
+  }
+
+  if (EPI == EPI_LNBWD) {  // gamma of the fused LayerNorm backward (tW is free: no LN prologue here)
+    if (threadIdx.x < 32) tW[threadIdx.x] = p.lnb_g[threadIdx.x];
   }
 
   const int64_t col_off = n0 + 4 * j;
@@ -469,9 +494,223 @@ __global__ __launch_bounds__(256, ((NSTEP <= 16 && EPI != EPI_LNBWD) ? 3 : 2)) v
       }
     }
     if (EPI == EPI_LNBWD) {
-      lnbwd_block(p, acc, b, col_off, col_ok, lane, wave, tW + 32 * RB);
+      lnbwd_block<4, GADD>(p, acc, b, col_off, col_ok, lane, wave, tW + 32 * RB, blockIdx.x, tW);
     } else {
       if (col_ok) store_block<4, (EPI == EPI_LNBWD ? EPI_PLAIN : EPI), false>(p, acc, b, m0 + rb * 32, col_off, h, p.ln ? tW + rb * 32 : nullptr);
+    }
+  }
+}
+
+// =================================================================================================
+// Kernel C — two chained GEMMs for the C = 32 MLP (layers/mlp.py:54-63 behind the second pre-norm
+// residual, factorizer.py:76): the 64-row hidden tensor is produced in the accumulators of GEMM 1,
+// transformed in registers and consumed as the B operand of GEMM 2 WITHOUT leaving the wave.
+//
+// Why no data movement is needed: after GEMM 1 register r of lane (j, h) holds row
+// (r&3) + 8(r>>2) + 4h of the row block at column j — and an MFMA K-step wants B[k = h-th of a
+// pair][column j].  So accumulator register r IS the operand of K-step r if the A operand (the
+// weights, staged in LDS) is laid out with k(step r, half h) = (r&3) + 8(r>>2) + 4h.  The order
+// of a reduction is free.
+//
+//   forward  (BWD = false): z = W1·LN(x1) + b1 → side (kept for the backward);
+//                           out = x1 + W2·gelu(z) + b2
+//   backward (BWD = true):  gz = (W2ᵀ·g2) ∘ gelu'(z) → side (kept for the weight gradients);
+//                           out = LayerNormBackward(W1ᵀ·gz; x1, stats, γ) + g2   (+ dγ, dβ partials)
+// Saves one write + one read of the 64-channel tensor per direction against the unfused layers.
+// =================================================================================================
+struct ChainArgs {
+  const float* wB;     // GEMM 2 weights: A[m][k] = wB_t ? wB[k*ldwB + m] : wB[m*ldwB + k]   (m < 32, k < 64)
+  int wB_t, ldwB;
+  const float* biasB;  // forward: [32] or null
+  float* side;         // (B, 64, V)
+};
+
+template <bool BWD, int NACC>
+__global__ __launch_bounds__(256, NACC == 2 ? 3 : 2) void gemm_chain_kernel(GemmArgs p, ChainArgs c, int ntiles) {
+  __shared__ float As1[16 * 2 * 64];
+  __shared__ float As2[32 * 64];
+  __shared__ float tW[64];
+  __shared__ float tB[32];
+  __shared__ float red[256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int tiles_per_sample = (int)((p.Ncol + 128 * NACC - 1) / (128 * NACC));
+
+  // weights in operand order (8 independent loads per thread before the LDS stores)
+  for (int base = threadIdx.x; base < 4096; base += 256 * 8) {
+    float tmp[8];
+#pragma unroll
+    for (int uu = 0; uu < 8; ++uu) {
+      const int idx = base + uu * 256;
+      float wv;
+      if (idx < 2048) {  // GEMM 1: step a, row block rb
+        const int l = idx & 63, rb = (idx >> 6) & 1, a = idx >> 7;
+        const int m = rb * 32 + (l & 31), k = 2 * a + (l >> 5);
+        wv = weight_at(p, m, k);
+        if (!BWD) wv *= p.ln_g[k];
+      } else {           // GEMM 2: step (rb, r) consumes accumulator register r of row block rb
+        const int i2 = idx - 2048;
+        const int l = i2 & 63, s2 = i2 >> 6;
+        const int r = s2 & 15, rb = s2 >> 4;
+        const int k = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), m = l & 31;
+        wv = c.wB_t ? c.wB[(int64_t)k * c.ldwB + m] : c.wB[(int64_t)m * c.ldwB + k];
+      }
+      tmp[uu] = wv;
+    }
+#pragma unroll
+    for (int uu = 0; uu < 8; ++uu) {
+      const int idx = base + uu * 256;
+      if (idx < 2048) As1[idx] = tmp[uu]; else As2[idx - 2048] = tmp[uu];
+    }
+  }
+  if (BWD) {
+    if (threadIdx.x < 32) tB[threadIdx.x] = p.lnb_g[threadIdx.x];
+  } else {
+    for (int r = threadIdx.x; r < 64; r += blockDim.x) {
+      float t = 0.f;
+      for (int k = 0; k < 32; ++k) t += weight_at(p, r, k) * p.ln_b[k];
+      tW[r] = t + (p.bias ? p.bias[r] : 0.f);
+      if (r < 32) tB[r] = c.biasB ? c.biasB[r] : 0.f;
+    }
+  }
+
+  // persistent over column tiles: the operand of the NEXT tile is fetched as soon as GEMM 1 has
+  // consumed the current one, so its latency hides behind the transform, GEMM 2 and the epilogue
+  int tile = blockIdx.x;
+  float bv[16][NACC];
+  // operand loads: channel 2s + h → uniform part (b*32 + 2s)*V in scalar registers + ONE lane offset
+  auto fetch_tile = [&](int t) {
+    const int bt = t / tiles_per_sample;
+    const int64_t ct = ((int64_t)(t % tiles_per_sample) * 4 + wave) * (32 * NACC) + NACC * j;
+    const unsigned lo = (unsigned)h * (unsigned)p.Ncol + (unsigned)(ct < p.Ncol ? ct : 0);
+    const float* xb = p.x[0] + (int64_t)bt * 32 * p.Ncol;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) vload<NACC>(xb + (int64_t)(2 * s) * p.Ncol + lo, bv[s]);
+  };
+  fetch_tile(tile);
+  __syncthreads();
+
+  for (; tile < ntiles; tile += gridDim.x) {
+    // compiler-only fence: without it the loop-invariant LDS reads (row constants, 48 per lane) are
+    // hoisted out of the tile loop and kept in VGPRs, which spills the accumulators
+    asm volatile("" ::: "memory");
+    const int b = tile / tiles_per_sample;
+    const int64_t col_off = ((int64_t)(tile % tiles_per_sample) * 4 + wave) * (32 * NACC) + NACC * j;
+    const bool col_ok = col_off < p.Ncol;
+    const int64_t nc = col_ok ? col_off : 0;
+    const unsigned lane_row = (unsigned)(4 * h) * (unsigned)p.Ncol + (unsigned)nc;
+
+    if (!BWD) {
+      // exact two-pass LayerNorm statistics (this lane holds the parity-h half of the channels)
+      float mu[NACC], rs[NACC];
+#pragma unroll
+      for (int e = 0; e < NACC; ++e) {
+        float t = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) t += bv[s][e];
+        t += __shfl_xor(t, 32, 64);
+        mu[e] = t / 32.0f;
+      }
+#pragma unroll
+      for (int e = 0; e < NACC; ++e) {
+        float t = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          const float d = bv[s][e] - mu[e];
+          t += d * d;
+        }
+        t += __shfl_xor(t, 32, 64);
+        rs[e] = 1.0f / sqrtf(t / 32.0f + p.ln_eps);
+      }
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+#pragma unroll
+        for (int e = 0; e < NACC; ++e) bv[s][e] = (bv[s][e] - mu[e]) * rs[e];
+      if (p.stats_out != nullptr && h == 0 && col_ok) {
+        float* so = p.stats_out + (int64_t)b * 2 * p.Vin;
+        vstore<NACC>(so + col_off, mu);
+        vstore<NACC>(so + p.Vin + col_off, rs);
+      }
+    }
+
+    // ---- GEMM 1: 64 rows x 128 columns per wave ----
+    f32x16 acc1[2][NACC];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int q = 0; q < NACC; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[rb][q][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        const float av = As1[(s * 2 + rb) * 64 + lane];
+#pragma unroll
+        for (int q = 0; q < NACC; ++q) acc1[rb][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[s][q], acc1[rb][q], 0, 0, 0);
+      }
+
+    // ---- prefetch the operand of the next tile (clamped re-read of this one on the last pass) ----
+    fetch_tile(tile + gridDim.x < ntiles ? tile + gridDim.x : tile);
+
+    // ---- hidden tensor: transform in registers, keep a copy in HBM for the other pass ----
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rbase = rb * 32 + (r & 3) + 8 * (r >> 2);
+        const int row = rbase + 4 * h;
+        const int64_t ob = ((int64_t)b * 64 + rbase) * p.Ncol;  // uniform row part; + one 32-bit lane offset
+        float v[NACC];
+        if (!BWD) {
+          const float add = tW[row];
+#pragma unroll
+          for (int q = 0; q < NACC; ++q) v[q] = acc1[rb][q][r] + add;
+          if (col_ok) vstore<NACC>(c.side + ob + lane_row, v);
+#pragma unroll
+          for (int q = 0; q < NACC; ++q) acc1[rb][q][r] = gelu_f(v[q]);
+        } else {
+          float e[NACC];
+          vload<NACC>(p.emul + ob + lane_row, e);
+#pragma unroll
+          for (int q = 0; q < NACC; ++q) v[q] = acc1[rb][q][r] * gelu_grad_f(e[q]);
+          if (col_ok) vstore<NACC>(c.side + ob + lane_row, v);
+#pragma unroll
+          for (int q = 0; q < NACC; ++q) acc1[rb][q][r] = v[q];
+        }
+      }
+
+    // ---- GEMM 2: 32 rows, K = 64 straight from the accumulators of GEMM 1 ----
+    f32x16 acc2[NACC];
+#pragma unroll
+    for (int q = 0; q < NACC; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[q][r] = 0.f;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float av = As2[(rb * 16 + r) * 64 + lane];
+#pragma unroll
+        for (int q = 0; q < NACC; ++q) acc2[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, acc1[rb][q][r], acc2[q], 0, 0, 0);
+      }
+
+    if (BWD) {
+      lnbwd_block<NACC, true>(p, acc2, b, col_off, col_ok, lane, wave, red, tile, tB);
+      __syncthreads();  // red is reused by the next tile
+    } else if (col_ok) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rbase = (r & 3) + 8 * (r >> 2);
+        const int row = rbase + 4 * h;
+        const int64_t ob = ((int64_t)b * 32 + rbase) * p.Ncol;
+        const float add = tB[row];
+        float e[NACC], v[NACC];
+        vload<NACC>(p.res + ob + lane_row, e);
+#pragma unroll
+        for (int q = 0; q < NACC; ++q) v[q] = acc2[q][r] + add + e[q];
+        vstore<NACC>(p.y + ob + lane_row, v);
+      }
     }
   }
 }
@@ -755,6 +994,7 @@ extern "C" int fz_gemm(const fz_gemm_desc* d, fz_stream_t stream) {
   if (d->epilogue == EPI_LNBWD && (d->M != 32 || (d->K != 32 && d->K != 64) || d->loader != LOAD_PLAIN || !d->lnb_x || !d->lnb_stats ||
                                    !d->lnb_g || !d->lnb_part || d->bias || d->res || d->emul || d->eact || d->ln))
     return fail(FZ_E_UNSUPPORTED, "fz_gemm: LayerNorm-backward epilogue needs M == 32, K <= 64, plain loader");
+  if (d->epilogue == EPI_LNBWD && d->Ncol > ((int64_t)1 << 27)) return fail(FZ_E_UNSUPPORTED, "fz_gemm: LayerNorm-backward epilogue: more than 2^27 voxels per sample");
   if (d->B < 0 || d->Cin < 1 || d->M < 1 || d->K < 1) return fail(FZ_E_SHAPE, "fz_gemm: sizes must be positive");
   if ((d->K & 1) && (d->loader != LOAD_PLAIN || d->ln))
     return fail(FZ_E_UNSUPPORTED, "fz_gemm: odd K only with the plain loader and no LayerNorm prologue");
@@ -801,7 +1041,9 @@ extern "C" int fz_gemm(const fz_gemm_desc* d, fz_stream_t stream) {
 #define FZ_RES(NS, E, BM) hipLaunchKernelGGL((gemm_resident_kernel<NS, E, BM>), grid, block, lds, st, a, RB)
     if (d->epilogue == EPI_LNBWD) {
       if (d->bmul) return fail(FZ_E_UNSUPPORTED, "fz_gemm: bmul with LayerNorm-backward epilogue");
-      if (nA <= 16) FZ_RES(16, EPI_LNBWD, false); else FZ_RES(32, EPI_LNBWD, false);
+#define FZ_RES_LNB(NS, GA) hipLaunchKernelGGL((gemm_resident_kernel<NS, EPI_LNBWD, false, GA>), grid, block, lds, st, a, RB)
+      if (d->lnb_gadd) { if (nA <= 16) FZ_RES_LNB(16, true); else FZ_RES_LNB(32, true); }
+      else { if (nA <= 16) FZ_RES_LNB(16, false); else FZ_RES_LNB(32, false); }
     } else if (d->epilogue == EPI_D2S) {
       if (d->bmul) return fail(FZ_E_UNSUPPORTED, "fz_gemm: bmul with depth-to-space epilogue");
       if (nA <= 16) FZ_RES(16, EPI_D2S, false); else FZ_RES(32, EPI_D2S, false);
@@ -866,4 +1108,63 @@ extern "C" int fz_gemm(const fz_gemm_desc* d, fz_stream_t stream) {
 extern "C" int64_t fz_gemm_lnbwd_partials(const fz_gemm_desc* d) {
   if (!d) return -1;
   return ((d->Ncol + 511) / 512) * d->B;  // one row per workgroup of the resident kernel
+}
+
+// MLP chain for C = 32, hidden 64 (see gemm_chain_kernel).  Replaces, per FactorizerBlock,
+// Linear∘LayerNorm + Linear∘GELU + residual (layers/mlp.py:54-63, factorizer.py:76) in the
+// forward and the two input-gradient GEMMs + LayerNorm backward in the backward.
+static int mlp_nacc() {
+  // columns per lane: 2 → 64-column wave tiles, ~150 VGPRs, 3 waves/SIMD with the next-tile prefetch
+  int na = 2;
+  const char* e = getenv("FZ_MLP_NACC");
+  if (e && atoi(e) == 4) na = 4;
+  return na;
+}
+
+extern "C" int64_t fz_mlp_partials(int B, int64_t V) {
+  const int64_t tw = 128 * mlp_nacc();
+  return ((V + tw - 1) / tw) * (int64_t)B;
+}
+
+extern "C" int fz_mlp_supported(int C, int H, int64_t V) {
+  return (C == 32 && H == 64 && V > 0 && (V % 4) == 0 && V <= ((int64_t)1 << 27)) ? 1 : 0;
+}
+
+extern "C" int fz_mlp_chain(const fz_mlp_desc* d, fz_stream_t stream) {
+  if (!d) return fail(FZ_E_ARG, "fz_mlp_chain: null descriptor");
+  if (!fz_mlp_supported(d->C, d->H, d->V)) return fail(FZ_E_UNSUPPORTED, "fz_mlp_chain: needs C == 32, H == 64, V % 4 == 0");
+  if (d->B < 0) return fail(FZ_E_SHAPE, "fz_mlp_chain: negative batch");
+  if (!d->in || !d->w1 || !d->w2 || !d->out || !d->z1 || !d->stats)
+    return fail(FZ_E_ARG, "fz_mlp_chain: null pointer");
+  if (d->mode == 0 && (!d->ln_g || !d->ln_b)) return fail(FZ_E_ARG, "fz_mlp_chain: forward needs the LayerNorm affine");
+  if (d->mode == 1 && (!d->gz1 || !d->x1 || !d->ln_g || !d->part)) return fail(FZ_E_ARG, "fz_mlp_chain: backward needs gz1, x1, gamma, part");
+  if (d->mode != 0 && d->mode != 1) return fail(FZ_E_ARG, "fz_mlp_chain: bad mode");
+  if (d->B == 0) return FZ_OK;
+  GemmArgs a = {};
+  ChainArgs c = {};
+  a.x[0] = d->in; a.nsrc = 1; a.c0 = 32; a.Cin = 32; a.Vin = d->V; a.M = 64; a.K = 32; a.Ncol = d->V; a.B = d->B;
+  hipStream_t st = (hipStream_t)stream;
+  const int ntiles = (int)fz_mlp_partials(d->B, d->V);
+  int wgs = mlp_nacc() == 4 ? 512 : 768;  // resident workgroups (2 or 3 per CU), each walking tiles with a stride of the grid
+  { const char* e = getenv("FZ_MLP_WGS"); if (e) wgs = atoi(e); }
+  dim3 grid((unsigned)(ntiles < wgs ? ntiles : wgs)), block(256);
+  if (d->mode == 0) {
+    a.w = d->w1; a.w_t = 0; a.ldw = 32;              // A1[m][k] = W1[m][k]
+    a.bias = d->b1; a.ln = 1; a.ln_g = d->ln_g; a.ln_b = d->ln_b; a.ln_eps = d->ln_eps; a.stats_out = d->stats;
+    a.res = d->in; a.y = d->out;
+    c.wB = d->w2; c.wB_t = 0; c.ldwB = 64;           // A2[m][k] = W2[m][k]
+    c.biasB = d->b2; c.side = d->z1;
+    if (mlp_nacc() == 4) hipLaunchKernelGGL((gemm_chain_kernel<false, 4>), grid, block, 0, st, a, c, ntiles);
+    else hipLaunchKernelGGL((gemm_chain_kernel<false, 2>), grid, block, 0, st, a, c, ntiles);
+  } else {
+    a.w = d->w2; a.w_t = 1; a.ldw = 64;              // A1[m = hidden][k = c] = W2[c][hidden]
+    a.emul = d->z1; a.y = d->out;
+    a.lnb_x = d->x1; a.lnb_stats = d->stats; a.lnb_g = d->ln_g; a.lnb_gadd = d->in; a.lnb_part = d->part;
+    c.wB = d->w1; c.wB_t = 1; c.ldwB = 32;           // A2[m = c][k = hidden] = W1[hidden][c]
+    c.side = d->gz1;
+    if (mlp_nacc() == 4) hipLaunchKernelGGL((gemm_chain_kernel<true, 4>), grid, block, 0, st, a, c, ntiles);
+    else hipLaunchKernelGGL((gemm_chain_kernel<true, 2>), grid, block, 0, st, a, c, ntiles);
+  }
+  FZ_LAUNCH_CHECK();
+  return FZ_OK;
 }

@@ -12,6 +12,7 @@ Each autograd Function below is one fused layer of the reference block:
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 import torch.nn.functional as F
@@ -132,6 +133,57 @@ def _dgrad_lnbwd(gz, w2, x, stats, ln_w, gadd):
         rc = N.lib().fz_reduce_rows(part.data_ptr(), rows, 64, gpar.data_ptr(), tmp.data_ptr(), N.stream_ptr(x))
         N.check(rc, "fz_reduce_rows")
     return gx, gpar[:32], gpar[32:]
+
+
+def _mlp_chain_ok(C, Hd, V):
+    return os.environ.get("FZ_MLP_CHAIN", "1") != "0" and bool(N.lib().fz_mlp_supported(C, Hd, V))
+
+
+def _mlp_fwd_chain(x1, ln_w, ln_b, eps, w12, b1, w22, b2):
+    """x2 = x1 + fc2(gelu(fc1(LN(x1)))) in ONE kernel (csrc/gemm.hip gemm_chain_kernel): the hidden
+    tensor goes from the accumulators of the first GEMM into the second; z1 (pre-activation) and
+    the LayerNorm statistics are written once for the backward."""
+    B, C = x1.shape[:2]
+    V = _vox(x1)
+    Hd = w12.shape[0]
+    z1 = torch.empty((B, Hd, *x1.shape[2:]), dtype=x1.dtype, device=x1.device)
+    st = torch.empty((B, 2, V), dtype=x1.dtype, device=x1.device)
+    x2 = torch.empty_like(x1)
+    d = N.MlpDesc()
+    d.mode, d.inp, d.w1, d.w2, d.b1, d.b2 = 0, x1.data_ptr(), w12.data_ptr(), w22.data_ptr(), _p(b1), _p(b2)
+    d.ln_g, d.ln_b, d.ln_eps = ln_w.data_ptr(), ln_b.data_ptr(), float(eps)
+    d.stats, d.z1, d.out = st.data_ptr(), z1.data_ptr(), x2.data_ptr()
+    d.B, d.C, d.H, d.V = B, C, Hd, V
+    with torch.cuda.device(x1.device):
+        rc = Fn._timed(f"mlp_chain_fwd_{C}", 4 * (2 * x1.numel() + z1.numel()),
+                       lambda: N.lib().fz_mlp_chain(ctypes.byref(d), N.stream_ptr(x1)))
+    N.check(rc, "fz_mlp_chain")
+    return x2, z1, st
+
+
+def _mlp_bwd_chain(g2, z1, w12, w22, x1, st, ln_w):
+    """(gz1, gx1, gγ, gβ): gz1 = (W2ᵀ g2) ∘ gelu'(z1); gx1 = LNbwd(W1ᵀ gz1) + g2, one kernel."""
+    B, C = x1.shape[:2]
+    V = _vox(x1)
+    Hd = w12.shape[0]
+    gz1 = torch.empty_like(z1)
+    gx1 = torch.empty_like(x1)
+    rows = N.lib().fz_mlp_partials(B, V)
+    part = torch.empty((rows, 64), dtype=x1.dtype, device=x1.device)
+    gpar = torch.empty(64, dtype=x1.dtype, device=x1.device)
+    tmp = torch.empty((64, 64), dtype=x1.dtype, device=x1.device)
+    d = N.MlpDesc()
+    d.mode, d.inp, d.w1, d.w2 = 1, g2.data_ptr(), w12.data_ptr(), w22.data_ptr()
+    d.ln_g, d.stats, d.z1, d.gz1, d.x1 = ln_w.data_ptr(), st.data_ptr(), z1.data_ptr(), gz1.data_ptr(), x1.data_ptr()
+    d.out, d.part = gx1.data_ptr(), part.data_ptr()
+    d.B, d.C, d.H, d.V = B, C, Hd, V
+    with torch.cuda.device(x1.device):
+        rc = Fn._timed(f"mlp_chain_bwd_{C}", 4 * (3 * x1.numel() + 2 * z1.numel()),
+                       lambda: N.lib().fz_mlp_chain(ctypes.byref(d), N.stream_ptr(x1)))
+        N.check(rc, "fz_mlp_chain")
+        rc = N.lib().fz_reduce_rows(part.data_ptr(), rows, 64, gpar.data_ptr(), tmp.data_ptr(), N.stream_ptr(x1))
+        N.check(rc, "fz_reduce_rows")
+    return gz1, gx1, gpar[:32], gpar[32:]
 
 
 def _native_ok(*ts):
@@ -514,13 +566,16 @@ class FactorizerBlockFn(torch.autograd.Function):
         x1 = new(C)
         _gemm([a], wout2, x1, B=B, Cin=C, Vin=V, M=C, K=C, Ncol=V, bias=bout, res=x, name="act_linear_res")
         # 4. z1 = fc1(LN2(x1)) ; x2 = x1 + fc2(gelu(z1))
-        z1 = new(Hd)
-        st2 = torch.empty((B, 2, V), dtype=x.dtype, device=x.device)
-        _gemm([x1], w12, z1, B=B, Cin=C, Vin=V, M=Hd, K=C, Ncol=V, bias=b1, ln=(n2w, n2b, cfg["eps2"]),
-              stats_out=st2, name="ln_linear")
-        x2 = new(C)
-        _gemm([z1], w22, x2, B=B, Cin=Hd, Vin=V, M=C, K=Hd, Ncol=V, bias=b2, bact=ACT["gelu"], res=x1,
-              name="act_linear_res")
+        if _mlp_chain_ok(C, Hd, V):
+            x2, z1, st2 = _mlp_fwd_chain(x1, n2w, n2b, cfg["eps2"], w12, b1, w22, b2)
+        else:
+            z1 = new(Hd)
+            st2 = torch.empty((B, 2, V), dtype=x.dtype, device=x.device)
+            _gemm([x1], w12, z1, B=B, Cin=C, Vin=V, M=Hd, K=C, Ncol=V, bias=b1, ln=(n2w, n2b, cfg["eps2"]),
+                  stats_out=st2, name="ln_linear")
+            x2 = new(C)
+            _gemm([z1], w22, x2, B=B, Cin=Hd, Vin=V, M=C, K=Hd, Ncol=V, bias=b2, bact=ACT["gelu"], res=x1,
+                  name="act_linear_res")
         ctx.save_for_backward(x, st1, t, a, x1, st2, z1, m, n1w, n1b, win2, u0c, v0c, wout2, n2w, n2b, w12, w22)
         ctx.cfg = cfg
         ctx.shapes = (win.shape, wout.shape, w1.shape, w2.shape)
@@ -537,13 +592,18 @@ class FactorizerBlockFn(torch.autograd.Function):
         dev, dt = x.device, x.dtype
         geo, T, G, solver, neps = cfg["geo"], cfg["T"], cfg["G"], cfg["solver"], cfg["nmf_eps"]
         # --- MLP ---
-        gz1 = torch.empty_like(z1)
-        _gemm([g2], w22, gz1, B=B, Cin=C, Vin=V, M=Hd, K=C, Ncol=V, w_t=True, ldw=Hd, emul=z1,
-              emul_kind=ACT["gelu"], name="linear_dgrad")
+        chain = _mlp_chain_ok(C, Hd, V)
+        if chain:
+            gz1, gx1, gg2, gbt2 = _mlp_bwd_chain(g2, z1, w12, w22, x1, st2, n2w)   # + residual path of the MLP
+        else:
+            gz1 = torch.empty_like(z1)
+            _gemm([g2], w22, gz1, B=B, Cin=C, Vin=V, M=Hd, K=C, Ncol=V, w_t=True, ldw=Hd, emul=z1,
+                  emul_kind=ACT["gelu"], name="linear_dgrad")
         gw2 = torch.empty_like(w22)
         gb2 = torch.empty(C, dtype=dt, device=dev)
         _wgrad(g2, [z1], gw2, B=B, M=C, Cin=Hd, K=Hd, Vq=V, Ncols=V, gbias=gb2, qact=ACT["gelu"], name="wgrad_linear")
-        gx1, gg2, gbt2 = _dgrad_lnbwd(gz1, w12, x1, st2, n2w, g2)      # + residual path of the MLP
+        if not chain:
+            gx1, gg2, gbt2 = _dgrad_lnbwd(gz1, w12, x1, st2, n2w, g2)      # + residual path of the MLP
         gw1 = torch.empty_like(w12)
         gb1 = torch.empty(Hd, dtype=dt, device=dev)
         _wgrad(gz1, [x1], gw1, B=B, M=Hd, Cin=C, K=C, Vq=V, Ncols=V, gbias=gb1, stats=st2, ln=(n2w, n2b),

@@ -181,6 +181,39 @@ int fz_reduce_rows(const float* part, int64_t rows, int n, float* out, float* tm
 
 int fz_gemm(const fz_gemm_desc* desc, fz_stream_t stream);
 
+/* ---- MLP chain (C = 32, hidden 64): two GEMMs, hidden tensor stays in the accumulators --------
+ * Replaces per FactorizerBlock (factorizer.py:76, layers/mlp.py:54-63, layers/norm.py:29-34):
+ *   mode 0  out = in + W2·gelu(W1·LN(in) + b1) + b2 ; z1 = W1·LN(in) + b1 and stats (mean, rstd)
+ *           are written for the backward
+ *   mode 1  gz1 = (W2ᵀ·in) ∘ gelu'(z1)  (written for the weight gradients) ;
+ *           out = LayerNormBackward(W1ᵀ·gz1; x1, stats, gamma) + in ; part receives
+ *           fz_mlp_partials(B, V) rows of 64 floats (dgamma | dbeta partial sums, reduce with
+ *           fz_reduce_rows)
+ */
+typedef struct fz_mlp_desc {
+  int mode;
+  const float* in;    /* mode 0: x1 (B, C, V) ; mode 1: g2 = dL/d(out of the block) (B, C, V)  */
+  const float* w1;    /* (H, C)                                                              */
+  const float* w2;    /* (C, H)                                                              */
+  const float* b1;    /* (H) or NULL, mode 0                                                 */
+  const float* b2;    /* (C) or NULL, mode 0                                                 */
+  const float* ln_g;  /* (C)                                                                 */
+  const float* ln_b;  /* (C), mode 0                                                         */
+  float ln_eps;
+  float* stats;       /* (B, 2, V): written in mode 0, read in mode 1                        */
+  float* z1;          /* (B, H, V): written in mode 0, read in mode 1                        */
+  float* gz1;         /* (B, H, V): written in mode 1                                        */
+  const float* x1;    /* (B, C, V): the LayerNorm input, mode 1                              */
+  float* out;         /* (B, C, V)                                                           */
+  float* part;        /* mode 1: fz_mlp_partials(B, V) x 64 floats                           */
+  int B, C, H;
+  int64_t V;
+} fz_mlp_desc;
+
+int fz_mlp_supported(int C, int H, int64_t V);
+int64_t fz_mlp_partials(int B, int64_t V);
+int fz_mlp_chain(const fz_mlp_desc* desc, fz_stream_t stream);
+
 /* ---- weight gradients of the GEMM family ------------------------------------------------
  * GW[m,k] = sum_{b,n} P[b,m,n] * Q(In)[b,k,n] — what autograd computes for the weights of
  * Conv1d(k=1) (layers/linear.py:44-58), Conv3d k2s2 / ConvTranspose3d k2s2 (unet.py:53,123)

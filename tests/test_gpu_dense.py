@@ -217,3 +217,40 @@ def test_dice_bce_loss_fused():
     assert _native.launch_count() > n0
     assert abs(ld.item() - lc.item()) <= 1e-5 * abs(lc.item()) + 1e-6
     _cmp(gd, gc, "dloss/dlogits", rtol=1e-4)
+
+
+@pytest.mark.parametrize("B,S", [(2, (8, 8, 8)), (1, (6, 4, 5)), (2, (16, 16, 12))])
+def test_mlp_chain_kernel(B, S):
+    """fz_mlp_chain (csrc/gemm.hip gemm_chain_kernel) against the layer-by-layer CPU composition
+    x + fc2(gelu(fc1(LN(x)))) (factorizer.py:76, mlp.py:54-60, norm.py:29-34): forward, the saved
+    pre-activation / statistics, and the backward chain (gz1, gx1, dγ, dβ).  V = 120 and 3072 cover
+    partial column tiles."""
+    torch.manual_seed(3)
+    C, Hd = 32, 64
+    x = torch.randn(B, C, *S) * 2 + 0.5
+    ln_w, ln_b = torch.rand(C) + 0.5, torch.randn(C) * 0.1
+    w1, b1 = torch.randn(Hd, C) * 0.2, torch.randn(Hd) * 0.1
+    w2, b2 = torch.randn(C, Hd) * 0.2, torch.randn(C) * 0.1
+    g2 = torch.randn(B, C, *S)
+    # CPU composition with autograd
+    xc = x.clone().requires_grad_(True)
+    lw, lb = ln_w.clone().requires_grad_(True), ln_b.clone().requires_grad_(True)
+    xn = F.layer_norm(xc.movedim(1, -1), (C,), lw, lb, 1e-5).movedim(-1, 1)
+    z1c = _lin_cpu(xn, w1.unsqueeze(-1), b1)
+    z1c.retain_grad()
+    yc = xc + _lin_cpu(F.gelu(z1c), w2.unsqueeze(-1), b2)
+    yc.backward(g2)
+    # device
+    d = lambda t: t.to(DEV).contiguous()  # noqa: E731
+    n0 = _native.launch_count()
+    x2, z1, st = PW._mlp_fwd_chain(d(x), d(ln_w), d(ln_b), 1e-5, d(w1), d(b1), d(w2), d(b2))
+    _cmp(x2, yc, "x2")
+    _cmp(z1, z1c, "z1")
+    mean = x.mean(1).reshape(B, -1)
+    _cmp(st[:, 0], mean, "mean")
+    gz1, gx1, gg, gb = PW._mlp_bwd_chain(d(g2), z1, d(w1), d(w2), d(x), st, d(ln_w))
+    assert _native.launch_count() > n0
+    _cmp(gz1, z1c.grad, "gz1", rtol=5e-4)
+    _cmp(gx1, xc.grad, "gx1", rtol=5e-4)
+    _cmp(gg, lw.grad, "dgamma", rtol=5e-4)
+    _cmp(gb, lb.grad, "dbeta", rtol=5e-4)
