@@ -726,37 +726,49 @@ constexpr int kAChunk = 64;  // A-operand steps staged in LDS at a time
 // basic block (ds_read → wait → MFMA serialised), so the variants are separate instantiations.
 enum { PRO_NONE = 0, PRO_LN = 1, PRO_GELU = 2, PRO_BMUL = 3 };
 
-template <int MB, int NACC, int LOADER, int EPI, int PRO>
+// KS = 4: the four waves of a workgroup share ONE column tile and split the K steps between them
+// (groups of kPF steps, round-robin), then add their accumulators through LDS.  For the deep
+// stages (8^3, 16^3 voxels; K = 256..2048) this gives 4x the workgroups and 4x shorter dependent
+// MFMA chains: 512->512 at 8^3 is 128 workgroups x 256 serial steps without it.
+template <int MB, int NACC, int LOADER, int EPI, int PRO, int KS = 1>
 __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgs p) {
   constexpr int TN = 32 * NACC;
   constexpr int NL = (LOADER == LOAD_S2D) ? 4 : NACC;  // floats fetched per load step
   // operand prefetch depth (load steps): narrow tiles are latency-bound (L2 round trip ≈ 500-900
   // cycles vs 64·NACC MFMA cycles per step), so they keep more loads in flight
   constexpr int kPF = (NL == 4) ? 8 : 16;
-  __shared__ float As[kAChunk * MB * 64];
+  constexpr int kRedFloats = (KS > 1) ? (KS - 1) * (MB * NACC * 16 + 2 * NACC) * 64 : 0;
+  constexpr int kAsFloats = kAChunk * MB * 64 > kRedFloats ? kAChunk * MB * 64 : kRedFloats;
+  __shared__ float As[kAsFloats];
   __shared__ float sW[32 * MB];
   __shared__ float tW[32 * MB];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, h = lane >> 5;
-  const int tiles_per_sample = (int)((p.Ncol + TN * 4 - 1) / (TN * 4));
+  constexpr int WT = (KS > 1) ? 1 : 4;  // column tiles per workgroup
+  const int tiles_per_sample = (int)((p.Ncol + TN * WT - 1) / (TN * WT));
   const int b = blockIdx.x / tiles_per_sample;
-  const int64_t n0 = ((int64_t)(blockIdx.x % tiles_per_sample) * 4 + wave) * TN;
+  const int64_t n0 = ((int64_t)(blockIdx.x % tiles_per_sample) * WT + (KS > 1 ? 0 : wave)) * TN;
   const int m0 = blockIdx.y * 32 * MB;
   const int nA = (p.K + 1) / 2;
 
   if (PRO == PRO_LN) {
-    for (int r = threadIdx.x; r < 32 * MB; r += blockDim.x) {
+    // s[m] = Σ_k W[m][k]·γ[k], t[m] = Σ_k W[m][k]·β[k]: 8 threads per row, k interleaved (a single
+    // thread per row is K dependent-latency loads: 60-110 us at K = 512..1024)
+    for (int r0 = 0; r0 < 32 * MB; r0 += 32) {
+      const int r = r0 + (threadIdx.x >> 3), part = threadIdx.x & 7;
       const int m = m0 + r;
       float s = 0.f, t = 0.f;
       if (m < p.M)
-        for (int k = 0; k < p.K; ++k) {
+        for (int k = part; k < p.K; k += 8) {
           const float wv = weight_at(p, m, k);
           s += wv * p.ln_g[k];
           t += wv * p.ln_b[k];
         }
-      sW[r] = s;
-      tW[r] = t;
+      s += __shfl_xor(s, 1, 64); t += __shfl_xor(t, 1, 64);
+      s += __shfl_xor(s, 2, 64); t += __shfl_xor(t, 2, 64);
+      s += __shfl_xor(s, 4, 64); t += __shfl_xor(t, 4, 64);
+      if (part == 0) { sW[r] = s; tW[r] = t; }
     }
   }
 
@@ -836,11 +848,21 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgs p) {
   float ring[kPF][NR];
   // unconditional, clamped prefetch: a load inside a branch costs an s_waitcnt vmcnt(0)
 #pragma unroll
-  for (int i = 0; i < kPF; ++i) fetch(i < nload ? i : nload - 1, ring[i]);
+  for (int i = 0; i < kPF; ++i) {
+    const int si = (KS > 1 ? wave * kPF : 0) + i;
+    fetch(si < nload ? si : nload - 1, ring[i]);
+  }
   if (PRO == PRO_LN) {
     // pivot = channel-0 value (held by half 0 in ring[0]): well-conditioned single-pass variance
+    if (KS > 1) {
+      float pv[NR];
+      fetch(0, pv);  // every wave needs the SAME pivot
 #pragma unroll
-    for (int e = 0; e < NACC; ++e) shift[e] = __shfl(ring[0][e % NL], j, 64);
+      for (int e = 0; e < NACC; ++e) shift[e] = __shfl(pv[e % NL], j, 64);
+    } else {
+#pragma unroll
+      for (int e = 0; e < NACC; ++e) shift[e] = __shfl(ring[0][e % NL], j, 64);
+    }
   }
 
   for (int a0 = 0; a0 < nA; a0 += kAChunk) {
@@ -852,7 +874,8 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgs p) {
     // into its own basic block: ds_read → s_waitcnt lgkmcnt(0) → MFMA, fully serialised); the tail
     // of the last group gets zero weights instead
     constexpr int kGroup = kPF * ((LOADER == LOAD_S2D) ? 2 : 1);
-    const int an_pad = ((an + kGroup - 1) / kGroup) * kGroup;
+    static_assert(kAChunk % (KS * kGroup) == 0, "chunk must hold whole rounds of K-split groups");
+    const int an_pad = ((an + KS * kGroup - 1) / (KS * kGroup)) * (KS * kGroup);
     for (int base = threadIdx.x; base < (p.dbg == 3 ? 0 : an_pad * MB * 64); base += blockDim.x * 8) {
       float tmp[8];
 #pragma unroll
@@ -881,7 +904,7 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgs p) {
     __syncthreads();
     constexpr int ASTEP = (LOADER == LOAD_S2D) ? 2 : 1;
     // kAChunk is a multiple of kPF*ASTEP, so the ring slot of a step is static after unrolling
-    for (int al = 0; al < an_pad; al += kPF * ASTEP) {
+    for (int al = (KS > 1 ? wave * kPF * ASTEP : 0); al < an_pad; al += KS * kPF * ASTEP) {
 #pragma unroll
       for (int u = 0; u < kPF; ++u) {
         const int ali = al + u * ASTEP;
@@ -890,7 +913,7 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgs p) {
 #pragma unroll
         for (int e = 0; e < NR; ++e) cur[e] = ring[u][e];
         {
-          const int sn = s + kPF;
+          const int sn = s + KS * kPF;
           fetch(sn < nload ? sn : nload - 1, ring[u]);  // tail: harmless re-read of the last step
         }
         {
@@ -917,7 +940,7 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgs p) {
                 t = cok ? t : 0.f;
               }
               if (PRO == PRO_LN) {
-                t -= shift[e];
+                t = cok ? t - shift[e] : 0.f;  // padded steps / lanes must not enter the statistics
                 s1[e] += t;
                 s2[e] += t * t;
               }
@@ -936,6 +959,43 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgs p) {
             }
           }
         }
+      }
+    }
+  }
+
+  if (KS > 1) {
+    // add the K-slices: waves 1..KS-1 park their accumulators (and LN sums) in LDS, wave 0 finishes
+    __syncthreads();  // everyone is done reading As
+    constexpr int kPer = (MB * NACC * 16 + 2 * NACC) * 64;
+    if (wave > 0) {
+      float* dst = As + (wave - 1) * kPer + lane;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int q = 0; q < NACC; ++q)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dst[((mb * NACC + q) * 16 + r) * 64] = acc[mb][q][r];
+#pragma unroll
+      for (int e = 0; e < NACC; ++e) {
+        dst[(MB * NACC * 16 + e) * 64] = s1[e];
+        dst[(MB * NACC * 16 + NACC + e) * 64] = s2[e];
+      }
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < KS - 1; ++w) {
+      const float* src = As + w * kPer + lane;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int q = 0; q < NACC; ++q)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mb][q][r] += src[((mb * NACC + q) * 16 + r) * 64];
+#pragma unroll
+      for (int e = 0; e < NACC; ++e) {
+        s1[e] += src[(MB * NACC * 16 + e) * 64];
+        s2[e] += src[(MB * NACC * 16 + NACC + e) * 64];
       }
     }
   }
@@ -1077,14 +1137,27 @@ extern "C" int fz_gemm(const fz_gemm_desc* d, fz_stream_t stream) {
     }
   }
   const int TN = 32 * nacc;
-  const int64_t tiles = (d->Ncol + TN * 4 - 1) / (TN * 4);
+  // K-split across the waves of a workgroup when the plain decomposition leaves most CUs idle
+  // and K is long enough to give every wave whole prefetch groups
+  int ks = 1;
+  {
+    const int64_t wg1 = ((d->Ncol + TN * 4 - 1) / (TN * 4)) * d->B * ((mblocks + MBsel - 1) / MBsel);
+    const bool shape_ok = MBsel == 1 && ((d->loader == LOAD_PLAIN && d->epilogue == EPI_PLAIN && nacc <= 2) ||
+                                         d->loader == LOAD_S2D);
+    if (shape_ok && wg1 < 256 && d->K >= 256) ks = 4;
+    const char* e = getenv("FZ_GEMM_KS");
+    if (e) ks = (atoi(e) == 4 && shape_ok) ? 4 : 1;
+  }
+  const int WT = ks > 1 ? 1 : 4;
+  const int64_t tiles = (d->Ncol + TN * WT - 1) / (TN * WT);
   dim3 grid((unsigned)(tiles * d->B), (unsigned)((mblocks + MBsel - 1) / MBsel)), block(256);
 #define FZ_STR(MB, NA, L, E, PR) hipLaunchKernelGGL((gemm_stream_kernel<MB, NA, L, E, PR>), grid, block, 0, st, a)
+#define FZ_STRK(MB, NA, L, E, PR) hipLaunchKernelGGL((gemm_stream_kernel<MB, NA, L, E, PR, 4>), grid, block, 0, st, a)
   if (d->bact == ACT_RELU) return fail(FZ_E_UNSUPPORTED, "fz_gemm: ReLU input prologue is not compiled (streaming)");
   const int pro = d->ln ? PRO_LN : (d->bact == ACT_GELU ? PRO_GELU : (d->bmul ? PRO_BMUL : PRO_NONE));
   if ((d->ln != 0) + (d->bact != 0) + (d->bmul != nullptr) > 1)
     return fail(FZ_E_UNSUPPORTED, "fz_gemm: at most one input prologue (LayerNorm / GELU / gate)");
-  if (d->loader == LOAD_S2D) { FZ_STR(1, 2, LOAD_S2D, EPI_PLAIN, PRO_NONE); }
+  if (d->loader == LOAD_S2D) { if (ks == 4) FZ_STRK(1, 2, LOAD_S2D, EPI_PLAIN, PRO_NONE); else FZ_STR(1, 2, LOAD_S2D, EPI_PLAIN, PRO_NONE); }
   else if (d->loader == LOAD_K3) { if (MBsel == 2) FZ_STR(2, 4, LOAD_K3, EPI_PLAIN, PRO_NONE); else FZ_STR(1, 4, LOAD_K3, EPI_PLAIN, PRO_NONE); }
   else if (d->epilogue == EPI_D2S) {
     if (pro != PRO_NONE) return fail(FZ_E_UNSUPPORTED, "fz_gemm: prologue with depth-to-space epilogue");
@@ -1093,8 +1166,8 @@ extern "C" int fz_gemm(const fz_gemm_desc* d, fz_stream_t stream) {
 #define FZ_STR_SHAPES(PR)                                                                                   \
   do {                                                                                                      \
     if (nacc == 4) { if (MBsel == 2) FZ_STR(2, 4, LOAD_PLAIN, EPI_PLAIN, PR); else FZ_STR(1, 4, LOAD_PLAIN, EPI_PLAIN, PR); } \
-    else if (nacc == 2) FZ_STR(1, 2, LOAD_PLAIN, EPI_PLAIN, PR);                                            \
-    else FZ_STR(1, 1, LOAD_PLAIN, EPI_PLAIN, PR);                                                           \
+    else if (nacc == 2) { if (ks == 4) FZ_STRK(1, 2, LOAD_PLAIN, EPI_PLAIN, PR); else FZ_STR(1, 2, LOAD_PLAIN, EPI_PLAIN, PR); } \
+    else { if (ks == 4) FZ_STRK(1, 1, LOAD_PLAIN, EPI_PLAIN, PR); else FZ_STR(1, 1, LOAD_PLAIN, EPI_PLAIN, PR); } \
   } while (0)
     if (pro == PRO_LN) FZ_STR_SHAPES(PRO_LN);
     else if (pro == PRO_GELU) FZ_STR_SHAPES(PRO_GELU);

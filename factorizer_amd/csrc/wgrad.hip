@@ -270,6 +270,164 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
   }
 }
 
+// ---- fast path: whole 32-row blocks, N % 32 == 0, plain loader, no P gate ------------------------
+// Same decomposition as wgrad_kernel, with the per-tile overheads taken out:
+//   * K-step s pairs voxel s (lane half 0) with voxel 16+s (half 1) instead of (2s, 2s+1) — the
+//     order of a reduction is free — so a lane needs 16 CONTIGUOUS voxels of its channel: four
+//     ds_read_b128 per 32-row block and tile replace sixteen ds_read_b32, all issued before the
+//     MFMA loop, which then runs on register operands only;
+//   * LDS rows are 36 floats (16-byte aligned): one ds_write_b128 per staged chunk instead of four
+//     scalar writes;
+//   * the Q prologue (LayerNorm statistics / GELU / ReLU) is a template parameter: no branches
+//     between the chunks;
+//   * addresses = uniform row base (scalar registers) + one 32-bit lane offset.
+enum { QP_NONE = 0, QP_STATS = 1, QP_GELU = 2, QP_RELU = 3 };
+constexpr int kStrideF = 36;
+
+template <int MBP, int MBQ, int QPRO>
+__global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int PR = 32 * MBP, QR = 32 * MBQ;
+  constexpr int NP = PR / 8, NQ = QR / 8;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* Pt = lds + wave * (PR + QR) * kStrideF;
+  float* Qt = Pt + PR * kStrideF;
+  const int m0 = blockIdx.y * PR;
+  const int k0 = blockIdx.z * QR;
+  const int64_t tiles_per_sample = a.N / kTile;
+  const int64_t total_tiles = tiles_per_sample * a.B;
+  const int64_t unit = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t t_begin = unit * a.tiles_per_chunk;
+  const int64_t t_end = min(t_begin + a.tiles_per_chunk, total_tiles);
+
+  f32x16 acc[MBP][MBQ];
+#pragma unroll
+  for (int i = 0; i < MBP; ++i)
+#pragma unroll
+    for (int jq = 0; jq < MBQ; ++jq)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][jq][r] = 0.f;
+  float psum[MBP];
+#pragma unroll
+  for (int i = 0; i < MBP; ++i) psum[i] = 0.f;
+
+  const int c = lane & 31, h = lane >> 5;
+  const int cq = lane & 7, r0 = lane >> 3;
+  const unsigned lane_p = (unsigned)r0 * (unsigned)a.N + (unsigned)(cq * 4);
+  const unsigned lane_q = (unsigned)r0 * (unsigned)a.Vq + (unsigned)(cq * 4);
+  float4 pv[NP], qv[NQ], mu4, rs4;
+
+  auto issue_loads = [&](int64_t t) {
+    const int b = (int)(t / tiles_per_sample);
+    const int64_t n0 = (t % tiles_per_sample) * kTile;
+    const float* pb = a.p + ((int64_t)b * a.M + m0) * a.N + n0;  // uniform
+#pragma unroll
+    for (int i = 0; i < NP; ++i) pv[i] = *reinterpret_cast<const float4*>(pb + (int64_t)(8 * i) * a.N + lane_p);
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int k = k0 + 8 * i;  // first row of this chunk group: uniform (c0 is a multiple of 8)
+      const bool first = k < a.c0;
+      const float* base = first ? a.q[0] : a.q[1];
+      const int cs = first ? a.c0 : a.Cin - a.c0;
+      const int ci = first ? k : k - a.c0;
+      qv[i] = *reinterpret_cast<const float4*>(base + ((int64_t)b * cs + ci) * a.Vq + n0 + lane_q);
+    }
+    if (QPRO == QP_STATS) {
+      const float* st = a.stats + (int64_t)b * 2 * a.Vq + n0 + cq * 4;
+      mu4 = *reinterpret_cast<const float4*>(st);
+      rs4 = *reinterpret_cast<const float4*>(st + a.Vq);
+    }
+  };
+
+  if (t_begin < t_end) issue_loads(t_begin);
+  for (int64_t t = t_begin; t < t_end; ++t) {
+    // ---- registers -> LDS (16-byte stores) ----
+#pragma unroll
+    for (int i = 0; i < NP; ++i) *reinterpret_cast<float4*>(Pt + (r0 + 8 * i) * kStrideF + cq * 4) = pv[i];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      float4 v = qv[i];
+      if (QPRO == QP_STATS) {
+        v.x = (v.x - mu4.x) * rs4.x; v.y = (v.y - mu4.y) * rs4.y; v.z = (v.z - mu4.z) * rs4.z; v.w = (v.w - mu4.w) * rs4.w;
+      } else if (QPRO == QP_GELU) {
+        v.x = gelu_w(v.x); v.y = gelu_w(v.y); v.z = gelu_w(v.z); v.w = gelu_w(v.w);
+      } else if (QPRO == QP_RELU) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      }
+      *reinterpret_cast<float4*>(Qt + (r0 + 8 * i) * kStrideF + cq * 4) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // ---- LDS -> operand registers: 16 contiguous voxels of channel c for this lane half ----
+    float pa[MBP][16], qb[MBQ][16];
+#pragma unroll
+    for (int i = 0; i < MBP; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float4 v = *reinterpret_cast<const float4*>(Pt + (i * 32 + c) * kStrideF + 16 * h + 4 * e);
+        pa[i][4 * e] = v.x; pa[i][4 * e + 1] = v.y; pa[i][4 * e + 2] = v.z; pa[i][4 * e + 3] = v.w;
+      }
+#pragma unroll
+    for (int jq = 0; jq < MBQ; ++jq)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float4 v = *reinterpret_cast<const float4*>(Qt + (jq * 32 + c) * kStrideF + 16 * h + 4 * e);
+        qb[jq][4 * e] = v.x; qb[jq][4 * e + 1] = v.y; qb[jq][4 * e + 2] = v.z; qb[jq][4 * e + 3] = v.w;
+      }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (t + 1 < t_end) issue_loads(t + 1);  // in flight during the MFMA loop below
+#pragma unroll
+    for (int i = 0; i < MBP; ++i) {
+      float ps = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) ps += pa[i][e];
+      psum[i] += ps;
+    }
+#pragma unroll
+    for (int sidx = 0; sidx < 16; ++sidx)
+#pragma unroll
+      for (int i = 0; i < MBP; ++i)
+#pragma unroll
+        for (int jq = 0; jq < MBQ; ++jq)
+          acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[i][sidx], qb[jq][sidx], acc[i][jq], 0, 0, 0);
+  }
+
+  // ---- reduce the 4 waves through LDS, then write this workgroup's partial block ----
+  __syncthreads();
+  float* red = lds;
+#pragma unroll
+  for (int i = 0; i < MBP; ++i) {
+#pragma unroll
+    for (int jq = 0; jq < MBQ; ++jq) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        red[wave * 1024 + row * 32 + c] = acc[i][jq][r];
+      }
+      __syncthreads();
+      for (int e = threadIdx.x; e < 1024; e += 256) {
+        const float sum = (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]);
+        const int row = e >> 5, col = e & 31;
+        const int m = m0 + i * 32 + row, k = k0 + jq * 32 + col;
+        a.part[((int64_t)blockIdx.x * a.M + m) * a.K + k] = sum;
+      }
+      __syncthreads();
+    }
+  }
+  if (a.part_bias != nullptr && blockIdx.z == 0) {
+#pragma unroll
+    for (int i = 0; i < MBP; ++i) {
+      const float sum = psum[i] + __shfl_xor(psum[i], 32, 64);
+      if (h == 0) red[wave * 32 + c] = sum;
+      __syncthreads();
+      if (threadIdx.x < 32) {
+        const float tot = (red[threadIdx.x] + red[32 + threadIdx.x]) + (red[64 + threadIdx.x] + red[96 + threadIdx.x]);
+        a.part_bias[(int64_t)blockIdx.x * a.M + m0 + i * 32 + threadIdx.x] = tot;
+      }
+      __syncthreads();
+    }
+  }
+}
+
 // out[e] = Σ_chunks part[chunk][e] in a fixed order: 32 strided partial sums per element (8
 // elements per 256-thread block), combined by a fixed tree through LDS — bitwise reproducible.
 __global__ __launch_bounds__(256) void chunk_reduce_kernel(const float* __restrict__ part, int nchunk, int64_t n,
@@ -369,7 +527,31 @@ extern "C" int fz_wgrad(const fz_wgrad_desc* d, void* workspace, fz_stream_t str
     else if (QR == 64) FZ_WG(1, 2, QL);                  \
     else FZ_WG(1, 1, QL);                                \
   } while (0)
-  if (d->loader == QL_PLAIN) FZ_WG_SHAPES(QL_PLAIN);
+  // fast path: whole blocks, whole tiles, at most two concatenated sources split on a multiple of 8
+  // (measured, tools/debug/wgrad_probe.py: 8-13 % faster for 64x64 blocks, slower for the HBM-bound
+  // 32-row blocks of stage 0, which keep the generic kernel)
+  bool fast = PR == 64 && QR == 64 && d->loader == QL_PLAIN && !d->pmul && (d->M % PR) == 0 && (d->K % QR) == 0 && (d->N % kTile) == 0 &&
+              d->N == d->Vq && (a.c0 % 8) == 0 && d->src_mode == 0 && !(d->stats && d->qact) &&
+              (int64_t)8 * d->N < ((int64_t)1 << 30);
+  { const char* e = getenv("FZ_WGRAD_FAST"); if (e && atoi(e) == 0) fast = false; }
+  if (fast) {
+    const int qp = d->stats ? QP_STATS : (d->qact == 2 ? QP_GELU : (d->qact == 1 ? QP_RELU : QP_NONE));
+    const size_t ldsf = (size_t)4 * (PR + QR) * kStrideF * sizeof(float);
+    const size_t ldsr = (size_t)4 * 1024 * sizeof(float);
+    const size_t ldsz = ldsf > ldsr ? ldsf : ldsr;
+#define FZ_WGF(MBP, MBQ, QP) hipLaunchKernelGGL((wgrad_fast_kernel<MBP, MBQ, QP>), grid, block, ldsz, st, a)
+#define FZ_WGF_SHAPES(QP)                                \
+  do {                                                   \
+    if (PR == 64 && QR == 64) FZ_WGF(2, 2, QP);          \
+    else if (PR == 64) FZ_WGF(2, 1, QP);                 \
+    else if (QR == 64) FZ_WGF(1, 2, QP);                 \
+    else FZ_WGF(1, 1, QP);                               \
+  } while (0)
+    if (qp == QP_STATS) FZ_WGF_SHAPES(QP_STATS);
+    else if (qp == QP_GELU) FZ_WGF_SHAPES(QP_GELU);
+    else if (qp == QP_RELU) FZ_WGF_SHAPES(QP_RELU);
+    else FZ_WGF_SHAPES(QP_NONE);
+  } else if (d->loader == QL_PLAIN) FZ_WG_SHAPES(QL_PLAIN);
   else if (d->loader == QL_S2D) FZ_WG_SHAPES(QL_S2D);
   else FZ_WG_SHAPES(QL_K3);
   FZ_LAUNCH_CHECK();
