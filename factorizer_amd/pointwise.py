@@ -186,6 +186,23 @@ def _mlp_bwd_chain(g2, z1, w12, w22, x1, st, ln_w):
     return gz1, gx1, gpar[:32], gpar[32:]
 
 
+_SIDE = {}
+
+
+def _side_stream(dev, ncols):
+    """Second HIP stream for the weight-gradient kernels of the small, deep stages: they are off
+    the critical path (only the optimizer consumes them) and, at <= 64^3 voxels, neither they nor
+    the input-gradient chain fill 256 CUs, so the two overlap.  FZ_SIDE_WGRAD=0 disables it,
+    FZ_SIDE_WGRAD=<columns> moves the size limit."""
+    lim = int(os.environ.get("FZ_SIDE_WGRAD", str(2 * 64 ** 3)))
+    if lim <= 0 or ncols > lim:
+        return None
+    key = (dev.type, dev.index)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=dev)
+    return _SIDE[key]
+
+
 def _native_ok(*ts):
     t0 = ts[0]
     return t0.is_cuda and all(t is None or (t.dtype == torch.float32) for t in ts) and _vox(t0) % 4 == 0
@@ -591,6 +608,18 @@ class FactorizerBlockFn(torch.autograd.Function):
         Hd = w12.shape[0]
         dev, dt = x.device, x.dtype
         geo, T, G, solver, neps = cfg["geo"], cfg["T"], cfg["G"], cfg["solver"], cfg["nmf_eps"]
+        cur = torch.cuda.current_stream(dev)
+        side = _side_stream(dev, B * V)
+        keep = []  # tensors read on the side stream stay referenced until the streams are joined
+
+        def wgrad(*args, **kw):
+            if side is None:
+                return _wgrad(*args, **kw)
+            side.wait_stream(cur)
+            keep.extend(t for t in (args[0], *args[1], kw.get("stats")) if t is not None)
+            with torch.cuda.stream(side):
+                return _wgrad(*args, **kw)
+
         # --- MLP ---
         chain = _mlp_chain_ok(C, Hd, V)
         if chain:
@@ -601,12 +630,12 @@ class FactorizerBlockFn(torch.autograd.Function):
                   emul_kind=ACT["gelu"], name="linear_dgrad")
         gw2 = torch.empty_like(w22)
         gb2 = torch.empty(C, dtype=dt, device=dev)
-        _wgrad(g2, [z1], gw2, B=B, M=C, Cin=Hd, K=Hd, Vq=V, Ncols=V, gbias=gb2, qact=ACT["gelu"], name="wgrad_linear")
+        wgrad(g2, [z1], gw2, B=B, M=C, Cin=Hd, K=Hd, Vq=V, Ncols=V, gbias=gb2, qact=ACT["gelu"], name="wgrad_linear")
         if not chain:
             gx1, gg2, gbt2 = _dgrad_lnbwd(gz1, w12, x1, st2, n2w, g2)      # + residual path of the MLP
         gw1 = torch.empty_like(w12)
         gb1 = torch.empty(Hd, dtype=dt, device=dev)
-        _wgrad(gz1, [x1], gw1, B=B, M=Hd, Cin=C, K=C, Vq=V, Ncols=V, gbias=gb1, stats=st2, ln=(n2w, n2b),
+        wgrad(gz1, [x1], gw1, B=B, M=Hd, Cin=C, K=C, Vq=V, Ncols=V, gbias=gb1, stats=st2, ln=(n2w, n2b),
                name="wgrad_ln_linear")
         del gz1
         # --- out_proj ---
@@ -614,7 +643,7 @@ class FactorizerBlockFn(torch.autograd.Function):
         _gemm([gx1], wout2, ga, B=B, Cin=C, Vin=V, M=C, K=C, Ncol=V, w_t=True, ldw=C, name="linear_dgrad")
         gwo = torch.empty_like(wout2)
         gbo = torch.empty(C, dtype=dt, device=dev)
-        _wgrad(gx1, [a], gwo, B=B, M=C, Cin=C, K=C, Vq=V, Ncols=V, gbias=gbo, name="wgrad_linear")
+        wgrad(gx1, [a], gwo, B=B, M=C, Cin=C, K=C, Vq=V, Ncols=V, gbias=gbo, name="wgrad_linear")
         # --- core (gradient arrives gated by [t > 0]) ---
         if G <= 0:
             gt = torch.zeros_like(t)
@@ -633,7 +662,10 @@ class FactorizerBlockFn(torch.autograd.Function):
         # --- in_proj + LN1 ---
         gx, gg1, gbt1 = _dgrad_lnbwd(gt, win2, x, st1, n1w, gx1)        # + residual path of the mixer
         gwi = torch.empty_like(win2)
-        _wgrad(gt, [x], gwi, B=B, M=C, Cin=C, K=C, Vq=V, Ncols=V, stats=st1, ln=(n1w, n1b), name="wgrad_ln_linear")
+        wgrad(gt, [x], gwi, B=B, M=C, Cin=C, K=C, Vq=V, Ncols=V, stats=st1, ln=(n1w, n1b), name="wgrad_ln_linear")
+        if side is not None:
+            cur.wait_stream(side)
+            keep.clear()
         s_in, s_out, s_1, s_2 = ctx.shapes
         return (gx, gg1, gbt1, gwi.reshape(s_in), None, None, gwo.reshape(s_out), gbo, gg2, gbt2,
                 gw1.reshape(s_1), gb1, gw2.reshape(s_2), gb2, None)
