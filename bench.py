@@ -41,7 +41,12 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s mea
 # MI355X_MICROARCH.md §HBM; tools/pmc_traffic.py → profiles/r01_pmc_traffic.json).  Counters cannot
 # be read from inside the benchmark, so the committed summary of the profiled run is quoted.
 PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-PMC_KERNEL = {"nmf_cf_bwd": "fz::nmf_cf_bwd_kernel<1, 1>", "nmf_cf_fwd": "fz::nmf_cf_fwd_kernel<1, 1>"}
+# timer key of a BASELINE-size (stage-0) launch -> kernel name in the PMC summary; the summary averages
+# the launches with the largest grid of each kernel, i.e. the same stage-0 launches the key times
+PMC_KERNEL = {"nmf_cf_bwd_32x128x128x128": "fz::nmf_cf_bwd_tile_kernel<1, 1, 4>",
+              "nmf_cf_fwd_32x128x128x128": "fz::nmf_cf_fwd_tile_kernel<1, 1, 8>",
+              "mlp_chain_bwd_32": "fz::gemm_chain_kernel<true, 2>",
+              "mlp_chain_fwd_32": "fz::gemm_chain_kernel<false, 2>"}
 
 
 def pmc_traffic(timer_name):

@@ -259,10 +259,11 @@ __device__ __forceinline__ float half_sum32(float v) {
   return v;
 }
 
-template <int NACC, bool GADD>
+template <int NACC, bool GADD, bool GADD_LDS = false>
 __device__ __forceinline__ void lnbwd_block(const GemmArgs& p, const f32x16 (&acc)[NACC], int b, int64_t ncol,
                                             bool col_ok, int lane, int wave, float* red /* [4][64] */,
-                                            int64_t part_row, const float* g_lds /* gamma[32] in LDS */) {
+                                            int64_t part_row, const float* g_lds /* gamma[32] in LDS */,
+                                            const float* gadd_lds = nullptr /* [32][32*NACC] tile of lnb_gadd */) {
   const int h = lane >> 5;
   const int64_t nc = col_ok ? ncol : 0;
   // row = rbase(r) + 4h: the row part of every address is wave-uniform (scalar base) and ONE
@@ -287,12 +288,13 @@ __device__ __forceinline__ void lnbwd_block(const GemmArgs& p, const f32x16 (&ac
   // the added gradient is fetched here, unconditionally and all rows at once: a load behind a
   // runtime `if` inside the row loop compiles to load → s_waitcnt vmcnt(0) per row (16 exposed
   // round trips per tile)
-  float ga[GADD ? 16 : 1][NACC];
-  if (GADD) {
+  // (with GADD_LDS the tile is already in LDS: read per row below, no registers held)
+  float ga[(GADD && !GADD_LDS) ? 16 : 1][NACC];
+  if (GADD && !GADD_LDS) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int rbase = (r & 3) + 8 * (r >> 2);
-      vload<NACC>(p.lnb_gadd + sample + (int64_t)rbase * p.Ncol + lane_off, ga[GADD ? r : 0]);
+      vload<NACC>(p.lnb_gadd + sample + (int64_t)rbase * p.Ncol + lane_off, ga[(GADD && !GADD_LDS) ? r : 0]);
     }
   }
 #pragma unroll
@@ -319,7 +321,8 @@ __device__ __forceinline__ void lnbwd_block(const GemmArgs& p, const f32x16 (&ac
     const int row = rbase + 4 * h;
     const int64_t so = sample + (int64_t)rbase * p.Ncol;  // uniform
     const float gc = g_lds[row];  // (a global load here is a dependent L2 round trip per row)
-    float v[NACC], nhr[NACC];
+    float v[NACC], nhr[NACC], gl[NACC];
+    if (GADD && GADD_LDS) vload<NACC>(gadd_lds + row * (32 * NACC) + NACC * (lane & 31), gl);
 #pragma unroll
     for (int q = 0; q < NACC; ++q) {
       nhr[q] = xs[r][q];
@@ -327,7 +330,7 @@ __device__ __forceinline__ void lnbwd_block(const GemmArgs& p, const f32x16 (&ac
     }
     if (GADD) {
 #pragma unroll
-      for (int q = 0; q < NACC; ++q) v[q] += ga[GADD ? r : 0][q];
+      for (int q = 0; q < NACC; ++q) v[q] += GADD_LDS ? gl[q] : ga[(GADD && !GADD_LDS) ? r : 0][q];
     }
     if (col_ok) vstore<NACC>(p.y + so + lane_off, v);
     // affine-gradient partials of this row over the wave's 32*NACC voxels
@@ -532,6 +535,10 @@ __global__ __launch_bounds__(256, NACC == 2 ? 3 : 2) void gemm_chain_kernel(Gemm
   __shared__ float tW[64];
   __shared__ float tB[32];
   __shared__ float red[256];
+  // raw operand tile of each wave (32 channels x 32*NACC columns): the epilogue needs the SAME tensor
+  // again in the accumulator layout (residual x1 / added gradient g2) — served from LDS instead of a
+  // second global read (PMC: 1 of 5 resp. 8 plane-sets of traffic)
+  __shared__ __attribute__((aligned(16))) float stash[4][32][32 * NACC];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, h = lane >> 5;
   const int tiles_per_sample = (int)((p.Ncol + 128 * NACC - 1) / (128 * NACC));
@@ -599,6 +606,8 @@ __global__ __launch_bounds__(256, NACC == 2 ? 3 : 2) void gemm_chain_kernel(Gemm
     const bool col_ok = col_off < p.Ncol;
     const int64_t nc = col_ok ? col_off : 0;
     const unsigned lane_row = (unsigned)(4 * h) * (unsigned)p.Ncol + (unsigned)nc;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) vstore<NACC>(&stash[wave][2 * s + h][NACC * j], bv[s]);
 
     if (!BWD) {
       // exact two-pass LayerNorm statistics (this lane holds the parity-h half of the channels)
@@ -654,31 +663,48 @@ __global__ __launch_bounds__(256, NACC == 2 ? 3 : 2) void gemm_chain_kernel(Gemm
     fetch_tile(tile + gridDim.x < ntiles ? tile + gridDim.x : tile);
 
     // ---- hidden tensor: transform in registers, keep a copy in HBM for the other pass ----
+    if (!BWD) {
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+      for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rbase = rb * 32 + (r & 3) + 8 * (r >> 2);
-        const int row = rbase + 4 * h;
-        const int64_t ob = ((int64_t)b * 64 + rbase) * p.Ncol;  // uniform row part; + one 32-bit lane offset
-        float v[NACC];
-        if (!BWD) {
+        for (int r = 0; r < 16; ++r) {
+          const int rbase = rb * 32 + (r & 3) + 8 * (r >> 2);
+          const int row = rbase + 4 * h;
+          const int64_t ob = ((int64_t)b * 64 + rbase) * p.Ncol;  // uniform row part; + one 32-bit lane offset
+          float v[NACC];
           const float add = tW[row];
 #pragma unroll
           for (int q = 0; q < NACC; ++q) v[q] = acc1[rb][q][r] + add;
           if (col_ok) vstore<NACC>(c.side + ob + lane_row, v);
 #pragma unroll
           for (int q = 0; q < NACC; ++q) acc1[rb][q][r] = gelu_f(v[q]);
-        } else {
-          float e[NACC];
-          vload<NACC>(p.emul + ob + lane_row, e);
+        }
+    } else {
+      // groups of 8 rows: 8 loads of the saved pre-activation in flight, then 8 transforms + stores
+      // (bounded on purpose: the scheduler otherwise hoists all 32 loads and spills accumulators)
 #pragma unroll
-          for (int q = 0; q < NACC; ++q) v[q] = acc1[rb][q][r] * gelu_grad_f(e[q]);
-          if (col_ok) vstore<NACC>(c.side + ob + lane_row, v);
+      for (int g8 = 0; g8 < 4; ++g8) {
+        float e[8][NACC];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int rr = g8 * 8 + i, rb = rr >> 4, r = rr & 15;
+          const int rbase = rb * 32 + (r & 3) + 8 * (r >> 2);
+          vload<NACC>(p.emul + ((int64_t)b * 64 + rbase) * p.Ncol + lane_row, e[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int rr = g8 * 8 + i, rb = rr >> 4, r = rr & 15;
+          const int rbase = rb * 32 + (r & 3) + 8 * (r >> 2);
+          float v[NACC];
+#pragma unroll
+          for (int q = 0; q < NACC; ++q) v[q] = acc1[rb][q][r] * gelu_grad_f(e[i][q]);
+          if (col_ok) vstore<NACC>(c.side + ((int64_t)b * 64 + rbase) * p.Ncol + lane_row, v);
 #pragma unroll
           for (int q = 0; q < NACC; ++q) acc1[rb][q][r] = v[q];
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
+    }
 
     // ---- GEMM 2: 32 rows, K = 64 straight from the accumulators of GEMM 1 ----
     f32x16 acc2[NACC];
@@ -696,7 +722,7 @@ __global__ __launch_bounds__(256, NACC == 2 ? 3 : 2) void gemm_chain_kernel(Gemm
       }
 
     if (BWD) {
-      lnbwd_block<NACC, true>(p, acc2, b, col_off, col_ok, lane, wave, red, tile, tB);
+      lnbwd_block<NACC, true, true>(p, acc2, b, col_off, col_ok, lane, wave, red, tile, tB, &stash[wave][0][0]);
       __syncthreads();  // red is reused by the next tile
     } else if (col_ok) {
 #pragma unroll
@@ -706,7 +732,7 @@ __global__ __launch_bounds__(256, NACC == 2 ? 3 : 2) void gemm_chain_kernel(Gemm
         const int64_t ob = ((int64_t)b * 32 + rbase) * p.Ncol;
         const float add = tB[row];
         float e[NACC], v[NACC];
-        vload<NACC>(p.res + ob + lane_row, e);
+        vload<NACC>(&stash[wave][row][NACC * j], e);
 #pragma unroll
         for (int q = 0; q < NACC; ++q) v[q] = acc2[q][r] + add + e[q];
         vstore<NACC>(p.y + ob + lane_row, v);
@@ -1186,13 +1212,9 @@ extern "C" int64_t fz_gemm_lnbwd_partials(const fz_gemm_desc* d) {
 // MLP chain for C = 32, hidden 64 (see gemm_chain_kernel).  Replaces, per FactorizerBlock,
 // Linear∘LayerNorm + Linear∘GELU + residual (layers/mlp.py:54-63, factorizer.py:76) in the
 // forward and the two input-gradient GEMMs + LayerNorm backward in the backward.
-static int mlp_nacc() {
-  // columns per lane: 2 → 64-column wave tiles, ~150 VGPRs, 3 waves/SIMD with the next-tile prefetch
-  int na = 2;
-  const char* e = getenv("FZ_MLP_NACC");
-  if (e && atoi(e) == 4) na = 4;
-  return na;
-}
+// columns per lane = 2: 64-column wave tiles, <= 168 VGPRs → 3 waves/SIMD with the next-tile prefetch
+// (4 columns per lane: 0.71 / 1.38 ms against 0.63 / 1.00 ms, tools/debug/mlp_probe.py)
+static int mlp_nacc() { return 2; }
 
 extern "C" int64_t fz_mlp_partials(int B, int64_t V) {
   const int64_t tw = 128 * mlp_nacc();
@@ -1227,16 +1249,14 @@ extern "C" int fz_mlp_chain(const fz_mlp_desc* d, fz_stream_t stream) {
     a.res = d->in; a.y = d->out;
     c.wB = d->w2; c.wB_t = 0; c.ldwB = 64;           // A2[m][k] = W2[m][k]
     c.biasB = d->b2; c.side = d->z1;
-    if (mlp_nacc() == 4) hipLaunchKernelGGL((gemm_chain_kernel<false, 4>), grid, block, 0, st, a, c, ntiles);
-    else hipLaunchKernelGGL((gemm_chain_kernel<false, 2>), grid, block, 0, st, a, c, ntiles);
+    hipLaunchKernelGGL((gemm_chain_kernel<false, 2>), grid, block, 0, st, a, c, ntiles);
   } else {
     a.w = d->w2; a.w_t = 1; a.ldw = 64;              // A1[m = hidden][k = c] = W2[c][hidden]
     a.emul = d->z1; a.y = d->out;
     a.lnb_x = d->x1; a.lnb_stats = d->stats; a.lnb_g = d->ln_g; a.lnb_gadd = d->in; a.lnb_part = d->part;
     c.wB = d->w1; c.wB_t = 1; c.ldwB = 32;           // A2[m = c][k = hidden] = W1[hidden][c]
     c.side = d->gz1;
-    if (mlp_nacc() == 4) hipLaunchKernelGGL((gemm_chain_kernel<true, 4>), grid, block, 0, st, a, c, ntiles);
-    else hipLaunchKernelGGL((gemm_chain_kernel<true, 2>), grid, block, 0, st, a, c, ntiles);
+    hipLaunchKernelGGL((gemm_chain_kernel<true, 2>), grid, block, 0, st, a, c, ntiles);
   }
   FZ_LAUNCH_CHECK();
   return FZ_OK;

@@ -268,7 +268,7 @@ class FactCoreFn(torch.autograd.Function):
         with _dev_guard(t):
             for w, s in enumerate(geo.shifts):
                 arr = (N._i * 3)(*s)
-                rc = _timed("nmf_cf_fwd", nb + (4 * t.numel() if w else 0), lambda: N.lib().fz_nmf_cf_fwd(
+                rc = _timed(f"nmf_cf_fwd_{geo.C}x" + "x".join(str(v) for v in geo.spatial), nb + (4 * t.numel() if w else 0), lambda: N.lib().fz_nmf_cf_fwd(
                     t.data_ptr(), u0.data_ptr(), v0.data_ptr(), out.data_ptr(), B, geo.C, *geo.spatial, arr,
                     int(w > 0), geo.nshift if w == geo.nshift - 1 else 1, R, T, N.SOLVER_ID[solver], eps,
                     N.stream_ptr(t)))
@@ -291,7 +291,7 @@ class FactCoreFn(torch.autograd.Function):
         with _dev_guard(t):
             for w, s in enumerate(geo.shifts):
                 arr = (N._i * 3)(*s)
-                rc = _timed("nmf_cf_bwd", nb + (4 * t.numel() if w else 0), lambda: N.lib().fz_nmf_cf_bwd(
+                rc = _timed(f"nmf_cf_bwd_{geo.C}x" + "x".join(str(v) for v in geo.spatial), nb + (4 * t.numel() if w else 0), lambda: N.lib().fz_nmf_cf_bwd(
                     t.data_ptr(), u0.data_ptr(), v0.data_ptr(), ga.data_ptr(), gt.data_ptr(), B, geo.C,
                     *geo.spatial, arr, int(w > 0), geo.nshift, int(relu_gate), R, T, G, N.SOLVER_ID[solver], eps,
                     N.stream_ptr(t)))
