@@ -5,6 +5,8 @@
 //
 // One thread owns 4 consecutive voxels (16-byte accesses, fully coalesced per channel plane)
 // and walks the channel dimension; HBM-bound: fwd reads C·V and writes C·V floats.
+#include <cstdlib>
+
 #include "fz_common.h"
 
 namespace fz {
@@ -208,6 +210,110 @@ __global__ __launch_bounds__(64 * NW) void ln_bwd_split_kernel(const float* __re
   }
 }
 
+// Channel-sliced backward with compile-time slices (C = 8·CS: the 64..512-channel stages).
+// 8 waves per workgroup, wave w owns channels [w·CS, (w+1)·CS), lanes = 64 consecutive voxel quads.
+// All loads of a pass are issued before the first use (no per-channel dependent round trips), the
+// optional added gradient and the affine partials are template flags (no branches in the loops),
+// and for CS <= 16 the slice stays in registers between the two passes (each tensor is read once).
+template <int CS, bool GADD, bool PART>
+__global__ __launch_bounds__(512) void ln_bwd_slice_kernel(const float* __restrict__ gl, const float* __restrict__ x,
+                                                           const float* __restrict__ stats,
+                                                           const float* __restrict__ g,
+                                                           const float* __restrict__ gadd, float* __restrict__ gx,
+                                                           float* __restrict__ part, int B, int64_t V) {
+  constexpr int NW = 8, C = NW * CS;
+  constexpr bool KEEP = CS <= 16;
+  constexpr int U = KEEP ? CS : 8;  // channels per batch of loads
+  __shared__ float red[NW][8][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t nvec = V / 4;
+  const int64_t total = nvec * B;
+  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+  const bool ok = i < total;
+  const int64_t ii = ok ? i : 0;
+  const int b = (int)(ii / nvec);
+  const int64_t v = (ii % nvec) * 4;
+  const int c0 = wave * CS;
+  const int64_t base = ((int64_t)b * C + c0) * V + v;
+  const float* sp = stats + (int64_t)b * 2 * V + v;
+  const float4 mu = *reinterpret_cast<const float4*>(sp);
+  const float4 rs = *reinterpret_cast<const float4*>(sp + V);
+  float m[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float4 t[U], d[U];
+#pragma unroll 1
+  for (int cb = 0; cb < CS; cb += U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      t[u] = *reinterpret_cast<const float4*>(x + base + (int64_t)(cb + u) * V);
+      d[u] = *reinterpret_cast<const float4*>(gl + base + (int64_t)(cb + u) * V);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float gc = g[c0 + cb + u];
+      // normalised input replaces x; reused by the second pass when the slice stays in registers
+      t[u].x = (t[u].x - mu.x) * rs.x; t[u].y = (t[u].y - mu.y) * rs.y;
+      t[u].z = (t[u].z - mu.z) * rs.z; t[u].w = (t[u].w - mu.w) * rs.w;
+      const float ax = d[u].x * gc, ay = d[u].y * gc, az = d[u].z * gc, aw = d[u].w * gc;
+      m[0] += ax; m[1] += ay; m[2] += az; m[3] += aw;
+      m[4] += ax * t[u].x; m[5] += ay * t[u].y; m[6] += az * t[u].z; m[7] += aw * t[u].w;
+      if (PART) {
+        const float sg = wave_sum(ok ? (d[u].x * t[u].x + d[u].y * t[u].y) + (d[u].z * t[u].z + d[u].w * t[u].w) : 0.f);
+        const float sb = wave_sum(ok ? (d[u].x + d[u].y) + (d[u].z + d[u].w) : 0.f);
+        if (lane == 0) {
+          part[(int64_t)blockIdx.x * 2 * C + c0 + cb + u] = sg;
+          part[(int64_t)blockIdx.x * 2 * C + C + c0 + cb + u] = sb;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[wave][e][lane] = m[e];
+  __syncthreads();
+  const float inv = 1.0f / (float)C;
+  float mm[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float acc = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) acc += red[w][e][lane];
+    mm[e] = acc * inv;
+  }
+#pragma unroll 1
+  for (int cb = 0; cb < CS; cb += U) {
+    float4 r[GADD ? U : 1];
+    if (GADD) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) r[GADD ? u : 0] = *reinterpret_cast<const float4*>(gadd + base + (int64_t)(cb + u) * V);
+    }
+    if (!KEEP) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        t[u] = *reinterpret_cast<const float4*>(x + base + (int64_t)(cb + u) * V);
+        d[u] = *reinterpret_cast<const float4*>(gl + base + (int64_t)(cb + u) * V);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        t[u].x = (t[u].x - mu.x) * rs.x; t[u].y = (t[u].y - mu.y) * rs.y;
+        t[u].z = (t[u].z - mu.z) * rs.z; t[u].w = (t[u].w - mu.w) * rs.w;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float gc = g[c0 + cb + u];
+      float4 o;
+      o.x = rs.x * (d[u].x * gc - mm[0] - t[u].x * mm[4]);
+      o.y = rs.y * (d[u].y * gc - mm[1] - t[u].y * mm[5]);
+      o.z = rs.z * (d[u].z * gc - mm[2] - t[u].z * mm[6]);
+      o.w = rs.w * (d[u].w * gc - mm[3] - t[u].w * mm[7]);
+      if (GADD) {
+        const float4 rr = r[GADD ? u : 0];
+        o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+      }
+      if (ok) *reinterpret_cast<float4*>(gx + base + (int64_t)(cb + u) * V) = o;
+    }
+  }
+}
+
 // out[grp][e] = Σ_{row in group grp} part[row][e], fixed order.  Rows are split into `groups`
 // contiguous slices (blockIdx.y); 32 outputs per block, 8 strided partial sums per output.
 __global__ __launch_bounds__(256) void ln_part_reduce_kernel(const float* __restrict__ part, int nrows, int n,
@@ -277,7 +383,8 @@ extern "C" int fz_ln_fwd(const float* x, const float* gamma, const float* beta, 
 // workspace: per-workgroup partial rows (C <= 64: <= 1024 rows; wider: one row per 64 quads) + 64
 // rows of scratch for the two-stage reduce
 extern "C" int64_t fz_ln_bwd_workspace_bytes2(int B, int C, int64_t V) {
-  const int64_t rows = C <= 64 ? 1024 : ((V / 4) * B + 63) / 64;
+  const int64_t wide = ((V / 4) * B + 63) / 64;
+  const int64_t rows = C < 64 ? 1024 : (wide > 1024 ? wide : 1024);  // C >= 64: one row per 64 quads
   return (rows + 64) * 2 * C * 4;
 }
 extern "C" int64_t fz_ln_bwd_workspace_bytes(int C) { return C <= 64 ? (int64_t)(1024 + 64) * 2 * C * 4 : 0; }
@@ -293,6 +400,29 @@ extern "C" int fz_ln_bwd(const float* gl, const float* x, const float* stats, co
   if (B == 0) return FZ_OK;
   hipStream_t st = (hipStream_t)stream;
   unsigned grid = ln_grid(V / 4 * B);
+  {
+    int slice = 1;
+    const char* e = getenv("FZ_LN_SLICE");
+    if (e) slice = atoi(e);
+    if (slice && (C == 64 || C == 128 || C == 256 || C == 512)) {
+      const int64_t quads = (V / 4) * B;
+      const unsigned gq = (unsigned)((quads + 63) / 64);
+      float* part = gparams ? (float*)workspace : nullptr;
+#define FZ_LNS(CS, GA, PA) hipLaunchKernelGGL((ln_bwd_slice_kernel<CS, GA, PA>), dim3(gq), dim3(512), 0, st, gl, x, stats, gamma, gadd, gx, part, B, V)
+#define FZ_LNS_F(CS)                                                                       \
+  do {                                                                                     \
+    if (gadd) { if (part) FZ_LNS(CS, true, true); else FZ_LNS(CS, true, false); }          \
+    else { if (part) FZ_LNS(CS, false, true); else FZ_LNS(CS, false, false); }             \
+  } while (0)
+      if (C == 64) FZ_LNS_F(8); else if (C == 128) FZ_LNS_F(16); else if (C == 256) FZ_LNS_F(32); else FZ_LNS_F(64);
+      FZ_LAUNCH_CHECK();
+      if (gparams) {
+        float* tmp = part + (int64_t)gq * 2 * C;
+        return fz_reduce_rows(part, gq, 2 * C, gparams, tmp, stream);
+      }
+      return FZ_OK;
+    }
+  }
   if (gparams != nullptr && C <= 64) {
     if (grid > 1024) grid = 1024;
     float* part = (float*)workspace;

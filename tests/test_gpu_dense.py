@@ -118,7 +118,8 @@ def test_cat_linear():
     _run_both(lambda a, b, w: PW.cat_linear(a, b, w), lambda a, b, w: _lin_cpu(torch.cat([a, b], 1), w), [x1, x2, w])
 
 
-@pytest.mark.parametrize("C,S", [(32, (8, 8, 8)), (16, (4, 4, 4)), (512, (4, 4, 4)), (6, (2, 2, 4))])
+@pytest.mark.parametrize("C,S", [(32, (8, 8, 8)), (16, (4, 4, 4)), (512, (4, 4, 4)), (6, (2, 2, 4)), (64, (8, 8, 6)),
+                                 (128, (4, 8, 8)), (256, (4, 4, 4))])
 def test_layernorm(C, S):
     torch.manual_seed(5)
     x = torch.randn(2, C, *S) * 3 + 1
