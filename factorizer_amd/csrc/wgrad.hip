@@ -456,6 +456,56 @@ __global__ __launch_bounds__(256) void chunk_reduce_kernel(const float* __restri
   }
 }
 
+// One launch that finishes a weight gradient: workgroups [0, nbw) reduce the M·K partial blocks
+// (8 elements each, 32 strided partial sums per element, fixed tree — bitwise reproducible),
+// optionally folding the LayerNorm affine  gw[m][k] = Σ_ch (γ_k·part[ch][m][k] + β_k·pb[ch][m]);
+// workgroups [nbw, nbw + nbb) reduce the M bias sums.  Replaces 2-4 tiny dependent launches.
+__global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restrict__ part,
+                                                           const float* __restrict__ part_bias, int nchunk, int M,
+                                                           int K, float* __restrict__ gw, float* __restrict__ gbias,
+                                                           const float* __restrict__ ln_g,
+                                                           const float* __restrict__ ln_b, int accumulate, int nbw) {
+  __shared__ float red[32][9];
+  const int el = threadIdx.x & 7, g = threadIdx.x >> 3;
+  const bool bias_blk = (int)blockIdx.x >= nbw;
+  const int64_t n = bias_blk ? (int64_t)M : (int64_t)M * K;
+  const int64_t e = (int64_t)(bias_blk ? blockIdx.x - nbw : blockIdx.x) * 8 + el;
+  const float* src = bias_blk ? part_bias : part;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (e < n) {
+    const bool fold = !bias_blk && ln_g != nullptr;
+    const int m = fold ? (int)(e / K) : 0, k = fold ? (int)(e % K) : 0;
+    const float gk = fold ? ln_g[k] : 1.f, bk = fold ? ln_b[k] : 0.f;
+    int ch = g;
+    if (fold) {
+      for (; ch + 96 < nchunk; ch += 128) {
+        s0 += gk * src[(int64_t)ch * n + e] + bk * part_bias[(int64_t)ch * M + m];
+        s1 += gk * src[(int64_t)(ch + 32) * n + e] + bk * part_bias[(int64_t)(ch + 32) * M + m];
+        s2 += gk * src[(int64_t)(ch + 64) * n + e] + bk * part_bias[(int64_t)(ch + 64) * M + m];
+        s3 += gk * src[(int64_t)(ch + 96) * n + e] + bk * part_bias[(int64_t)(ch + 96) * M + m];
+      }
+      for (; ch < nchunk; ch += 32) s0 += gk * src[(int64_t)ch * n + e] + bk * part_bias[(int64_t)ch * M + m];
+    } else {
+      for (; ch + 96 < nchunk; ch += 128) {  // 4 independent loads in flight
+        s0 += src[(int64_t)ch * n + e];
+        s1 += src[(int64_t)(ch + 32) * n + e];
+        s2 += src[(int64_t)(ch + 64) * n + e];
+        s3 += src[(int64_t)(ch + 96) * n + e];
+      }
+      for (; ch < nchunk; ch += 32) s0 += src[(int64_t)ch * n + e];
+    }
+  }
+  red[g][el] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (g == 0 && e < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) t += red[i][el];
+    float* out = bias_blk ? gbias : gw;
+    out[e] = accumulate ? out[e] + t : t;
+  }
+}
+
 // LayerNorm affine folded into the weight gradient: gw[m][k] = γ_k · acc[m][k] + β_k · gb[m]
 __global__ __launch_bounds__(256) void ln_fold_kernel(float* __restrict__ gw, const float* __restrict__ acc,
                                                       const float* __restrict__ gb, const float* __restrict__ ln_g,
@@ -556,32 +606,11 @@ extern "C" int fz_wgrad(const fz_wgrad_desc* d, void* workspace, fz_stream_t str
   else FZ_WG_SHAPES(QL_K3);
   FZ_LAUNCH_CHECK();
   const int64_t MK = (int64_t)d->M * d->K;
-  float* acc_tmp = a.part_bias + (int64_t)nchunk * d->M;  // [M*K]
-  float* gb_tmp = acc_tmp + MK;                           // [M]
   const bool fold = d->ln_g != nullptr;
-  if (fold || d->gbias != nullptr) {
-    float* gb_out = (d->gbias != nullptr && !d->accumulate) ? d->gbias : gb_tmp;
-    hipLaunchKernelGGL(chunk_reduce_kernel, dim3((unsigned)((d->M + 7) / 8)), dim3(256), 0, st, a.part_bias,
-                       nchunk, (int64_t)d->M, gb_out, 0);
-    FZ_LAUNCH_CHECK();
-    if (d->gbias != nullptr && d->accumulate) {
-      // accumulate mode keeps the fresh sums in gb_tmp for the fold and adds them to gbias
-      hipLaunchKernelGGL(chunk_reduce_kernel, dim3((unsigned)((d->M + 7) / 8)), dim3(256), 0, st, a.part_bias,
-                         nchunk, (int64_t)d->M, d->gbias, 1);
-      FZ_LAUNCH_CHECK();
-    }
-    if (fold) {
-      hipLaunchKernelGGL(chunk_reduce_kernel, dim3((unsigned)((MK + 7) / 8)), dim3(256), 0, st, a.part, nchunk,
-                         MK, acc_tmp, 0);
-      FZ_LAUNCH_CHECK();
-      hipLaunchKernelGGL(ln_fold_kernel, dim3((unsigned)((MK + 255) / 256)), dim3(256), 0, st, d->gw, acc_tmp,
-                         gb_out, d->ln_g, d->ln_b, d->M, d->K, d->accumulate);
-      FZ_LAUNCH_CHECK();
-      return FZ_OK;
-    }
-  }
-  hipLaunchKernelGGL(chunk_reduce_kernel, dim3((unsigned)((MK + 7) / 8)), dim3(256), 0, st, a.part, nchunk, MK,
-                     d->gw, d->accumulate);
+  const int nbw = (int)((MK + 7) / 8);
+  const int nbb = d->gbias != nullptr ? (d->M + 7) / 8 : 0;
+  hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)(nbw + nbb)), dim3(256), 0, st, a.part, a.part_bias, nchunk,
+                     d->M, d->K, d->gw, d->gbias, fold ? d->ln_g : (const float*)nullptr, d->ln_b, d->accumulate, nbw);
   FZ_LAUNCH_CHECK();
   return FZ_OK;
 }
