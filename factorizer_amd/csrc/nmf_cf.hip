@@ -175,9 +175,31 @@ struct CfTile {
   static constexpr int STAGE_FLOATS = 2 * 64 * LW;
 };
 
+// HALF (W-axis shift ≡ 2 mod 4, e.g. the production windows [None, 2, 4, 6]): a 16-byte chunk of the
+// shifted run starts 8 bytes into an aligned quad of the tensor and may straddle the cyclic wrap, so
+// it moves as two 8-byte halves with separately wrapped addresses (off2 = offset of voxels +2, +3).
+template <bool HALF>
+__device__ __forceinline__ float4 cf_ld4(const float* p, int64_t o, int64_t o2) {
+  if (HALF) {
+    const float2 a = *reinterpret_cast<const float2*>(p + o);
+    const float2 b = *reinterpret_cast<const float2*>(p + o2);
+    return make_float4(a.x, a.y, b.x, b.y);
+  }
+  return *reinterpret_cast<const float4*>(p + o);
+}
+template <bool HALF>
+__device__ __forceinline__ void cf_st4(float* p, int64_t o, int64_t o2, float4 v) {
+  if (HALF) {
+    *reinterpret_cast<float2*>(p + o) = make_float2(v.x, v.y);
+    *reinterpret_cast<float2*>(p + o2) = make_float2(v.z, v.w);
+  } else {
+    *reinterpret_cast<float4*>(p + o) = v;
+  }
+}
+
 template <int WPB>
 __device__ __forceinline__ void cf_tile_decode(const CfGeom& q, int64_t blk, int tid, int64_t& base, int64_t& V,
-                                               int64_t (&off)[2], int (&lidx)[2]) {
+                                               int64_t (&off)[2], int (&lidx)[2], int64_t (&off2)[2]) {
   using TL = CfTile<WPB>;
   // 32-bit index arithmetic (the host rejects > 2^31 matrices): 64-bit div/mod is ~100 instructions each
   const unsigned ngrp = (unsigned)(q.G2 / WPB);
@@ -197,6 +219,8 @@ __device__ __forceinline__ void cf_tile_decode(const CfGeom& q, int64_t blk, int
     int z1 = g1 * 8 + (row & 7) - q.s1; if (z1 < 0) z1 += q.H;
     int z2 = gq * WPB * 8 + chunk * 4 - q.s2; if (z2 < 0) z2 += q.W;
     off[k] = ((int64_t)z0 * q.H + z1) * q.W + z2;
+    int z2b = z2 + 2; if (z2b >= q.W) z2b -= q.W;
+    off2[k] = ((int64_t)z0 * q.H + z1) * q.W + z2b;
     lidx[k] = row * TL::LW + chunk * 4;
   }
 }
@@ -231,8 +255,8 @@ __device__ __forceinline__ void cf_to_owner(float* S, const int (&lidx)[2], int 
   }
 }
 
-template <int R, int SOLVER, int WPB>
-__global__ __launch_bounds__(WPB * 64, WPB == 8 ? 2 : 1) void nmf_cf_fwd_tile_kernel(const float* __restrict__ t,
+template <int R, int SOLVER, int WPB, bool HALF = false>
+__global__ __launch_bounds__(WPB * 64, WPB == 8 ? 2 : (WPB == 4 ? 4 : (WPB == 1 ? 8 : 1))) void nmf_cf_fwd_tile_kernel(const float* __restrict__ t,
                                                                    const float* __restrict__ u0,
                                                                    const float* __restrict__ v0,
                                                                    float* __restrict__ out, CfGeom q, int T, float eps,
@@ -241,9 +265,9 @@ __global__ __launch_bounds__(WPB * 64, WPB == 8 ? 2 : 1) void nmf_cf_fwd_tile_ke
   extern __shared__ __attribute__((aligned(16))) float fz_lds_tile[];
   float* S = fz_lds_tile;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int64_t base, V, off[2];
+  int64_t base, V, off[2], off2[2];
   int lidx[2];
-  cf_tile_decode<WPB>(q, cf_logical_block(xcd_remap), tid, base, V, off, lidx);
+  cf_tile_decode<WPB>(q, cf_logical_block(xcd_remap), tid, base, V, off, lidx, off2);
   const int own0 = cf_owner_lidx<WPB>(lane, wave, 0), own1 = cf_owner_lidx<WPB>(lane, wave, 1);
 
   float x[8][8];
@@ -251,7 +275,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 8 ? 2 : 1) void nmf_cf_fwd_tile_ke
   for (int dd = 0; dd < 8; ++dd)
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const float4 v = *reinterpret_cast<const float4*>(t + base + dd * V + off[k]);
+      const float4 v = cf_ld4<HALF>(t + base + dd * V, off[k], off2[k]);
       x[dd][k * 4 + 0] = v.x; x[dd][k * 4 + 1] = v.y; x[dd][k * 4 + 2] = v.z; x[dd][k * 4 + 3] = v.w;
     }
   cf_to_owner<WPB>(S, lidx, own0, own1, x);
@@ -269,7 +293,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 8 ? 2 : 1) void nmf_cf_fwd_tile_ke
 #pragma unroll
     for (int dd = 0; dd < 8; ++dd)
 #pragma unroll
-      for (int k = 0; k < 2; ++k) old[dd][k] = *reinterpret_cast<const float4*>(out + base + dd * V + off[k]);
+      for (int k = 0; k < 2; ++k) old[dd][k] = cf_ld4<HALF>(out + base + dd * V, off[k], off2[k]);
   }
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
@@ -294,7 +318,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 8 ? 2 : 1) void nmf_cf_fwd_tile_ke
           o = make_float4(0.0f + z.x, 0.0f + z.y, 0.0f + z.z, 0.0f + z.w);
         }
         if (q.divisor > 1) o = cf_divide4(o, dv, dv_pow2);
-        *reinterpret_cast<float4*>(out + base + (2 * s + c) * V + off[k]) = o;
+        cf_st4<HALF>(out + base + (2 * s + c) * V, off[k], off2[k], o);
       }
     __syncthreads();
   }
@@ -342,8 +366,8 @@ __global__ __launch_bounds__(512, 2) void nmf_cf_bwd_kernel(const float* __restr
 
 // line-coalesced backward: same exchange for t and for the incoming gradient, ReLU gate applied on
 // the owner side before the exchange back, read-modify-write of gt with the coalesced map
-template <int R, int SOLVER, int WPB>
-__global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : 1) void nmf_cf_bwd_tile_kernel(
+template <int R, int SOLVER, int WPB, bool HALF = false>
+__global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : (WPB == 1 ? 8 : 1)) void nmf_cf_bwd_tile_kernel(
     const float* __restrict__ t, const float* __restrict__ u0, const float* __restrict__ v0,
     const float* __restrict__ ga, float* __restrict__ gt, CfGeom q, int T, int G, float eps, int relu_gate,
     int xcd_remap) {
@@ -351,9 +375,9 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : 1) void nmf_cf_bwd_tile_ke
   extern __shared__ __attribute__((aligned(16))) float fz_lds_cf[];
   float* S = fz_lds_cf;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int64_t base, V, off[2];
+  int64_t base, V, off[2], off2[2];
   int lidx[2];
-  cf_tile_decode<WPB>(q, cf_logical_block(xcd_remap), tid, base, V, off, lidx);
+  cf_tile_decode<WPB>(q, cf_logical_block(xcd_remap), tid, base, V, off, lidx, off2);
   const int own0 = cf_owner_lidx<WPB>(lane, wave, 0), own1 = cf_owner_lidx<WPB>(lane, wave, 1);
   Hist<8, 8, R> h;
   h.carve(fz_lds_cf + TL::STAGE_FLOATS + wave * Hist<8, 8, R>::floats(G), G);
@@ -363,14 +387,14 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : 1) void nmf_cf_bwd_tile_ke
   for (int dd = 0; dd < 8; ++dd)
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const float4 v = *reinterpret_cast<const float4*>(t + base + dd * V + off[k]);
+      const float4 v = cf_ld4<HALF>(t + base + dd * V, off[k], off2[k]);
       x[dd][k * 4 + 0] = v.x; x[dd][k * 4 + 1] = v.y; x[dd][k * 4 + 2] = v.z; x[dd][k * 4 + 3] = v.w;
     }
 #pragma unroll
   for (int dd = 0; dd < 8; ++dd)
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const float4 v = *reinterpret_cast<const float4*>(ga + base + dd * V + off[k]);
+      const float4 v = cf_ld4<HALF>(ga + base + dd * V, off[k], off2[k]);
       g[dd][k * 4 + 0] = v.x; g[dd][k * 4 + 1] = v.y; g[dd][k * 4 + 2] = v.z; g[dd][k * 4 + 3] = v.w;
     }
   cf_to_owner<WPB>(S, lidx, own0, own1, x);
@@ -391,7 +415,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : 1) void nmf_cf_bwd_tile_ke
 #pragma unroll
     for (int dd = 0; dd < 8; ++dd)
 #pragma unroll
-      for (int k = 0; k < 2; ++k) old[dd][k] = *reinterpret_cast<const float4*>(gt + base + dd * V + off[k]);
+      for (int k = 0; k < 2; ++k) old[dd][k] = cf_ld4<HALF>(gt + base + dd * V, off[k], off2[k]);
   }
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
@@ -412,7 +436,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : 1) void nmf_cf_bwd_tile_ke
           const float4 o = old[2 * s + c][k];
           z.x += o.x; z.y += o.y; z.z += o.z; z.w += o.w;
         }
-        *reinterpret_cast<float4*>(gt + base + (2 * s + c) * V + off[k]) = z;
+        cf_st4<HALF>(gt + base + (2 * s + c) * V, off[k], off2[k], z);
       }
     __syncthreads();
   }
@@ -426,7 +450,7 @@ static int cf_geom(CfGeom& q, int B, int C, int D, int H, int W, const int* shif
   int s[3];
   const int S[3] = {D, H, W};
   for (int i = 0; i < 3; ++i) { s[i] = shift[i] % S[i]; if (s[i] < 0) s[i] += S[i]; }
-  if (s[2] % 4) return fail(FZ_E_UNSUPPORTED, "fz_nmf_cf: W-axis shift must be a multiple of 4");
+  if (s[2] % 2) return fail(FZ_E_UNSUPPORTED, "fz_nmf_cf: W-axis shift must be even");
   q.s0 = s[0]; q.s1 = s[1]; q.s2 = s[2];
   q.accumulate = accumulate; q.divisor = divisor; q.gscale_div = 1.0f;
   return FZ_OK;
@@ -467,21 +491,23 @@ extern "C" int fz_nmf_cf_fwd(const float* t, const float* u0, const float* v0, f
   hipStream_t st = (hipStream_t)stream;
   int tile = 1;
   { const char* e = getenv("FZ_CF_TILE"); if (e) tile = atoi(e); }
-  if (tile && (q.G2 % 8) == 0) {
-    // line-coalesced kernel: WPB patches along W per workgroup
-    // 8 patches per workgroup, two workgroups per CU out of phase: 0.524 ms vs 0.554 (16) vs 0.747 (direct)
-    const int twpb = (tile == 16 && (q.G2 % 16) == 0) ? 16 : 8;
+  const bool half = (q.s2 % 4) != 0;  // W-axis shift ≡ 2 (mod 4): only the line-coalesced kernels handle it
+  if (half || (tile && (q.G2 % 8) == 0)) {
+    // line-coalesced kernel: WPB patches along W per workgroup.  8 patches per workgroup, two
+    // workgroups per CU out of phase: 0.524 ms vs 0.554 (16) vs 0.747 (direct gather) at stage 0
+    const int twpb = (q.G2 % 8) == 0 ? 8 : ((q.G2 % 4) == 0 ? 4 : 1);
     const unsigned nblk = (unsigned)(nmat / twpb);
-#define FZ_CF_TILE(RR, SS, WW)                                                                              \
+#define FZ_CF_TILE(RR, SS, WW, HH)                                                                          \
   do {                                                                                                      \
-    auto kern = nmf_cf_fwd_tile_kernel<RR, SS, WW>;                                                         \
+    auto kern = nmf_cf_fwd_tile_kernel<RR, SS, WW, HH>;                                                     \
     const int lds = CfTile<WW>::STAGE_FLOATS * (int)sizeof(float);                                          \
-    if (lds > 65536)                                                                                        \
-      FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                    \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));                      \
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(64 * WW), lds, st, t, u0, v0, out, q, T, eps, xr);            \
   } while (0)
-#define FZ_CF_TILE_W(RR, SS) do { if (twpb == 16) FZ_CF_TILE(RR, SS, 16); else FZ_CF_TILE(RR, SS, 8); } while (0)
+#define FZ_CF_TILE_W(RR, SS)                                                                                \
+  do {                                                                                                      \
+    if (half) { if (twpb == 8) FZ_CF_TILE(RR, SS, 8, true); else if (twpb == 4) FZ_CF_TILE(RR, SS, 4, true); else FZ_CF_TILE(RR, SS, 1, true); } \
+    else FZ_CF_TILE(RR, SS, 8, false);                                                                      \
+  } while (0)
     if (R == 1) { if (solver == FZ_SOLVER_MU) FZ_CF_TILE_W(1, SOLVER_MU); else FZ_CF_TILE_W(1, SOLVER_HALS); }
     else { if (solver == FZ_SOLVER_MU) FZ_CF_TILE_W(2, SOLVER_MU); else FZ_CF_TILE_W(2, SOLVER_HALS); }
     FZ_LAUNCH_CHECK();
@@ -522,24 +548,27 @@ extern "C" int fz_nmf_cf_bwd(const float* t, const float* u0, const float* v0, c
   hipStream_t st = (hipStream_t)stream;
   int tile = 1;
   { const char* e = getenv("FZ_CF_TILE_BWD"); if (e) tile = atoi(e); }
-  if (tile && (q.G2 % 4) == 0) {
-    int twpb = (tile == 8 && (q.G2 % 8) == 0) ? 8 : 4;
-    int tlds = (twpb == 8 ? CfTile<8>::STAGE_FLOATS : CfTile<4>::STAGE_FLOATS) * (int)sizeof(float) + per_wave * twpb;
-    if (twpb == 8 && tlds > 160 * 1024) {
-      twpb = 4;
-      tlds = CfTile<4>::STAGE_FLOATS * (int)sizeof(float) + per_wave * 4;
-    }
-    if (tlds <= 160 * 1024) {
+  const bool half = (q.s2 % 4) != 0;
+  if (half || (tile && (q.G2 % 4) == 0)) {
+    const int twpb = (q.G2 % 4) == 0 ? 4 : 1;
+    const int tlds = (twpb == 4 ? CfTile<4>::STAGE_FLOATS : CfTile<1>::STAGE_FLOATS) * (int)sizeof(float) + per_wave * twpb;
+    if (tlds > 160 * 1024) {
+      if (half) return fail(FZ_E_UNSUPPORTED, "fz_nmf_cf_bwd: history exceeds LDS for a W-axis shift of 2 (mod 4)");
+    } else {
       const unsigned nblk = (unsigned)(nmat / twpb);
-#define FZ_CF_BWD_TILE(RR, SS, WW)                                                                          \
+#define FZ_CF_BWD_TILE(RR, SS, WW, HH)                                                                      \
   do {                                                                                                      \
-    auto kern = nmf_cf_bwd_tile_kernel<RR, SS, WW>;                                                         \
+    auto kern = nmf_cf_bwd_tile_kernel<RR, SS, WW, HH>;                                                     \
     if (tlds > 65536)                                                                                       \
       FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                    \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, tlds));                     \
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(64 * WW), tlds, st, t, u0, v0, ga, gt, q, T, G, eps, relu_gate, xr); \
   } while (0)
-#define FZ_CF_BWD_TILE_W(RR, SS) do { if (twpb == 8) FZ_CF_BWD_TILE(RR, SS, 8); else FZ_CF_BWD_TILE(RR, SS, 4); } while (0)
+#define FZ_CF_BWD_TILE_W(RR, SS)                                                                            \
+  do {                                                                                                      \
+    if (half) { if (twpb == 4) FZ_CF_BWD_TILE(RR, SS, 4, true); else FZ_CF_BWD_TILE(RR, SS, 1, true); }     \
+    else FZ_CF_BWD_TILE(RR, SS, 4, false);                                                                  \
+  } while (0)
       if (R == 1) { if (solver == FZ_SOLVER_MU) FZ_CF_BWD_TILE_W(1, SOLVER_MU); else FZ_CF_BWD_TILE_W(1, SOLVER_HALS); }
       else { if (solver == FZ_SOLVER_MU) FZ_CF_BWD_TILE_W(2, SOLVER_MU); else FZ_CF_BWD_TILE_W(2, SOLVER_HALS); }
       FZ_LAUNCH_CHECK();

@@ -250,7 +250,7 @@ def nmf_decompose(x, u0, v0, T, G, solver, eps=1e-16):
 
 # ---- fused FactMixer core on channels-first tensors ------------------------------------------
 def nmf_cf_supported(geo: Geometry, R, T, G) -> bool:
-    if len(geo.spatial) != 3 or any(s[2] % 4 for s in geo.shifts):
+    if len(geo.spatial) != 3 or any(s[2] % 2 for s in geo.shifts):  # odd W-axis shifts: modular kernels
         return False
     return bool(N.lib().fz_nmf_cf_supported(geo.C, *geo.spatial, geo.d, *geo.patch, int(R), int(T), int(G)))
 

@@ -344,14 +344,18 @@ def test_block_cfg2_full_size_runs():
 
 
 # ---------------------------------------------------------------- fused FactMixer core -----
-@pytest.mark.parametrize("shifts", [None, [None, 4, (4, 0, 4), (0, 4, 0)], [None]])
+@pytest.mark.parametrize("S", [(16, 8, 24), (8, 16, 64), (8, 8, 32)])
+@pytest.mark.parametrize("shifts", [None, [None, 4, (4, 0, 4), (0, 4, 0)], [None], [None, 2, 4, 6], [(2, 6, 2), (5, 3, 6)]])
 @pytest.mark.parametrize("solver,R", [("hals", 1), ("mu", 2), ("hals", 2)])
-def test_fact_core_fused_vs_modular(shifts, solver, R):
+def test_fact_core_fused_vs_modular(S, shifts, solver, R):
     """csrc/nmf_cf.hip (gather → NMF → scatter/average per window) against the modular chain
-    SWMatricize → NMF → inverse (itself checked against the reference goldens)."""
+    SWMatricize → NMF → inverse (itself checked against the reference goldens).  W = 24: direct
+    gather kernels (3 patches along W); W = 64 / 32: line-coalesced kernels with 8 / 4 patches per
+    workgroup; W-axis shifts 2 and 6 (the BraTS bundle's windows, train.yaml:50-54) move as 8-byte
+    halves and, at W = 32, 24 use the 4- / 1-patch variants."""
     from factorizer_amd import functional as Fn
     torch.manual_seed(11)
-    C, S = 16, (16, 8, 24)
+    C = 16
     m = ft.SWMatricize((None, C, *S), head_dim=8, patch_size=8, shifts=shifts)
     nmf = ft.NMF(size=(8, 512), rank=R, num_iters=4, num_grad_steps=3, init="uniform", solver=solver).to(DEV)
     t = torch.rand(2, C, *S, device=DEV)

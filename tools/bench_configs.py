@@ -87,7 +87,32 @@ def cfg3():
                       "volumes_per_s": round(2 / ms * 1e3, 1)}))
 
 
+def prod():
+    """the BraTS bundle's model (model_zoo/factorizer_brats23/configs/train.yaml:44-66):
+    shift windows [None, 2, 4, 6], mlp_ratio 4 — training step (fwd + bwd) and eval forward, B = 2."""
+    torch.manual_seed(0)
+    kw = dict(in_channels=4, out_channels=3, spatial_size=(128, 128, 128), norm=ft.LayerNorm,
+              reshape=(ft.SWMatricize, {"head_dim": 8, "patch_size": 8, "shifts": [None, 2, 4, 6]}), act=nn.ReLU,
+              factorize=ft.NMF, rank=1, num_iters=5, init="uniform", solver="hals", mlp_ratio=4, dropout=0.1)
+    model = ft.Factorizer(**kw).to(DEV).train()
+    x = torch.rand(2, 4, 128, 128, 128, device=DEV)
+    t = (torch.rand(2, 3, 128, 128, 128, device=DEV) > 0.5).float()
+
+    def fb():
+        for p in model.parameters():
+            p.grad = None
+        ft.dice_bce_loss(model(x), t).backward()
+    ms = gpu_time(fb, 10, 3)
+    print(json.dumps({"config": "f-1 production Swin Factorizer (4 shift windows, mlp_ratio 4) fwd+bwd B=2",
+                      "ms": round(ms, 3), "volumes_per_s": round(2 / ms * 1e3, 1)}))
+    model.eval()
+    with torch.no_grad():
+        ms = gpu_time(lambda: model(x), 20, 3)
+    print(json.dumps({"config": "f-1 production Swin Factorizer eval forward B=2", "ms": round(ms, 3),
+                      "volumes_per_s": round(2 / ms * 1e3, 1)}))
+
+
 if __name__ == "__main__":
-    cfg1()
-    cfg2()
-    cfg3()
+    which = sys.argv[1:] or ["cfg1", "cfg2", "cfg3", "prod"]
+    for name in which:
+        {"cfg1": cfg1, "cfg2": cfg2, "cfg3": cfg3, "prod": prod}[name]()
