@@ -292,6 +292,23 @@ int fz_dice_bce_sums(const float* z, const float* t, float* part, int planes, in
 int fz_dice_bce_grad(const float* z, const float* t, const float* coef, float* gz, int planes, int64_t V,
                      float cd, float cb, const float* gscale, fz_stream_t stream);
 
+/* ---- sliding-window inference stitching -------------------------------------
+ * What MONAI's SlidingWindowInfererAdapt(roi 128^3, sw_batch 2, overlap 0.5, mode "gaussian") does
+ * around the network (model_zoo/factorizer_brats23/configs/inference.yaml:96-102, train.yaml:206-212):
+ * per window  gather: win (C, rd, rh, rw) <- vol (C, D, H, W)[:, z0:, y0:, x0:]
+ *             accumulate: out (C, D, H, W)[window] += g * prob (C, rd, rh, rw) ; cnt (D, H, W)[window] += g
+ *             with g[z,y,x] = max(gz[z]*gy[y]*gx[x], wmin)  (separable Gaussian importance map)
+ * and once    finalize: out /= cnt.
+ * One sample per call; rw a multiple of 4 (16-byte vectors on the volume side when W and x0 are
+ * too).  Windows must be accumulated by separate
+ * (stream-ordered) calls: they overlap. */
+int fz_sw_gather(const float* vol, float* win, int C, int D, int H, int W, int rd, int rh, int rw, int z0, int y0,
+                 int x0, fz_stream_t stream);
+int fz_sw_accumulate(const float* prob, float* out, float* cnt, const float* gz, const float* gy, const float* gx,
+                     float wmin, int C, int D, int H, int W, int rd, int rh, int rw, int z0, int y0, int x0,
+                     fz_stream_t stream);
+int fz_sw_finalize(float* out, const float* cnt, int C, int64_t V, fz_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -481,3 +481,50 @@ def dice_bce_loss(logits, target, smooth=1e-5):
     dice = 1.0 - (2.0 * inter + smooth) / (den + smooth)
     bce = F.binary_cross_entropy_with_logits(logits, target)
     return dice.mean() + bce
+
+
+# ---- sliding-window inference ---------------------------------------------------------
+def sliding_window_oracle(inputs, roi, sw_batch, predictor, overlap=0.5, mode="gaussian", sigma_scale=0.125):
+    """Plain restatement of MONAI's published `sliding_window_inference` (monai/inferers/utils.py,
+    the bundle pins it through SlidingWindowInfererAdapt, inference.yaml:96-102) with explicit loops and a
+    DENSE importance map, for volumes at least as large as the roi: dense windows at interval
+    int(roi*(1-overlap)) with the last one pulled back to the border; map = product of 1-D Gaussians
+    (sigma = sigma_scale*roi) clamped at max(min, 1e-3); output = sum(map*net(window)) / sum(map).
+    parity: unpinned against MONAI itself (absent from the image); pinned to its documented algorithm."""
+    import itertools
+    import math
+    B = inputs.shape[0]
+    size = tuple(inputs.shape[2:])
+    roi = tuple(roi)
+    assert all(s >= r for s, r in zip(size, roi))
+    starts = []
+    for im, r in zip(size, roi):
+        it = r if r == im else max(int(r * (1 - overlap)), 1)
+        n = int(math.ceil((im - r) / it)) + 1
+        starts.append([min(i * it, im - r) for i in range(n)])
+    if mode == "gaussian":
+        w = torch.ones(roi, dtype=torch.float64)
+        for ax, r in enumerate(roi):
+            x = torch.arange(r, dtype=torch.float64) - (r - 1) / 2.0
+            g = torch.exp(-(x ** 2) / (2 * (sigma_scale * r) ** 2)).to(torch.float32).to(torch.float64)
+            shape = [1, 1, 1]
+            shape[ax] = r
+            w = w * g.view(shape)
+        w = w.to(torch.float32)
+        w = w.clamp_min(max(float(w[w != 0].min()), 1e-3))
+    else:
+        w = torch.ones(roi, dtype=torch.float32)
+    out = cnt = None
+    jobs = [(b, s) for b in range(B) for s in itertools.product(*starts)]
+    for j0 in range(0, len(jobs), sw_batch):
+        chunk = jobs[j0:j0 + sw_batch]
+        win = torch.stack([inputs[b, :, s[0]:s[0] + roi[0], s[1]:s[1] + roi[1], s[2]:s[2] + roi[2]] for b, s in chunk])
+        prob = predictor(win)
+        if out is None:
+            out = torch.zeros((B, prob.shape[1], *size), dtype=prob.dtype)
+            cnt = torch.zeros((B, 1, *size), dtype=prob.dtype)
+        for i, (b, s) in enumerate(chunk):
+            sl = (slice(s[0], s[0] + roi[0]), slice(s[1], s[1] + roi[1]), slice(s[2], s[2] + roi[2]))
+            out[(b, slice(None)) + sl] += w * prob[i]
+            cnt[(b, 0) + sl] += w
+    return out / cnt

@@ -216,3 +216,47 @@ def test_factmixer_global_matricize_mu():
     assert y.shape == x.shape and torch.isfinite(y).all()
     y.sum().backward()
     assert torch.isfinite(x.grad).all()
+
+
+# ---- sliding-window inference -------------------------------------------------------
+def _toy_net(w):
+    conv = torch.nn.Conv3d(2, 3, 3, padding=1)
+    with torch.no_grad():
+        conv.weight.copy_(w)
+        conv.bias.fill_(0.1)
+    return lambda x: torch.tanh(conv(x))
+
+
+@pytest.mark.parametrize("size,roi,ov,mode", [((20, 24, 27), (16, 16, 16), 0.5, "gaussian"),
+                                              ((16, 16, 16), (16, 16, 16), 0.5, "gaussian"),
+                                              ((24, 16, 20), (16, 16, 8), 0.25, "constant")])
+def test_sliding_window_inference_matches_restated_algorithm(size, roi, ov, mode):
+    """ft.sliding_window_inference (composed CPU path) against the dense-map restatement of MONAI's
+    published algorithm in oracle/cpu_ref.py; window grid of the bundle's settings checked explicitly."""
+    from oracle import cpu_ref as O
+    from factorizer_amd import inference as I
+    torch.manual_seed(0)
+    net = _toy_net(torch.randn(3, 2, 3, 3, 3) * 0.2)
+    x = torch.randn(2, 2, *size)
+    with torch.no_grad():
+        y = ft.sliding_window_inference(x, roi, 2, net, overlap=ov, mode=mode)
+        yo = O.sliding_window_oracle(x, roi, 2, net, overlap=ov, mode=mode)
+    assert y.shape == (2, 3, *size)
+    assert torch.allclose(y, yo, rtol=1e-5, atol=1e-6)
+    # BraTS geometry of the bundle (inference.yaml:96-102): 240x240x155, roi 128^3, overlap 0.5
+    st = I.window_starts((240, 240, 155), (128,) * 3, I.scan_interval((240, 240, 155), (128,) * 3, (0.5,) * 3))
+    assert len(st) == 3 * 3 * 2 and st[0] == (0, 0, 0) and st[-1] == (112, 112, 27)
+
+
+def test_sliding_window_pads_small_volumes():
+    torch.manual_seed(1)
+    net = _toy_net(torch.randn(3, 2, 3, 3, 3) * 0.2)
+    x = torch.randn(1, 2, 12, 16, 10)
+    inf = ft.SlidingWindowInfererAdapt(roi_size=(16, 16, 16), sw_batch_size=2, overlap=0.5, mode="gaussian",
+                                       cache_roi_weight_map=True)
+    with torch.no_grad():
+        y = inf(x, net)
+        xp = torch.nn.functional.pad(x, (3, 3, 0, 0, 2, 2))
+        ref = net(xp)[:, :, 2:14, :, 3:13]
+    assert y.shape == (1, 3, 12, 16, 10)
+    assert torch.allclose(y, ref, rtol=1e-5, atol=1e-6)  # a single window: the weights cancel

@@ -110,6 +110,15 @@ def prod():
         ms = gpu_time(lambda: model(x), 20, 3)
     print(json.dumps({"config": "f-1 production Swin Factorizer eval forward B=2", "ms": round(ms, 3),
                       "volumes_per_s": round(2 / ms * 1e3, 1)}))
+    # the bundle's inference: one BraTS volume through SlidingWindowInfererAdapt (inference.yaml:96-102)
+    vol = torch.rand(1, 4, 240, 240, 155, device=DEV)
+    inf = ft.SlidingWindowInfererAdapt(roi_size=(128, 128, 128), sw_batch_size=2, overlap=0.5, mode="gaussian")
+    with torch.no_grad():
+        ms = gpu_time(lambda: inf(vol, model), 5, 2)
+        net_only = gpu_time(lambda: model(x), 10, 2) * 9  # 18 windows = 9 batches of 2
+    print(json.dumps({"config": "f-1 sliding-window inference, 240x240x155 volume, roi 128^3, overlap 0.5, gaussian",
+                      "ms_per_volume": round(ms, 2), "of_which_network_ms": round(net_only, 2),
+                      "windows": 18}))
 
 
 if __name__ == "__main__":
