@@ -121,6 +121,7 @@ _SIGS.update({
     "fz_gemm": ([_c.POINTER(GemmDesc), _vp], _i),
     "fz_gemm_lnbwd_partials": ([_c.POINTER(GemmDesc)], _i64),
     "fz_reduce_rows": ([_vp, _i64, _i, _vp, _vp, _vp], _i),
+    "fz_adamw_step": ([_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _vp], _i),
     "fz_sw_gather": ([_vp, _vp] + [_i] * 10 + [_vp], _i),
     "fz_sw_accumulate": ([_vp] * 6 + [_f] + [_i] * 10 + [_vp], _i),
     "fz_sw_finalize": ([_vp, _vp, _i, _i64, _vp], _i),

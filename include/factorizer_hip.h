@@ -309,6 +309,13 @@ int fz_sw_accumulate(const float* prob, float* out, float* cnt, const float* gz,
                      fz_stream_t stream);
 int fz_sw_finalize(float* out, const float* cnt, int C, int64_t V, fz_stream_t stream);
 
+/* ---- AdamW over one flat buffer (torch.optim.AdamW of the training recipe,
+ * model_zoo/factorizer_brats23/configs/train.yaml:72-76).  step >= 1 is the 1-based update count;
+ * grad_scale multiplies the gradient first (1/world after a summed all-reduce). */
+int fz_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                  fz_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

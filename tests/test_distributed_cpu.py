@@ -17,7 +17,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, overlap, out):
+def _worker(rank, world, port, overlap, out, flat_opt=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -30,7 +30,8 @@ def _worker(rank, world, port, overlap, out):
                               factorize=ft.NMF, rank=1, num_iters=3, solver="hals", mlp_ratio=2, dropout=0.0)
         sync = FlatGradSync(model, num_buckets=3, overlap=overlap)
         sync.broadcast_state(0)
-        opt = torch.optim.SGD(model.parameters(), lr=0.1)
+        opt = (ft.FlatAdamW(model, lr=0.01, weight_decay=1e-5, flat_grad=sync.flat, grad_views=sync.views)
+               if flat_opt else torch.optim.SGD(model.parameters(), lr=0.1))
         torch.manual_seed(7 + rank)
         x = torch.rand(2, 2, 8, 8, 8)
         sync.zero_grad()
@@ -82,3 +83,14 @@ def test_flat_grad_sync_world2(tmp_path, overlap):
     assert torch.equal(res["g"][0], res["g"][1])
     assert torch.equal(res["w"][0], res["w"][1])   # replicas stay identical after the step
     assert torch.equal(res["b"][0], res["b"][1])   # u0/v0 buffers were broadcast
+
+
+def test_flat_adamw_on_the_reduced_buffer_world2(tmp_path):
+    """bench.py's optimizer path: FlatAdamW reads the gradient buffer RCCL/gloo reduced in place; the
+    replicas stay bit-identical after the step."""
+    world = 2
+    out = str(tmp_path / "res.pt")
+    mp.spawn(_worker, args=(world, _free_port(), True, out, True), nprocs=world, join=True)
+    res = torch.load(out)
+    assert torch.equal(res["w"][0], res["w"][1]) and torch.equal(res["g"][0], res["g"][1])
+    assert torch.isfinite(res["w"][0]).all()

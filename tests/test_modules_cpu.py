@@ -260,3 +260,61 @@ def test_sliding_window_pads_small_volumes():
         ref = net(xp)[:, :, 2:14, :, 3:13]
     assert y.shape == (1, 3, 12, 16, 10)
     assert torch.allclose(y, ref, rtol=1e-5, atol=1e-6)  # a single window: the weights cancel
+
+
+# ---- training-step pieces -------------------------------------------------------------
+def test_flat_adamw_matches_torch_adamw():
+    """FlatAdamW (one flat buffer; train.yaml:72-76 recipe) against torch.optim.AdamW, 6 steps, and the
+    parameters stay views of the flat buffer through state_dict round trips."""
+    import copy
+    torch.manual_seed(0)
+    m1 = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.GELU(), torch.nn.Linear(5, 3))
+    m2 = copy.deepcopy(m1)
+    o1 = ft.FlatAdamW(m1, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    o2 = torch.optim.AdamW(m2.parameters(), lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    for _ in range(6):
+        x = torch.randn(4, 7)
+        for m, o in ((m1, o1), (m2, o2)):
+            o.zero_grad()
+            m(x).pow(2).sum().backward()
+            o.step()
+    for a, b in zip(m1.parameters(), m2.parameters()):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
+    m1.load_state_dict(m2.state_dict())
+    assert all(p.data_ptr() >= o1.flat_param.data_ptr() for p in m1.parameters())
+    assert torch.equal(o1.flat_param[:35].view(5, 7), m2[0].weight)
+
+
+def test_warmup_cosine_schedule_values():
+    """MONAI WarmupCosineSchedule restated; the bundle's numbers (train.yaml:26-32,79-83): 500 epochs,
+    warmup_steps 5, t_total 501, warmup_multiplier 0.1."""
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1e-4)
+    s = ft.WarmupCosineSchedule(opt, warmup_steps=5, t_total=501, warmup_multiplier=0.1)
+    assert abs(opt.param_groups[0]["lr"] - 1e-5) < 1e-12        # step 0: multiplier 0.1
+    lrs = []
+    for _ in range(501):
+        s.step()
+        lrs.append(opt.param_groups[0]["lr"])
+    assert abs(lrs[0] - 1e-4 * (0.1 + 0.9 * 1 / 5)) < 1e-12      # step 1
+    assert abs(lrs[4] - 1e-4) < 1e-12                            # step 5: end of warm-up
+    assert abs(lrs[252] - 1e-4 * 0.5) < 1e-9                     # step 253: half-way through the cosine
+    assert lrs[-1] < 1e-12 and all(a >= b - 1e-15 for a, b in zip(lrs[4:], lrs[5:]))
+
+
+def test_load_checkpoint_interchange(tmp_path):
+    """scripts/utils.py:10-26 semantics: objects[key].load_state_dict(checkpoint[key]); reference-keyed
+    state_dicts load into the module unchanged (keys pinned by tests/golden/g6_readme_model_keys.npz)."""
+    torch.manual_seed(0)
+    kw = dict(in_channels=2, out_channels=2, spatial_size=(16, 16, 16), encoder_depth=(1, 1), encoder_width=(8, 16),
+              strides=(1, 2), decoder_depth=(1,), norm=ft.LayerNorm,
+              reshape=(ft.SWMatricize, {"head_dim": 8, "patch_size": 4}), act=nn.ReLU, factorize=ft.NMF, rank=1,
+              num_iters=2, init="uniform", solver="hals", mlp_ratio=2, dropout=0.0)
+    src, dst = ft.Factorizer(**kw), ft.Factorizer(**kw)
+    path = tmp_path / "ckpt.pt"
+    torch.save({"network": src.state_dict(), "epoch": 3}, path)
+    ft.load_checkpoint({"network": dst}, str(path))
+    for (k1, v1), (k2, v2) in zip(src.state_dict().items(), dst.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+    ft.load_checkpoint({"network": dst}, src.state_dict())     # a bare state_dict
+    with pytest.raises(KeyError):
+        ft.load_checkpoint({"optimizer": dst}, {"network": src.state_dict(), "x": 1})
