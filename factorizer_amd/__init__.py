@@ -7,8 +7,9 @@ Device tensors run hand-written gfx950 kernels through libfactorizer_hip.so
 """
 from .utils import as_tuple, has_args, is_partializable, partialize
 from .matricize import Matricize, Reshape, SWMatricize
-from .nmf import (NMF, BCDSolver, Compose, CoordinateDescent, Initializer, MatrixFactorization,
-                  MultiplicativeUpdate, RandomInit, relative_error)
+from .nmf import (NMF, SVD, BCDSolver, Compose, CoordinateDescent, FastMultiplicativeUpdate, Initializer,
+                  LeastSquares, MatrixFactorization, MultiplicativeUpdate, NNDSVDInit, ProjectedGradient,
+                  RandomInit, SemiMultiplicativeUpdate, SVDInit, WeightedMultiplicativeUpdate, relative_error)
 from .layers import MLP, LayerNorm, Linear, PosEmbed, PositionalEmbedding
 from .convs import Conv3d, ConvTranspose3d
 from .blocks import FactMixer, FactorizerBlock, FactorizerStage

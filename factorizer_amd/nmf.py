@@ -100,30 +100,210 @@ class CoordinateDescent(BCDSolver):
         return composed.cd_update(x, u, v, self.eps, self.project)
 
 
-class Compose(nn.Module):
-    """Apply several solvers in sequence per iteration (matrix_factorization.py:386-400)."""
+def _gram(x, v):
+    """a = X V (M x R), b = V^T V (R x R): the two products every least-squares-type half-step needs"""
+    return x @ v, v.mT @ v
 
-    def __init__(self, solvers, **kwargs):
+
+def _pair_dot(p, q):
+    """<p, q> over the last two dims, kept as a trailing singleton (operations.py:13-29)"""
+    return (p * q).sum(dim=(-2, -1)).unsqueeze(-1)
+
+
+class LeastSquares(BCDSolver):
+    """Exact minimiser of ||X - U V^T|| over U, optionally projected ("ls", "nnls" with ReLU)
+    (matrix_factorization.py:139-165).  Tall X uses the pseudo-inverse of V, wide X the normal
+    equations — the reference's two branches, kept because they round differently."""
+
+    def __init__(self, factor=(0, 1), eps: float = 1e-16, project=None, **kwargs):
+        super().__init__(factor=factor)
+        self.eps = eps
+        self.project = partialize(nn.Identity if project is None else project)()
+
+    def update_u(self, x, u, v):
+        M, N = x.shape[-2:]
+        if M >= N:
+            sol = x @ torch.linalg.pinv(v).mT
+        else:
+            a, b = _gram(x, v)
+            sol = torch.linalg.solve(b, a.mT).mT
+        return self.project(sol)
+
+
+class ProjectedGradient(BCDSolver):
+    """One exact-line-search gradient step on ||X - U V^T||^2 followed by the projection
+    (matrix_factorization.py:168-191): g = XV - U V^T V, step = <g,g> / <g, g V^T V>."""
+
+    def __init__(self, factor=(0, 1), project=None, eps: float = 1e-16, **kwargs):
+        super().__init__(factor=factor)
+        self.eps = eps
+        self.project = partialize(nn.Identity if project is None else project)()
+
+    def update_u(self, x, u, v):
+        a, b = _gram(x, v)
+        g = a - u @ b
+        step = (_pair_dot(g, g) + self.eps) / (_pair_dot(g, g @ b) + self.eps)
+        return self.project(u + step.unsqueeze(-1) * g)
+
+
+class FastMultiplicativeUpdate(BCDSolver):
+    """The multiplicative update written as three-operand contractions, with an explicit V half-step
+    (matrix_factorization.py:250-274).  Algebraically the "mu" update; it differs in rounding only."""
+
+    def __init__(self, factor=(0, 1), eps: float = 1e-16, **kwargs):
+        super().__init__(factor=factor)
+        self.eps = eps
+
+    def update_u(self, x, u, v):
+        num = torch.einsum("...ij,...ir,...jr->...ir", x, u, v) + self.eps
+        den = torch.einsum("...is,...js,...jr->...ir", u, v, v) + self.eps
+        return num / den
+
+    def update_v(self, x, u, v):
+        num = torch.einsum("...ij,...ir,...jr->...jr", x, u, v) + self.eps
+        den = torch.einsum("...ir,...is,...js->...jr", u, u, v) + self.eps
+        return num / den
+
+
+class WeightedMultiplicativeUpdate(BCDSolver):
+    """Multiplicative update of min ||W ∘ (X - U V^T)||^2, U, V >= 0 (matrix_factorization.py:277-316);
+    `forward(x, (u, v), w=None)` — unit weights when `w` is omitted."""
+
+    def __init__(self, factor=(0, 1), eps: float = 1e-16, **kwargs):
+        super().__init__(factor=factor)
+        self.eps = eps
+
+    def update_u(self, x, u, v, w):
+        num = u * ((w * x) @ v) + self.eps
+        den = (w * (u @ v.mT)) @ v + self.eps
+        return num / den
+
+    def update_v(self, x, u, v, w):
+        return self.update_u(x.mT, v, u, w.mT)
+
+    def forward(self, x, factor_matrices, w=None):
+        u, v = factor_matrices
+        w = torch.ones_like(x) if w is None else w
+        for j in self.factor:
+            if j == 0:
+                u = self.update_u(x, u, v, w)
+            else:
+                v = self.update_v(x, u, v, w)
+        return u, v
+
+
+class SemiMultiplicativeUpdate(BCDSolver):
+    """Semi-NMF update (X of any sign, the updated factor >= 0), matrix_factorization.py:319-341:
+    U <- U ∘ sqrt((a+ + U b-) / (a- + U b+)) with a = XV, b = V^T V split into positive/negative parts."""
+
+    def __init__(self, factor=(0, 1), eps: float = 1e-16, **kwargs):
+        super().__init__(factor=factor)
+        self.eps = eps
+
+    def update_u(self, x, u, v):
+        a, b = _gram(x, v)
+        num = torch.relu(a) + u @ torch.relu(-b) + self.eps
+        den = torch.relu(-a) + u @ torch.relu(b) + self.eps
+        return u * torch.sqrt(num / den)
+
+
+class Compose(BCDSolver):
+    """Apply several solvers in sequence per iteration (matrix_factorization.py:344-378); indexable like
+    the reference's (`compose[i]`, `len(compose)`), `factor` = the member solvers' factor tuples."""
+
+    def __init__(self, solvers=None, **kwargs):
         super().__init__()
-        self.solvers = nn.ModuleList(partialize(s)(**kwargs) for s in solvers)
+        built = [partialize(s)(**kwargs) for s in as_tuple([] if solvers is None else solvers)]
+        self.solvers = nn.ModuleList(built)
+        self.factor = [getattr(m, "factor") for m in built]
+        self.size, self.rank = kwargs.get("size"), kwargs.get("rank")
 
     def forward(self, x, factor_matrices):
-        for s in self.solvers:
-            factor_matrices = s(x, factor_matrices)
-        return factor_matrices
+        u, v = factor_matrices
+        for m in self.solvers:
+            u, v = m(x, (u, v))
+        return u, v
+
+    def __setitem__(self, idx, solver):
+        self.solvers[idx] = solver
+
+    def __getitem__(self, idx):
+        return self.solvers[idx]
+
+    def __len__(self):
+        return len(self.solvers)
 
 
-class _Unavailable:
-    """Placeholder for solver/init keys of the reference that this build does not implement
-    (svd/nndsvd init, fmu/wmu/smu/ls/nnls solvers)."""
+class SVD(nn.Module):
+    """Truncated SVD layer (matrix_factorization.py:386-451): `torch.svd_lowrank` of rank R.  Like the
+    reference it re-seeds the GLOBAL torch RNG with 42 before every decomposition (:434) — a side
+    effect callers can observe, kept for drop-in behaviour."""
 
-    def __init__(self, key):
-        self.key = key
+    def __init__(self, size, rank: Optional[int] = None, compression: float = 10, no_grad: bool = False,
+                 verbose: bool = False):
+        super().__init__()
+        self.size = M, N = tuple(size)
+        self.no_grad = no_grad
+        assert (rank, compression) != (None, None), "'rank' or 'compression' must be specified."
+        if rank is None:
+            rank = max(math.ceil(M * N / (compression * (M + N))), 1)
+        self.rank = rank
+        self.compression = M * N / (rank * (M + N))
+        self.verbose = verbose
 
-    def __call__(self, *a, **k):
-        raise NotImplementedError(
-            f"'{self.key}' is outside the accelerated Factorizer hot path (uniform/normal init, "
-            "mu / hals / cd solvers); see DESIGN.md 'out of scope'.")
+    def context(self):
+        return torch.no_grad() if self.no_grad else nullcontext()
+
+    def decompose(self, x: Tensor):
+        with self.context():
+            torch.manual_seed(42)
+            u, s, v = torch.svd_lowrank(x, self.rank)
+            if self.verbose:
+                print(f"loss = {self.loss(x, u, s, v)}")
+        return u, s, v
+
+    def reconstruct(self, u, s, v):
+        return (u * s.unsqueeze(-2)) @ v.mT
+
+    def loss(self, x, u, s, v):
+        return relative_error(x, self.reconstruct(u, s, v))
+
+    def forward(self, x: Tensor) -> Tensor:
+        return self.reconstruct(*self.decompose(x))
+
+
+class SVDInit(Initializer):
+    """U0 = U sqrt(S), V0 = V sqrt(S) from the truncated SVD of the input (matrix_factorization.py:61-71)"""
+
+    def __init__(self, size, rank: Optional[int] = None):
+        super().__init__()
+        self.svd = SVD(size=size, rank=rank)
+
+    def forward(self, x: Tensor):
+        u, s, v = self.svd.decompose(x)
+        r = torch.sqrt(s).unsqueeze(-2)
+        return u * r, v * r
+
+
+class NNDSVDInit(Initializer):
+    """Non-negative double SVD start (matrix_factorization.py:74-100), input (B, M, N): per component keep
+    the sign pattern — positive parts (a+, b+) or negative parts (a-, b-) — with the larger
+    ||a±||·||b±||, chosen per batch element."""
+
+    def __init__(self, size, rank: Optional[int] = None):
+        super().__init__()
+        self.svd = SVD(size, rank)
+
+    def forward(self, x: Tensor):
+        u, s, v = self.svd.decompose(x)
+        r = torch.sqrt(s).unsqueeze(-2)
+        u, v = u * r, v * r
+        up, un, vp, vn = torch.relu(u), torch.relu(-u), torch.relu(v), torch.relu(-v)
+        # column norms over the row axis: (B, R)
+        pos = up.square().sum(-2).sqrt() * vp.square().sum(-2).sqrt()
+        neg = un.square().sum(-2).sqrt() * vn.square().sum(-2).sqrt()
+        keep_pos = (pos >= neg).unsqueeze(-2)
+        return torch.where(keep_pos, up, un), torch.where(keep_pos, vp, vn)
 
 
 INIT_DISPATCH_MAP = {
@@ -131,8 +311,8 @@ INIT_DISPATCH_MAP = {
     "normal": (RandomInit, {"method": "normal"}),
     "normal-uniform": (RandomInit, {"method": ("normal", "uniform")}),
     "uniform-normal": (RandomInit, {"method": ("uniform", "normal")}),
-    "svd": _Unavailable("svd"),
-    "nndsvd": _Unavailable("nndsvd"),
+    "svd": SVDInit,
+    "nndsvd": NNDSVDInit,
 }
 
 SOLVER_DISPATCH_MAP = {
@@ -148,13 +328,23 @@ SOLVER_DISPATCH_MAP = {
     "hals": (CoordinateDescent, {"project": nn.ReLU}),
     "hals-0": (CoordinateDescent, {"factor": 0, "project": nn.ReLU}),
     "hals-1": (CoordinateDescent, {"factor": 1, "project": nn.ReLU}),
+    "fmu": FastMultiplicativeUpdate,
+    "fmu-0": (FastMultiplicativeUpdate, {"factor": 0}),
+    "fmu-1": (FastMultiplicativeUpdate, {"factor": 1}),
+    "wmu": WeightedMultiplicativeUpdate,
     # the reference maps "wmu-0"/"wmu-1" to the plain multiplicative update (:598-599)
     "wmu-0": (MultiplicativeUpdate, {"factor": 0}),
     "wmu-1": (MultiplicativeUpdate, {"factor": 1}),
+    "smu": SemiMultiplicativeUpdate,
+    "smu-0": (SemiMultiplicativeUpdate, {"factor": 0}),
+    "smu-1": (SemiMultiplicativeUpdate, {"factor": 1}),
+    "ls": LeastSquares,
+    "ls-0": (LeastSquares, {"factor": 0}),
+    "ls-1": (LeastSquares, {"factor": 1}),
+    "nnls": (LeastSquares, {"project": nn.ReLU}),
+    "nnls-0": (LeastSquares, {"factor": 0, "project": nn.ReLU}),
+    "nnls-1": (LeastSquares, {"factor": 1, "project": nn.ReLU}),
 }
-for _k in ("fmu", "fmu-0", "fmu-1", "wmu", "smu", "smu-0", "smu-1", "ls", "ls-0", "ls-1", "nnls",
-           "nnls-0", "nnls-1"):
-    SOLVER_DISPATCH_MAP[_k] = _Unavailable(_k)
 
 
 def _parse_init(obj):

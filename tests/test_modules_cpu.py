@@ -107,8 +107,9 @@ def test_solver_string_table_and_partial_specs():
     comp = ft.NMF((8, 16), rank=2, solver=["mu", "hals"])
     assert isinstance(comp.solver, ft.Compose) and len(comp.solver.solvers) == 2
     ft.NMF((8, 16), rank=2, solver=[ft.MultiplicativeUpdate, {"eps": 1e-8}])  # YAML-style list spec
-    with pytest.raises(NotImplementedError):
-        ft.NMF((8, 16), rank=2, solver="fmu")
+    assert isinstance(ft.NMF((8, 16), rank=2, solver="fmu").solver, ft.FastMultiplicativeUpdate)
+    assert isinstance(ft.NMF((8, 16), rank=2, solver="nnls-1").solver.project, nn.ReLU)
+    assert isinstance(ft.NMF((8, 16), rank=2, init="nndsvd").init, ft.NNDSVDInit)
     with pytest.raises(ValueError):
         ft.NMF((8, 16), rank=2, solver="nope")
     f = ft.partialize((nn.Linear, (3,), {"out_features": 4}))
@@ -318,3 +319,59 @@ def test_load_checkpoint_interchange(tmp_path):
     ft.load_checkpoint({"network": dst}, src.state_dict())     # a bare state_dict
     with pytest.raises(KeyError):
         ft.load_checkpoint({"optimizer": dst}, {"network": src.state_dict(), "x": 1})
+
+
+# ---- remaining solver / initialiser keys ----------------------------------------------
+F3_CASES = {"fmu": dict(solver="fmu", init="uniform"), "smu": dict(solver="smu", init="uniform"),
+            "ls": dict(solver="ls", init="uniform"), "nnls": dict(solver="nnls", init="uniform"),
+            "cd": dict(solver="cd", init="normal"), "nncd": dict(solver="nncd", init="uniform"),
+            "mu_0": dict(solver="mu-0", init="uniform"), "hals_1": dict(solver="hals-1", init="uniform"),
+            "compose_mu_hals": dict(solver=["mu", "hals"], init="uniform"),
+            "compose_ls1_nnls0": dict(solver=["ls-1", "nnls-0"], init="uniform-normal"),
+            "mu_svd": dict(solver="mu", init="svd"), "hals_nndsvd": dict(solver="hals", init="nndsvd"),
+            "ls_tall": dict(solver="ls", init="uniform")}
+
+
+@pytest.mark.parametrize("name", sorted(F3_CASES))
+def test_solver_and_init_keys_vs_reference(golden, name):
+    """Every key of the reference's INIT / SOLVER dispatch tables (matrix_factorization.py:581-618)
+    against outputs of the reference itself (tests/golden/g8_solvers.npz, tools/make_goldens.py:g8)."""
+    g = golden("g8_solvers").case(name)
+    kw = dict(F3_CASES[name])
+    torch.manual_seed(0)
+    mf = ft.MatrixFactorization(size=tuple(g["x"].shape[-2:]), rank=2, num_iters=3, **kw)
+    x = g["x"].clone().requires_grad_(True)
+    u0, v0 = mf.init(x)
+    tol = dict(rtol=2e-4, atol=2e-5) if kw["init"] in ("svd", "nndsvd") else dict(rtol=1e-5, atol=1e-6)
+    assert torch.allclose(u0, g["u_init"], **tol) and torch.allclose(v0, g["v_init"], **tol)
+    u, v = mf.decompose(x)
+    y = mf(x)
+    assert torch.allclose(u, g["u"], **tol) and torch.allclose(v, g["v"], **tol)
+    assert torch.allclose(y, g["y"], **tol)
+    if "gx" in g:
+        (gx,) = torch.autograd.grad(y, x, g["gy"])
+        s = g["gx"].abs().max().item()
+        assert (gx - g["gx"]).abs().max().item() <= 1e-4 * s + 1e-6
+
+
+def test_weighted_mu_and_svd_layer_vs_reference(golden):
+    g = golden("g8_solvers").case("wmu")
+    torch.manual_seed(0)
+    mf = ft.NMF(size=(8, 24), rank=2, num_iters=3, init="uniform", solver="wmu")
+    u, v = mf.decompose(g["x"], g["w"])
+    assert torch.allclose(u, g["u"], rtol=1e-5, atol=1e-6) and torch.allclose(v, g["v"], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(mf.loss(g["x"], u, v, g["w"]), g["loss"], rtol=1e-5, atol=1e-7)
+    s = golden("g8_solvers").case("svd")
+    from factorizer_amd.nmf import SVD
+    torch.manual_seed(123)
+    y = SVD(size=(8, 24), rank=3)(s["x"])
+    assert torch.allclose(y, s["y"], rtol=2e-4, atol=2e-5)
+    assert torch.initial_seed() == 42   # the reference's global re-seed (matrix_factorization.py:434)
+
+
+def test_compose_is_a_sequence_of_solvers():
+    from factorizer_amd.nmf import Compose, MultiplicativeUpdate, CoordinateDescent
+    c = Compose(["mu", ("hals-1", {})] if False else [MultiplicativeUpdate, (CoordinateDescent, {"factor": 1})],
+                size=(8, 16), rank=2)
+    assert len(c) == 2 and isinstance(c[0], MultiplicativeUpdate) and c.factor == [(0, 1), (1,)]
+    assert c.size == (8, 16) and c.rank == 2

@@ -215,9 +215,55 @@ def g7():
     npz("g7_layers", **arrs)
 
 
+def g8():
+    """the remaining solver / initialiser keys of the dispatch tables
+    (matrix_factorization.py:581-618) on (3, 8, 24), rank 2, 3 iterations."""
+    arrs = {}
+    cases = {"fmu": dict(solver="fmu", init="uniform"), "smu": dict(solver="smu", init="uniform"),
+             "ls": dict(solver="ls", init="uniform"), "nnls": dict(solver="nnls", init="uniform"),
+             "cd": dict(solver="cd", init="normal"), "nncd": dict(solver="nncd", init="uniform"),
+             "mu_0": dict(solver="mu-0", init="uniform"), "hals_1": dict(solver="hals-1", init="uniform"),
+             "compose_mu_hals": dict(solver=["mu", "hals"], init="uniform"),
+             "compose_ls1_nnls0": dict(solver=["ls-1", "nnls-0"], init="uniform-normal"),
+             "mu_svd": dict(solver="mu", init="svd"), "hals_nndsvd": dict(solver="hals", init="nndsvd"),
+             "ls_tall": dict(solver="ls", init="uniform", shape=(2, 24, 8))}
+    for name, kw in cases.items():
+        kw = dict(kw)
+        shape = kw.pop("shape", (3, 8, 24))
+        torch.manual_seed(0)
+        mf = ft.MatrixFactorization(size=shape[-2:], rank=2, num_iters=3, **kw)
+        torch.manual_seed(5)
+        x = (torch.rand(*shape) if kw["solver"] != "cd" else torch.randn(*shape)).requires_grad_(True)
+        u0, v0 = mf.init(x)
+        u, v = mf.decompose(x)
+        y = mf(x)
+        arrs.update({f"{name}:x": x, f"{name}:u_init": u0, f"{name}:v_init": v0, f"{name}:u": u, f"{name}:v": v,
+                     f"{name}:y": y})
+        if kw["init"] not in ("svd", "nndsvd"):
+            torch.manual_seed(1)
+            gy = torch.rand_like(y)
+            (gx,) = torch.autograd.grad(y, x, gy)
+            arrs.update({f"{name}:gy": gy, f"{name}:gx": gx})
+    # weighted multiplicative update: the weights travel through decompose(x, w)
+    torch.manual_seed(0)
+    mf = ft.NMF(size=(8, 24), rank=2, num_iters=3, init="uniform", solver="wmu")
+    torch.manual_seed(5)
+    x, w = torch.rand(3, 8, 24), torch.rand(3, 8, 24)
+    u, v = mf.decompose(x, w)
+    arrs.update({"wmu:x": x, "wmu:w": w, "wmu:u": u, "wmu:v": v, "wmu:loss": mf.loss(x, u, v, w)})
+    # SVD layer
+    svd = ft.SVD(size=(8, 24), rank=3) if hasattr(ft, "SVD") else None
+    if svd is None:
+        from factorizer.factorization.matrix_factorization import SVD
+        svd = SVD(size=(8, 24), rank=3)
+    arrs.update({"svd:x": x, "svd:y": svd(x)})
+    npz("g8_solvers", **arrs)
+
+
 if __name__ == "__main__":
     g1()
     g2_g4()
     g5()
     g6()
     g7()
+    g8()
