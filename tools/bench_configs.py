@@ -121,7 +121,37 @@ def prod():
                       "windows": 18}))
 
 
+def cfg5(batches=(1, 2, 4)):
+    """BASELINE configs[4] (SURVEY "cfg 5"), one GPU's share: 160x192x160 volumes, rank 2, 10 iterations.
+    p = 8 does not divide the deeper stages of this shape (SURVEY headline 5), so the patch is (5, 6, 5)
+    (N = 150: the masked 8x<=512 NMF family through the modular matricize -> NMF -> inverse kernels).
+    fp32 throughout: the native kernels do not take the bf16 shortcut of the stress config."""
+    torch.manual_seed(0)
+    model = ft.Factorizer(in_channels=4, out_channels=3, spatial_size=(160, 192, 160), norm=ft.LayerNorm,
+                          reshape=(ft.SWMatricize, {"head_dim": 8, "patch_size": (5, 6, 5)}), act=nn.ReLU,
+                          factorize=ft.NMF, rank=2, num_iters=10, init="uniform", solver="hals", mlp_ratio=2,
+                          dropout=0.1).to(DEV).train()
+    for B in batches:
+        x = torch.rand(B, 4, 160, 192, 160, device=DEV)
+        t = (torch.rand(B, 3, 160, 192, 160, device=DEV) > 0.5).float()
+
+        def fb():
+            for p in model.parameters():
+                p.grad = None
+            loss = ft.dice_bce_loss(model(x), t)
+            loss.backward()
+            return loss
+        torch.cuda.reset_peak_memory_stats()
+        loss = fb()
+        assert torch.isfinite(loss).item()
+        ms = gpu_time(fb, 3, 1)
+        print(json.dumps({"config": f"cfg5 stress shape 160x192x160, HALS R2 T10, patch (5,6,5), fp32, fwd+bwd B={B}",
+                          "ms": round(ms, 2), "volumes_per_s": round(B / ms * 1e3, 2),
+                          "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1)}), flush=True)
+        del x, t
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["cfg1", "cfg2", "cfg3", "prod"]
     for name in which:
-        {"cfg1": cfg1, "cfg2": cfg2, "cfg3": cfg3, "prod": prod}[name]()
+        {"cfg1": cfg1, "cfg2": cfg2, "cfg3": cfg3, "prod": prod, "cfg5": cfg5}[name]()
