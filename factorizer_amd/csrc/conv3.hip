@@ -135,16 +135,16 @@ struct Conv3WgradArgs {
   int tiles_per_unit;
 };
 
-constexpr int kXs = 36;  // halo row stride (34 used)
+constexpr int kXs = 40;  // halo row stride: [3] = w0-1, [4..35] = the 32 interior voxels (16-byte aligned), [36] = w0+32
 
 template <int KB>  // KB = number of 32-column blocks covering 27*Cin (4 for Cin = 4)
 __global__ __launch_bounds__(256) void conv3_wgrad_kernel(Conv3WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nrow = a.Cin * 9;                      // halo rows per tile
-  const int per_wave = 32 * 33 + nrow * kXs;
-  float* Pt = lds + wave * per_wave;               // [32][33] gY tile
-  float* Xs = Pt + 32 * 33;                        // [Cin*9][36] halo rows (index 0 = w0-1)
+  const int nrow = a.Cin * 9;                      // halo rows per tile (<= 36: host-checked)
+  const int per_wave = 32 * 36 + 36 * kXs;
+  float* Pt = lds + wave * per_wave;               // [32][36] gY tile
+  float* Xs = Pt + 32 * 36;                        // [Cin*9][40] halo rows
   const int K = 27 * a.Cin;
   const int m0 = blockIdx.y * 32;
   const int64_t V = (int64_t)a.D * a.H * a.W;
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(Conv3WgradArgs a) {
     const int k = jb * 32 + c;
     const int kc = k < K ? k : 0;
     const int ci = kc / 27, tap = kc % 27;
-    xoff[jb] = (ci * 9 + tap / 3) * kXs + (tap % 3);  // row (ci,kd,kh), shift kw
+    xoff[jb] = (ci * 9 + tap / 3) * kXs + 3 + (tap % 3);  // row (ci,kd,kh), shift kw
   }
   f32x16 acc[KB];
 #pragma unroll
@@ -170,37 +170,73 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(Conv3WgradArgs a) {
     for (int r = 0; r < 16; ++r) acc[jb][r] = 0.f;
   float psum = 0.f;
 
-  for (int64_t t = t_begin; t < t_end; ++t) {
+  // Static per-lane staging plan (tile-invariant): 5 interior chunks (row q>>3, 16-byte chunk q&7 of
+  // the 32 aligned interior voxels; 36 rows x 8 = 288 chunks) and 2 edge voxels (w0-1 / w0+32 of
+  // row id>>1; 72 of them).  The next tile's 4 + 5 + 2 loads are issued before the MFMA loop of
+  // the current one (the old per-element halo gather — 20 dependent scalar loads with div/mod
+  // index math per lane and tile, not prefetched — was 2/3 of the kernel's time).
+  float4 pv[4], hv[5];
+  float ev[2];
+  auto issue = [&](int64_t t) {
     const int b = (int)(t / tiles_per_sample);
     const int64_t n0 = (t % tiles_per_sample) * 32;
     const int w0 = (int)(n0 % a.W);
     const int h0 = (int)((n0 / a.W) % a.H);
     const int d0 = (int)(n0 / ((int64_t)a.W * a.H));
-    // gY tile: 32 rows x 8 chunks of 16 bytes = 4 chunks per lane
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = (lane >> 3) + 8 * i, cq = lane & 7;
       const int m = m0 + r;
       const int mc = m < a.M ? m : a.M - 1;
       const float4 v = *reinterpret_cast<const float4*>(a.gy + ((int64_t)b * a.M + mc) * V + n0 + cq * 4);
-      const bool ok = m < a.M;
-      float* d = Pt + r * 33 + cq * 4;
-      d[0] = ok ? v.x : 0.f; d[1] = ok ? v.y : 0.f; d[2] = ok ? v.z : 0.f; d[3] = ok ? v.w : 0.f;
+      pv[i] = m < a.M ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    // halo rows: nrow x 34 floats (w0-1 .. w0+32), zero padded
-    for (int idx = lane; idx < nrow * 34; idx += 64) {
-      const int rr = idx / 34, e = idx % 34;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int q = lane + 64 * i;
+      const int rr = min(q >> 3, nrow - 1), cq = q & 7;
       const int ci = rr / 9, kd = (rr % 9) / 3, kh = rr % 3;
-      const int zd = d0 + kd - 1, zh = h0 + kh - 1, zw = w0 + e - 1;
-      const bool ok = zd >= 0 && zd < a.D && zh >= 0 && zh < a.H && zw >= 0 && zw < a.W;
+      const int zd = d0 + kd - 1, zh = h0 + kh - 1;
+      const bool ok = (q >> 3) < nrow && zd >= 0 && zd < a.D && zh >= 0 && zh < a.H;
+      const int zdc = min(max(zd, 0), a.D - 1), zhc = min(max(zh, 0), a.H - 1);
+      const float4 v = *reinterpret_cast<const float4*>(a.x + ((int64_t)b * a.Cin + ci) * V +
+                                                        ((int64_t)zdc * a.H + zhc) * a.W + w0 + cq * 4);
+      hv[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int id = lane + 64 * i;
+      const int rr = min(id >> 1, nrow - 1), side = id & 1;
+      const int ci = rr / 9, kd = (rr % 9) / 3, kh = rr % 3;
+      const int zd = d0 + kd - 1, zh = h0 + kh - 1, zw = side ? w0 + 32 : w0 - 1;
+      const bool ok = (id >> 1) < nrow && zd >= 0 && zd < a.D && zh >= 0 && zh < a.H && zw >= 0 && zw < a.W;
       const int zdc = min(max(zd, 0), a.D - 1), zhc = min(max(zh, 0), a.H - 1), zwc = min(max(zw, 0), a.W - 1);
       const float v = a.x[((int64_t)b * a.Cin + ci) * V + ((int64_t)zdc * a.H + zhc) * a.W + zwc];
-      Xs[rr * kXs + e] = ok ? v : 0.f;
+      ev[i] = ok ? v : 0.f;
+    }
+  };
+
+  if (t_begin < t_end) issue(t_begin);
+  for (int64_t t = t_begin; t < t_end; ++t) {
+    // registers -> LDS
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<float4*>(Pt + ((lane >> 3) + 8 * i) * 36 + (lane & 7) * 4) = pv[i];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int q = lane + 64 * i;
+      if (q < 288) *reinterpret_cast<float4*>(Xs + (q >> 3) * kXs + 4 + (q & 7) * 4) = hv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int id = lane + 64 * i;
+      if (id < 72) Xs[(id >> 1) * kXs + ((id & 1) ? 36 : 3)] = ev[i];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (t + 1 < t_end) issue(t + 1);  // in flight during the MFMA loop
 #pragma unroll 4
     for (int s = 0; s < 16; ++s) {
-      const float av = Pt[c * 33 + 2 * s + h];
+      const float av = Pt[c * 36 + 2 * s + h];
       psum += av;
 #pragma unroll
       for (int jb = 0; jb < KB; ++jb) {
@@ -284,11 +320,11 @@ extern "C" int fz_conv3_wgrad_chunks(int B, int D, int H, int W) {
 extern "C" int fz_conv3_wgrad_partials(const float* gy, const float* x, float* part, float* part_bias, int B, int Cin,
                                        int M, int D, int H, int W, fz_stream_t stream) {
   if (!gy || !x || !part || !part_bias) return fail(FZ_E_ARG, "fz_conv3_wgrad: null pointer");
-  if (B < 1 || Cin < 1 || M < 1 || (W % 32) || 27 * Cin > 128)
-    return fail(FZ_E_UNSUPPORTED, "fz_conv3_wgrad: needs W % 32 == 0 and 27*C_in <= 128");
+  if (B < 1 || Cin < 1 || M < 1 || (W % 32) || 27 * Cin > 128 || Cin * 9 > 36)
+    return fail(FZ_E_UNSUPPORTED, "fz_conv3_wgrad: needs W % 32 == 0 and C_in <= 4");
   Conv3WgradArgs a{gy, x, part, part_bias, B, Cin, M, D, H, W, 1};
   const int nchunk = conv3_units(((int64_t)D * H * W / 32) * B, &a.tiles_per_unit);
-  const size_t lds = (size_t)4 * (32 * 33 + Cin * 9 * kXs) * sizeof(float);
+  const size_t lds = (size_t)4 * (32 * 36 + 36 * kXs) * sizeof(float);
   const size_t lds_red = 4096 * sizeof(float);
   dim3 grid(nchunk, (M + 31) / 32), block(256);
   hipLaunchKernelGGL(conv3_wgrad_kernel<4>, grid, block, lds > lds_red ? lds : lds_red, (hipStream_t)stream, a);
