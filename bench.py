@@ -43,8 +43,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s mea
 PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
 # timer key of a BASELINE-size (stage-0) launch -> kernel name in the PMC summary; the summary averages
 # the launches with the largest grid of each kernel, i.e. the same stage-0 launches the key times
-PMC_KERNEL = {"nmf_cf_bwd_32x128x128x128": "fz::nmf_cf_bwd_tile_kernel<1, 1, 4>",
-              "nmf_cf_fwd_32x128x128x128": "fz::nmf_cf_fwd_tile_kernel<1, 1, 8>",
+PMC_KERNEL = {"nmf_cf_bwd_32x128x128x128": "fz::nmf_cf_bwd_tile_kernel<1, 1, 4, false>",
+              "nmf_cf_fwd_32x128x128x128": "fz::nmf_cf_fwd_tile_kernel<1, 1, 8, false>",
               "mlp_chain_bwd_32": "fz::gemm_chain_kernel<true, 2>",
               "mlp_chain_fwd_32": "fz::gemm_chain_kernel<false, 2>"}
 
