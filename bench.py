@@ -176,6 +176,22 @@ def main():
         elapsed = float(t.item())
     assert torch.isfinite(loss).item(), "loss is not finite"
 
+    copy_gbs = None
+    if rank == 0:
+        # context for the roofline fraction: what a plain device-to-device copy of one stage-0 activation
+        # (537 MB read + 537 MB written) reaches on THIS box (4.6-5.3 TB/s; the 8 TB/s spec is not reachable)
+        src = torch.empty(2 * 32 * 128 ** 3, device=dev)
+        dst = torch.empty_like(src)
+        for _ in range(2):
+            dst.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = round(5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+        del src, dst
     if rank == 0:
         agg = timer.summary()
         roof = None
@@ -188,6 +204,7 @@ def main():
                     "avg_launch_ms": round(avg_ms, 4), "launches": a["calls"],
                     "algorithmic_bytes_per_launch": a["bytes"] // a["calls"],
                     "share_of_step": round(a["ms"] / (elapsed * 1e3), 4),
+                    "device_copy_GBps_this_box": copy_gbs,
                     "timed_with_events": "dominant kernel only (chosen from the fully instrumented warm-up steps)"
                     if dominant is not None else "all native launches",
                     "native_kernels_ms_per_step": {k: round(v["ms"] / max(args.warmup, 1), 3) for k, v in (wagg or agg).items()},
