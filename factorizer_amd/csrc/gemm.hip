@@ -763,8 +763,15 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgs p) {
   // operand prefetch depth (load steps): narrow tiles are latency-bound (L2 round trip ≈ 500-900
   // cycles vs 64·NACC MFMA cycles per step), so they keep more loads in flight
   constexpr int kPF = (NL == 4) ? 8 : 16;
+  // Without the K-split the weight chunks are DOUBLE-BUFFERED: the next chunk's weights travel global →
+  // registers while the MFMAs of the current chunk run, and are stored to the other LDS buffer
+  // afterwards (one barrier per chunk).  Exposed fills were 15-20 % of the K >= 256 GEMMs and convs.
+  constexpr bool DB = (KS == 1);
+  constexpr int CH = DB ? kAChunk / 2 : kAChunk;                 // A steps per chunk
+  constexpr int kBufFloats = CH * MB * 64;
+  constexpr int NWR = kBufFloats / 256;                          // staged weights per thread and chunk
   constexpr int kRedFloats = (KS > 1) ? (KS - 1) * (MB * NACC * 16 + 2 * NACC) * 64 : 0;
-  constexpr int kAsFloats = kAChunk * MB * 64 > kRedFloats ? kAChunk * MB * 64 : kRedFloats;
+  constexpr int kAsFloats = (DB ? 2 : 1) * kBufFloats > kRedFloats ? (DB ? 2 : 1) * kBufFloats : kRedFloats;
   __shared__ float As[kAsFloats];
   __shared__ float sW[32 * MB];
   __shared__ float tW[32 * MB];
@@ -891,43 +898,45 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgs p) {
     }
   }
 
-  for (int a0 = 0; a0 < nA; a0 += kAChunk) {
-    const int an = min(kAChunk, nA - a0);
-    __syncthreads();
-    // batched fill: issue 8 independent weight loads per thread before the LDS stores, so the
-    // (L2-resident) weight fetch latency overlaps instead of serialising load→store pairs
-    // steps are processed in groups of kPF*ASTEP with NO per-step guard (a guard turns every K-step
-    // into its own basic block: ds_read → s_waitcnt lgkmcnt(0) → MFMA, fully serialised); the tail
-    // of the last group gets zero weights instead
-    constexpr int kGroup = kPF * ((LOADER == LOAD_S2D) ? 2 : 1);
-    static_assert(kAChunk % (KS * kGroup) == 0, "chunk must hold whole rounds of K-split groups");
-    const int an_pad = ((an + KS * kGroup - 1) / (KS * kGroup)) * (KS * kGroup);
-    for (int base = threadIdx.x; base < (p.dbg == 3 ? 0 : an_pad * MB * 64); base += blockDim.x * 8) {
-      float tmp[8];
+  constexpr int kGroup = kPF * ((LOADER == LOAD_S2D) ? 2 : 1);
+  static_assert(CH % (KS * kGroup) == 0, "chunk must hold whole rounds of (K-split) prefetch groups");
+  // steps are processed in groups of kPF*ASTEP with NO per-step guard (a guard turns every K-step into
+  // its own basic block: ds_read → s_waitcnt lgkmcnt(0) → MFMA, fully serialised); the tail of the
+  // last group gets zero weights instead
+  float wreg[NWR];
+  // weights of chunk [a0, a0+an) in operand order → registers; branch-free (clamped address + select)
+  auto load_chunk = [&](int a0, int an) {
 #pragma unroll
-      for (int uu = 0; uu < 8; ++uu) {
-        const int idx = base + uu * blockDim.x;
-        float wv = 0.f;
-        if (idx < an * MB * 64) {
-          const int l = idx & 63;
-          const int mb = (idx >> 6) % MB;
-          const int a = a0 + idx / (64 * MB);
-          const int m = m0 + mb * 32 + (l & 31);
-          const int k = a_k<LOADER>(a, l >> 5);
-          if (m < p.M && k < p.K) {
-            wv = weight_at(p, m, k);
-            if (PRO == PRO_LN) wv *= p.ln_g[k];
-          }
-        }
-        tmp[uu] = wv;
-      }
-#pragma unroll
-      for (int uu = 0; uu < 8; ++uu) {
-        const int idx = base + uu * blockDim.x;
-        if (idx < an_pad * MB * 64) As[idx] = tmp[uu];
-      }
+    for (int uu = 0; uu < NWR; ++uu) {
+      const int idx = threadIdx.x + uu * 256;
+      const int l = idx & 63;
+      const int mb = (idx >> 6) % MB;
+      const int a = a0 + idx / (64 * MB);
+      const int m = m0 + mb * 32 + (l & 31);
+      const int kk = a_k<LOADER>(a, l >> 5);
+      const bool ok = idx < an * MB * 64 && m < p.M && kk < p.K && p.dbg != 3;
+      const int mc = m < p.M ? m : p.M - 1, kc = kk < p.K ? kk : p.K - 1;
+      float wv = weight_at(p, mc, kc);
+      if (PRO == PRO_LN) wv *= p.ln_g[kc];
+      wreg[uu] = ok ? wv : 0.f;
     }
-    __syncthreads();
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int uu = 0; uu < NWR; ++uu) As[buf * kBufFloats + threadIdx.x + uu * 256] = wreg[uu];
+  };
+
+  __syncthreads();  // sW / tW (and the previous use of LDS) settled
+  load_chunk(0, min(CH, nA));
+  store_chunk(0);
+  __syncthreads();
+  int cbuf = 0;
+  for (int a0 = 0; a0 < nA; a0 += CH) {
+    const int an = min(CH, nA - a0);
+    const int an_pad = ((an + KS * kGroup - 1) / (KS * kGroup)) * (KS * kGroup);
+    const bool more = a0 + CH < nA;
+    if (DB && more) load_chunk(a0 + CH, min(CH, nA - a0 - CH));  // in flight during the MFMAs below
+    const float* Ab = As + cbuf * kBufFloats;
     constexpr int ASTEP = (LOADER == LOAD_S2D) ? 2 : 1;
     // kAChunk is a multiple of kPF*ASTEP, so the ring slot of a step is static after unrolling
     for (int al = (KS > 1 ? wave * kPF * ASTEP : 0); al < an_pad; al += KS * kPF * ASTEP) {
@@ -946,8 +955,8 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgs p) {
           if (LOADER == LOAD_S2D) {
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
-              const float av0 = As[(ali * MB + mb) * 64 + lane];        // tw = 0
-              const float av1 = As[((ali + 1) * MB + mb) * 64 + lane];  // tw = 1
+              const float av0 = Ab[(ali * MB + mb) * 64 + lane];        // tw = 0
+              const float av1 = Ab[((ali + 1) * MB + mb) * 64 + lane];  // tw = 1
               acc[mb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, cur[0], acc[mb][0], 0, 0, 0);
               acc[mb][1 % NACC] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, cur[2 % NL], acc[mb][1 % NACC], 0, 0, 0);
               acc[mb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, cur[1 % NL], acc[mb][0], 0, 0, 0);
@@ -978,7 +987,7 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgs p) {
             }
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
-              const float av = As[(ali * MB + mb) * 64 + lane];
+              const float av = Ab[(ali * MB + mb) * 64 + lane];
 #pragma unroll
               for (int q = 0; q < NACC; ++q)
                 acc[mb][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bvv[q], acc[mb][q], 0, 0, 0);
@@ -986,6 +995,18 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgs p) {
           }
         }
       }
+    }
+    // next chunk: registers → the other buffer (double-buffered) or, with the K-split, a plain refill
+    if (more) {
+      if (DB) {
+        store_chunk(cbuf ^ 1);
+        cbuf ^= 1;
+      } else {
+        __syncthreads();  // everyone is done reading the single buffer
+        load_chunk(a0 + CH, min(CH, nA - a0 - CH));
+        store_chunk(0);
+      }
+      __syncthreads();
     }
   }
 
