@@ -61,6 +61,7 @@ struct GemmArgs {
   int B;
   int dbg;             // diagnostics (FZ_GEMM_DBG): 3 = skip the weight staging
   int tile_map;        // workgroup -> column-tile order: 0 linear, 1 XCD-contiguous, 2 scattered
+  int ygroups, xtiles; // streaming kernel: > 1 row-block groups -> 1-D XCD-aware grid of xtiles column tiles
   // EPI_LNBWD (M == 32): the result is gl = dL/d(LN output); the epilogue applies the LayerNorm
   // backward in registers: y = rstd*(gl*g - mean_c(gl*g) - n*mean_c(gl*g*n)) + lnb_gadd
   const float* lnb_x;      // (B, 32, V) LayerNorm input
@@ -780,9 +781,20 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgs p) {
   const int j = lane & 31, h = lane >> 5;
   constexpr int WT = (KS > 1) ? 1 : 4;  // column tiles per workgroup
   const int tiles_per_sample = (int)((p.Ncol + TN * WT - 1) / (TN * WT));
-  const int b = blockIdx.x / tiles_per_sample;
-  const int64_t n0 = ((int64_t)(blockIdx.x % tiles_per_sample) * WT + (KS > 1 ? 0 : wave)) * TN;
-  const int m0 = blockIdx.y * 32 * MB;
+  // Workgroup -> (column tile bx, row-block group by).  With several row-block groups (M > 32·MB) the
+  // grid is 1-D and XCD-aware: workgroups are dealt round-robin over the 8 XCDs, so the `ygroups`
+  // groups of ONE column tile are given consecutive slots of the SAME XCD — they run concurrently and
+  // share the operand tile in that XCD's L2 instead of each pulling it from HBM / Infinity Cache.
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (p.ygroups > 1) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    by = slot % p.ygroups;
+    bx = (slot / p.ygroups) * 8 + xcd;
+    if (bx >= p.xtiles) return;  // padding of the last round (before any barrier)
+  }
+  const int b = bx / tiles_per_sample;
+  const int64_t n0 = ((int64_t)(bx % tiles_per_sample) * WT + (KS > 1 ? 0 : wave)) * TN;
+  const int m0 = by * 32 * MB;
   const int nA = (p.K + 1) / 2;
 
   if (PRO == PRO_LN) {
@@ -1060,7 +1072,7 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgs p) {
       mu_d[e] = md;
       rstd[e] = 1.0f / sqrtf(var + p.ln_eps);
     }
-    if (p.stats_out != nullptr && blockIdx.y == 0 && h == 0 && col_ok) {
+    if (p.stats_out != nullptr && by == 0 && h == 0 && col_ok) {
       float mean[NACC];
 #pragma unroll
       for (int e = 0; e < NACC; ++e) mean[e] = shift[e] + mu_d[e];
@@ -1128,6 +1140,7 @@ extern "C" int fz_gemm(const fz_gemm_desc* d, fz_stream_t stream) {
   a.emul_kind = d->emul_kind; a.y = d->y; a.Ncol = d->Ncol; a.Ho = d->Ho; a.Wo = d->Wo; a.B = d->B;
   { const char* e = getenv("FZ_GEMM_DBG"); a.dbg = e ? atoi(e) : 0; }
   { const char* e = getenv("FZ_GEMM_TILEMAP"); a.tile_map = e ? atoi(e) : 1; }
+  a.ygroups = 0; a.xtiles = 0;
   a.lnb_x = d->lnb_x; a.lnb_stats = d->lnb_stats; a.lnb_g = d->lnb_g; a.lnb_gadd = d->lnb_gadd; a.lnb_part = d->lnb_part;
   hipStream_t st = (hipStream_t)stream;
   const int mblocks = (d->M + 31) / 32;
@@ -1163,6 +1176,10 @@ extern "C" int fz_gemm(const fz_gemm_desc* d, fz_stream_t stream) {
     return FZ_OK;
   }
 
+  // (A persistent variant of the streaming kernel — whole weight block resident, the prefetch ring running
+  // across tile boundaries — was measured for 32 < K <= 128 at stages 0/1 and was not faster:
+  // those GEMMs sit at 56-71 TFLOP/s of fp32 MFMA with the operand loads as the stall reason, not the
+  // per-tile prologue / epilogue; tools/debug/persist_probe.py.)
   // ---- Kernel B: streaming; pick the column-tile width so the grid fills the chip ----
   // tile choice from a sweep on MI355X (tools/debug/gemm_probe3.py, FZ_GEMM_CFG): take the widest
   // column tile that still gives >= 256 workgroups (one per CU); two row blocks per workgroup only
@@ -1197,7 +1214,16 @@ extern "C" int fz_gemm(const fz_gemm_desc* d, fz_stream_t stream) {
   }
   const int WT = ks > 1 ? 1 : 4;
   const int64_t tiles = (d->Ncol + TN * WT - 1) / (TN * WT);
-  dim3 grid((unsigned)(tiles * d->B), (unsigned)((mblocks + MBsel - 1) / MBsel)), block(256);
+  const int ygr = (mblocks + MBsel - 1) / MBsel;
+  int xcd_grid = 1;
+  { const char* e = getenv("FZ_GEMM_XCDGRID"); if (e) xcd_grid = atoi(e); }
+  // (only where the COLUMN operand dominates the traffic: few row-block groups, many column tiles;
+  // with e.g. 32 groups x 16 tiles — the deep transposed convs — the weights dominate and the
+  // x-fastest order, which runs equal-weight workgroups together, is the better one: 61 vs 105 us)
+  a.ygroups = (xcd_grid && ygr > 1 && ygr <= 8 && tiles * d->B >= 64) ? ygr : 0;
+  a.xtiles = (int)(tiles * d->B);
+  dim3 grid((unsigned)(tiles * d->B), (unsigned)ygr), block(256);
+  if (a.ygroups > 1) grid = dim3((unsigned)(((tiles * d->B + 7) / 8) * 8 * ygr), 1);
 #define FZ_STR(MB, NA, L, E, PR) hipLaunchKernelGGL((gemm_stream_kernel<MB, NA, L, E, PR>), grid, block, 0, st, a)
 #define FZ_STRK(MB, NA, L, E, PR) hipLaunchKernelGGL((gemm_stream_kernel<MB, NA, L, E, PR, 4>), grid, block, 0, st, a)
   if (d->bact == ACT_RELU) return fail(FZ_E_UNSUPPORTED, "fz_gemm: ReLU input prologue is not compiled (streaming)");
