@@ -1179,7 +1179,7 @@ extern "C" int fz_gemm(const fz_gemm_desc* d, fz_stream_t stream) {
   // (A persistent variant of the streaming kernel — whole weight block resident, the prefetch ring running
   // across tile boundaries — was measured for 32 < K <= 128 at stages 0/1 and was not faster:
   // those GEMMs sit at 56-71 TFLOP/s of fp32 MFMA with the operand loads as the stall reason, not the
-  // per-tile prologue / epilogue; tools/debug/persist_probe.py.)
+  // per-tile prologue / epilogue.)
   // ---- Kernel B: streaming; pick the column-tile width so the grid fills the chip ----
   // tile choice from a sweep on MI355X (tools/debug/gemm_probe3.py, FZ_GEMM_CFG): take the widest
   // column tile that still gives >= 256 workgroups (one per CU); two row blocks per workgroup only
