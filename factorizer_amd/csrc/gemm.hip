@@ -529,11 +529,14 @@ struct ChainArgs {
   float* side;         // (B, 64, V)
 };
 
-template <bool BWD, int NACC>
-__global__ __launch_bounds__(256, NACC == 2 ? 3 : 2) void gemm_chain_kernel(GemmArgs p, ChainArgs c, int ntiles) {
-  __shared__ float As1[16 * 2 * 64];
-  __shared__ float As2[32 * 64];
-  __shared__ float tW[64];
+// HB = 32-row blocks of the hidden tensor: 2 (mlp_ratio 2, the README model) or 4 (mlp_ratio 4, the
+// BraTS bundle, train.yaml:62)
+template <bool BWD, int NACC, int HB>
+__global__ __launch_bounds__(256, (NACC == 2 && HB == 2) ? 3 : 2) void gemm_chain_kernel(GemmArgs p, ChainArgs c, int ntiles) {
+  constexpr int HID = 32 * HB, N1 = 16 * HB * 64;  // hidden rows; floats of each staged weight block
+  __shared__ float As1[N1];
+  __shared__ float As2[N1];
+  __shared__ float tW[HID];
   __shared__ float tB[32];
   __shared__ float red[256];
   // raw operand tile of each wave (32 channels x 32*NACC columns): the epilogue needs the SAME tensor
@@ -545,19 +548,19 @@ __global__ __launch_bounds__(256, NACC == 2 ? 3 : 2) void gemm_chain_kernel(Gemm
   const int tiles_per_sample = (int)((p.Ncol + 128 * NACC - 1) / (128 * NACC));
 
   // weights in operand order (8 independent loads per thread before the LDS stores)
-  for (int base = threadIdx.x; base < 4096; base += 256 * 8) {
+  for (int base = threadIdx.x; base < 2 * N1; base += 256 * 8) {
     float tmp[8];
 #pragma unroll
     for (int uu = 0; uu < 8; ++uu) {
       const int idx = base + uu * 256;
       float wv;
-      if (idx < 2048) {  // GEMM 1: step a, row block rb
-        const int l = idx & 63, rb = (idx >> 6) & 1, a = idx >> 7;
+      if (idx < N1) {  // GEMM 1: step a, row block rb
+        const int l = idx & 63, rb = (idx >> 6) % HB, a = idx / (64 * HB);
         const int m = rb * 32 + (l & 31), k = 2 * a + (l >> 5);
         wv = weight_at(p, m, k);
         if (!BWD) wv *= p.ln_g[k];
       } else {           // GEMM 2: step (rb, r) consumes accumulator register r of row block rb
-        const int i2 = idx - 2048;
+        const int i2 = idx - N1;
         const int l = i2 & 63, s2 = i2 >> 6;
         const int r = s2 & 15, rb = s2 >> 4;
         const int k = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), m = l & 31;
@@ -568,13 +571,13 @@ __global__ __launch_bounds__(256, NACC == 2 ? 3 : 2) void gemm_chain_kernel(Gemm
 #pragma unroll
     for (int uu = 0; uu < 8; ++uu) {
       const int idx = base + uu * 256;
-      if (idx < 2048) As1[idx] = tmp[uu]; else As2[idx - 2048] = tmp[uu];
+      if (idx < N1) As1[idx] = tmp[uu]; else As2[idx - N1] = tmp[uu];
     }
   }
   if (BWD) {
     if (threadIdx.x < 32) tB[threadIdx.x] = p.lnb_g[threadIdx.x];
   } else {
-    for (int r = threadIdx.x; r < 64; r += blockDim.x) {
+    for (int r = threadIdx.x; r < HID; r += blockDim.x) {
       float t = 0.f;
       for (int k = 0; k < 32; ++k) t += weight_at(p, r, k) * p.ln_b[k];
       tW[r] = t + (p.bias ? p.bias[r] : 0.f);
@@ -644,9 +647,9 @@ __global__ __launch_bounds__(256, NACC == 2 ? 3 : 2) void gemm_chain_kernel(Gemm
     }
 
     // ---- GEMM 1: 64 rows x 128 columns per wave ----
-    f32x16 acc1[2][NACC];
+    f32x16 acc1[HB][NACC];
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int rb = 0; rb < HB; ++rb)
 #pragma unroll
       for (int q = 0; q < NACC; ++q)
 #pragma unroll
@@ -654,8 +657,8 @@ __global__ __launch_bounds__(256, NACC == 2 ? 3 : 2) void gemm_chain_kernel(Gemm
 #pragma unroll
     for (int s = 0; s < 16; ++s)
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb) {
-        const float av = As1[(s * 2 + rb) * 64 + lane];
+      for (int rb = 0; rb < HB; ++rb) {
+        const float av = As1[(s * HB + rb) * 64 + lane];
 #pragma unroll
         for (int q = 0; q < NACC; ++q) acc1[rb][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[s][q], acc1[rb][q], 0, 0, 0);
       }
@@ -666,12 +669,12 @@ __global__ __launch_bounds__(256, NACC == 2 ? 3 : 2) void gemm_chain_kernel(Gemm
     // ---- hidden tensor: transform in registers, keep a copy in HBM for the other pass ----
     if (!BWD) {
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb)
+      for (int rb = 0; rb < HB; ++rb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int rbase = rb * 32 + (r & 3) + 8 * (r >> 2);
           const int row = rbase + 4 * h;
-          const int64_t ob = ((int64_t)b * 64 + rbase) * p.Ncol;  // uniform row part; + one 32-bit lane offset
+          const int64_t ob = ((int64_t)b * HID + rbase) * p.Ncol;  // uniform row part; + one 32-bit lane offset
           float v[NACC];
           const float add = tW[row];
 #pragma unroll
@@ -684,13 +687,13 @@ __global__ __launch_bounds__(256, NACC == 2 ? 3 : 2) void gemm_chain_kernel(Gemm
       // groups of 8 rows: 8 loads of the saved pre-activation in flight, then 8 transforms + stores
       // (bounded on purpose: the scheduler otherwise hoists all 32 loads and spills accumulators)
 #pragma unroll
-      for (int g8 = 0; g8 < 4; ++g8) {
+      for (int g8 = 0; g8 < 2 * HB; ++g8) {
         float e[8][NACC];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int rr = g8 * 8 + i, rb = rr >> 4, r = rr & 15;
           const int rbase = rb * 32 + (r & 3) + 8 * (r >> 2);
-          vload<NACC>(p.emul + ((int64_t)b * 64 + rbase) * p.Ncol + lane_row, e[i]);
+          vload<NACC>(p.emul + ((int64_t)b * HID + rbase) * p.Ncol + lane_row, e[i]);
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -699,7 +702,7 @@ __global__ __launch_bounds__(256, NACC == 2 ? 3 : 2) void gemm_chain_kernel(Gemm
           float v[NACC];
 #pragma unroll
           for (int q = 0; q < NACC; ++q) v[q] = acc1[rb][q][r] * gelu_grad_f(e[i][q]);
-          if (col_ok) vstore<NACC>(c.side + ((int64_t)b * 64 + rbase) * p.Ncol + lane_row, v);
+          if (col_ok) vstore<NACC>(c.side + ((int64_t)b * HID + rbase) * p.Ncol + lane_row, v);
 #pragma unroll
           for (int q = 0; q < NACC; ++q) acc1[rb][q][r] = v[q];
         }
@@ -714,7 +717,7 @@ __global__ __launch_bounds__(256, NACC == 2 ? 3 : 2) void gemm_chain_kernel(Gemm
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc2[q][r] = 0.f;
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int rb = 0; rb < HB; ++rb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float av = As2[(rb * 16 + r) * 64 + lane];
@@ -1269,12 +1272,12 @@ extern "C" int64_t fz_mlp_partials(int B, int64_t V) {
 }
 
 extern "C" int fz_mlp_supported(int C, int H, int64_t V) {
-  return (C == 32 && H == 64 && V > 0 && (V % 4) == 0 && V <= ((int64_t)1 << 27)) ? 1 : 0;
+  return (C == 32 && (H == 64 || H == 128) && V > 0 && (V % 4) == 0 && V <= ((int64_t)1 << 27)) ? 1 : 0;
 }
 
 extern "C" int fz_mlp_chain(const fz_mlp_desc* d, fz_stream_t stream) {
   if (!d) return fail(FZ_E_ARG, "fz_mlp_chain: null descriptor");
-  if (!fz_mlp_supported(d->C, d->H, d->V)) return fail(FZ_E_UNSUPPORTED, "fz_mlp_chain: needs C == 32, H == 64, V % 4 == 0");
+  if (!fz_mlp_supported(d->C, d->H, d->V)) return fail(FZ_E_UNSUPPORTED, "fz_mlp_chain: needs C == 32, H in {64, 128}, V % 4 == 0");
   if (d->B < 0) return fail(FZ_E_SHAPE, "fz_mlp_chain: negative batch");
   if (!d->in || !d->w1 || !d->w2 || !d->out || !d->z1 || !d->stats)
     return fail(FZ_E_ARG, "fz_mlp_chain: null pointer");
@@ -1284,26 +1287,28 @@ extern "C" int fz_mlp_chain(const fz_mlp_desc* d, fz_stream_t stream) {
   if (d->B == 0) return FZ_OK;
   GemmArgs a = {};
   ChainArgs c = {};
-  a.x[0] = d->in; a.nsrc = 1; a.c0 = 32; a.Cin = 32; a.Vin = d->V; a.M = 64; a.K = 32; a.Ncol = d->V; a.B = d->B;
+  a.x[0] = d->in; a.nsrc = 1; a.c0 = 32; a.Cin = 32; a.Vin = d->V; a.M = d->H; a.K = 32; a.Ncol = d->V; a.B = d->B;
   hipStream_t st = (hipStream_t)stream;
   const int ntiles = (int)fz_mlp_partials(d->B, d->V);
-  int wgs = mlp_nacc() == 4 ? 512 : 768;  // resident workgroups (2 or 3 per CU), each walking tiles with a stride of the grid
+  int wgs = d->H == 128 ? 512 : 768;  // resident workgroups (2 or 3 per CU), each walking tiles with a stride of the grid
   { const char* e = getenv("FZ_MLP_WGS"); if (e) wgs = atoi(e); }
   dim3 grid((unsigned)(ntiles < wgs ? ntiles : wgs)), block(256);
   if (d->mode == 0) {
     a.w = d->w1; a.w_t = 0; a.ldw = 32;              // A1[m][k] = W1[m][k]
     a.bias = d->b1; a.ln = 1; a.ln_g = d->ln_g; a.ln_b = d->ln_b; a.ln_eps = d->ln_eps; a.stats_out = d->stats;
     a.res = d->in; a.y = d->out;
-    c.wB = d->w2; c.wB_t = 0; c.ldwB = 64;           // A2[m][k] = W2[m][k]
+    c.wB = d->w2; c.wB_t = 0; c.ldwB = d->H;         // A2[m][k] = W2[m][k]
     c.biasB = d->b2; c.side = d->z1;
-    hipLaunchKernelGGL((gemm_chain_kernel<false, 2>), grid, block, 0, st, a, c, ntiles);
+    if (d->H == 128) hipLaunchKernelGGL((gemm_chain_kernel<false, 2, 4>), grid, block, 0, st, a, c, ntiles);
+    else hipLaunchKernelGGL((gemm_chain_kernel<false, 2, 2>), grid, block, 0, st, a, c, ntiles);
   } else {
-    a.w = d->w2; a.w_t = 1; a.ldw = 64;              // A1[m = hidden][k = c] = W2[c][hidden]
+    a.w = d->w2; a.w_t = 1; a.ldw = d->H;            // A1[m = hidden][k = c] = W2[c][hidden]
     a.emul = d->z1; a.y = d->out;
     a.lnb_x = d->x1; a.lnb_stats = d->stats; a.lnb_g = d->ln_g; a.lnb_gadd = d->in; a.lnb_part = d->part;
     c.wB = d->w1; c.wB_t = 1; c.ldwB = 32;           // A2[m = c][k = hidden] = W1[hidden][c]
     c.side = d->gz1;
-    hipLaunchKernelGGL((gemm_chain_kernel<true, 2>), grid, block, 0, st, a, c, ntiles);
+    if (d->H == 128) hipLaunchKernelGGL((gemm_chain_kernel<true, 2, 4>), grid, block, 0, st, a, c, ntiles);
+    else hipLaunchKernelGGL((gemm_chain_kernel<true, 2, 2>), grid, block, 0, st, a, c, ntiles);
   }
   FZ_LAUNCH_CHECK();
   return FZ_OK;
