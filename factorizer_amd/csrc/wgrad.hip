@@ -486,7 +486,17 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restri
       }
       for (; ch < nchunk; ch += 32) s0 += gk * src[(int64_t)ch * n + e] + bk * part_bias[(int64_t)ch * M + m];
     } else {
-      for (; ch + 96 < nchunk; ch += 128) {  // 4 independent loads in flight
+      // 8 independent loads in flight: the kernel is pure dependent-load latency (1024 partial blocks
+      // = 32 per thread at stage 0)
+      for (; ch + 224 < nchunk; ch += 256) {
+        const float a0 = src[(int64_t)ch * n + e], a1 = src[(int64_t)(ch + 32) * n + e];
+        const float a2 = src[(int64_t)(ch + 64) * n + e], a3 = src[(int64_t)(ch + 96) * n + e];
+        const float a4 = src[(int64_t)(ch + 128) * n + e], a5 = src[(int64_t)(ch + 160) * n + e];
+        const float a6 = src[(int64_t)(ch + 192) * n + e], a7 = src[(int64_t)(ch + 224) * n + e];
+        s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+        s0 += a4; s1 += a5; s2 += a6; s3 += a7;
+      }
+      for (; ch + 96 < nchunk; ch += 128) {
         s0 += src[(int64_t)ch * n + e];
         s1 += src[(int64_t)(ch + 32) * n + e];
         s2 += src[(int64_t)(ch + 64) * n + e];
