@@ -60,7 +60,7 @@ class FactorizerBlock(nn.Module):
         dropout — then LayerNorm, bias, ReLU, GELU and both residual adds are fused into the GEMM
         kernels (csrc/gemm.hip) instead of running as separate full-tensor passes."""
         f, m = self.fact, self.mlp
-        if not (x.is_cuda and x.dtype == torch.float32 and PW._vox(x) % 4 == 0 and x.shape[1] % 2 == 0):
+        if not (x.is_cuda and x.numel() and x.dtype == torch.float32 and PW._vox(x) % 4 == 0 and x.shape[1] % 2 == 0):
             return False
         if not (isinstance(self.norm1, LayerNorm) and isinstance(self.norm2, LayerNorm)
                 and self.norm1.norm.elementwise_affine and self.norm2.norm.elementwise_affine

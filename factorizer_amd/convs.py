@@ -18,7 +18,7 @@ def _all(v, n):
 
 class Conv3d(nn.Conv3d):
     def forward(self, x):
-        ok = (x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and self.groups == 1
+        ok = (x.is_cuda and x.numel() and x.dtype == torch.float32 and x.dim() == 5 and self.groups == 1
               and _all(self.dilation, 1) and self.padding_mode == "zeros")
         if ok:
             C = self.in_channels
@@ -40,13 +40,13 @@ class Conv3d(nn.Conv3d):
 
 class ConvTranspose3d(nn.ConvTranspose3d):
     def forward(self, x, output_size=None):
-        ok = (x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and self.groups == 1 and output_size is None
+        ok = (x.is_cuda and x.numel() and x.dtype == torch.float32 and x.dim() == 5 and self.groups == 1 and output_size is None
               and _all(self.dilation, 1) and _all(self.kernel_size, 2) and _all(self.stride, 2)
               and _all(self.padding, 0) and _all(self.output_padding, 0) and self.in_channels % 2 == 0
               and (x.shape[2] * x.shape[3] * x.shape[4]) % 4 == 0)
         if ok:
             return PW.TConvK2S2Fn.apply(x, self.weight, self.bias)
-        if x.is_cuda:
+        if x.is_cuda and x.numel():
             composed.warn_once(f"tconv3d{self.kernel_size}{self.stride}{tuple(x.shape[2:])}",
                                f"ConvTranspose3d kernel={self.kernel_size} stride={self.stride} on "
                                f"{tuple(x.shape)} is outside the native kernel set; using ATen on device")

@@ -62,7 +62,7 @@ class DiceBCEFn(torch.autograd.Function):
 
 def dice_bce_loss(logits, target, smooth: float = 1e-5):
     planes = logits.shape[0] * logits.shape[1]
-    if logits.is_cuda and logits.dtype == torch.float32 and target.dtype == torch.float32 \
+    if logits.is_cuda and logits.numel() and logits.dtype == torch.float32 and target.dtype == torch.float32 \
             and (logits.numel() // planes) % 4 == 0:
         return DiceBCEFn.apply(logits, target, smooth)
     return dice_bce_loss_composed(logits, target, smooth)

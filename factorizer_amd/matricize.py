@@ -87,7 +87,7 @@ class _WindowedMatricize(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         self._check_input(x)
         x = x.as_subclass(torch.Tensor)
-        if x.is_cuda:
+        if x.is_cuda and x.numel():
             return Fn.swm_forward(x, self.geometry)
         return composed.swm_forward(x, self.geometry)
 
@@ -96,6 +96,8 @@ class _WindowedMatricize(nn.Module):
         geo = self.geometry
         if y.shape[0] % (geo.nshift * geo.h) or tuple(y.shape[1:]) != (geo.G, geo.d, geo.P):
             raise ValueError(f"expected (num_shifts*B*{geo.h}, {geo.G}, {geo.d}, {geo.P}), got {tuple(y.shape)}")
+        if not y.numel():
+            return composed.swm_inverse(y, geo)
         if y.is_cuda and y.dtype == torch.float32:
             return Fn.swm_inverse(y, geo)
         if y.is_cuda:

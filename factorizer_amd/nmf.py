@@ -405,7 +405,7 @@ class MatrixFactorization(nn.Module):
     # -- which path -------------------------------------------------------------------
     def _native_solver(self, x: Tensor):
         """Solver id if this call is covered by the gfx950 kernels, else None."""
-        if not x.is_cuda or self.verbose:
+        if not x.is_cuda or self.verbose or not x.numel():
             return None
         sid = getattr(self.solver, "native_id", None)
         if sid is None or not isinstance(self.init, RandomInit) or self.solver.factor != (0, 1):

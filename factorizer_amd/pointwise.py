@@ -205,7 +205,7 @@ def _side_stream(dev, ncols):
 
 def _native_ok(*ts):
     t0 = ts[0]
-    return t0.is_cuda and all(t is None or (t.dtype == torch.float32) for t in ts) and _vox(t0) % 4 == 0
+    return t0.is_cuda and t0.numel() > 0 and all(t is None or (t.dtype == torch.float32) for t in ts) and _vox(t0) % 4 == 0
 
 
 # ---- LayerNorm → Linear → [ReLU] -----------------------------------------------------------
@@ -500,7 +500,7 @@ def linear_cf(x, weight, bias=None):
     if _native_ok(x, weight, bias) and weight.shape[1] % 2 == 0:
         return LinearFn.apply(x, weight, bias)
     B, C = x.shape[:2]
-    y = torch.matmul(weight.reshape(weight.shape[0], weight.shape[1]), x.reshape(B, C, -1))
+    y = torch.matmul(weight.reshape(weight.shape[0], weight.shape[1]), x.reshape(B, C, _vox(x)))
     if bias is not None:
         y = y + bias.view(1, -1, 1)
     return y.reshape(B, weight.shape[0], *x.shape[2:])

@@ -500,3 +500,46 @@ def test_sliding_window_brats_volume_with_factorizer():
     # partition of unity: a constant network comes back exactly constant
     ones = inf(x, lambda w: torch.ones(w.shape[0], 1, *w.shape[2:], device=w.device))
     assert torch.allclose(ones, torch.ones_like(ones), rtol=0, atol=1e-6)
+
+
+# ---------------------------------------------------------------- edge cases: empty / single inputs ------
+def test_empty_batch_through_modules():
+    """Batch 0 takes the zero-work framework path on device (nothing to launch) and keeps shapes."""
+    m = ft.SWMatricize((None, 16, 8, 8, 8), head_dim=8, patch_size=4)
+    x = torch.rand(0, 16, 8, 8, 8, device=DEV)
+    y = m(x)
+    assert y.shape == (0, 8, 8, 64) and m.inverse_forward(y).shape == x.shape
+    nmf = ft.NMF(size=(8, 64), rank=2, num_iters=3, init="uniform", solver="hals").to(DEV)
+    assert nmf(y).shape == y.shape
+    u, v = nmf.decompose(y)
+    assert u.shape == (0, 8, 8, 2) and v.shape == (0, 8, 64, 2)
+    blk = ft.FactorizerBlock(channels=32, spatial_size=(8, 8, 8), norm=ft.LayerNorm,
+                             reshape=(ft.SWMatricize, {"head_dim": 8, "patch_size": 8}), act=nn.ReLU,
+                             factorize=ft.NMF, rank=1, num_iters=5, init="uniform", solver="hals", mlp_ratio=2,
+                             dropout=0.0).to(DEV)
+    xb = torch.rand(0, 32, 8, 8, 8, device=DEV, requires_grad=True)
+    yb = blk(xb)
+    assert yb.shape == xb.shape
+    yb.sum().backward()
+    assert xb.grad.shape == xb.shape
+
+
+def test_single_matrix_and_single_patch():
+    """One matrix per launch (BASELINE cfg 1 on device) and a volume that is exactly one patch."""
+    torch.manual_seed(0)
+    nmf = ft.NMF(size=(8, 512), rank=2, num_iters=5, init="uniform", solver="mu")
+    x = torch.rand(1, 8, 512)
+    ref = nmf(x)
+    with Launches():
+        out = nmf.to(DEV)(x.to(DEV))
+    assert torch.allclose(out.cpu(), ref, rtol=1e-4, atol=1e-5)
+    torch.manual_seed(0)
+    blk = ft.FactorizerBlock(channels=8, spatial_size=(8, 8, 8), norm=ft.LayerNorm,
+                             reshape=(ft.SWMatricize, {"head_dim": 8, "patch_size": 8}), act=nn.ReLU,
+                             factorize=ft.NMF, rank=1, num_iters=5, init="uniform", solver="hals", mlp_ratio=2,
+                             dropout=0.0)
+    xs = torch.rand(1, 8, 8, 8, 8)
+    ref = blk(xs)
+    with Launches():
+        out = blk.to(DEV)(xs.to(DEV))
+    assert torch.allclose(out.cpu(), ref, rtol=1e-4, atol=1e-5)

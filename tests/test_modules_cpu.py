@@ -375,3 +375,21 @@ def test_compose_is_a_sequence_of_solvers():
                 size=(8, 16), rank=2)
     assert len(c) == 2 and isinstance(c[0], MultiplicativeUpdate) and c.factor == [(0, 1), (1,)]
     assert c.size == (8, 16) and c.rank == 2
+
+
+def test_empty_batch_keeps_shapes():
+    """Batch 0 (the reference's einops/ATen chain accepts it): shapes survive forward and backward."""
+    m = ft.SWMatricize((None, 16, 8, 8, 8), head_dim=8, patch_size=4)
+    x = torch.rand(0, 16, 8, 8, 8)
+    y = m(x)
+    assert y.shape == (0, 8, 8, 64) and m.inverse_forward(y).shape == x.shape
+    nmf = ft.NMF(size=(8, 64), rank=2, num_iters=3, init="uniform", solver="hals")
+    assert nmf(y).shape == y.shape
+    blk = ft.FactorizerBlock(channels=32, spatial_size=(8, 8, 8), norm=ft.LayerNorm,
+                             reshape=(ft.SWMatricize, {"head_dim": 8, "patch_size": 8}), act=nn.ReLU,
+                             factorize=ft.NMF, rank=1, num_iters=5, init="uniform", solver="hals", mlp_ratio=2,
+                             dropout=0.0)
+    xb = torch.rand(0, 32, 8, 8, 8, requires_grad=True)
+    yb = blk(xb)
+    yb.sum().backward()
+    assert yb.shape == xb.shape and xb.grad.shape == xb.shape
