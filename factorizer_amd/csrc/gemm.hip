@@ -760,6 +760,9 @@ enum { PRO_NONE = 0, PRO_LN = 1, PRO_GELU = 2, PRO_BMUL = 3 };
 // (groups of kPF steps, round-robin), then add their accumulators through LDS.  For the deep
 // stages (8^3, 16^3 voxels; K = 256..2048) this gives 4x the workgroups and 4x shorter dependent
 // MFMA chains: 512->512 at 8^3 is 128 workgroups x 256 serial steps without it.
+// (2 workgroups per CU: 3 or 4 — narrower tiles under tighter launch bounds — measured no faster,
+// an occupancy sweep: the operand traffic of these launches runs at 4.1-5.1 TB/s even with the
+// MFMAs compiled out (tools/debug/gemm_probe7.py), the fp32 MFMA time comes largely on top of it.)
 template <int MB, int NACC, int LOADER, int EPI, int PRO, int KS = 1>
 __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgs p) {
   constexpr int TN = 32 * NACC;
@@ -963,10 +966,6 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgs p) {
 #pragma unroll
         for (int e = 0; e < NR; ++e) cur[e] = ring[u][e];
         {
-          const int sn = s + KS * kPF;
-          fetch(sn < nload ? sn : nload - 1, ring[u]);  // tail: harmless re-read of the last step
-        }
-        {
           if (LOADER == LOAD_S2D) {
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
@@ -1004,11 +1003,28 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgs p) {
             for (int mb = 0; mb < MB; ++mb) {
               const float av = Ab[(ali * MB + mb) * 64 + lane];
 #pragma unroll
-              for (int q = 0; q < NACC; ++q)
+              for (int q = 0; q < NACC; ++q) {
+#if defined(FZ_PROBE_MFMA_NONE)
+                acc[mb][q][0] += av * bvv[q];  // diagnostics build: operand traffic only
+#elif defined(FZ_PROBE_MFMA_HALF)
+                if (q & 1) acc[mb][q][0] += av * bvv[q];
+                else acc[mb][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bvv[q], acc[mb][q], 0, 0, 0);
+#else
                 acc[mb][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bvv[q], acc[mb][q], 0, 0, 0);
+#endif
+              }
             }
           }
         }
+        // Refill the slot right behind the MFMAs that consumed it, and pin it there: the slot registers
+        // are the MFMA operands, so the refill cannot be issued earlier; left alone, the scheduler sinks
+        // all kPF refills of a group to the bottom of the unrolled body and the first slot of the next
+        // group is awaited right after it was requested — one exposed memory round trip per group.
+        {
+          const int sn = s + KS * kPF;
+          fetch(sn < nload ? sn : nload - 1, ring[u]);  // tail: harmless re-read of the last step
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     // next chunk: registers → the other buffer (double-buffered) or, with the K-split, a plain refill

@@ -1,0 +1,25 @@
+"""Isolated weight-gradient launches at the mid/deep stage shapes: GB/s and TFLOP/s."""
+import os, sys, torch
+sys.path.insert(0, '.')
+from factorizer_amd import pointwise as PW
+DEV = 'cuda:0'
+def timeit(fn, iters=10, warm=3):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+B = 2
+for (M, K, S) in ((64, 64, 64), (64, 128, 64), (128, 64, 64), (128, 128, 32), (128, 256, 32), (256, 128, 32), (256, 256, 16), (256, 512, 16), (512, 512, 8), (512, 1024, 8)):
+    V = S ** 3
+    p = torch.randn(B, M, V, device=DEV); q = torch.randn(B, K, V, device=DEV)
+    st = torch.rand(B, 2, V, device=DEV) + 0.5
+    g, bt = torch.rand(K, device=DEV), torch.rand(K, device=DEV)
+    gw = torch.empty(M, K, device=DEV); gb = torch.empty(M, device=DEV)
+    nb = (p.numel() + q.numel()) * 4
+    fl = 2.0 * M * K * V * B
+    t0 = timeit(lambda: PW._wgrad(p, [q], gw, B=B, M=M, Cin=K, K=K, Vq=V, Ncols=V, gbias=gb))
+    t1 = timeit(lambda: PW._wgrad(p, [q], gw, B=B, M=M, Cin=K, K=K, Vq=V, Ncols=V, gbias=gb, stats=st, ln=(g, bt)))
+    print(f"{M:4d}x{K:4d} {S}^3: plain {t0*1e3:.1f} us ({nb/t0/1e6:.0f} GB/s, {fl/t0/1e9:.1f} TF)  ln {t1*1e3:.1f} us")
