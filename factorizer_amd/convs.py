@@ -17,14 +17,27 @@ def _all(v, n):
 
 
 class Conv3d(nn.Conv3d):
+    def _k2s2_native(self, x) -> bool:
+        return (x.is_cuda and x.numel() and x.dtype == torch.float32 and x.dim() == 5 and self.groups == 1
+                and _all(self.dilation, 1) and self.padding_mode == "zeros"
+                and _all(self.kernel_size, 2) and _all(self.stride, 2) and _all(self.padding, 0)
+                and x.shape[-1] % 4 == 0 and x.shape[-2] % 2 == 0 and x.shape[-3] % 2 == 0
+                and (x.shape[2] * x.shape[3] * x.shape[4] // 8) % 4 == 0 and self.in_channels % 2 == 0)
+
+    def forward_fork(self, x):
+        """``(x, self(x))`` for an ``x`` that is also kept as a skip connection: on the native path both
+        come out of one autograd node whose backward adds the skip gradient inside the input-gradient
+        kernel (PW.SkipConvK2S2Fn) instead of leaving the sum to a separate accumulation pass."""
+        if self._k2s2_native(x) and x.requires_grad and torch.is_grad_enabled():
+            return PW.SkipConvK2S2Fn.apply(x, self.weight, self.bias)
+        return x, self(x)
+
     def forward(self, x):
         ok = (x.is_cuda and x.numel() and x.dtype == torch.float32 and x.dim() == 5 and self.groups == 1
               and _all(self.dilation, 1) and self.padding_mode == "zeros")
         if ok:
             C = self.in_channels
-            if _all(self.kernel_size, 2) and _all(self.stride, 2) and _all(self.padding, 0) \
-                    and x.shape[-1] % 4 == 0 and x.shape[-2] % 2 == 0 and x.shape[-3] % 2 == 0 \
-                    and (x.shape[2] * x.shape[3] * x.shape[4] // 8) % 4 == 0 and C % 2 == 0:
+            if self._k2s2_native(x):
                 return PW.ConvK2S2Fn.apply(x, self.weight, self.bias)
             if _all(self.kernel_size, 3) and _all(self.stride, 1) and _all(self.padding, 1) \
                     and x.shape[-1] % 4 == 0 and C % 2 == 0:

@@ -219,18 +219,27 @@ __device__ __forceinline__ void store_block(const GemmArgs& p, const f32x16 (&ac
       if (o >= Mo) continue;
       const int th = (r0 >> 1) & 1, td = h;
       const float bs = p.bias ? p.bias[o] : 0.f;
-      float* ybase = p.y + ((int64_t)b * Mo + o) * Vf;
+      const int64_t obase = ((int64_t)b * Mo + o) * Vf;
+      float* ybase = p.y + obase;
+      // p.res: a fine-resolution tensor added to the scattered block (the skip-connection gradient
+      // joining the down-convolution's input gradient, unet.py:95-99 / autograd's accumulation)
       if (NACC == 4 && (p.Wo & 3) == 0) {
         const int wo = (int)(ncol % p.Wo);
         const int64_t t2 = ncol / p.Wo;
         const int ho = (int)(t2 % p.Ho);
         const int dz = (int)(t2 / p.Ho);
         const int64_t fo = ((int64_t)(2 * dz + td) * Hf + (2 * ho + th)) * Wf + 2 * wo;
-        *reinterpret_cast<float4*>(ybase + fo) =
-            make_float4(acc[0][r0] + bs, acc[0][r0 + 1] + bs, acc[1 % NACC][r0] + bs, acc[1 % NACC][r0 + 1] + bs);
-        *reinterpret_cast<float4*>(ybase + fo + 4) =
-            make_float4(acc[2 % NACC][r0] + bs, acc[2 % NACC][r0 + 1] + bs, acc[3 % NACC][r0] + bs,
-                        acc[3 % NACC][r0 + 1] + bs);
+        float4 lo4 = make_float4(acc[0][r0] + bs, acc[0][r0 + 1] + bs, acc[1 % NACC][r0] + bs, acc[1 % NACC][r0 + 1] + bs);
+        float4 hi4 = make_float4(acc[2 % NACC][r0] + bs, acc[2 % NACC][r0 + 1] + bs, acc[3 % NACC][r0] + bs,
+                                 acc[3 % NACC][r0 + 1] + bs);
+        if (p.res) {
+          const float4 ra = *reinterpret_cast<const float4*>(p.res + obase + fo);
+          const float4 rb = *reinterpret_cast<const float4*>(p.res + obase + fo + 4);
+          lo4.x += ra.x; lo4.y += ra.y; lo4.z += ra.z; lo4.w += ra.w;
+          hi4.x += rb.x; hi4.y += rb.y; hi4.z += rb.z; hi4.w += rb.w;
+        }
+        *reinterpret_cast<float4*>(ybase + fo) = lo4;
+        *reinterpret_cast<float4*>(ybase + fo + 4) = hi4;
       } else {
 #pragma unroll
         for (int q = 0; q < NACC; ++q) {
@@ -240,7 +249,12 @@ __device__ __forceinline__ void store_block(const GemmArgs& p, const f32x16 (&ac
           const int ho = (int)(t2 % p.Ho);
           const int dz = (int)(t2 / p.Ho);
           const int64_t fo = ((int64_t)(2 * dz + td) * Hf + (2 * ho + th)) * Wf + 2 * wo;
-          *reinterpret_cast<float2*>(ybase + fo) = make_float2(acc[q][r0] + bs, acc[q][r0 + 1] + bs);
+          float2 v2 = make_float2(acc[q][r0] + bs, acc[q][r0 + 1] + bs);
+          if (p.res) {
+            const float2 r2 = *reinterpret_cast<const float2*>(p.res + obase + fo);
+            v2.x += r2.x; v2.y += r2.y;
+          }
+          *reinterpret_cast<float2*>(ybase + fo) = v2;
         }
       }
     }
@@ -1009,6 +1023,8 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgs p) {
 #elif defined(FZ_PROBE_MFMA_HALF)
                 if (q & 1) acc[mb][q][0] += av * bvv[q];
                 else acc[mb][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bvv[q], acc[mb][q], 0, 0, 0);
+#elif defined(FZ_PROBE_MFMA_AGPR)
+                asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[mb][q]) : "v"(av), "v"(bvv[q]));
 #else
                 acc[mb][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bvv[q], acc[mb][q], 0, 0, 0);
 #endif

@@ -370,7 +370,7 @@ class ConvK2S2Fn(torch.autograd.Function):
         return y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, g_skip=None):
         x, w = ctx.saved_tensors
         gy = gy.contiguous()
         B, C, D, H, W = x.shape
@@ -380,14 +380,34 @@ class ConvK2S2Fn(torch.autograd.Function):
         gx = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
+            if g_skip is not None:
+                g_skip = g_skip.contiguous()
             # rows (ci, tap), reduction over o:  A[m][k] = w[k*(8C) + m]
             _gemm([gy], w, gx, B=B, Cin=O, Vin=Vc, M=8 * C, K=O, Ncol=Vc, w_t=True, ldw=8 * C,
-                  epilogue=EPI_D2S, Ho=Ho, Wo=Wo, name="conv_k2s2_dgrad")
+                  epilogue=EPI_D2S, Ho=Ho, Wo=Wo, res=g_skip, name="conv_k2s2_dgrad")
         gw = torch.empty_like(w)
         gb = torch.empty(O, dtype=x.dtype, device=x.device)
         _wgrad(gy, [x], gw, B=B, M=O, Cin=C, K=8 * C, Vq=D * H * W, Ncols=Vc, gbias=gb, loader=LOAD_S2D,
                D=D, H=H, W=W, Ho=Ho, Wo=Wo, name="wgrad_conv_k2s2")
         return gx, gw, (gb if ctx.has_bias else None)
+
+
+class SkipConvK2S2Fn(torch.autograd.Function):
+    """(x, Conv3d(k=2, s=2)(x)) as ONE node: the encoder output feeds both the skip connection and
+    the next stage's down-convolution (unet.py:95-99), so its gradient is the sum of two terms that
+    autograd would add in a separate full-tensor pass; here the skip gradient is the residual of the
+    depth-to-space epilogue of the convolution's input-gradient kernel."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        y = ConvK2S2Fn.forward(ctx, x, w, b)
+        return x.view_as(x), y
+
+    @staticmethod
+    def backward(ctx, g_skip, gy):
+        if gy is None:  # the down path took no part in the loss
+            return g_skip, None, None
+        return ConvK2S2Fn.backward(ctx, gy, g_skip=g_skip)
 
 
 class TConvK2S2Fn(torch.autograd.Function):

@@ -85,6 +85,15 @@ class UNetEncoderBlock(nn.Module):
     def forward(self, x):
         return self.block(self.downsample(x))
 
+    def forward_fork(self, x):
+        """``(x_for_the_skip, self(x))``: lets a native down-convolution take over the addition of the
+        two gradients of ``x`` (skip + down path), see convs.Conv3d.forward_fork."""
+        fork = getattr(self.downsample, "forward_fork", None)
+        if fork is None:
+            return x, self(x)
+        skip, y = fork(x)
+        return skip, self.block(y)
+
 
 class UNetEncoder(nn.Module):
     def __init__(self, in_channels, out_channels=(32, 64, 128, 256, 512), depth=(1, 1, 1, 1, 1),
@@ -101,8 +110,11 @@ class UNetEncoder(nn.Module):
 
     def forward(self, x):
         feats = []
-        for stage in self.blocks:
-            x = stage(x)
+        for i, stage in enumerate(self.blocks):
+            if i == 0:
+                x = stage(x)
+            else:
+                feats[-1], x = stage.forward_fork(x)  # x is both a skip connection and this stage's input
             feats.append(x)
         return feats
 

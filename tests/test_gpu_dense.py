@@ -142,6 +142,37 @@ def test_conv_k2s2(Cin, Cout, S):
     _cmp(d(x.to(DEV)), m(x), "module")
 
 
+@pytest.mark.parametrize("Cin,Cout,S", [(32, 64, (8, 8, 8)), (8, 16, (4, 4, 12)), (64, 128, (4, 4, 8))])
+def test_skip_plus_conv_k2s2_one_node(Cin, Cout, S):
+    """An encoder output that feeds both the skip connection and the down-convolution
+    (unet.py:95-99): the fused node (Conv3d.forward_fork) adds the two gradients inside the
+    input-gradient kernel; same values as autograd's separate accumulation on CPU."""
+    torch.manual_seed(3)
+    conv = ft.Conv3d(Cin, Cout, kernel_size=2, stride=2)
+    x = torch.randn(2, Cin, *S)
+    gs, gd = torch.randn(2, Cin, *S), torch.randn(2, Cout, *(d // 2 for d in S))
+    xc = x.clone().requires_grad_(True)
+    (xc * gs).sum().add((conv(xc) * gd).sum()).backward()
+    ref_w, ref_b = conv.weight.grad.clone(), conv.bias.grad.clone()
+    conv.zero_grad()
+    conv = conv.to(DEV)
+    xd = x.to(DEV).requires_grad_(True)
+    h = xd * 1.0     # a non-leaf, as in the encoder
+    n0 = _native.launch_count()
+    skip, y = conv.forward_fork(h)
+    assert skip.data_ptr() == h.data_ptr()
+    ((skip * gs.to(DEV)).sum() + (y * gd.to(DEV)).sum()).backward()
+    assert _native.launch_count() > n0
+    _cmp(xd.grad, xc.grad, "gx", rtol=5e-4)
+    _cmp(conv.weight.grad, ref_w, "gw", rtol=5e-4)
+    _cmp(conv.bias.grad, ref_b, "gb", rtol=5e-4)
+    # only the skip branch reaches the loss: the node passes its gradient through
+    xd2 = x.to(DEV).requires_grad_(True)
+    skip, y = conv.forward_fork(xd2 * 1.0)
+    (skip * gs.to(DEV)).sum().backward()
+    _cmp(xd2.grad, gs, "gx skip only")
+
+
 @pytest.mark.parametrize("Cin,Cout,S", [(64, 32, (4, 4, 4)), (16, 8, (4, 4, 4)), (512, 256, (2, 2, 4)),
                                         (32, 16, (2, 4, 2))])
 def test_tconv_k2s2(Cin, Cout, S):
