@@ -45,8 +45,8 @@ PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
 # the launches with the largest grid of each kernel, i.e. the same stage-0 launches the key times
 PMC_KERNEL = {"nmf_cf_bwd_32x128x128x128": "fz::nmf_cf_bwd_tile_kernel<1, 1, 4, false>",
               "nmf_cf_fwd_32x128x128x128": "fz::nmf_cf_fwd_tile_kernel<1, 1, 8, false>",
-              "mlp_chain_bwd_32": "fz::gemm_chain_kernel<true, 2>",
-              "mlp_chain_fwd_32": "fz::gemm_chain_kernel<false, 2>"}
+              "mlp_chain_bwd_32": "fz::gemm_chain_kernel<true, 2, 2>",
+              "mlp_chain_fwd_32": "fz::gemm_chain_kernel<false, 2, 2>"}
 
 
 def pmc_traffic(timer_name):

@@ -37,7 +37,7 @@ def main():
     out.append("| kernel | fetch (corrected) MB | write MB | traffic MB | algorithmic MB |\n|---|---|---|---|---|")
     alg = {"fz::nmf_cf_bwd_tile_kernel<1, 1, 4, false>": (3.5 * 536.87, " (avg over the 2 windows)"),
            "fz::nmf_cf_fwd_tile_kernel<1, 1, 8, false>": (2.5 * 536.87, " (avg over the 2 windows)"),
-           "fz::gemm_chain_kernel<true, 2>": (7 * 536.87, ""), "fz::gemm_chain_kernel<false, 2>": (4 * 536.87, "")}
+           "fz::gemm_chain_kernel<true, 2, 2>": (7 * 536.87, ""), "fz::gemm_chain_kernel<false, 2, 2>": (4 * 536.87, "")}
     for k, (a, note) in alg.items():
         if k in pmc:
             v = pmc[k]
