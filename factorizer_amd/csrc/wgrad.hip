@@ -531,10 +531,30 @@ __global__ __launch_bounds__(256) void ln_fold_kernel(float* __restrict__ gw, co
 
 using namespace fz;
 
-static int pick_chunks(int64_t total_tiles, int out_blocks, int* tiles_per_chunk) {
-  // aim at ~2048 (workgroup, wave) units over the whole grid, at least 1 tile each
-  // ~4 workgroups per CU for latency hiding; partial-sum workspace stays modest for big outputs
-  int64_t units_target = 4096 / (out_blocks > 0 ? out_blocks : 1);
+// Register-operand kernel (wgrad_fast_kernel): whole 64x64 blocks, whole tiles, at most two concatenated
+// sources split on a multiple of 8 (measured, tools/debug/wgrad_probe.py: 8-13 % faster for 64x64
+// blocks, slower for the HBM-bound 32-row blocks of stage 0, which keep the generic kernel)
+static bool use_fast(const fz_wgrad_desc* d) {
+  const int PR = d->M > 32 ? 64 : 32, QR = d->K > 32 ? 64 : 32;
+  const int c0 = d->c0 > 0 ? d->c0 : d->Cin;
+  bool fast = PR == 64 && QR == 64 && d->loader == QL_PLAIN && !d->pmul && (d->M % PR) == 0 && (d->K % QR) == 0 &&
+              (d->N % kTile) == 0 && d->N == d->Vq && (c0 % 8) == 0 && d->src_mode == 0 && !(d->stats && d->qact) &&
+              (int64_t)8 * d->N < ((int64_t)1 << 30);
+  const char* e = getenv("FZ_WGRAD_FAST");
+  if (e && atoi(e) == 0) fast = false;
+  return fast;
+}
+
+static int pick_chunks(int64_t total_tiles, int out_blocks, bool fast, int* tiles_per_chunk) {
+  // (workgroup, wave) units over the whole grid, at least 1 tile each.  Measured sweep on MI355X
+  // (tools/debug/wgrad_probe2.py, FZ_WGRAD_UNITS): every workgroup pays a fixed prologue (first tile's
+  // round trip) and epilogue (4-wave reduction, partial block) of a few microseconds, and a grid that is
+  // not a whole number of workgroups per CU leaves a tail — ONE workgroup per CU (1024 units) is the
+  // optimum for the register-operand kernel (64x64 at 64^3: 83 us against 107 with 4 per CU), two per CU
+  // for the HBM-bound generic kernel (32x64 at 128^3: 370 against 400 us); 1.5 per CU loses to both.
+  int64_t total_units = fast ? 1024 : 2048;
+  { const char* e = getenv("FZ_WGRAD_UNITS"); if (e && atoi(e) > 0) total_units = atoi(e); }
+  int64_t units_target = total_units / (out_blocks > 0 ? out_blocks : 1);
   if (units_target < 16) units_target = 16;
   int64_t tpc = (total_tiles + units_target - 1) / units_target;
   if (tpc < 1) tpc = 1;
@@ -549,7 +569,7 @@ extern "C" int64_t fz_wgrad_workspace_bytes(const fz_wgrad_desc* d) {
   const int out_blocks = ((d->M + PR - 1) / PR) * ((d->K + QR - 1) / QR);
   const int64_t total_tiles = ((d->N + kTile - 1) / kTile) * d->B;
   int tpc;
-  const int nchunk = pick_chunks(total_tiles, out_blocks, &tpc);
+  const int nchunk = pick_chunks(total_tiles, out_blocks, use_fast(d), &tpc);
   // partial blocks + partial row sums + (LN fold) reduced accumulator and row sums
   return ((int64_t)nchunk * d->M * d->K + (int64_t)nchunk * d->M + (int64_t)d->M * d->K + d->M) *
          (int64_t)sizeof(float);
@@ -567,7 +587,8 @@ extern "C" int fz_wgrad(const fz_wgrad_desc* d, void* workspace, fz_stream_t str
   const int gy = (d->M + PR - 1) / PR, gz = (d->K + QR - 1) / QR;
   const int64_t total_tiles = ((d->N + kTile - 1) / kTile) * d->B;
   int tpc;
-  const int nchunk = pick_chunks(total_tiles, gy * gz, &tpc);
+  const bool fast = use_fast(d);
+  const int nchunk = pick_chunks(total_tiles, gy * gz, fast, &tpc);
   WgradArgs a;
   a.p = d->p; a.M = d->M; a.pmul = d->pmul; a.pmul_kind = d->pmul_kind;
   for (int i = 0; i < 4; ++i) a.q[i] = d->q[i];
@@ -587,13 +608,6 @@ extern "C" int fz_wgrad(const fz_wgrad_desc* d, void* workspace, fz_stream_t str
     else if (QR == 64) FZ_WG(1, 2, QL);                  \
     else FZ_WG(1, 1, QL);                                \
   } while (0)
-  // fast path: whole blocks, whole tiles, at most two concatenated sources split on a multiple of 8
-  // (measured, tools/debug/wgrad_probe.py: 8-13 % faster for 64x64 blocks, slower for the HBM-bound
-  // 32-row blocks of stage 0, which keep the generic kernel)
-  bool fast = PR == 64 && QR == 64 && d->loader == QL_PLAIN && !d->pmul && (d->M % PR) == 0 && (d->K % QR) == 0 && (d->N % kTile) == 0 &&
-              d->N == d->Vq && (a.c0 % 8) == 0 && d->src_mode == 0 && !(d->stats && d->qact) &&
-              (int64_t)8 * d->N < ((int64_t)1 << 30);
-  { const char* e = getenv("FZ_WGRAD_FAST"); if (e && atoi(e) == 0) fast = false; }
   if (fast) {
     const int qp = d->stats ? QP_STATS : (d->qact == 2 ? QP_GELU : (d->qact == 1 ? QP_RELU : QP_NONE));
     const size_t ldsf = (size_t)4 * (PR + QR) * kStrideF * sizeof(float);
