@@ -105,6 +105,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch-per-gpu", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-late-join", action="store_true",
+                    help="await the side-stream weight gradients at the end of every block backward "
+                         "(factorizer_amd/pointwise.py:_LateJoin)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -129,7 +132,7 @@ def main():
 
     torch.manual_seed(0)
     model = ft.Factorizer(**MODEL_KW).to(dev).train()
-    sync = FlatGradSync(model, num_buckets=2, overlap=True)
+    sync = FlatGradSync(model, num_buckets=2, overlap=True, late_wgrad_join=not args.no_late_join)
     sync.broadcast_state(0)
     # AdamW of the recipe (train.yaml:72-76: lr 1e-4, wd 1e-5) as ONE kernel over the flat parameter /
     # gradient / moment buffers (csrc/optim.hip); the gradient buffer is the one RCCL reduces in place

@@ -18,7 +18,14 @@ import torch.distributed as dist
 
 class FlatGradSync:
     def __init__(self, module: torch.nn.Module, process_group=None, num_buckets: int = 2,
-                 overlap: bool = True):
+                 overlap: bool = True, late_wgrad_join: bool = False):
+        # late_wgrad_join: the side-stream weight-gradient kernels of the deep blocks are awaited once,
+        # right before the gradients are read (bucket collectives / optimizer), not at the end of every
+        # block backward (pointwise._LateJoin)
+        self.late_join = bool(late_wgrad_join)
+        if self.late_join:
+            from . import pointwise as _PW
+            _PW.late_wgrad_join(True)
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -70,6 +77,9 @@ class FlatGradSync:
 
     def _launch(self, bi):
         b = self.buckets[bi]
+        if self.late_join:
+            from . import pointwise as _PW
+            _PW.wait_wgrad_streams()  # (ownership is checked in finish(), once every gradient is assigned)
         # pack the bucket's gradients into the flat buffer with one multi-tensor copy (autograd
         # produced them as separate tensors: assigning, not accumulating, costs no kernel)
         ps = [p for p in b["params"] if p.grad is not None]
@@ -91,6 +101,9 @@ class FlatGradSync:
 
     def finish(self):
         """Call after backward(): waits for the bucket collectives and averages."""
+        if self.late_join:
+            from . import pointwise as _PW
+            _PW.join_wgrad_streams()
         if self.world == 1:
             return
         if not self.overlap:

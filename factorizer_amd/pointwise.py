@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import weakref
 
 import torch
 import torch.nn.functional as F
@@ -201,6 +202,51 @@ def _side_stream(dev, ncols):
     if key not in _SIDE:
         _SIDE[key] = torch.cuda.Stream(device=dev)
     return _SIDE[key]
+
+
+class _LateJoin:
+    """Opt-in (`late_wgrad_join`): the weight-gradient kernels that a block backward puts on the second
+    stream are NOT awaited at the end of that block (the current stream then idles 30-120 us per block
+    for the last of them) but once, before anything reads the gradients: `join_wgrad_streams()`, called
+    by `FlatGradSync` (before its collectives) and `FlatAdamW.step()`.  Until then `p.grad` holds the
+    tensor the side stream is still writing, so this is only for callers that own the step: autograd
+    must take the returned tensors over without copying them (it does when `p.grad` is None), which
+    the join VERIFIES — a gradient that was copied early raises instead of training on garbage."""
+    enabled = False
+    keep = []      # tensors read by in-flight side-stream kernels
+    owed = []      # (weakref(param), data_ptr of the gradient tensor written on the side stream)
+    devices = set()
+
+
+def late_wgrad_join(flag: bool = True):
+    if not flag:
+        join_wgrad_streams()
+    _LateJoin.enabled = bool(flag) and os.environ.get("FZ_LATE_JOIN", "1") != "0"
+
+
+def wait_wgrad_streams():
+    """Current stream waits for the side-stream weight gradients issued so far (no ownership check:
+    usable from inside backward, e.g. a bucket hook, while later gradients are still to be assigned)."""
+    d = _LateJoin
+    for key in list(d.devices):
+        dev = torch.device(*key)
+        torch.cuda.current_stream(dev).wait_stream(_SIDE[key])
+    d.devices.clear()
+    d.keep.clear()
+
+
+def join_wgrad_streams():
+    """After backward: `wait_wgrad_streams()` + check that every parameter still holds the very tensor
+    its gradient was written into."""
+    d = _LateJoin
+    wait_wgrad_streams()
+    owed, d.owed = d.owed, []
+    for ref, ptr in owed:
+        prm = ref()
+        if prm is not None and prm.is_leaf and prm.requires_grad and (prm.grad is None or prm.grad.data_ptr() != ptr):
+            raise RuntimeError("late_wgrad_join: a weight gradient was copied or replaced before the kernel "
+                               "writing it had finished (accumulating into an existing .grad?); call "
+                               "factorizer_amd.pointwise.late_wgrad_join(False) for this training loop")
 
 
 def _native_ok(*ts):
@@ -616,6 +662,7 @@ class FactorizerBlockFn(torch.autograd.Function):
         ctx.save_for_backward(x, st1, t, a, x1, st2, z1, m, n1w, n1b, win2, u0c, v0c, wout2, n2w, n2b, w12, w22)
         ctx.cfg = cfg
         ctx.shapes = (win.shape, wout.shape, w1.shape, w2.shape)
+        ctx.prm = tuple(weakref.ref(t) for t in (win, wout, bout, w1, b1, w2, b2))
         return x2
 
     @staticmethod
@@ -684,7 +731,12 @@ class FactorizerBlockFn(torch.autograd.Function):
         gwi = torch.empty_like(win2)
         wgrad(gt, [x], gwi, B=B, M=C, Cin=C, K=C, Vq=V, Ncols=V, stats=st1, ln=(n1w, n1b), name="wgrad_ln_linear")
         if side is not None:
-            cur.wait_stream(side)
+            if _LateJoin.enabled:
+                _LateJoin.keep.extend(keep)
+                _LateJoin.devices.add((dev.type, dev.index))
+                _LateJoin.owed.extend(zip(ctx.prm, (t.data_ptr() for t in (gwi, gwo, gbo, gw1, gb1, gw2, gb2))))
+            else:
+                cur.wait_stream(side)
             keep.clear()
         s_in, s_out, s_1, s_2 = ctx.shapes
         return (gx, gg1, gbt1, gwi.reshape(s_in), None, None, gwo.reshape(s_out), gbo, gg2, gbt2,

@@ -65,6 +65,8 @@ class FlatAdamW:
 
     @torch.no_grad()
     def step(self, grad_scale: float = 1.0):
+        from . import pointwise as _PW
+        _PW.join_wgrad_streams()  # no-op unless late_wgrad_join is on (pointwise._LateJoin)
         src = [p for p in self.params if p.grad is not None and p.grad.data_ptr() != self.grad_views[p].data_ptr()]
         if src:
             torch._foreach_copy_([self.grad_views[p] for p in src], [p.grad for p in src])

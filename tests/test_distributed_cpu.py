@@ -28,7 +28,7 @@ def _worker(rank, world, port, overlap, out, flat_opt=False):
                               encoder_width=(8, 16), strides=(1, 2), decoder_depth=(1,),
                               reshape=(ft.SWMatricize, {"head_dim": 8, "patch_size": 4}), act=nn.ReLU,
                               factorize=ft.NMF, rank=1, num_iters=3, solver="hals", mlp_ratio=2, dropout=0.0)
-        sync = FlatGradSync(model, num_buckets=3, overlap=overlap)
+        sync = FlatGradSync(model, num_buckets=3, overlap=overlap, late_wgrad_join=overlap)
         sync.broadcast_state(0)
         opt = (ft.FlatAdamW(model, lr=0.01, weight_decay=1e-5, flat_grad=sync.flat, grad_views=sync.views)
                if flat_opt else torch.optim.SGD(model.parameters(), lr=0.1))

@@ -543,3 +543,57 @@ def test_single_matrix_and_single_patch():
     with Launches():
         out = blk.to(DEV)(xs.to(DEV))
     assert torch.allclose(out.cpu(), ref, rtol=1e-4, atol=1e-5)
+
+
+def _small_unet():
+    torch.manual_seed(0)
+    return ft.Factorizer(in_channels=4, out_channels=3, spatial_size=(32, 32, 32), encoder_depth=(1, 1, 1),
+                         encoder_width=(32, 64, 128), strides=(1, 2, 2), decoder_depth=(1, 1), norm=ft.LayerNorm,
+                         reshape=(ft.SWMatricize, {"head_dim": 8, "patch_size": 8}), act=nn.ReLU, factorize=ft.NMF,
+                         rank=1, num_iters=5, init="uniform", solver="hals", mlp_ratio=2, dropout=0.0).to(DEV)
+
+
+def test_late_wgrad_join_matches_per_block_join():
+    """Awaiting the side-stream weight gradients once per step (pointwise._LateJoin) instead of once per
+    block changes when the streams meet, not the values: every gradient is bit-identical."""
+    from factorizer_amd import pointwise as PW
+    from factorizer_amd.parallel import FlatGradSync
+    model = _small_unet()
+    x = torch.rand(2, 4, 32, 32, 32, device=DEV)
+    t = (torch.rand(2, 3, 32, 32, 32, device=DEV) > 0.5).float()
+
+    def grads(late):
+        sync = FlatGradSync(model, num_buckets=2, late_wgrad_join=late)
+        sync.zero_grad()
+        ft.dice_bce_loss(model(x), t).backward()
+        if late:
+            assert PW._LateJoin.owed, "no block put its weight gradients on the side stream"
+        sync.finish()
+        assert not PW._LateJoin.owed and not PW._LateJoin.keep
+        torch.cuda.synchronize()
+        out = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+        PW.late_wgrad_join(False)
+        return out
+
+    a, b = grads(False), grads(True)
+    for n in a:
+        assert torch.equal(a[n], b[n]), n
+
+
+def test_late_wgrad_join_refuses_copied_gradients():
+    """If autograd had to copy a returned weight gradient (here: accumulation into an existing .grad), the
+    copy was taken before the side stream wrote it: the join raises instead of handing it to the optimizer."""
+    from factorizer_amd import pointwise as PW
+    model = _small_unet()
+    x = torch.rand(2, 4, 32, 32, 32, device=DEV)
+    for p in model.parameters():
+        p.grad = torch.zeros_like(p)
+    PW.late_wgrad_join(True)
+    try:
+        model(x).sum().backward()
+        with pytest.raises(RuntimeError, match="late_wgrad_join"):
+            PW.join_wgrad_streams()
+    finally:
+        PW._LateJoin.owed.clear()
+        PW.late_wgrad_join(False)
+        torch.cuda.synchronize()
