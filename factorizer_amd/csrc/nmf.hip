@@ -22,8 +22,14 @@ int nmf_launch_bwd_r4(const NmfArgs&);
 
 static int hist_floats(int M, int N, int R, int G) {
   int MP, NPL;
-  if (M <= 8 && N <= 512) { MP = 8; NPL = 8; }
+  // same order as launch_shape (nmf_kernels.inc): the smallest register footprint that holds the matrix
+  if (M <= 8 && N <= 64) { MP = 8; NPL = 1; }
+  else if (M <= 8 && N <= 128) { MP = 8; NPL = 2; }
+  else if (M <= 8 && N <= 256) { MP = 8; NPL = 4; }
+  else if (M <= 8 && N <= 512) { MP = 8; NPL = 8; }
+  else if (M <= 16 && N <= 64) { MP = 16; NPL = 1; }
   else if (M <= 16 && N <= 256) { MP = 16; NPL = 4; }
+  else if (M <= 32 && N <= 64) { MP = 32; NPL = 1; }
   else if (M <= 32 && N <= 128) { MP = 32; NPL = 2; }
   else return -1;
   return (G + 1) * R * NPL * 64 + (G + 1) * MP * R + G * (MP * R + R * R);

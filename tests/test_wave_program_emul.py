@@ -80,7 +80,7 @@ def test_emul_vs_reference_goldens(emu, golden, name):
     assert (gx - g["gx"]).abs().max().item() <= 1e-4 * scale + 1e-5
 
 
-@pytest.mark.parametrize("M,N", [(8, 512), (8, 150), (4, 64), (16, 256), (16, 64), (32, 128), (32, 64), (5, 100)])
+@pytest.mark.parametrize("M,N", [(8, 512), (8, 200), (8, 150), (8, 100), (4, 64), (16, 256), (16, 64), (32, 128), (32, 64), (5, 100)])
 @pytest.mark.parametrize("solver", ["mu", "hals"])
 def test_emul_vs_oracle_shapes(emu, M, N, solver):
     torch.manual_seed(M * 1000 + N)
