@@ -1186,7 +1186,14 @@ extern "C" int fz_gemm(const fz_gemm_desc* d, fz_stream_t stream) {
   int res_maxk = 32;
   { const char* e = getenv("FZ_GEMM_RESMAXK"); if (e) res_maxk = atoi(e); }
   if (d->epilogue == EPI_LNBWD) res_maxk = 64;
-  if (d->loader == LOAD_PLAIN && d->K <= res_maxk) {
+  // ... except one 32-row block without a residual or gate: with the ring refills pinned the streaming
+  // kernel overlaps its MFMAs with the loads still in flight, which the LayerNorm prologue of the
+  // resident kernel cannot (it needs the whole column first): 32->32 at 128^3, LayerNorm + ReLU 345 -> 274 us,
+  // plain 278 -> 248 us; with a residual (357 vs 362 us) or two row blocks (391 vs 439 us) the resident
+  // kernel stays ahead (tools/debug/gemm_probe9.py)
+  const bool stream_small = mblocks == 1 && d->K >= 16 && d->K <= 32 && !d->res && !d->bmul && !d->emul &&
+                            d->epilogue == EPI_PLAIN && d->bact == 0 && !getenv("FZ_GEMM_RESMAXK");
+  if (d->loader == LOAD_PLAIN && d->K <= res_maxk && !stream_small) {
     const int nA = (d->K + 1) / 2;
     int RB = mblocks < 8 ? mblocks : 8;
     while ((size_t)(nA * RB * 64 + 32 * RB) * sizeof(float) > 65536) --RB;
