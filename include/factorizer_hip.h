@@ -155,7 +155,8 @@ typedef struct fz_gemm_desc {
   const float* bmul;   /* input operand *= act'(bmul) (same shape as the input) or NULL        */
   int bmul_kind;
   int eact;            /* activation applied to the result                                     */
-  const float* res;    /* residual added to the result (same shape as y) or NULL               */
+  const float* res;    /* residual added to the result (same shape as y; with FZ_EPI_D2S: the fine-
+                          resolution tensor, e.g. the skip-connection gradient) or NULL            */
   const float* emul;   /* result *= act'(emul) (same shape as y) or NULL                       */
   int emul_kind;
   float* y;
