@@ -15,6 +15,7 @@ from .convs import Conv3d, ConvTranspose3d
 from .blocks import FactMixer, FactorizerBlock, FactorizerStage
 from .losses import dice_bce_loss
 from .training import FlatAdamW, WarmupCosineSchedule, load_checkpoint
+from .parallel import FlatGradSync
 from .inference import SlidingWindowInferer, SlidingWindowInfererAdapt, sliding_window_inference
 from .ushape import (Factorizer, Same, UNet, UNetDecoder, UNetDecoderBlock, UNetEncoder,
                    UNetEncoderBlock, UNetStage)
