@@ -19,6 +19,23 @@
 namespace fz {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// fp32 -> (hi, mid) bf16 pair with round-to-nearest at both levels: x = hi + mid + O(2^-18 |x|).
+// v_cvt_pk_bf16_f32 converts two floats per instruction: 2.5 VALU instructions per element.
+__device__ __forceinline__ void split_bf16x8(const float (&x)[8], bf16x8& hi, bf16x8& mid) {
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) {
+    const f32x2 v = {x[e], x[e + 1]};
+    const bf16x2 h2 = __builtin_convertvector(v, bf16x2);
+    const f32x2 r = v - __builtin_convertvector(h2, f32x2);
+    const bf16x2 m2 = __builtin_convertvector(r, bf16x2);
+    hi[e] = h2[0]; hi[e + 1] = h2[1];
+    mid[e] = m2[0]; mid[e + 1] = m2[1];
+  }
+}
 
 enum { QL_PLAIN = 0, QL_S2D = 1, QL_K3 = 2 };
 
@@ -284,7 +301,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 enum { QP_NONE = 0, QP_STATS = 1, QP_GELU = 2, QP_RELU = 3 };
 constexpr int kStrideF = 36;
 
-template <int MBP, int MBQ, int QPRO>
+// BF3: the products run on the bf16 matrix pipe as three terms (hi·hi + hi·mid + mid·hi) of a two-level
+// bf16 split of both operands — 16 voxels per MFMA at twice the issue rate of the fp32 MFMA's 2, i.e. 3
+// instead of 16 MFMA slots per 16 voxels, for a relative error of <= 3·2^-18 per product.  A weight
+// gradient is a sum over 10^4..10^6 voxels whose rounding errors average out and feed nothing but the
+// optimizer; the input-gradient / forward GEMMs stay on fp32 MFMAs (errors there chain through ~40 layers).
+// The k index of an MFMA operand element is (lane half, element): ANY assignment of voxels to it is
+// valid as long as both operands use the same one — half h, element e <-> voxel 16·t + 8·h + e of K-step t.
+template <int MBP, int MBQ, int QPRO, bool BF3 = false>
 __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int PR = 32 * MBP, QR = 32 * MBQ;
@@ -359,18 +383,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(WgradArgs a) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     // ---- LDS -> operand registers: 16 contiguous voxels of channel c for this lane half ----
     float pa[MBP][16], qb[MBQ][16];
+    // fp32 MFMAs: 16 contiguous voxels from 16h; bf16 split: voxels 8h.. (K-step 0) and 16 + 8h.. (K-step 1)
 #pragma unroll
     for (int i = 0; i < MBP; ++i)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float4 v = *reinterpret_cast<const float4*>(Pt + (i * 32 + c) * kStrideF + 16 * h + 4 * e);
+        const int off = BF3 ? (16 * (e >> 1) + 8 * h + 4 * (e & 1)) : (16 * h + 4 * e);
+        const float4 v = *reinterpret_cast<const float4*>(Pt + (i * 32 + c) * kStrideF + off);
         pa[i][4 * e] = v.x; pa[i][4 * e + 1] = v.y; pa[i][4 * e + 2] = v.z; pa[i][4 * e + 3] = v.w;
       }
 #pragma unroll
     for (int jq = 0; jq < MBQ; ++jq)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float4 v = *reinterpret_cast<const float4*>(Qt + (jq * 32 + c) * kStrideF + 16 * h + 4 * e);
+        const int off = BF3 ? (16 * (e >> 1) + 8 * h + 4 * (e & 1)) : (16 * h + 4 * e);
+        const float4 v = *reinterpret_cast<const float4*>(Qt + (jq * 32 + c) * kStrideF + off);
         qb[jq][4 * e] = v.x; qb[jq][4 * e + 1] = v.y; qb[jq][4 * e + 2] = v.z; qb[jq][4 * e + 3] = v.w;
       }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -382,13 +409,42 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(WgradArgs a) {
       for (int e = 0; e < 16; ++e) ps += pa[i][e];
       psum[i] += ps;
     }
+    if (BF3) {
 #pragma unroll
-    for (int sidx = 0; sidx < 16; ++sidx)
+      for (int t = 0; t < 2; ++t) {
+        bf16x8 ph[MBP], pm[MBP], qh[MBQ], qm[MBQ];
 #pragma unroll
-      for (int i = 0; i < MBP; ++i)
+        for (int i = 0; i < MBP; ++i) {
+          float x8[8];
 #pragma unroll
-        for (int jq = 0; jq < MBQ; ++jq)
-          acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[i][sidx], qb[jq][sidx], acc[i][jq], 0, 0, 0);
+          for (int e = 0; e < 8; ++e) x8[e] = pa[i][8 * t + e];
+          split_bf16x8(x8, ph[i], pm[i]);
+        }
+#pragma unroll
+        for (int jq = 0; jq < MBQ; ++jq) {
+          float x8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x8[e] = qb[jq][8 * t + e];
+          split_bf16x8(x8, qh[jq], qm[jq]);
+        }
+#pragma unroll
+        for (int i = 0; i < MBP; ++i)
+#pragma unroll
+          for (int jq = 0; jq < MBQ; ++jq) {
+            acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pm[i], qh[jq], acc[i][jq], 0, 0, 0);
+            acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph[i], qm[jq], acc[i][jq], 0, 0, 0);
+            acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph[i], qh[jq], acc[i][jq], 0, 0, 0);
+          }
+      }
+    } else {
+#pragma unroll
+      for (int sidx = 0; sidx < 16; ++sidx)
+#pragma unroll
+        for (int i = 0; i < MBP; ++i)
+#pragma unroll
+          for (int jq = 0; jq < MBQ; ++jq)
+            acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[i][sidx], qb[jq][sidx], acc[i][jq], 0, 0, 0);
+    }
   }
 
   // ---- reduce the 4 waves through LDS, then write this workgroup's partial block ----
@@ -655,7 +711,13 @@ extern "C" int fz_wgrad(const fz_wgrad_desc* d, void* workspace, fz_stream_t str
     const size_t ldsf = (size_t)4 * (PR + QR) * kStrideF * sizeof(float);
     const size_t ldsr = (size_t)4 * 1024 * sizeof(float);
     const size_t ldsz = ldsf > ldsr ? ldsf : ldsr;
-#define FZ_WGF(MBP, MBQ, QP) hipLaunchKernelGGL((wgrad_fast_kernel<MBP, MBQ, QP>), grid, block, ldsz, st, a)
+    int bf3 = 0;
+    { const char* e = getenv("FZ_WGRAD_BF3"); if (e) bf3 = atoi(e); }
+#define FZ_WGF(MBP, MBQ, QP)                                                                              \
+  do {                                                                                                    \
+    if (bf3) hipLaunchKernelGGL((wgrad_fast_kernel<MBP, MBQ, QP, true>), grid, block, ldsz, st, a);       \
+    else hipLaunchKernelGGL((wgrad_fast_kernel<MBP, MBQ, QP, false>), grid, block, ldsz, st, a);          \
+  } while (0)
 #define FZ_WGF_SHAPES(QP)                                \
   do {                                                   \
     if (PR == 64 && QR == 64) FZ_WGF(2, 2, QP);          \

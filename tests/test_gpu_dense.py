@@ -308,3 +308,24 @@ def test_flat_adamw_kernel_matches_torch():
         o_dev.step()
     assert _native.launch_count() >= n0 + 5
     assert torch.allclose(dev.detach().cpu(), ref.detach(), rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("M,K,S", [(64, 64, (16, 16, 16)), (128, 64, (8, 8, 16)), (64, 128, (8, 16, 16))])
+def test_wgrad_split_bf16_mode(monkeypatch, M, K, S):
+    """Opt-in FZ_WGRAD_BF3=1: the register-operand weight-gradient kernel forms its products from a two-level
+    bf16 split of both operands (three bf16 MFMAs per product, fp32 accumulation).  Error against float64
+    stays below 2e-5 of the largest entry — the default fp32-MFMA path is ~5e-7."""
+    torch.manual_seed(5)
+    V = S[0] * S[1] * S[2]
+    p = torch.randn(2, M, V, device=DEV)
+    q = torch.randn(2, K, V, device=DEV)
+    ref = torch.einsum("bmv,bkv->mk", p.double(), q.double())
+    errs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("FZ_WGRAD_BF3", mode)
+        gw = torch.empty(M, K, device=DEV)
+        gb = torch.empty(M, device=DEV)
+        PW._wgrad(p, [q], gw, B=2, M=M, Cin=K, K=K, Vq=V, Ncols=V, gbias=gb)
+        errs[mode] = ((gw.double() - ref).abs().max() / ref.abs().max()).item()
+        assert torch.allclose(gb.double(), p.double().sum((0, 2)), rtol=1e-4, atol=1e-3)
+    assert errs["0"] <= 2e-6 and errs["1"] <= 2e-5, errs
