@@ -70,7 +70,8 @@ __device__ __forceinline__ float gelu_grad_w(float x) {
 }
 
 // MBP x MBQ blocks of 32x32 outputs per workgroup; 4 waves split the voxel tiles.
-template <int MBP, int MBQ, int QL>
+// BF3: split-bf16 products (see wgrad_fast_kernel), opt-in.
+template <int MBP, int MBQ, int QL, bool BF3 = false>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int PR = 32 * MBP, QR = 32 * MBQ;
@@ -228,6 +229,35 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     }
     if (t + 1 < t_end) issue_loads(t + 1);  // in flight during the MFMA loop below
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (BF3) {
+      // ---- 2 K-steps of 16 voxels: lane half h, element e <-> voxel 16·t + 8·h + e ----
+#pragma unroll
+      for (int t16 = 0; t16 < 2; ++t16) {
+        bf16x8 ph[MBP], pm[MBP], qh[MBQ], qm[MBQ];
+#pragma unroll
+        for (int i = 0; i < MBP; ++i) {
+          float x8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { x8[e] = Pt[(i * 32 + c) * kStride + 16 * t16 + 8 * h + e]; psum[i] += x8[e]; }
+          split_bf16x8(x8, ph[i], pm[i]);
+        }
+#pragma unroll
+        for (int jq = 0; jq < MBQ; ++jq) {
+          float x8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x8[e] = Qt[(jq * 32 + c) * kStride + 16 * t16 + 8 * h + e];
+          split_bf16x8(x8, qh[jq], qm[jq]);
+        }
+#pragma unroll
+        for (int i = 0; i < MBP; ++i)
+#pragma unroll
+          for (int jq = 0; jq < MBQ; ++jq) {
+            acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pm[i], qh[jq], acc[i][jq], 0, 0, 0);
+            acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph[i], qm[jq], acc[i][jq], 0, 0, 0);
+            acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph[i], qh[jq], acc[i][jq], 0, 0, 0);
+          }
+      }
+    } else
     // ---- 16 K-steps of 2 voxels ----
 #pragma unroll 4
     for (int s = 0; s < kTile / 2; ++s) {
@@ -698,7 +728,13 @@ extern "C" int fz_wgrad(const fz_wgrad_desc* d, void* workspace, fz_stream_t str
   dim3 grid(nchunk, gy, gz), block(256);
   const size_t lds = (size_t)4 * (PR + QR) * kStride * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-#define FZ_WG(MBP, MBQ, QL) hipLaunchKernelGGL((wgrad_kernel<MBP, MBQ, QL>), grid, block, lds, st, a)
+  int bf3g = 0;
+  { const char* e = getenv("FZ_WGRAD_BF3"); if (e) bf3g = atoi(e); }
+#define FZ_WG(MBP, MBQ, QL)                                                                        \
+  do {                                                                                             \
+    if (bf3g) hipLaunchKernelGGL((wgrad_kernel<MBP, MBQ, QL, true>), grid, block, lds, st, a);     \
+    else hipLaunchKernelGGL((wgrad_kernel<MBP, MBQ, QL, false>), grid, block, lds, st, a);         \
+  } while (0)
 #define FZ_WG_SHAPES(QL)                                 \
   do {                                                   \
     if (PR == 64 && QR == 64) FZ_WG(2, 2, QL);           \

@@ -13,7 +13,7 @@ def timeit(fn, iters=10, warm=3):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters
 B = 2
-for (M, K, S) in ((64, 64, 64), (64, 128, 64), (128, 64, 64), (128, 128, 32), (128, 256, 32), (256, 256, 16), (512, 512, 8), (512, 1024, 8)):
+for (M, K, S) in ((32, 32, 128), (32, 64, 128), (64, 32, 128), (3, 32, 128), (64, 64, 64), (64, 128, 64), (128, 64, 64), (128, 128, 32), (128, 256, 32), (256, 256, 16), (512, 512, 8), (512, 1024, 8)):
     V = S ** 3
     torch.manual_seed(0)
     p = torch.randn(B, M, V, device=DEV); q = torch.randn(B, K, V, device=DEV)
