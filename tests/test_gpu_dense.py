@@ -310,9 +310,10 @@ def test_flat_adamw_kernel_matches_torch():
     assert torch.allclose(dev.detach().cpu(), ref.detach(), rtol=1e-6, atol=1e-7)
 
 
-@pytest.mark.parametrize("M,K,S", [(64, 64, (16, 16, 16)), (128, 64, (8, 8, 16)), (64, 128, (8, 16, 16))])
+@pytest.mark.parametrize("M,K,S", [(64, 64, (16, 16, 16)), (128, 64, (8, 8, 16)), (64, 128, (8, 16, 16)), (32, 64, (16, 16, 16)),
+                                   (3, 32, (8, 8, 12))])
 def test_wgrad_split_bf16_mode(monkeypatch, M, K, S):
-    """Opt-in FZ_WGRAD_BF3=1: the register-operand weight-gradient kernel forms its products from a two-level
+    """Opt-in FZ_WGRAD_BF3=1: the weight-gradient kernels (register-operand and generic) form their products from a two-level
     bf16 split of both operands (three bf16 MFMAs per product, fp32 accumulation).  Error against float64
     stays below 2e-5 of the largest entry — the default fp32-MFMA path is ~5e-7."""
     torch.manual_seed(5)
