@@ -38,23 +38,39 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s mea
 
 # HBM traffic per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
 # passes of this same command, FETCH_SIZE doubled per the gfx950 correction of
-# MI355X_MICROARCH.md §HBM; tools/pmc_traffic.py → profiles/r01_pmc_traffic.json).  Counters cannot
-# be read from inside the benchmark, so the committed summary of the profiled run is quoted.
-PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-# timer key of a BASELINE-size (stage-0) launch -> kernel name in the PMC summary; the summary averages
+# MI355X_MICROARCH.md §HBM; tools/pmc_traffic.py → profiles/rNN_pmc_traffic.json).  Counters cannot be
+# read from inside the benchmark: the committed summary of the profiled run is quoted, and
+# `traffic_source` says which file (with its content hash and the commit it was measured at), so a stale
+# number is visible as such.
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", os.environ.get("FZ_PMC_TRAFFIC", "r02_pmc_traffic.json"))
+# timer key of a BASELINE-size (stage-0) launch -> kernel-name prefix in the PMC summary; the summary averages
 # the launches with the largest grid of each kernel, i.e. the same stage-0 launches the key times
-PMC_KERNEL = {"nmf_cf_bwd_32x128x128x128": "fz::nmf_cf_bwd_tile_kernel<1, 1, 4, false>",
-              "nmf_cf_fwd_32x128x128x128": "fz::nmf_cf_fwd_tile_kernel<1, 1, 8, false>",
-              "mlp_chain_bwd_32": "fz::gemm_chain_kernel<true, 2, 2>",
-              "mlp_chain_fwd_32": "fz::gemm_chain_kernel<false, 2, 2>"}
+PMC_KERNEL = {"nmf_cf_bwd_32x128x128x128": "fz::nmf_cf_bwd_tile_kernel<",
+              "nmf_cf_fwd_32x128x128x128": "fz::nmf_cf_fwd_tile_kernel<",
+              "mlp_chain_bwd_32": "fz::gemm_chain_kernel<true",
+              "mlp_chain_fwd_32": "fz::gemm_chain_kernel<false"}
 
 
 def pmc_traffic(timer_name):
+    """(bytes per launch or None, traffic_source string).  Loud on stderr when the summary has no entry for
+    the kernel the roofline line is about."""
+    import hashlib
     try:
-        d = json.load(open(PMC_TRAFFIC))
-        return d[PMC_KERNEL[timer_name]]["traffic_bytes"]
-    except Exception:
-        return None
+        raw = open(PMC_TRAFFIC, "rb").read()
+        d = json.loads(raw)
+    except Exception as e:
+        print(f"[bench] PMC traffic summary {PMC_TRAFFIC} unreadable: {e}", file=sys.stderr, flush=True)
+        return None, f"missing: {os.path.relpath(PMC_TRAFFIC, ROOT)}"
+    src = (f"{os.path.relpath(PMC_TRAFFIC, ROOT)} sha256:{hashlib.sha256(raw).hexdigest()[:12]} "
+           f"measured_at_commit:{d.get('_meta', {}).get('commit', 'unknown')}")
+    pre = PMC_KERNEL.get(timer_name)
+    hits = [v for k, v in d.items() if pre and k.startswith(pre) and isinstance(v, dict) and "traffic_bytes" in v]
+    if not hits:
+        print(f"[bench] NO PMC traffic entry for kernel {timer_name!r} (prefix {pre!r}) in {PMC_TRAFFIC}: "
+              "roofline.traffic is null — re-run tools/pmc_traffic.py", file=sys.stderr, flush=True)
+        return None, src + " (no entry for this kernel)"
+    return max(h["traffic_bytes"] for h in hits), src
+
 
 MODEL_KW = dict(in_channels=4, out_channels=3, spatial_size=(128, 128, 128),
                 encoder_depth=(1, 1, 1, 1, 1), encoder_width=(32, 64, 128, 256, 512),
@@ -85,17 +101,63 @@ def cpu_baseline_sample():
     cfg = dict(reshape=dict(head_dim=8, patch_size=8), num_iters=5, solver="hals")
     x = torch.rand(1, 32, 128, 128, 128, requires_grad=True)
     g = torch.rand(1, 32, 128, 128, 128)
-    reps, t0 = 0, time.perf_counter()
-    while reps < 2 or time.perf_counter() - t0 < 10.0:  # ≈ 10-15 s of CPU work
+    def once():
         y = O.factorizer_block(x, full, "", cfg)
         torch.autograd.grad(y, [x] + list(params.values()), g)
+
+    once()  # warm-up repetition (allocator, thread pool): not timed
+    reps, t0 = 0, time.perf_counter()
+    while reps < 2 or time.perf_counter() - t0 < 10.0:  # ≈ 10-15 s of CPU work
+        once()
         reps += 1
     t = (time.perf_counter() - t0) / reps
+    # BASELINE cfg 1 (plumbing): ft.NMF((8,512), rank 2, 5 iterations, MU) forward on one matrix
+    torch.manual_seed(0)
+    x1 = torch.rand(1, 8, 512)
+    u0, v0 = torch.rand(8, 2), torch.rand(512, 2)
+    O.nmf_forward(x1, u0, v0, 5, "mu")
+    t1 = time.perf_counter()
+    for _ in range(20):
+        O.nmf_forward(x1, u0, v0, 5, "mu")
+    t_cfg1 = (time.perf_counter() - t1) / 20
     return {"value": 1.0 / (2 * t), "unit": "volumes/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": "oracle FactorizerBlock(C=32,d=8,p=8,HALS R1 T5) fwd+bwd on one 128^3 volume "
-                      f"(BASELINE configs[1]): {t:.2f} s each, {reps} repetitions; x2 full-resolution blocks per volume "
-                      "(upper bound on the whole-model CPU rate)",
-            "seconds_sample": t}
+                      f"(BASELINE configs[1]): {t:.2f} s each, {reps} timed repetitions after 1 warm-up; the model runs 2 such "
+                      "full-resolution blocks per volume, which hold >85 % of its CPU time, so value = 1/(2 t) is an "
+                      "UPPER bound on the whole-model CPU rate; measured whole-model CPU runs: profiles/r02_cpu_baseline.json",
+            "seconds_sample": t, "cfg1_nmf_8x512_mu_r2_t5_fwd_us": round(t_cfg1 * 1e6, 1),
+            "host_cpus": os.cpu_count()}
+
+
+NMF_FLOP_FWD = 95312  # HALS R=1 T=5 on one 8x512 matrix, forward (T·F_iter + F_recon)
+
+
+def nmf_gflops(table, nsteps, B):
+    """BASELINE.json's second metric, "NMF-iter GFLOP/s": algorithmic NMF flops of the fused
+    matricize→NMF→inverse kernels ÷ their measured time (HIP events, per-kernel table).  Forward 95 312 flop per
+    8x512 matrix; backward 3x (in-kernel recompute + reverse sweep).  Matrices per window launch at
+    stage s of the README model: B·h·G."""
+    stages = {"32x128x128x128": 4 * 4096, "64x64x64x64": 8 * 512, "128x32x32x32": 16 * 64,
+              "256x16x16x16": 32 * 8, "512x8x8x8": 64}
+    out = {}
+    for kind, mult in (("fwd", 1.0), ("bwd", 3.0)):
+        flops = ms = 0.0
+        for shape, per_b in stages.items():
+            a = table.get(f"nmf_cf_{kind}_{shape}")
+            if not a:
+                continue
+            f = a["calls"] * B * per_b * NMF_FLOP_FWD * mult
+            if shape == "32x128x128x128":
+                out[f"{kind}_stage0"] = round(f / (a["ms"] * 1e-3) / 1e9, 1)
+            flops += f
+            ms += a["ms"]
+        if ms > 0:
+            out[f"{kind}_all_stages"] = round(flops / (ms * 1e-3) / 1e9, 1)
+    out["unit"] = "GFLOP/s"
+    out["flop_per_matrix_fwd"] = NMF_FLOP_FWD
+    out["note"] = ("fused matricize+NMF+inverse launches (HBM-bound: 2.9 flop/B, SURVEY §8d); time includes the "
+                   "gather/scatter of the same launch")
+    return out
 
 
 def main():
@@ -105,6 +167,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch-per-gpu", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the RCCL process group and run the hook-launched bucket all-reduces and "
+                         "finish() even with one rank (the N = 1 line then executes the N > 1 code path)")
     ap.add_argument("--no-late-join", action="store_true",
                     help="await the side-stream weight gradients at the end of every block backward "
                          "(factorizer_amd/pointwise.py:_LateJoin)")
@@ -122,8 +187,13 @@ def main():
     dev_index = local_rank % ndev  # one process per GPU; the modulo only matters for the 1-GPU gloo self-test
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         backend = os.environ.get("FZ_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -132,7 +202,8 @@ def main():
 
     torch.manual_seed(0)
     model = ft.Factorizer(**MODEL_KW).to(dev).train()
-    sync = FlatGradSync(model, num_buckets=2, overlap=True, late_wgrad_join=not args.no_late_join)
+    sync = FlatGradSync(model, num_buckets=2, overlap=True, late_wgrad_join=not args.no_late_join,
+                        force_collectives=args.force_dist)
     sync.broadcast_state(0)
     # AdamW of the recipe (train.yaml:72-76: lr 1e-4, wd 1e-5) as ONE kernel over the flat parameter /
     # gradient / moment buffers (csrc/optim.hip); the gradient buffer is the one RCCL reduces in place
@@ -144,10 +215,10 @@ def main():
 
     def step():
         sync.zero_grad()
-        loss = ft.dice_bce_loss(model(x), target)
+        loss = ft.dice_ce_loss(model(x), target)   # the recipe's DiceCELoss(sigmoid, squared_pred), train.yaml:67-70
         loss.backward()
-        sync.finish()
-        opt.step()
+        scale = sync.finish(average=False)          # SUM stays in the buffer; 1/world is applied by the optimizer kernel
+        opt.step(grad_scale=scale)
         return loss
 
     # Warm-up steps run with EVERY native launch bracketed by HIP events: that pass yields the per-kernel
@@ -169,13 +240,13 @@ def main():
     dominant = max(wagg.items(), key=lambda kv: kv[1]["ms"])[0] if wagg else None
     timer = Fn.KernelTimer(only=None if dominant is None else {dominant})
     Fn.set_timer(timer)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -209,8 +280,10 @@ def main():
             name, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
             avg_ms = a["ms"] / a["calls"]
             gbs = a["bytes"] / a["calls"] / (avg_ms * 1e-3) / 1e9
+            traffic, traffic_source = pmc_traffic(name)
             roof = {"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(name),
+                    "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "traffic_source": traffic_source,
                     "avg_launch_ms": round(avg_ms, 4), "launches": a["calls"],
                     "algorithmic_bytes_per_launch": a["bytes"] // a["calls"],
                     "share_of_step": round(a["ms"] / (elapsed * 1e3), 4),
@@ -237,11 +310,15 @@ def main():
                                    "training step fwd+bwd+AdamW (BASELINE configs[3])",
                        "global_batch": world * B, "batch_per_gpu": B, "parallelism": f"dp{world}"},
             "roofline": roof,
+            "nmf_iter_gflops": nmf_gflops(wagg or agg, wsteps if wagg else max(args.steps, 1), B),
+            "rccl": ("process group 'nccl' (RCCL), hook-launched bucket all-reduces executed"
+                     if use_dist and os.environ.get("FZ_BENCH_BACKEND", "nccl") == "nccl" else
+                     ("gloo" if use_dist else "not initialised (single rank; --force-dist runs it)")),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_sample()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -13,8 +13,8 @@ from .nmf import (NMF, SVD, BCDSolver, Compose, CoordinateDescent, FastMultiplic
 from .layers import MLP, LayerNorm, Linear, PosEmbed, PositionalEmbedding
 from .convs import Conv3d, ConvTranspose3d
 from .blocks import FactMixer, FactorizerBlock, FactorizerStage
-from .losses import dice_bce_loss
-from .training import FlatAdamW, WarmupCosineSchedule, load_checkpoint
+from .losses import DiceCELoss, dice_bce_loss, dice_ce_loss
+from .training import FlatAdamW, WarmupCosineSchedule, load_checkpoint, load_checkpoints
 from .parallel import FlatGradSync
 from .inference import SlidingWindowInferer, SlidingWindowInfererAdapt, sliding_window_inference
 from .ushape import (Factorizer, Same, UNet, UNetDecoder, UNetDecoderBlock, UNetEncoder,

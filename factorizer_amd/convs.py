@@ -37,6 +37,13 @@ class Conv3d(nn.Conv3d):
               and _all(self.dilation, 1) and self.padding_mode == "zeros")
         if ok:
             C = self.in_channels
+            if C % 2 and _all(self.kernel_size, 3) and _all(self.stride, 1) and _all(self.padding, 1) \
+                    and x.shape[-1] % 4 == 0:
+                # odd C_in (1- or 3-modality stems: ISLES / BraTS variants): the kernels consume channel
+                # pairs, so run them on one extra all-zero channel (input 1/C larger, weights padded to match)
+                xp = torch.nn.functional.pad(x, (0, 0, 0, 0, 0, 0, 0, 1))
+                wp = torch.nn.functional.pad(self.weight, (0, 0, 0, 0, 0, 0, 0, 1))
+                return PW.ConvK3Fn.apply(xp, wp, self.bias)
             if self._k2s2_native(x):
                 return PW.ConvK2S2Fn.apply(x, self.weight, self.bias)
             if _all(self.kernel_size, 3) and _all(self.stride, 1) and _all(self.padding, 1) \

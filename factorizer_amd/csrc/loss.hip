@@ -72,6 +72,118 @@ __global__ __launch_bounds__(256) void dice_bce_grad_kernel(const float* __restr
   }
 }
 
+
+// ---- DiceCELoss(sigmoid=True, squared_pred=True) for C > 1 channels, as MONAI 1.4 evaluates it
+// (the bundle pins monai==1.4.0, docs/requirements.txt:11; train.yaml:67-70): soft Dice on
+// sigmoid(z) per (b, c) plane + nn.CrossEntropyLoss over the CHANNEL softmax with the float
+// multi-label target as class "probabilities":  CE = mean_{b,v} Σ_c t_c · (logsumexp_c'(z) − z_c).
+// One pass: per batch item and chunk the 3·C Dice sums {Σ p t, Σ p², Σ t²}_c and Σ CE.
+template <int C>
+__global__ __launch_bounds__(256) void dice_ce_sums_kernel(const float* __restrict__ z, const float* __restrict__ t,
+                                                           float* __restrict__ part, int64_t V, int nchunk) {
+  __shared__ float red[4][3 * C + 1];
+  const int b = blockIdx.x, chunk = blockIdx.y;
+  const int64_t per = ((V / 4 + nchunk - 1) / nchunk) * 4;
+  const int64_t v0 = chunk * per, v1 = min(V, v0 + per);
+  const float* zp = z + (int64_t)b * C * V;
+  const float* tp = t + (int64_t)b * C * V;
+  float s[3 * C + 1];
+#pragma unroll
+  for (int i = 0; i < 3 * C + 1; ++i) s[i] = 0.f;
+  for (int64_t v = v0 + threadIdx.x * 4; v < v1; v += 1024) {
+    float zs[C][4], ts[C][4];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float4 zz = *reinterpret_cast<const float4*>(zp + c * V + v);
+      const float4 tt = *reinterpret_cast<const float4*>(tp + c * V + v);
+      zs[c][0] = zz.x, zs[c][1] = zz.y, zs[c][2] = zz.z, zs[c][3] = zz.w;
+      ts[c][0] = tt.x, ts[c][1] = tt.y, ts[c][2] = tt.z, ts[c][3] = tt.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float mx = zs[0][e];
+#pragma unroll
+      for (int c = 1; c < C; ++c) mx = fmaxf(mx, zs[c][e]);
+      float se = 0.f, st = 0.f, stz = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float zc = zs[c][e], tc = ts[c][e];
+        se += __expf(zc - mx);
+        st += tc;
+        stz += tc * zc;
+        const float ex = __expf(-fabsf(zc));
+        const float p = zc >= 0.f ? 1.0f / (1.0f + ex) : ex / (1.0f + ex);
+        s[3 * c + 0] += p * tc;
+        s[3 * c + 1] += p * p;
+        s[3 * c + 2] += tc * tc;
+      }
+      s[3 * C] += st * (mx + __logf(se)) - stz;
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 3 * C + 1; ++i) {
+    const float r = wave_sum(s[i]);
+    if (lane == 0) red[wave][i] = r;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3 * C + 1) {
+    const int i = threadIdx.x;
+    part[((int64_t)b * nchunk + chunk) * (3 * C + 1) + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+  }
+}
+
+// dL/dz_c = g·[ cd·dDice_c/dp·p(1−p) + cb·(softmax_c·Σ_c' t_c' − t_c) ]; coef (B·C, 2) as in dice_bce_grad.
+template <int C>
+__global__ __launch_bounds__(256) void dice_ce_grad_kernel(const float* __restrict__ z, const float* __restrict__ t,
+                                                           const float* __restrict__ coef, float* __restrict__ gz,
+                                                           int64_t V, int B, float cd, float cb,
+                                                           const float* __restrict__ gscale) {
+  const float g = gscale ? gscale[0] : 1.0f;
+  const int64_t total = (int64_t)B * V;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < total;
+       i += (int64_t)gridDim.x * blockDim.x * 4) {
+    const int b = (int)(i / V);
+    const int64_t v = i - (int64_t)b * V;
+    const int64_t base = (int64_t)b * C * V + v;
+    float zs[C][4], ts[C][4];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float4 zz = *reinterpret_cast<const float4*>(z + base + c * V);
+      const float4 tt = *reinterpret_cast<const float4*>(t + base + c * V);
+      zs[c][0] = zz.x, zs[c][1] = zz.y, zs[c][2] = zz.z, zs[c][3] = zz.w;
+      ts[c][0] = tt.x, ts[c][1] = tt.y, ts[c][2] = tt.z, ts[c][3] = tt.w;
+    }
+    float o[C][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float mx = zs[0][e];
+#pragma unroll
+      for (int c = 1; c < C; ++c) mx = fmaxf(mx, zs[c][e]);
+      float ez[C], se = 0.f, st = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        ez[c] = __expf(zs[c][e] - mx);
+        se += ez[c];
+        st += ts[c][e];
+      }
+      const float inv = st / se;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float zc = zs[c][e], tc = ts[c][e];
+        const float num = coef[(b * C + c) * 2], den = coef[(b * C + c) * 2 + 1];
+        const float ex = __expf(-fabsf(zc));
+        const float p = zc >= 0.f ? 1.0f / (1.0f + ex) : ex / (1.0f + ex);
+        const float ddp = -2.0f * tc / den + num * 2.0f * p / (den * den);
+        o[c][e] = g * (cd * ddp * p * (1.0f - p) + cb * (ez[c] * inv - tc));
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+      *reinterpret_cast<float4*>(gz + base + c * V) = make_float4(o[c][0], o[c][1], o[c][2], o[c][3]);
+  }
+}
+
 }  // namespace fz
 
 using namespace fz;
@@ -106,6 +218,44 @@ extern "C" int fz_dice_bce_grad(const float* z, const float* t, const float* coe
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(dice_bce_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, z, t, coef, gz, V,
                      total, cd, cb, gscale);
+  FZ_LAUNCH_CHECK();
+  return FZ_OK;
+}
+
+// ---- multi-channel DiceCE (C in 2..8) ----
+// part: (B, nchunk, 3C+1) = per channel {Σ p t, Σ p², Σ t²}, then Σ CE
+#define FZ_CE_DISPATCH(C_, CALL) \
+  switch (C_) {                  \
+    case 2: { constexpr int CC = 2; CALL; } break; \
+    case 3: { constexpr int CC = 3; CALL; } break; \
+    case 4: { constexpr int CC = 4; CALL; } break; \
+    case 5: { constexpr int CC = 5; CALL; } break; \
+    case 6: { constexpr int CC = 6; CALL; } break; \
+    case 7: { constexpr int CC = 7; CALL; } break; \
+    case 8: { constexpr int CC = 8; CALL; } break; \
+    default: return fail(FZ_E_UNSUPPORTED, "fz_dice_ce: 2 <= C <= 8"); \
+  }
+
+extern "C" int fz_dice_ce_sums(const float* z, const float* t, float* part, int B, int C, int64_t V,
+                               fz_stream_t stream) {
+  if (!z || !t || !part) return fail(FZ_E_ARG, "fz_dice_ce_sums: null pointer");
+  if (B < 1 || V < 4 || (V % 4)) return fail(FZ_E_SHAPE, "fz_dice_ce_sums: bad sizes");
+  const int nchunk = fz_dice_bce_chunks(V);
+  FZ_CE_DISPATCH(C, hipLaunchKernelGGL(dice_ce_sums_kernel<CC>, dim3(B, nchunk), dim3(256), 0, (hipStream_t)stream,
+                                       z, t, part, V, nchunk));
+  FZ_LAUNCH_CHECK();
+  return FZ_OK;
+}
+
+// coef: (B·C, 2) = {2·inter + smooth, den + smooth};  cd = 1/(B·C), cb = 1/(B·V)
+extern "C" int fz_dice_ce_grad(const float* z, const float* t, const float* coef, float* gz, int B, int C, int64_t V,
+                               float cd, float cb, const float* gscale, fz_stream_t stream) {
+  if (!z || !t || !coef || !gz) return fail(FZ_E_ARG, "fz_dice_ce_grad: null pointer");
+  if (B < 1 || V < 4 || (V % 4)) return fail(FZ_E_SHAPE, "fz_dice_ce_grad: bad sizes");
+  int64_t blocks = ((int64_t)B * V / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  FZ_CE_DISPATCH(C, hipLaunchKernelGGL(dice_ce_grad_kernel<CC>, dim3((unsigned)blocks), dim3(256), 0,
+                                       (hipStream_t)stream, z, t, coef, gz, V, B, cd, cb, gscale));
   FZ_LAUNCH_CHECK();
   return FZ_OK;
 }

@@ -18,7 +18,9 @@ import torch.distributed as dist
 
 class FlatGradSync:
     def __init__(self, module: torch.nn.Module, process_group=None, num_buckets: int = 2,
-                 overlap: bool = True, late_wgrad_join: bool = False):
+                 overlap: bool = True, late_wgrad_join: bool = False, force_collectives: bool = False):
+        # force_collectives: run the hook-launched all-reduces and finish() even in a one-rank group
+        # (bench.py --force-dist: the N = 1 line then executes the same RCCL path as N > 1)
         # late_wgrad_join: the side-stream weight-gradient kernels of the deep blocks are awaited once,
         # right before the gradients are read (bucket collectives / optimizer), not at the end of every
         # block backward (pointwise._LateJoin)
@@ -55,7 +57,9 @@ class FlatGradSync:
             self.buckets.append({"params": cur, "lo": start, "hi": off})
         self._pending = []
         self._ready = [0] * len(self.buckets)
-        self.overlap = overlap and self.world > 1
+        self._launched = [False] * len(self.buckets)
+        self.active = self.world > 1 or (force_collectives and dist.is_initialized())
+        self.overlap = overlap and self.active
         if self.overlap:
             for bi, b in enumerate(self.buckets):
                 for p in b["params"]:
@@ -77,6 +81,7 @@ class FlatGradSync:
 
     def _launch(self, bi):
         b = self.buckets[bi]
+        self._launched[bi] = True
         if self.late_join:
             from . import pointwise as _PW
             _PW.wait_wgrad_streams()  # (ownership is checked in finish(), once every gradient is assigned)
@@ -98,21 +103,31 @@ class FlatGradSync:
         for p in self.params:
             p.grad = None
         self._ready = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
 
-    def finish(self):
-        """Call after backward(): waits for the bucket collectives and averages."""
+    def finish(self, average: bool = True) -> float:
+        """Call after backward(): launches the buckets whose hooks did not all fire (a parameter that took
+        no part in the loss never fires its hook: its slice of the flat buffer is zero-filled and reduced
+        like the rest, as DistributedDataParallel(find_unused_parameters=True) does), waits for the
+        collectives and averages.  `average=False` leaves the SUM in the buffer and returns the factor
+        1/world for the optimizer to apply (`FlatAdamW.step(grad_scale=...)`: no extra pass)."""
         if self.late_join:
             from . import pointwise as _PW
             _PW.join_wgrad_streams()
-        if self.world == 1:
-            return
-        if not self.overlap:
-            for bi in range(len(self.buckets)):
+        if not self.active:
+            return 1.0
+        for bi in range(len(self.buckets)):
+            if not self._launched[bi]:
                 self._launch(bi)
         for w in self._pending:
             w.wait()
         self._pending = []
-        self.flat.div_(self.world)
-        for p in self.params:  # the optimizer reads the averaged gradients through the flat views
+        scale = 1.0 / self.world
+        if average and self.world > 1:
+            self.flat.div_(self.world)
+            scale = 1.0
+        for p in self.params:  # the optimizer reads the reduced gradients through the flat views
             p.grad = self.views[p]
         self._ready = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
+        return scale

@@ -216,6 +216,13 @@ class _LateJoin:
     keep = []      # tensors read by in-flight side-stream kernels
     owed = []      # (weakref(param), data_ptr of the gradient tensor written on the side stream)
     devices = set()
+    queued = False  # an end-of-backward engine callback is pending
+    verified = 0    # gradients whose ownership has been checked so far (tests)
+
+
+def _end_of_backward():
+    _LateJoin.queued = False
+    join_wgrad_streams()
 
 
 def late_wgrad_join(flag: bool = True):
@@ -241,6 +248,7 @@ def join_wgrad_streams():
     d = _LateJoin
     wait_wgrad_streams()
     owed, d.owed = d.owed, []
+    d.verified += len(owed)
     for ref, ptr in owed:
         prm = ref()
         if prm is not None and prm.is_leaf and prm.requires_grad and (prm.grad is None or prm.grad.data_ptr() != ptr):
@@ -532,7 +540,8 @@ class ConvK3Fn(torch.autograd.Function):
         V = D * H * W
         gx = None
         if ctx.needs_input_grad[0]:
-            # not on the training path (the stem's input is data); composed from ATen
+            # not on the training path (the stem's input is data); composed from ATen, and said so
+            _warn_composed("Conv3d(k=3) input gradient", x)
             gx = torch.nn.grad.conv3d_input(x.shape, w, gy, padding=1)
         gw = torch.empty_like(w)
         gb = torch.empty(O, dtype=x.dtype, device=x.device)
@@ -562,9 +571,21 @@ class ConvK3Fn(torch.autograd.Function):
 
 
 # ---- public dispatchers (device → native, CPU → composed ATen) ---------------------------------------
+def _warn_composed(op, x, *more):
+    """A device tensor is about to take the composed-ATen path: say so, once per (op, shape, dtype)."""
+    if x.is_cuda and x.numel():
+        from .composed import warn_once
+        dts = sorted({str(t.dtype) for t in (x, *more) if t is not None})
+        warn_once(f"{op}:{tuple(x.shape)}:{dts}",
+                  f"{op} on {tuple(x.shape)} ({', '.join(dts)}) is outside the native kernel set (needs fp32 or "
+                  "bf16 activations with fp32 parameters, an even channel count and a voxel count divisible by 4); "
+                  "using composed framework ops on device")
+
+
 def linear_cf(x, weight, bias=None):
     if _native_ok(x, weight, bias) and weight.shape[1] % 2 == 0:
         return LinearFn.apply(x, weight, bias)
+    _warn_composed("Linear", x, weight, bias)
     B, C = x.shape[:2]
     y = torch.matmul(weight.reshape(weight.shape[0], weight.shape[1]), x.reshape(B, C, _vox(x)))
     if bias is not None:
@@ -575,6 +596,7 @@ def linear_cf(x, weight, bias=None):
 def layernorm_cf(x, weight, bias, eps):
     if weight is not None and bias is not None and _native_ok(x, weight, bias):
         return LayerNormFn.apply(x, weight, bias, eps)
+    _warn_composed("LayerNorm", x, weight, bias)
     y = F.layer_norm(x.movedim(1, -1), (x.shape[1],), weight, bias, eps)
     return y.movedim(-1, 1).contiguous()
 
@@ -583,6 +605,7 @@ def mlp_cf(x, w1, b1, w2, b2):
     if _native_ok(x, w1, b1, w2, b2) and w1.shape[1] % 2 == 0 and w2.shape[1] % 2 == 0:
         z = LinearFn.apply(x, w1, b1)
         return ActLinearResFn.apply(z, w2, b2, None, "gelu")
+    _warn_composed("MLP", x, w1, b1, w2, b2)
     return linear_cf(F.gelu(linear_cf(x, w1, b1)), w2, b2)
 
 
@@ -591,6 +614,7 @@ def ln_linear(x, ln_w, ln_b, eps, w, b, act="none"):
     incoming gradient is already gated by the consumer — FactCoreFn — so backward skips it)."""
     if _native_ok(x, ln_w, ln_b, w, b) and w.shape[1] % 2 == 0:
         return LNLinearFn.apply(x, ln_w, ln_b, eps, w, b, act)
+    _warn_composed("LayerNorm+Linear", x, ln_w, ln_b, w, b)
     y = linear_cf(layernorm_cf(x, ln_w, ln_b, eps), w, b)
     return torch.relu(y) if act != "none" else y
 
@@ -599,6 +623,7 @@ def act_linear_res(z, w, b, res, act="none"):
     """res + Linear(act(z))."""
     if _native_ok(z, w, b, res) and w.shape[1] % 2 == 0:
         return ActLinearResFn.apply(z, w, b, res, act)
+    _warn_composed("Linear+residual", z, w, b, res)
     y = linear_cf(F.gelu(z) if act == "gelu" else z, w, b)
     return y if res is None else res + y
 
@@ -607,6 +632,7 @@ def cat_linear(x1, x2, w, b=None):
     """Linear(cat([x1, x2], dim=1)) without materialising the concatenation."""
     if _native_ok(x1, x2, w, b) and x1.shape[1] % 2 == 0 and x2.shape[1] % 2 == 0:
         return CatLinearFn.apply(x1, x2, w, b)
+    _warn_composed("cat+Linear", x1, x2, w, b)
     return linear_cf(torch.cat([x1, x2], dim=1), w, b)
 
 
@@ -735,6 +761,11 @@ class FactorizerBlockFn(torch.autograd.Function):
                 _LateJoin.keep.extend(keep)
                 _LateJoin.devices.add((dev.type, dev.index))
                 _LateJoin.owed.extend(zip(ctx.prm, (t.data_ptr() for t in (gwi, gwo, gbo, gw1, gb1, gw2, gb2))))
+                if not _LateJoin.queued:
+                    # the streams always meet (and ownership is verified) before backward() returns: any
+                    # reader of p.grad after backward — a stock optimizer, gradient clipping — is safe
+                    _LateJoin.queued = True
+                    torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
             else:
                 cur.wait_stream(side)
             keep.clear()

@@ -25,12 +25,19 @@ class FlatAdamW:
     """AdamW (decoupled weight decay, no amsgrad) over the trainable parameters of `module`, moved
     into one flat buffer (each `p.data` becomes a view, so `state_dict`/`load_state_dict` and the
     forward are unaffected).  `step()` packs the gradients (one multi-tensor copy, or none when
-    `grad_views` — e.g. FlatGradSync.views after `finish()` — already alias `flat_grad`)."""
+    `grad_views` — e.g. FlatGradSync.views after `finish()` — already alias `flat_grad`).
+
+    Semantics are torch.optim.AdamW's (train.yaml:72-76), including: a parameter whose `.grad` is None
+    is skipped entirely (no decay, no moment update, its step count does not advance), and
+    `state_dict()` / `load_state_dict()` use torch's layout — `{"state": {i: {"step", "exp_avg",
+    "exp_avg_sq"}}, "param_groups": [...]}` with i the position in the parameter list — so optimizer
+    checkpoints interchange with the reference recipe's (train.yaml:354-358)."""
 
     def __init__(self, module_or_params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, flat_grad=None,
                  grad_views=None):
         params = module_or_params.parameters() if isinstance(module_or_params, torch.nn.Module) else module_or_params
-        self.params = [p for p in params if p.requires_grad]
+        self.all_params = list(params)               # torch's param_groups[0]["params"] order
+        self.params = [p for p in self.all_params if p.requires_grad]
         if not self.params:
             raise ValueError("FlatAdamW: no trainable parameters")
         dev, dt = self.params[0].device, self.params[0].dtype
@@ -46,7 +53,7 @@ class FlatAdamW:
             raise ValueError("FlatAdamW: flat_grad size mismatch")
         self.exp_avg = torch.zeros(total, device=dev, dtype=dt)
         self.exp_avg_sq = torch.zeros(total, device=dev, dtype=dt)
-        self.grad_views, off = {}, 0
+        self.grad_views, self.offsets, off = {}, {}, 0
         with torch.no_grad():
             for p in order:  # same order as the gradient buffer
                 n = p.numel()
@@ -54,14 +61,58 @@ class FlatAdamW:
                 view.copy_(p.data)
                 p.data = view
                 self.grad_views[p] = grad_views[p] if grad_views is not None else self.flat_grad[off:off + n].view_as(p)
+                self.offsets[p] = off
                 off += n
+        self.order = order
         self.lr, self.betas, self.eps, self.weight_decay = float(lr), tuple(betas), float(eps), float(weight_decay)
         self.base_lr = float(lr)
-        self.t = 0
+        self.steps = {p: 0 for p in self.params}     # per-parameter step counts, as torch keeps them
 
-    def zero_grad(self):
+    @property
+    def t(self) -> int:
+        return max(self.steps.values())
+
+    def __deepcopy__(self, memo):
+        """nn.Parameter deep-copies by cloning, which would untie the copies from the copied flat buffer:
+        re-point them (scripts/utils.py:21 deep-copies {network, optimizer} before loading)."""
+        import copy
+        new = object.__new__(type(self))
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            setattr(new, k, copy.deepcopy(v, memo))
+        with torch.no_grad():
+            for q in new.order:
+                lo, n = new.offsets[q], q.numel()
+                q.data = new.flat_param[lo:lo + n].view_as(q)
+        return new
+
+    @property
+    def param_groups(self):
+        """Read-only torch-style view (lr schedulers written against torch optimizers read it)."""
+        return [{"lr": self.lr, "initial_lr": self.base_lr, "betas": self.betas, "eps": self.eps,
+                 "weight_decay": self.weight_decay, "amsgrad": False, "params": self.all_params}]
+
+    def zero_grad(self, set_to_none: bool = True):
         for p in self.params:
             p.grad = None
+
+    def _update(self, lo, hi, t, grad_scale):
+        b1, b2 = self.betas
+        P, G, M, V = (x[lo:hi] for x in (self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq))
+        if self.flat_param.is_cuda:
+            with torch.cuda.device(self.flat_param.device):
+                rc = N.lib().fz_adamw_step(P.data_ptr(), G.data_ptr(), M.data_ptr(), V.data_ptr(), hi - lo, self.lr,
+                                           b1, b2, self.eps, self.weight_decay, t, float(grad_scale),
+                                           N.stream_ptr(self.flat_param))
+            N.check(rc, "fz_adamw_step")
+            return
+        g = G * grad_scale
+        P.mul_(1.0 - self.lr * self.weight_decay)
+        M.mul_(b1).add_(g, alpha=1.0 - b1)
+        V.mul_(b2).addcmul_(g, g, value=1.0 - b2)
+        bc1, bc2 = 1.0 - b1 ** t, 1.0 - b2 ** t
+        denom = (V.sqrt() / math.sqrt(bc2)).add_(self.eps)
+        P.addcdiv_(M, denom, value=-self.lr / bc1)
 
     @torch.no_grad()
     def step(self, grad_scale: float = 1.0):
@@ -70,51 +121,102 @@ class FlatAdamW:
         src = [p for p in self.params if p.grad is not None and p.grad.data_ptr() != self.grad_views[p].data_ptr()]
         if src:
             torch._foreach_copy_([self.grad_views[p] for p in src], [p.grad for p in src])
-        for p in self.params:
+        # one launch per maximal run of buffer-adjacent parameters that have a gradient and share a step
+        # count: ONE launch over the whole buffer in the usual case
+        run = None  # [lo, hi, t]
+        for p in self.order:
             if p.grad is None:
-                self.grad_views[p].zero_()
-        self.t += 1
-        b1, b2 = self.betas
-        if self.flat_param.is_cuda:
-            with torch.cuda.device(self.flat_param.device):
-                rc = N.lib().fz_adamw_step(self.flat_param.data_ptr(), self.flat_grad.data_ptr(),
-                                           self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
-                                           self.flat_param.numel(), self.lr, b1, b2, self.eps, self.weight_decay,
-                                           self.t, float(grad_scale), N.stream_ptr(self.flat_param))
-            N.check(rc, "fz_adamw_step")
-            return
-        g = self.flat_grad * grad_scale
-        self.flat_param.mul_(1.0 - self.lr * self.weight_decay)
-        self.exp_avg.mul_(b1).add_(g, alpha=1.0 - b1)
-        self.exp_avg_sq.mul_(b2).addcmul_(g, g, value=1.0 - b2)
-        bc1, bc2 = 1.0 - b1 ** self.t, 1.0 - b2 ** self.t
-        denom = (self.exp_avg_sq.sqrt() / math.sqrt(bc2)).add_(self.eps)
-        self.flat_param.addcdiv_(self.exp_avg, denom, value=-self.lr / bc1)
+                if run:
+                    self._update(*run, grad_scale)
+                    run = None
+                continue
+            self.steps[p] += 1
+            lo = self.offsets[p]
+            if run and run[1] == lo and run[2] == self.steps[p]:
+                run[1] = lo + p.numel()
+            else:
+                if run:
+                    self._update(*run, grad_scale)
+                run = [lo, lo + p.numel(), self.steps[p]]
+        if run:
+            self._update(*run, grad_scale)
 
     def state_dict(self) -> Dict[str, Any]:
-        return {"t": self.t, "lr": self.lr, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq}
+        state = {}
+        for i, p in enumerate(self.all_params):
+            if p in self.steps and self.steps[p] > 0:
+                lo, n = self.offsets[p], p.numel()
+                state[i] = {"step": torch.tensor(float(self.steps[p])),
+                            "exp_avg": self.exp_avg[lo:lo + n].view_as(p).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[lo:lo + n].view_as(p).clone()}
+        group = {"lr": self.lr, "initial_lr": self.base_lr, "betas": self.betas, "eps": self.eps,
+                 "weight_decay": self.weight_decay, "amsgrad": False, "maximize": False, "foreach": None,
+                 "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(self.all_params)))}
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd: Dict[str, Any]):
-        self.t, self.lr = int(sd["t"]), float(sd["lr"])
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        """Accepts torch.optim.AdamW's state_dict (the recipe's checkpoints) — and this class's."""
+        if "param_groups" not in sd:  # round-1 flat layout
+            for p in self.params:
+                self.steps[p] = int(sd["t"])
+            self.lr = float(sd["lr"])
+            self.exp_avg.copy_(sd["exp_avg"])
+            self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+            return
+        groups = sd["param_groups"]
+        ids = [i for g in groups for i in g["params"]]
+        if len(ids) != len(self.all_params):
+            raise ValueError(f"FlatAdamW.load_state_dict: checkpoint has {len(ids)} parameters, optimizer has "
+                             f"{len(self.all_params)}")
+        g0 = groups[0]
+        self.lr = float(g0["lr"])
+        self.base_lr = float(g0.get("initial_lr", self.base_lr))
+        self.betas, self.eps = tuple(g0.get("betas", self.betas)), float(g0.get("eps", self.eps))
+        self.weight_decay = float(g0.get("weight_decay", self.weight_decay))
+        if g0.get("amsgrad", False):
+            raise ValueError("FlatAdamW: amsgrad checkpoints are not supported")
+        with torch.no_grad():
+            self.exp_avg.zero_()
+            self.exp_avg_sq.zero_()
+            for p in self.params:
+                self.steps[p] = 0
+            for pos, key in enumerate(ids):
+                st = sd["state"].get(key)
+                p = self.all_params[pos]
+                if st is None or p not in self.steps:
+                    continue
+                lo, n = self.offsets[p], p.numel()
+                self.steps[p] = int(float(st["step"]))
+                self.exp_avg[lo:lo + n].view_as(p).copy_(st["exp_avg"])
+                self.exp_avg_sq[lo:lo + n].view_as(p).copy_(st["exp_avg_sq"])
 
 
 class WarmupCosineSchedule:
     """lr(step) = base_lr · λ(step);  λ = warmup_multiplier + (1 − warmup_multiplier)·step/warmup_steps for
     step < warmup_steps, else max(0, ½(1 + cos(π·2·cycles·progress))), progress = (step − warmup_steps) /
     max(1, t_total − warmup_steps).  The bundle: warmup_steps = num_epochs // 100, t_total = num_epochs + 1,
-    warmup_multiplier = 0.1, stepped once per epoch (train.yaml:26-32, 79-83)."""
+    warmup_multiplier = 0.1, stepped once per epoch (train.yaml:26-32, 79-83).  MONAI's class is a
+    torch `LambdaLR`; `state_dict()` / `load_state_dict()` carry that layout's `last_epoch` / `base_lrs`."""
 
     def __init__(self, optimizer, warmup_steps: int, t_total: int, cycles: float = 0.5, last_epoch: int = -1,
                  warmup_multiplier: float = 0.0):
         self.optimizer, self.warmup_steps, self.t_total = optimizer, int(warmup_steps), int(t_total)
         self.cycles, self.warmup_multiplier = float(cycles), float(warmup_multiplier)
-        self.base_lr = getattr(optimizer, "base_lr", None)
-        if self.base_lr is None:
-            self.base_lr = [g["lr"] for g in optimizer.param_groups]
+        self._flat = isinstance(optimizer, FlatAdamW)
+        if self._flat:
+            self.base_lrs = [optimizer.base_lr]
+        else:
+            for g in optimizer.param_groups:
+                g.setdefault("initial_lr", g["lr"])
+            self.base_lrs = [g["initial_lr"] for g in optimizer.param_groups]
         self.last_epoch = last_epoch
+        self._step_count = 0
         self.step()
+
+    @property
+    def base_lr(self):
+        return self.base_lrs[0] if self._flat else list(self.base_lrs)
 
     def factor(self, step: int) -> float:
         if step < self.warmup_steps:
@@ -123,33 +225,69 @@ class WarmupCosineSchedule:
         progress = float(step - self.warmup_steps) / float(max(1, self.t_total - self.warmup_steps))
         return max(0.0, 0.5 * (1.0 + math.cos(math.pi * float(self.cycles) * 2.0 * progress)))
 
+    def _apply(self):
+        f = self.factor(self.last_epoch)
+        if self._flat:
+            self.optimizer.lr = self.base_lrs[0] * f
+        else:
+            for g, b in zip(self.optimizer.param_groups, self.base_lrs):
+                g["lr"] = b * f
+
     def step(self):
         self.last_epoch += 1
-        f = self.factor(self.last_epoch)
-        if isinstance(self.base_lr, list):
-            for g, b in zip(self.optimizer.param_groups, self.base_lr):
-                g["lr"] = b * f
-        else:
-            self.optimizer.lr = self.base_lr * f
+        self._step_count += 1
+        self._apply()
 
     def get_last_lr(self):
-        if isinstance(self.base_lr, list):
-            return [g["lr"] for g in self.optimizer.param_groups]
-        return [self.optimizer.lr]
+        if self._flat:
+            return [self.optimizer.lr]
+        return [g["lr"] for g in self.optimizer.param_groups]
+
+    def state_dict(self) -> Dict[str, Any]:
+        return {"last_epoch": self.last_epoch, "base_lrs": list(self.base_lrs), "_step_count": self._step_count,
+                "_last_lr": self.get_last_lr(), "warmup_steps": self.warmup_steps, "t_total": self.t_total,
+                "cycles": self.cycles, "warmup_multiplier": self.warmup_multiplier}
+
+    def load_state_dict(self, sd: Dict[str, Any]):
+        self.last_epoch = int(sd["last_epoch"])
+        self.base_lrs = [float(b) for b in sd.get("base_lrs", self.base_lrs)]
+        self._step_count = int(sd.get("_step_count", self.last_epoch + 1))
+        for k in ("warmup_steps", "t_total"):
+            if k in sd:
+                setattr(self, k, int(sd[k]))
+        for k in ("cycles", "warmup_multiplier"):
+            if k in sd:
+                setattr(self, k, float(sd[k]))
+        if self._flat:
+            self.optimizer.base_lr = self.base_lrs[0]
+        self._apply()
 
 
-def load_checkpoint(objects: Dict[str, Any], path_or_data, strict: bool = True, **torch_load_kw) -> Dict[str, Any]:
-    """`objects[key].load_state_dict(checkpoint[key])` for every key (ignite `Checkpoint.load_objects`, as
-    used by the bundle's scripts/utils.py:10-26); a bare `state_dict` is accepted for a single object."""
+def load_checkpoint(objects: Dict[str, Any], path_or_data, strict: bool = True, inplace: bool = False,
+                    **torch_load_kw) -> Dict[str, Any]:
+    """The bundle's `load_checkpoint` (scripts/utils.py:10-26): deep-copy `objects`, then
+    `objects[key].load_state_dict(checkpoint[key])` for every key (ignite `Checkpoint.load_objects`), and
+    return the loaded COPIES — its `load_checkpoints` ensemble (inference.yaml:141-142) relies on every
+    call yielding independent objects.  `inplace=True` loads into the objects passed in.  A bare
+    `state_dict` is accepted for a single object."""
     data = torch.load(path_or_data, **torch_load_kw) if isinstance(path_or_data, (str, bytes)) or hasattr(path_or_data, "read") \
         else path_or_data
     if len(objects) == 1 and not any(k in data for k in objects) and all(torch.is_tensor(v) for v in data.values()):
         data = {next(iter(objects)): data}
-    for key, obj in objects.items():
+    for key in objects:
         if key not in data:
             raise KeyError(f"load_checkpoint: checkpoint has no entry {key!r}")
+    if not inplace:
+        import copy
+        objects = copy.deepcopy(objects)   # one memo: a model and the optimizer over its flat buffer stay tied
+    for key, obj in objects.items():
         if isinstance(obj, torch.nn.Module):
             obj.load_state_dict(data[key], strict=strict)
         else:
             obj.load_state_dict(data[key])
     return objects
+
+
+def load_checkpoints(objects: Dict[str, Any], paths: Iterable, **kw):
+    """scripts/utils.py:29-32: one independent loaded copy of `objects` per checkpoint (fold ensemble)."""
+    return [load_checkpoint(objects, p, **kw) for p in paths]

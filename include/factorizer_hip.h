@@ -293,6 +293,16 @@ int fz_dice_bce_sums(const float* z, const float* t, float* part, int planes, in
 int fz_dice_bce_grad(const float* z, const float* t, const float* coef, float* gz, int planes, int64_t V,
                      float cd, float cb, const float* gscale, fz_stream_t stream);
 
+/* DiceCELoss(sigmoid=True, squared_pred=True) as MONAI 1.4 evaluates it for C > 1 channels (the bundle
+ * pins monai==1.4.0, model_zoo/factorizer_brats23/docs/requirements.txt:11; train.yaml:67-70): soft Dice on
+ * sigmoid(z) per (b,c) plane + nn.CrossEntropyLoss over the channel softmax with the float target as class
+ * probabilities.  z, t: (B, C, V), 2 <= C <= 8.
+ * sums: part (B, fz_dice_bce_chunks(V), 3C+1) = per channel {sum p*t, sum p^2, sum t^2}, then sum CE.
+ * grad: gz = gscale * (cd * dDice/dz + cb * (softmax_c * sum_c' t_c' - t_c)), coef (B*C, 2) = {2*inter+s, den+s}. */
+int fz_dice_ce_sums(const float* z, const float* t, float* part, int B, int C, int64_t V, fz_stream_t stream);
+int fz_dice_ce_grad(const float* z, const float* t, const float* coef, float* gz, int B, int C, int64_t V,
+                    float cd, float cb, const float* gscale, fz_stream_t stream);
+
 /* ---- sliding-window inference stitching -------------------------------------
  * What MONAI's SlidingWindowInfererAdapt(roi 128^3, sw_batch 2, overlap 0.5, mode "gaussian") does
  * around the network (model_zoo/factorizer_brats23/configs/inference.yaml:96-102, train.yaml:206-212):

@@ -483,6 +483,25 @@ def dice_bce_loss(logits, target, smooth=1e-5):
     return dice.mean() + bce
 
 
+def dice_ce_loss(logits, target, smooth=1e-5):
+    """The recipe's loss, `DiceCELoss(sigmoid=True, squared_pred=True)`
+    (model_zoo/factorizer_brats23/configs/train.yaml:67-70), as MONAI 1.4.0 evaluates it
+    (pinned at model_zoo/factorizer_brats23/docs/requirements.txt:11; third-party, absent from the
+    tree — published algorithm restated: monai/losses/dice.py, `DiceLoss.forward` with
+    sigmoid / squared_pred / smooth_nr = smooth_dr = 1e-5 / reduction mean over (b, c), and
+    `DiceCELoss.forward`: `self.ce` = `nn.CrossEntropyLoss()(input, float target)` when the prediction
+    has more than one channel, `self.bce` = `nn.BCEWithLogitsLoss()` for one channel).  The CE part IS
+    torch's own function; the Dice part is unpinned against MONAI (not importable here)."""
+    p = torch.sigmoid(logits)
+    dims = tuple(range(2, logits.ndim))
+    inter = (p * target).sum(dims)
+    den = (p * p).sum(dims) + (target * target).sum(dims)
+    dice = (1.0 - (2.0 * inter + smooth) / (den + smooth)).mean()
+    if logits.shape[1] == 1:
+        return dice + F.binary_cross_entropy_with_logits(logits, target)
+    return dice + torch.nn.CrossEntropyLoss()(logits, target)
+
+
 # ---- sliding-window inference (SURVEY §8 f-1) ---------------------------------------------------------
 def sliding_window_oracle(inputs, roi, sw_batch, predictor, overlap=0.5, mode="gaussian", sigma_scale=0.125):
     """Plain restatement of MONAI's published `sliding_window_inference` (monai/inferers/utils.py,

@@ -52,3 +52,23 @@ def golden():
         return cache[name]
 
     return get
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Leave the achieved parity errors of a GPU run behind (tests/parity.py)."""
+    import json
+
+    import parity
+    if not parity.RECORDS:
+        return
+    out = os.environ.get("FZ_PARITY_OUT", os.path.join(ROOT, "gpurun_out", "parity.json"))
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    worst = {}
+    for r in parity.RECORDS:
+        if "rel_err" in r and r["rel_err"] > worst.get(r["test"], {}).get("rel_err", -1.0):
+            worst[r["test"]] = r
+    with open(out, "w") as f:
+        json.dump({"device": torch.cuda.get_device_name(0) if torch.cuda.is_available() else "cpu",
+                   "n_comparisons": len(parity.RECORDS),
+                   "worst_rel_err": max((r["rel_err"] for r in parity.RECORDS if "rel_err" in r), default=0.0),
+                   "worst_per_test": worst, "records": parity.RECORDS}, f, indent=1)

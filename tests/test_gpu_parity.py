@@ -10,6 +10,7 @@ from torch import nn
 import factorizer_amd as ft
 from factorizer_amd import _native
 from oracle import cpu_ref as O
+import parity as P
 from test_oracle_golden import G1_CASES, NMF_CASES
 
 pytestmark = pytest.mark.gpu
@@ -143,12 +144,10 @@ def test_nmf_goldens(golden, name):
         u, v = nmf.decompose(x)
         y = nmf(x)
         (gx,) = torch.autograd.grad(y, x, g["gy"].to(DEV))
-    tol = dict(rtol=1e-4, atol=1e-5)
-    assert torch.allclose(u.cpu(), g["u"], **tol)
-    assert torch.allclose(v.cpu(), g["v"], **tol)
-    assert torch.allclose(y.cpu(), g["y"], **tol)
-    s = g["gx"].abs().max().item()
-    assert (gx.cpu() - g["gx"]).abs().max().item() <= 1e-4 * s + 1e-5
+    P.close("u", u, g["u"])
+    P.close("v", v, g["v"])
+    P.close("y", y, g["y"])
+    P.close("gx", gx, g["gx"])
     assert (u >= 0).all() and (v >= 0).all()
 
 
@@ -171,17 +170,25 @@ def test_nmf_8x512_vs_oracle(solver, R):
     yo = O.nmf_forward(x, u0, v0, 5, solver)
     gxo = O.nmf_backward(x, u0, v0, gy, 5, solver)
     gx64 = O.nmf_backward(x.double(), u0.double(), v0.double(), gy.double(), 5, solver).float()
-    assert torch.allclose(y.cpu(), yo, rtol=1e-4, atol=1e-5)
+    P.close("y", y, yo)
     kink = (gxo - gx64).abs().amax(dim=(-1, -2))          # fp32-vs-fp64 disagreement of the oracle
     # HALS gates its gradient by [w > 0]: matrices with a ReLU pre-activation within fp32
     # rounding of 0 have no well-defined fp32 gradient (rounding order flips the gate)
     well = torch.ones_like(kink, dtype=torch.bool)
     if solver == "hals":
         well = O.hals_gate_margin(x, u0, v0, 5) > 2e-6
-        assert well.float().mean() > 0.7
-    err = (gx.cpu() - gx64).abs().amax(dim=(-1, -2))
+        excluded = 1.0 - well.float().mean().item()
+        P.note("hals_gate_excluded_fraction", value=excluded, R=R, matrices=well.numel())
+        assert excluded < 0.10, f"{excluded:.3f} of the matrices sit on a ReLU kink"
+    w = well.reshape(*well.shape, 1, 1).expand_as(gx64)
+    gdev = gx.cpu()
+    # per-matrix bound: the fp32 oracle's own distance to fp64 is the error budget of ANY fp32
+    # evaluation order of these T unrolled iterations (it is what "kink" measures)
+    err = (gdev - gx64).abs().amax(dim=(-1, -2))
     scale = gx64.abs().amax(dim=(-1, -2))
-    assert (err <= 1e-4 * scale + 1e-5 + 30 * kink)[well].all()
+    P.note("nmf_grad_err_over_fp32_oracle_err", solver=solver, R=R,
+           worst_ratio=float((err[well] / (kink[well] + 1e-4 * scale[well] + 1e-12)).max()))
+    P.close("gx (well-conditioned matrices, vs fp64 oracle)", torch.where(w, gdev, gx64), gx64)
 
 
 @pytest.mark.parametrize("M,N", [(8, 150), (4, 64), (16, 256), (16, 64), (32, 128), (5, 100), (8, 64)])
@@ -202,10 +209,9 @@ def test_nmf_masked_families_vs_oracle(M, N):
             yo = O.nmf_forward(x, u0, v0, 4, solver)
             gx64 = O.nmf_backward(x.double(), u0.double(), v0.double(), gy.double(), 4, solver, 3).float()
             gxo = O.nmf_backward(x, u0, v0, gy, 4, solver, 3)
-            assert torch.allclose(y.cpu(), yo, rtol=1e-4, atol=1e-5), (solver, R)
-            kink = (gxo - gx64).abs().max().item()
-            s = gx64.abs().max().item()
-            assert (gx.cpu() - gx64).abs().max().item() <= 2e-4 * s + 1e-5 + 30 * kink, (solver, R)
+            P.close(f"y {solver} R{R}", y, yo)
+            kink = (gxo - gx64).abs().max().item()   # the fp32 oracle's own distance to fp64
+            P.close(f"gx {solver} R{R} (vs fp64 oracle)", gx, gx64, extra=kink)
 
 
 def test_nmf_decompose_backward():
@@ -222,10 +228,9 @@ def test_nmf_decompose_backward():
         with Launches():
             ud, vd = nd.decompose(xd)
             (gxd,) = torch.autograd.grad([ud, vd], xd, [gu.to(DEV), gv.to(DEV)])
-        assert torch.allclose(ud.cpu(), u, rtol=1e-4, atol=1e-5)
-        assert torch.allclose(vd.cpu(), v, rtol=1e-4, atol=1e-5)
-        s = gxc.abs().max().item()
-        assert (gxd.cpu() - gxc).abs().max().item() <= 2e-4 * s + 1e-5
+        P.close(f"u {solver}", ud, u)
+        P.close(f"v {solver}", vd, v)
+        P.close(f"gx {solver}", gxd, gxc)
 
 
 def test_nmf_full_size_properties():
@@ -244,15 +249,14 @@ def test_nmf_full_size_properties():
     a = torch.rand(1024, 8, 1, device=DEV) + 0.1
     b = torch.rand(1024, 1, 512, device=DEV) + 0.1
     r1 = a * b
-    assert torch.allclose(nmf(r1), r1, rtol=1e-4, atol=1e-6)
+    P.close("rank-1 recovery", nmf(r1), r1)
     xs = x[:4096].clone().requires_grad_(True)
     ys = nmf(xs)
     g1, g2 = torch.rand_like(ys), torch.rand_like(ys)
     (ga,) = torch.autograd.grad(ys, xs, g1, retain_graph=True)
     (gb,) = torch.autograd.grad(ys, xs, g2, retain_graph=True)
     (gab,) = torch.autograd.grad(ys, xs, g1 + 2 * g2)
-    s = gab.abs().max().item()
-    assert (gab - (ga + 2 * gb)).abs().max().item() <= 1e-4 * s
+    P.close("backward linearity", gab, ga + 2 * gb)
 
 
 def test_nmf_unsupported_shape_uses_composed_path_with_warning():
@@ -261,7 +265,7 @@ def test_nmf_unsupported_shape_uses_composed_path_with_warning():
     with pytest.warns(RuntimeWarning):
         y = nmf(x)
     yo = O.nmf_forward(x.cpu(), nmf.init.u0.cpu(), nmf.init.v0.cpu(), 2, "hals")
-    assert torch.allclose(y.cpu(), yo, rtol=1e-4, atol=1e-5)
+    P.close("y (composed path)", y, yo)
 
 
 # ---------------------------------------------------------------- blocks / model ---------
@@ -281,11 +285,10 @@ def test_block_goldens(golden, name):
         y = blk(x)
         names = [k for k, _ in blk.named_parameters()]
         grads = torch.autograd.grad(y, [x] + list(blk.parameters()), g["gy"].to(DEV))
-    assert torch.allclose(y.cpu(), g["y"], rtol=1e-4, atol=1e-4)
-    assert torch.allclose(grads[0].cpu(), g["gx"], rtol=1e-3, atol=2e-4)
+    P.close("y", y, g["y"])
+    P.close("gx", grads[0], g["gx"])
     for k, gr in zip(names, grads[1:]):
-        r = g["grad:" + k]
-        assert (gr.cpu() - r).abs().max().item() <= 1e-3 * (r.abs().max().item() + 1e-6), k
+        P.close("grad:" + k, gr, g["grad:" + k])
 
 
 def test_model_goldens(golden):
@@ -299,11 +302,10 @@ def test_model_goldens(golden):
         y = model(x)
         names = [k for k, _ in model.named_parameters()]
         grads = torch.autograd.grad(y, [x] + list(model.parameters()), g["gy"].to(DEV))
-    assert torch.allclose(y.cpu(), g["y"], rtol=1e-4, atol=1e-4)
-    assert torch.allclose(grads[0].cpu(), g["gx"], rtol=1e-3, atol=1e-4)
+    P.close("y", y, g["y"])
+    P.close("gx", grads[0], g["gx"])
     for k, gr in zip(names, grads[1:]):
-        r = g["grad:" + k]
-        assert (gr.cpu() - r).abs().max().item() <= 2e-3 * (r.abs().max().item() + 1e-6), k
+        P.close("grad:" + k, gr, g["grad:" + k])
 
 
 def test_block_cfg2_shape_vs_oracle_reduced():
@@ -325,8 +327,8 @@ def test_block_cfg2_shape_vs_oracle_reduced():
     with Launches():
         yd = blk(xd)
         (gxd,) = torch.autograd.grad(yd, xd, gy.to(DEV))
-    assert torch.allclose(yd.cpu(), yo, rtol=1e-4, atol=1e-4)
-    assert torch.allclose(gxd.cpu(), gxo, rtol=1e-3, atol=1e-4)
+    P.close("y", yd, yo)
+    P.close("gx", gxd, gxo)
 
 
 def test_block_cfg2_full_size_runs():
@@ -367,12 +369,11 @@ def test_fact_core_fused_vs_modular(S, shifts, solver, R):
     with Launches():
         a1 = Fn.FactCoreFn.apply(t1, nmf.init.u0, nmf.init.v0, m.geometry, 4, G, solver, 1e-16, False)
     a2 = m.inverse_forward(nmf(m(t2)))
-    assert torch.allclose(a1, a2, rtol=1e-5, atol=1e-6)
+    P.close("a fused vs modular", a1, a2, rel=1e-5)
     ga = torch.rand_like(a1)
     (g1,) = torch.autograd.grad(a1, t1, ga)
     (g2,) = torch.autograd.grad(a2, t2, ga)
-    s = g2.abs().max().item()
-    assert (g1 - g2).abs().max().item() <= 2e-4 * s + 1e-6
+    P.close("gt fused vs modular", g1, g2)
     # relu_gate = True gates the gradient by [t > 0]
     t3 = t.clone().requires_grad_(True)
     a3 = Fn.FactCoreFn.apply(t3, nmf.init.u0, nmf.init.v0, m.geometry, 4, G, solver, 1e-16, True)
@@ -381,7 +382,7 @@ def test_fact_core_fused_vs_modular(S, shifts, solver, R):
 
 
 # ---------------------------------------------------------------- other BASELINE / §8f configs ------
-def _block_vs_oracle(C, S, reshape_kw, nmf_kw, mlp_ratio=2, B=1, tol=1e-4):
+def _block_vs_oracle(C, S, reshape_kw, nmf_kw, mlp_ratio=2, B=1, tol=1e-4, why=None):
     torch.manual_seed(0)
     blk = ft.FactorizerBlock(channels=C, spatial_size=S, norm=ft.LayerNorm, reshape=(ft.SWMatricize, reshape_kw),
                              act=nn.ReLU, factorize=ft.NMF, init="uniform", mlp_ratio=mlp_ratio, dropout=0.0,
@@ -398,9 +399,8 @@ def _block_vs_oracle(C, S, reshape_kw, nmf_kw, mlp_ratio=2, B=1, tol=1e-4):
     with Launches():
         yd = blk(xd)
         (gxd,) = torch.autograd.grad(yd, xd, gy.to(DEV))
-    assert torch.allclose(yd.cpu(), yo, rtol=tol, atol=tol)
-    s = gxo.abs().max().item()
-    assert (gxd.cpu() - gxo).abs().max().item() <= 10 * tol * s + tol
+    P.close("y", yd, yo, rel=tol, why=why)
+    P.close("gx", gxd, gxo, rel=tol, why=why)
 
 
 def test_block_production_four_shift_windows():
@@ -414,7 +414,7 @@ def test_block_cfg5_shape_rank2_t10():
     """BASELINE cfg 5 stress shape at reduced extent: anisotropic patch (5,6,5) (p = 8 is invalid for
     160x192x160, SURVEY headline 5), rank 2, 10 iterations — the masked 8x150 NMF family."""
     _block_vs_oracle(16, (10, 12, 20), dict(head_dim=8, patch_size=(5, 6, 5)),
-                     dict(rank=2, num_iters=10, solver="hals"), tol=2e-4)
+                     dict(rank=2, num_iters=10, solver="hals"))
 
 
 def test_block_mu_rank2_fused_core():
@@ -440,24 +440,37 @@ def test_block_training_dropout_runs():
 
 def test_readme_model_full_size_train_step():
     """BASELINE cfg 3/4: README Swin Factorizer (in 4, out 3, 128^3, widths 32-512) forward, backward
-    and one optimizer step at B = 1; outputs / gradients finite, replicas deterministic."""
+    and one AdamW step (the flat one-kernel optimizer of bench.py) at the per-GPU batch of cfg 4, B = 2;
+    outputs / gradients finite, every parameter moved, replicas deterministic."""
     torch.manual_seed(0)
     model = ft.Factorizer(in_channels=4, out_channels=3, spatial_size=(128, 128, 128), norm=ft.LayerNorm,
                           reshape=(ft.SWMatricize, {"head_dim": 8, "patch_size": 8}), act=nn.ReLU,
                           factorize=ft.NMF, rank=1, num_iters=5, init="uniform", solver="hals", mlp_ratio=2,
                           dropout=0.1).to(DEV).eval()
-    x = torch.rand(1, 4, 128, 128, 128, device=DEV)
-    t = (torch.rand(1, 3, 128, 128, 128, device=DEV) > 0.5).float()
+    x = torch.rand(2, 4, 128, 128, 128, device=DEV)
+    t = (torch.rand(2, 3, 128, 128, 128, device=DEV) > 0.5).float()
+    opt = ft.FlatAdamW(model, lr=1e-4, weight_decay=1e-5)      # train.yaml:72-76
     with Launches():
         y = model(x)
-        loss = ft.dice_bce_loss(y, t)
+        loss = ft.dice_ce_loss(y, t)
         loss.backward()
-    assert y.shape == (1, 3, 128, 128, 128) and torch.isfinite(y).all() and torch.isfinite(loss)
+    assert y.shape == (2, 3, 128, 128, 128) and torch.isfinite(y).all() and torch.isfinite(loss)
     for n, p in model.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all(), n
     with torch.no_grad():
         y2 = model(x)
     assert torch.equal(y, y2)  # deterministic kernels (no float atomics)
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    opt.step()
+    for n, p in model.named_parameters():
+        assert torch.isfinite(p).all(), n
+        if before[n].abs().max() > 0 and p.grad.abs().max() > 0:
+            assert not torch.equal(p.detach(), before[n]), n
+        # first AdamW step: |Δp| <= lr·(1 + wd·|p|) elementwise
+        assert ((p.detach() - before[n]).abs() <= 1.001e-4 * (1 + 1e-5 * before[n].abs()) + 1e-12).all(), n
+    with torch.no_grad():
+        y3 = model(x)
+    assert torch.isfinite(y3).all() and not torch.equal(y3, y)
 
 
 # ---------------------------------------------------------------- sliding-window inference (§8 f-1) ----
@@ -532,7 +545,7 @@ def test_single_matrix_and_single_patch():
     ref = nmf(x)
     with Launches():
         out = nmf.to(DEV)(x.to(DEV))
-    assert torch.allclose(out.cpu(), ref, rtol=1e-4, atol=1e-5)
+    P.close("single matrix", out, ref)
     torch.manual_seed(0)
     blk = ft.FactorizerBlock(channels=8, spatial_size=(8, 8, 8), norm=ft.LayerNorm,
                              reshape=(ft.SWMatricize, {"head_dim": 8, "patch_size": 8}), act=nn.ReLU,
@@ -542,7 +555,7 @@ def test_single_matrix_and_single_patch():
     ref = blk(xs)
     with Launches():
         out = blk.to(DEV)(xs.to(DEV))
-    assert torch.allclose(out.cpu(), ref, rtol=1e-4, atol=1e-5)
+    P.close("single patch block", out, ref)
 
 
 def _small_unet():
@@ -565,9 +578,10 @@ def test_late_wgrad_join_matches_per_block_join():
     def grads(late):
         sync = FlatGradSync(model, num_buckets=2, late_wgrad_join=late)
         sync.zero_grad()
-        ft.dice_bce_loss(model(x), t).backward()
-        if late:
-            assert PW._LateJoin.owed, "no block put its weight gradients on the side stream"
+        n0 = PW._LateJoin.verified
+        ft.dice_ce_loss(model(x), t).backward()
+        if late:  # joined (and ownership verified) by the end-of-backward callback
+            assert PW._LateJoin.verified > n0, "no block put its weight gradients on the side stream"
         sync.finish()
         assert not PW._LateJoin.owed and not PW._LateJoin.keep
         torch.cuda.synchronize()
@@ -590,9 +604,8 @@ def test_late_wgrad_join_refuses_copied_gradients():
         p.grad = torch.zeros_like(p)
     PW.late_wgrad_join(True)
     try:
-        model(x).sum().backward()
         with pytest.raises(RuntimeError, match="late_wgrad_join"):
-            PW.join_wgrad_streams()
+            model(x).sum().backward()      # raised by the end-of-backward join
     finally:
         PW._LateJoin.owed.clear()
         PW.late_wgrad_join(False)

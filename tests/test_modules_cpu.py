@@ -313,12 +313,108 @@ def test_load_checkpoint_interchange(tmp_path):
     src, dst = ft.Factorizer(**kw), ft.Factorizer(**kw)
     path = tmp_path / "ckpt.pt"
     torch.save({"network": src.state_dict(), "epoch": 3}, path)
-    ft.load_checkpoint({"network": dst}, str(path))
+    before = {k: v.clone() for k, v in dst.state_dict().items()}
+    loaded = ft.load_checkpoint({"network": dst}, str(path))["network"]   # a loaded COPY (scripts/utils.py:21)
+    assert loaded is not dst
+    for (k1, v1), (k2, v2) in zip(src.state_dict().items(), loaded.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+    for k, v in dst.state_dict().items():
+        assert torch.equal(v, before[k])                        # the object passed in is untouched
+    ft.load_checkpoint({"network": dst}, str(path), inplace=True)
     for (k1, v1), (k2, v2) in zip(src.state_dict().items(), dst.state_dict().items()):
         assert k1 == k2 and torch.equal(v1, v2)
     ft.load_checkpoint({"network": dst}, src.state_dict())     # a bare state_dict
     with pytest.raises(KeyError):
         ft.load_checkpoint({"optimizer": dst}, {"network": src.state_dict(), "x": 1})
+    # load_checkpoints (scripts/utils.py:29-32; the fold ensemble of inference.yaml:141-142): independent copies
+    src2 = ft.Factorizer(**kw)
+    p2 = tmp_path / "ckpt2.pt"
+    torch.save({"network": src2.state_dict()}, p2)
+    a, b = ft.load_checkpoints({"network": dst}, [str(path), str(p2)])
+    assert a["network"] is not b["network"]
+    assert torch.equal(a["network"].state_dict()["stem.weight"], src.state_dict()["stem.weight"])
+    assert torch.equal(b["network"].state_dict()["stem.weight"], src2.state_dict()["stem.weight"])
+
+
+def test_optimizer_and_scheduler_checkpoint_interchange_with_torch():
+    """The recipe checkpoints {trainer, model, optimizer, lr_scheduler} (train.yaml:354-358): FlatAdamW emits and
+    accepts torch.optim.AdamW's state_dict layout, the schedule carries last_epoch / base_lrs."""
+    import copy
+    torch.manual_seed(0)
+    m_t = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.GELU(), torch.nn.Linear(5, 3))
+    m_f = copy.deepcopy(m_t)
+    o_t = torch.optim.AdamW(m_t.parameters(), lr=1e-2, weight_decay=1e-2)
+    s_t = ft.WarmupCosineSchedule(o_t, warmup_steps=2, t_total=11, warmup_multiplier=0.1)
+    xs = [torch.randn(4, 7) for _ in range(6)]
+    for x in xs[:3]:
+        o_t.zero_grad()
+        m_t(x).pow(2).sum().backward()
+        o_t.step()
+        s_t.step()
+    # torch -> flat: resume the same run with the flat optimizer
+    o_f = ft.FlatAdamW(m_f, lr=1e-2, weight_decay=1e-2)
+    s_f = ft.WarmupCosineSchedule(o_f, warmup_steps=2, t_total=11, warmup_multiplier=0.1)
+    objs = ft.load_checkpoint({"model": m_f, "optimizer": o_f, "lr_scheduler": s_f},
+                              {"model": m_t.state_dict(), "optimizer": o_t.state_dict(),
+                               "lr_scheduler": s_t.state_dict()})
+    m_f, o_f, s_f = objs["model"], objs["optimizer"], objs["lr_scheduler"]
+    assert s_f.optimizer is o_f and all(p.data_ptr() >= o_f.flat_param.data_ptr() for p in m_f.parameters())
+    assert abs(o_f.lr - o_t.param_groups[0]["lr"]) < 1e-15 and o_f.base_lr == 1e-2 and o_f.t == 3
+    for x in xs[3:]:
+        for m, o, sch in ((m_t, o_t, s_t), (m_f, o_f, s_f)):
+            o.zero_grad()
+            m(x).pow(2).sum().backward()
+            o.step()
+            sch.step()
+    for a, b in zip(m_t.parameters(), m_f.parameters()):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
+    assert abs(o_f.lr - o_t.param_groups[0]["lr"]) < 1e-15
+    # flat -> torch
+    m_2 = copy.deepcopy(m_t)
+    o_2 = torch.optim.AdamW(m_2.parameters(), lr=1.0)
+    o_2.load_state_dict(o_f.state_dict())
+    sd_t = o_t.state_dict()
+    for i, st in o_2.state_dict()["state"].items():
+        assert float(st["step"]) == float(sd_t["state"][i]["step"]) == 6.0
+        assert torch.allclose(st["exp_avg"], sd_t["state"][i]["exp_avg"], rtol=1e-5, atol=1e-8)
+        assert torch.allclose(st["exp_avg_sq"], sd_t["state"][i]["exp_avg_sq"], rtol=1e-5, atol=1e-10)
+    assert abs(o_2.param_groups[0]["lr"] - o_t.param_groups[0]["lr"]) < 1e-15
+
+
+def test_flat_adamw_skips_parameters_without_gradient():
+    """torch.optim.AdamW leaves a parameter whose .grad is None untouched (no decay, no step count)."""
+    import copy
+    torch.manual_seed(0)
+    m1 = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.Linear(4, 4), torch.nn.Linear(4, 4))
+    m2 = copy.deepcopy(m1)
+    o1 = ft.FlatAdamW(m1, lr=1e-2, weight_decay=0.1)
+    o2 = torch.optim.AdamW(m2.parameters(), lr=1e-2, weight_decay=0.1)
+    for it in range(5):
+        x = torch.randn(3, 4)
+        for m, o in ((m1, o1), (m2, o2)):
+            o.zero_grad()
+            (m[0](x).sum() + (m[2](x).pow(2).sum() if it != 2 else 0.0)).backward()   # m[1] never, m[2] skips once
+            o.step()
+    for a, b in zip(m1.parameters(), m2.parameters()):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-8)
+    assert o1.steps[m1[1].weight] == 0 and o1.steps[m1[2].weight] == 4 and o1.steps[m1[0].weight] == 5
+
+
+def test_dice_ce_loss_matches_oracle_and_torch():
+    """The recipe's DiceCELoss(sigmoid=True, squared_pred=True) in MONAI >= 1.3 semantics (softmax cross entropy
+    with float multi-label targets for a multi-channel head; BCE for one channel)."""
+    from oracle import cpu_ref as O
+    torch.manual_seed(3)
+    for C in (1, 3):
+        z = torch.randn(2, C, 4, 6, 8, requires_grad=True)
+        t = (torch.rand(2, C, 4, 6, 8) > 0.5).float()
+        a, b = ft.dice_ce_loss(z, t), O.dice_ce_loss(z, t)
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
+    z = torch.randn(2, 3, 4, 6, 8)
+    ce = -(t * torch.log_softmax(z, dim=1)).sum(1).mean()      # the formula in the docstring
+    p = torch.sigmoid(z)
+    dice = (1 - (2 * (p * t).sum((2, 3, 4)) + 1e-5) / ((p * p).sum((2, 3, 4)) + (t * t).sum((2, 3, 4)) + 1e-5)).mean()
+    assert torch.allclose(ft.DiceCELoss()(z, t), dice + ce, rtol=1e-6, atol=1e-7)
 
 
 # ---- remaining solver / initialiser keys (SURVEY §8 f-3) ----------------------------------------------

@@ -101,7 +101,7 @@ def prod():
     def fb():
         for p in model.parameters():
             p.grad = None
-        ft.dice_bce_loss(model(x), t).backward()
+        ft.dice_ce_loss(model(x), t).backward()
     ms = gpu_time(fb, 10, 3)
     print(json.dumps({"config": "f-1 production Swin Factorizer (4 shift windows, mlp_ratio 4) fwd+bwd B=2",
                       "ms": round(ms, 3), "volumes_per_s": round(2 / ms * 1e3, 1)}))
@@ -138,7 +138,7 @@ def cfg5(batches=(1, 2, 4)):
         def fb():
             for p in model.parameters():
                 p.grad = None
-            loss = ft.dice_bce_loss(model(x), t)
+            loss = ft.dice_ce_loss(model(x), t)
             loss.backward()
             return loss
         torch.cuda.reset_peak_memory_stats()
