@@ -188,7 +188,13 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     use_dist = world > 1 or args.force_dist
+    json_fd = None
     if use_dist:
+        # RCCL prints its version banner to the C-level stdout: keep the ONE JSON line alone there by
+        # pointing fd 1 at stderr for the life of the process group and writing the line to the saved fd
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -317,7 +323,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_sample()
-        print(json.dumps(out), flush=True)
+        if json_fd is not None:
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
+        else:
+            print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
 

@@ -180,15 +180,28 @@ def test_nmf_8x512_vs_oracle(solver, R):
         excluded = 1.0 - well.float().mean().item()
         P.note("hals_gate_excluded_fraction", value=excluded, R=R, matrices=well.numel())
         assert excluded < 0.10, f"{excluded:.3f} of the matrices sit on a ReLU kink"
-    w = well.reshape(*well.shape, 1, 1).expand_as(gx64)
     gdev = gx.cpu()
-    # per-matrix bound: the fp32 oracle's own distance to fp64 is the error budget of ANY fp32
-    # evaluation order of these T unrolled iterations (it is what "kink" measures)
+    # per-matrix comparison against the fp64 oracle, each matrix normalised by its own gradient scale (an
+    # all-zero matrix divides by eps = 1e-16: its gradient is ~1e7 times larger than its neighbours' and
+    # would otherwise set the scale for all of them)
     err = (gdev - gx64).abs().amax(dim=(-1, -2))
-    scale = gx64.abs().amax(dim=(-1, -2))
-    P.note("nmf_grad_err_over_fp32_oracle_err", solver=solver, R=R,
-           worst_ratio=float((err[well] / (kink[well] + 1e-4 * scale[well] + 1e-12)).max()))
-    P.close("gx (well-conditioned matrices, vs fp64 oracle)", torch.where(w, gdev, gx64), gx64)
+    scale = gx64.abs().amax(dim=(-1, -2)) + 1e-30
+    # a matrix is well-posed in fp32 when the fp32 ORACLE itself is within 1e-5 of fp64: where it is not
+    # (eps-dominated ratios), no fp32 evaluation order can be asked to hit 1e-4 — those are held to twice
+    # the oracle's own fp32 error instead
+    posed = well & (kink <= 1e-5 * scale)
+    frac_ill = 1.0 - posed.float().mean().item()
+    P.note("nmf_grad_matrices_ill_posed_in_fp32", solver=solver, R=R, fraction=frac_ill,
+           worst_err_over_oracle_fp32_err=float((err[~posed & well] / (kink[~posed & well] + 1e-30)).max())
+           if (~posed & well).any() else 0.0)
+    assert frac_ill < 0.10
+    w = posed.reshape(*posed.shape, 1, 1)
+    sc = scale.reshape(*scale.shape, 1, 1)
+    P.close("gx / per-matrix max|gx| (matrices well-posed in fp32, vs fp64 oracle)",
+            torch.where(w, gdev / sc, torch.zeros_like(gdev)), torch.where(w, gx64 / sc, torch.zeros_like(gx64)),
+            floor=1e-7)
+    ill = ~posed & well
+    assert (err[ill] <= 1e-4 * scale[ill] + 2.0 * kink[ill]).all()
 
 
 @pytest.mark.parametrize("M,N", [(8, 150), (4, 64), (16, 256), (16, 64), (32, 128), (5, 100), (8, 64)])
