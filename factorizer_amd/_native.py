@@ -17,6 +17,17 @@ LIB_PATH = os.path.join(_HERE, "libfactorizer_hip.so")
 FZ_OK = 0
 FZ_E_UNSUPPORTED = -2
 SOLVER_ID = {"mu": 0, "hals": 1}
+STORE_F32, STORE_BF16 = 0, 1   # include/factorizer_hip.h: FZ_STORE_*
+
+
+def act_dtype(t: torch.Tensor) -> int:
+    """FZ_STORE_* code of an activation tensor (fp32, or bf16 storage with fp32 arithmetic)."""
+    if t.dtype == torch.float32:
+        return STORE_F32
+    if t.dtype == torch.bfloat16:
+        return STORE_BF16
+    raise TypeError(f"native kernels take float32 or bfloat16 activations, got {t.dtype} "
+                    "(float16 is refused on purpose: the NMF eps 1e-16 underflows in it, SURVEY.md §5)")
 
 _lock = threading.Lock()
 _lib = None
@@ -29,9 +40,9 @@ _SIGS = {
     "fz_last_error_string": ([], _c.c_char_p),
     "fz_launch_count": ([], _i64),
     "fz_swm_fwd": ([_vp, _vp] + [_i] * 10 + [_c.POINTER(_i), _i, _i, _i, _vp], _i),
-    "fz_swm_inv": ([_vp, _vp] + [_i] * 10 + [_c.POINTER(_i), _i, _vp, _vp], _i),
-    "fz_nmf_fwd": ([_vp] * 6 + [_i64] + [_i] * 5 + [_f, _vp], _i),
-    "fz_nmf_bwd": ([_vp] * 7 + [_i64] + [_i] * 6 + [_f, _vp], _i),
+    "fz_swm_inv": ([_vp, _vp] + [_i] * 10 + [_c.POINTER(_i), _i, _vp, _i, _vp], _i),
+    "fz_nmf_fwd": ([_vp] * 6 + [_i64] + [_i] * 5 + [_f, _i, _vp], _i),
+    "fz_nmf_bwd": ([_vp] * 7 + [_i64] + [_i] * 6 + [_f, _i, _vp], _i),
     "fz_nmf_supported": ([_i] * 5, _i),
 }
 
@@ -98,26 +109,27 @@ class GemmDesc(_c.Structure):
                 ("bias", _vp), ("ln", _i), ("ln_g", _vp), ("ln_b", _vp), ("ln_eps", _f), ("stats_out", _vp),
                 ("bact", _i), ("bmul", _vp), ("bmul_kind", _i), ("eact", _i), ("res", _vp), ("emul", _vp), ("emul_kind", _i), ("y", _vp),
                 ("Ncol", _i64), ("Ho", _i), ("Wo", _i), ("B", _i), ("loader", _i), ("epilogue", _i), ("lnb_x", _vp), ("lnb_stats", _vp), ("lnb_g", _vp),
-                ("lnb_gadd", _vp), ("lnb_part", _vp)]
+                ("lnb_gadd", _vp), ("lnb_part", _vp), ("act_dtype", _i)]
 
 
 class MlpDesc(_c.Structure):
     _fields_ = [("mode", _i), ("inp", _vp), ("w1", _vp), ("w2", _vp), ("b1", _vp), ("b2", _vp), ("ln_g", _vp),
                 ("ln_b", _vp), ("ln_eps", _f), ("stats", _vp), ("z1", _vp), ("gz1", _vp), ("x1", _vp), ("out", _vp),
-                ("part", _vp), ("B", _i), ("C", _i), ("H", _i), ("V", _i64)]
+                ("part", _vp), ("B", _i), ("C", _i), ("H", _i), ("V", _i64), ("act_dtype", _i)]
 
 
 class WgradDesc(_c.Structure):
     _fields_ = [("p", _vp), ("M", _i), ("pmul", _vp), ("pmul_kind", _i), ("q", _vp * 4), ("nsrc", _i),
                 ("src_mode", _i), ("c0", _i), ("Cin", _i), ("K", _i), ("Vq", _i64), ("D", _i), ("H", _i),
                 ("W", _i), ("N", _i64), ("Ho", _i), ("Wo", _i), ("stats", _vp), ("qact", _i), ("ln_g", _vp),
-                ("ln_b", _vp), ("gw", _vp), ("gbias", _vp), ("accumulate", _i), ("B", _i), ("loader", _i)]
+                ("ln_b", _vp), ("gw", _vp), ("gbias", _vp), ("accumulate", _i), ("B", _i), ("loader", _i),
+                ("act_dtype", _i)]
 
 
 _SIGS.update({
     "fz_nmf_cf_supported": ([_i] * 11, _i),
-    "fz_nmf_cf_fwd": ([_vp] * 4 + [_i] * 5 + [_c.POINTER(_i)] + [_i] * 5 + [_f, _vp], _i),
-    "fz_nmf_cf_bwd": ([_vp] * 5 + [_i] * 5 + [_c.POINTER(_i)] + [_i] * 7 + [_f, _vp], _i),
+    "fz_nmf_cf_fwd": ([_vp] * 4 + [_i] * 5 + [_c.POINTER(_i)] + [_i] * 5 + [_f, _i, _vp], _i),
+    "fz_nmf_cf_bwd": ([_vp] * 5 + [_i] * 5 + [_c.POINTER(_i)] + [_i] * 7 + [_f, _i, _vp], _i),
     "fz_gemm": ([_c.POINTER(GemmDesc), _vp], _i),
     "fz_gemm_lnbwd_partials": ([_c.POINTER(GemmDesc)], _i64),
     "fz_reduce_rows": ([_vp, _i64, _i, _vp, _vp, _vp], _i),
@@ -130,9 +142,9 @@ _SIGS.update({
     "fz_mlp_chain": ([_c.POINTER(MlpDesc), _vp], _i),
     "fz_wgrad": ([_c.POINTER(WgradDesc), _vp, _vp], _i),
     "fz_wgrad_workspace_bytes": ([_c.POINTER(WgradDesc)], _i64),
-    "fz_conv3_fwd": ([_vp] * 4 + [_i] * 6 + [_vp], _i),
+    "fz_conv3_fwd": ([_vp] * 4 + [_i] * 7 + [_vp], _i),
     "fz_conv3_wgrad_chunks": ([_i] * 4, _i),
-    "fz_conv3_wgrad_partials": ([_vp] * 4 + [_i] * 6 + [_vp], _i),
+    "fz_conv3_wgrad_partials": ([_vp] * 4 + [_i] * 7 + [_vp], _i),
     "fz_chunk_reduce": ([_vp, _i, _i64, _vp, _i, _vp], _i),
     "fz_dice_bce_chunks": ([_i64], _i),
     "fz_dice_bce_sums": ([_vp, _vp, _vp, _i, _i64, _vp], _i),
@@ -140,9 +152,9 @@ _SIGS.update({
     "fz_dice_ce_sums": ([_vp, _vp, _vp, _i, _i, _i64, _vp], _i),
     "fz_dice_ce_grad": ([_vp, _vp, _vp, _vp, _i, _i, _i64, _f, _f, _vp, _vp], _i),
     "fz_rowsum_chunks": ([_i64], _i),
-    "fz_rowsum": ([_vp, _vp, _vp, _i, _i, _i64, _vp], _i),
-    "fz_ln_fwd": ([_vp] * 5 + [_i, _i, _i64, _f, _vp], _i),
-    "fz_ln_bwd": ([_vp] * 8 + [_i, _i, _i64, _vp], _i),
+    "fz_rowsum": ([_vp, _vp, _vp, _i, _i, _i64, _i, _vp], _i),
+    "fz_ln_fwd": ([_vp] * 5 + [_i, _i, _i64, _f, _i, _vp], _i),
+    "fz_ln_bwd": ([_vp] * 8 + [_i, _i, _i64, _i, _vp], _i),
     "fz_ln_bwd_workspace_bytes": ([_i], _i64),
     "fz_ln_bwd_workspace_bytes2": ([_i, _i, _i64], _i64),
 })

@@ -56,11 +56,14 @@ class FactorizerBlock(nn.Module):
         self.mlp = MLP(channels, ratio=mlp_ratio, dropout=dropout)
 
     def _fusable(self, x) -> bool:
-        """Standard Swin block on a device fp32 tensor: LayerNorm / ReLU / exact GELU, no live
+        """Standard Swin block on a device tensor (fp32, or bf16 activations with fp32 parameters): LayerNorm / ReLU / exact GELU, no live
         dropout — then LayerNorm, bias, ReLU, GELU and both residual adds are fused into the GEMM
         kernels (csrc/gemm.hip) instead of running as separate full-tensor passes."""
         f, m = self.fact, self.mlp
-        if not (x.is_cuda and x.numel() and x.dtype == torch.float32 and PW._vox(x) % 4 == 0 and x.shape[1] % 2 == 0):
+        if not (x.is_cuda and x.numel() and x.dtype in (torch.float32, torch.bfloat16) and PW._vox(x) % 4 == 0
+                and x.shape[1] % 2 == 0):
+            return False
+        if any(p.dtype != torch.float32 for p in self.parameters()):  # bf16 activations keep fp32 parameters
             return False
         if not (isinstance(self.norm1, LayerNorm) and isinstance(self.norm2, LayerNorm)
                 and self.norm1.norm.elementwise_affine and self.norm2.norm.elementwise_affine

@@ -18,7 +18,7 @@ def _all(v, n):
 
 class Conv3d(nn.Conv3d):
     def _k2s2_native(self, x) -> bool:
-        return (x.is_cuda and x.numel() and x.dtype == torch.float32 and x.dim() == 5 and self.groups == 1
+        return (x.is_cuda and x.numel() and x.dtype in (torch.float32, torch.bfloat16) and self.weight.dtype == torch.float32 and x.dim() == 5 and self.groups == 1
                 and _all(self.dilation, 1) and self.padding_mode == "zeros"
                 and _all(self.kernel_size, 2) and _all(self.stride, 2) and _all(self.padding, 0)
                 and x.shape[-1] % 4 == 0 and x.shape[-2] % 2 == 0 and x.shape[-3] % 2 == 0
@@ -33,7 +33,7 @@ class Conv3d(nn.Conv3d):
         return x, self(x)
 
     def forward(self, x):
-        ok = (x.is_cuda and x.numel() and x.dtype == torch.float32 and x.dim() == 5 and self.groups == 1
+        ok = (x.is_cuda and x.numel() and x.dtype in (torch.float32, torch.bfloat16) and self.weight.dtype == torch.float32 and x.dim() == 5 and self.groups == 1
               and _all(self.dilation, 1) and self.padding_mode == "zeros")
         if ok:
             C = self.in_channels
@@ -60,7 +60,7 @@ class Conv3d(nn.Conv3d):
 
 class ConvTranspose3d(nn.ConvTranspose3d):
     def forward(self, x, output_size=None):
-        ok = (x.is_cuda and x.numel() and x.dtype == torch.float32 and x.dim() == 5 and self.groups == 1 and output_size is None
+        ok = (x.is_cuda and x.numel() and x.dtype in (torch.float32, torch.bfloat16) and self.weight.dtype == torch.float32 and x.dim() == 5 and self.groups == 1 and output_size is None
               and _all(self.dilation, 1) and _all(self.kernel_size, 2) and _all(self.stride, 2)
               and _all(self.padding, 0) and _all(self.output_padding, 0) and self.in_channels % 2 == 0
               and (x.shape[2] * x.shape[3] * x.shape[4]) % 4 == 0)

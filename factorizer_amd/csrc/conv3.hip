@@ -20,17 +20,19 @@ namespace fz {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-struct Conv3Args {
-  const float* x;     // (B, Cin, D, H, W)
+// AT = storage type of the activation tensors x / y / gy (float or bf16)
+template <typename AT>
+struct Conv3ArgsT {
+  const AT* x;        // (B, Cin, D, H, W)
   const float* w;     // (M, Cin, 3, 3, 3)
   const float* bias;  // (M) or null
-  float* y;           // (B, M, D, H, W)
+  AT* y;              // (B, M, D, H, W)
   int B, Cin, M, D, H, W;
 };
 
 // ---------------------------------------------------------------------------------------------
-template <int MB>
-__global__ __launch_bounds__(256, 2) void conv3_fwd_kernel(Conv3Args p) {
+template <int MB, typename AT>
+__global__ __launch_bounds__(256, 2) void conv3_fwd_kernel(Conv3ArgsT<AT> p) {
   extern __shared__ __attribute__((aligned(16))) float As[];  // [Cin/2 * 27][MB][64]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, h = lane >> 5;
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void conv3_fwd_kernel(Conv3Args p) {
       for (int r = 0; r < 16; ++r) acc[mb][q][r] = 0.f;
 
   for (int cp = 0; cp < ncp; ++cp) {
-    const float* plane = p.x + ((int64_t)b * p.Cin + 2 * cp + h) * V;
+    const AT* plane = p.x + ((int64_t)b * p.Cin + 2 * cp + h) * V;
 #pragma unroll
     for (int kd = 0; kd < 3; ++kd) {
 #pragma unroll
@@ -90,10 +92,10 @@ __global__ __launch_bounds__(256, 2) void conv3_fwd_kernel(Conv3Args p) {
         const bool ok = col_ok && zd >= 0 && zd < p.D && zh >= 0 && zh < p.H;
         const int zdc = zd < 0 ? 0 : (zd >= p.D ? p.D - 1 : zd);
         const int zhc = zh < 0 ? 0 : (zh >= p.H ? p.H - 1 : zh);
-        const float* row = plane + ((int64_t)zdc * p.H + zhc) * p.W;
-        const float4 t = *reinterpret_cast<const float4*>(row + w0);
-        const float lf = row[lok ? w0 - 1 : w0];
-        const float rt = row[rok ? w0 + 4 : w0];
+        const AT* row = plane + ((int64_t)zdc * p.H + zhc) * p.W;
+        const float4 t = ld4(row + w0);
+        const float lf = aget(row + (lok ? w0 - 1 : w0));
+        const float rt = aget(row + (rok ? w0 + 4 : w0));
         const float c0 = ok ? t.x : 0.f, c1 = ok ? t.y : 0.f, c2 = ok ? t.z : 0.f, c3 = ok ? t.w : 0.f;
         const float l0 = (ok && lok) ? lf : 0.f, r0 = (ok && rok) ? rt : 0.f;
         const float bv[3][4] = {{l0, c0, c1, c2}, {c0, c1, c2, c3}, {c1, c2, c3, r0}};
@@ -119,16 +121,17 @@ __global__ __launch_bounds__(256, 2) void conv3_fwd_kernel(Conv3Args p) {
       const int m = m0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
       if (m >= p.M) continue;
       const float bs = p.bias ? p.bias[m] : 0.f;
-      *reinterpret_cast<float4*>(p.y + ((int64_t)b * p.M + m) * V + col) =
-          make_float4(acc[mb][0][r] + bs, acc[mb][1][r] + bs, acc[mb][2][r] + bs, acc[mb][3][r] + bs);
+      st4(p.y + ((int64_t)b * p.M + m) * V + col,
+          make_float4(acc[mb][0][r] + bs, acc[mb][1][r] + bs, acc[mb][2][r] + bs, acc[mb][3][r] + bs));
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // weight gradient: GW[m][(ci, kd, kh, kw)] = Σ_{b,v} gY[b,m,v] · x[b,ci,v + off(kd,kh,kw)]
-struct Conv3WgradArgs {
-  const float* gy;  // (B, M, D, H, W)
-  const float* x;   // (B, Cin, D, H, W)
+template <typename AT>
+struct Conv3WgradArgsT {
+  const AT* gy;     // (B, M, D, H, W)
+  const AT* x;      // (B, Cin, D, H, W)
   float* part;      // [nchunk][M][27*Cin]
   float* part_bias; // [nchunk][M]
   int B, Cin, M, D, H, W;
@@ -137,8 +140,8 @@ struct Conv3WgradArgs {
 
 constexpr int kXs = 40;  // halo row stride: [3] = w0-1, [4..35] = the 32 interior voxels (16-byte aligned), [36] = w0+32
 
-template <int KB>  // KB = number of 32-column blocks covering 27*Cin (4 for Cin = 4)
-__global__ __launch_bounds__(256) void conv3_wgrad_kernel(Conv3WgradArgs a) {
+template <int KB, typename AT>  // KB = number of 32-column blocks covering 27*Cin (4 for Cin = 4)
+__global__ __launch_bounds__(256) void conv3_wgrad_kernel(Conv3WgradArgsT<AT> a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nrow = a.Cin * 9;                      // halo rows per tile (<= 36: host-checked)
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(Conv3WgradArgs a) {
       const int r = (lane >> 3) + 8 * i, cq = lane & 7;
       const int m = m0 + r;
       const int mc = m < a.M ? m : a.M - 1;
-      const float4 v = *reinterpret_cast<const float4*>(a.gy + ((int64_t)b * a.M + mc) * V + n0 + cq * 4);
+      const float4 v = ld4(a.gy + ((int64_t)b * a.M + mc) * V + n0 + cq * 4);
       pv[i] = m < a.M ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
@@ -199,8 +202,7 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(Conv3WgradArgs a) {
       const int zd = d0 + kd - 1, zh = h0 + kh - 1;
       const bool ok = (q >> 3) < nrow && zd >= 0 && zd < a.D && zh >= 0 && zh < a.H;
       const int zdc = min(max(zd, 0), a.D - 1), zhc = min(max(zh, 0), a.H - 1);
-      const float4 v = *reinterpret_cast<const float4*>(a.x + ((int64_t)b * a.Cin + ci) * V +
-                                                        ((int64_t)zdc * a.H + zhc) * a.W + w0 + cq * 4);
+      const float4 v = ld4(a.x + ((int64_t)b * a.Cin + ci) * V + ((int64_t)zdc * a.H + zhc) * a.W + w0 + cq * 4);
       hv[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(Conv3WgradArgs a) {
       const int zd = d0 + kd - 1, zh = h0 + kh - 1, zw = side ? w0 + 32 : w0 - 1;
       const bool ok = (id >> 1) < nrow && zd >= 0 && zd < a.D && zh >= 0 && zh < a.H && zw >= 0 && zw < a.W;
       const int zdc = min(max(zd, 0), a.D - 1), zhc = min(max(zh, 0), a.H - 1), zwc = min(max(zw, 0), a.W - 1);
-      const float v = a.x[((int64_t)b * a.Cin + ci) * V + ((int64_t)zdc * a.H + zhc) * a.W + zwc];
+      const float v = aget(a.x + ((int64_t)b * a.Cin + ci) * V + ((int64_t)zdc * a.H + zhc) * a.W + zwc);
       ev[i] = ok ? v : 0.f;
     }
   };
@@ -282,13 +284,10 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(Conv3WgradArgs a) {
 
 using namespace fz;
 
-extern "C" int fz_conv3_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int M, int D,
+template <typename AT>
+static int conv3_fwd_launch(const void* x, const float* w, const float* bias, void* y, int B, int Cin, int M, int D,
                             int H, int W, fz_stream_t stream) {
-  if (!x || !w || !y) return fail(FZ_E_ARG, "fz_conv3_fwd: null pointer");
-  if (B < 0 || Cin < 2 || (Cin & 1) || M < 1 || D < 1 || H < 1 || W < 4 || (W & 3))
-    return fail(FZ_E_UNSUPPORTED, "fz_conv3_fwd: needs even C_in and W % 4 == 0");
-  if (B == 0) return FZ_OK;
-  Conv3Args p{x, w, bias, y, B, Cin, M, D, H, W};
+  Conv3ArgsT<AT> p{(const AT*)x, w, bias, (AT*)y, B, Cin, M, D, H, W};
   const int64_t V = (int64_t)D * H * W;
   const int mblocks = (M + 31) / 32;
   const int MB = mblocks >= 2 ? 2 : 1;
@@ -296,10 +295,21 @@ extern "C" int fz_conv3_fwd(const float* x, const float* w, const float* bias, f
   if (lds > 65536) return fail(FZ_E_UNSUPPORTED, "fz_conv3_fwd: C_in too large for the stem kernel");
   dim3 grid((unsigned)(((V + 511) / 512) * B), (unsigned)((mblocks + MB - 1) / MB)), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (MB == 2) hipLaunchKernelGGL(conv3_fwd_kernel<2>, grid, block, lds, st, p);
-  else hipLaunchKernelGGL(conv3_fwd_kernel<1>, grid, block, lds, st, p);
+  if (MB == 2) hipLaunchKernelGGL((conv3_fwd_kernel<2, AT>), grid, block, lds, st, p);
+  else hipLaunchKernelGGL((conv3_fwd_kernel<1, AT>), grid, block, lds, st, p);
   FZ_LAUNCH_CHECK();
   return FZ_OK;
+}
+
+extern "C" int fz_conv3_fwd(const void* x, const float* w, const float* bias, void* y, int B, int Cin, int M, int D,
+                            int H, int W, int act_dtype, fz_stream_t stream) {
+  if (!x || !w || !y) return fail(FZ_E_ARG, "fz_conv3_fwd: null pointer");
+  if (B < 0 || Cin < 2 || (Cin & 1) || M < 1 || D < 1 || H < 1 || W < 4 || (W & 3))
+    return fail(FZ_E_UNSUPPORTED, "fz_conv3_fwd: needs even C_in and W % 4 == 0");
+  if (B == 0) return FZ_OK;
+  if (act_dtype == FZ_STORE_F32) return conv3_fwd_launch<float>(x, w, bias, y, B, Cin, M, D, H, W, stream);
+  if (act_dtype == FZ_STORE_BF16) return conv3_fwd_launch<bf16>(x, w, bias, y, B, Cin, M, D, H, W, stream);
+  return fail(FZ_E_ARG, "fz_conv3_fwd: bad act_dtype");
 }
 
 static int conv3_units(int64_t total_tiles, int* tiles_per_unit) {
@@ -317,17 +327,25 @@ extern "C" int fz_conv3_wgrad_chunks(int B, int D, int H, int W) {
   return conv3_units(((int64_t)D * H * W / 32) * B, &tpu);
 }
 
-extern "C" int fz_conv3_wgrad_partials(const float* gy, const float* x, float* part, float* part_bias, int B, int Cin,
-                                       int M, int D, int H, int W, fz_stream_t stream) {
-  if (!gy || !x || !part || !part_bias) return fail(FZ_E_ARG, "fz_conv3_wgrad: null pointer");
-  if (B < 1 || Cin < 1 || M < 1 || (W % 32) || 27 * Cin > 128 || Cin * 9 > 36)
-    return fail(FZ_E_UNSUPPORTED, "fz_conv3_wgrad: needs W % 32 == 0 and C_in <= 4");
-  Conv3WgradArgs a{gy, x, part, part_bias, B, Cin, M, D, H, W, 1};
+template <typename AT>
+static int conv3_wgrad_launch(const void* gy, const void* x, float* part, float* part_bias, int B, int Cin,
+                              int M, int D, int H, int W, fz_stream_t stream) {
+  Conv3WgradArgsT<AT> a{(const AT*)gy, (const AT*)x, part, part_bias, B, Cin, M, D, H, W, 1};
   const int nchunk = conv3_units(((int64_t)D * H * W / 32) * B, &a.tiles_per_unit);
   const size_t lds = (size_t)4 * (32 * 36 + 36 * kXs) * sizeof(float);
   const size_t lds_red = 4096 * sizeof(float);
   dim3 grid(nchunk, (M + 31) / 32), block(256);
-  hipLaunchKernelGGL(conv3_wgrad_kernel<4>, grid, block, lds > lds_red ? lds : lds_red, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((conv3_wgrad_kernel<4, AT>), grid, block, lds > lds_red ? lds : lds_red, (hipStream_t)stream, a);
   FZ_LAUNCH_CHECK();
   return FZ_OK;
+}
+
+extern "C" int fz_conv3_wgrad_partials(const void* gy, const void* x, float* part, float* part_bias, int B, int Cin,
+                                       int M, int D, int H, int W, int act_dtype, fz_stream_t stream) {
+  if (!gy || !x || !part || !part_bias) return fail(FZ_E_ARG, "fz_conv3_wgrad: null pointer");
+  if (B < 1 || Cin < 1 || M < 1 || (W % 32) || 27 * Cin > 128 || Cin * 9 > 36)
+    return fail(FZ_E_UNSUPPORTED, "fz_conv3_wgrad: needs W % 32 == 0 and C_in <= 4");
+  if (act_dtype == FZ_STORE_F32) return conv3_wgrad_launch<float>(gy, x, part, part_bias, B, Cin, M, D, H, W, stream);
+  if (act_dtype == FZ_STORE_BF16) return conv3_wgrad_launch<bf16>(gy, x, part, part_bias, B, Cin, M, D, H, W, stream);
+  return fail(FZ_E_ARG, "fz_conv3_wgrad: bad act_dtype");
 }

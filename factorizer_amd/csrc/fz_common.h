@@ -36,6 +36,100 @@ inline int fail(int code, const char* msg) {
   } while (0)
 
 #if defined(__HIPCC__)
+// ---- activation storage types -----------------------------------------------------------------
+// Mixed precision (BASELINE configs[4]): activations and their gradients may be STORED
+// as bf16 in HBM; every kernel converts to fp32 on load and rounds (RNE, v_cvt_pk_bf16_f32) on store,
+// so all arithmetic — MFMA accumulation, LayerNorm statistics, and the NMF factors / Grams / eps of
+// matrix_factorization.py:200,236 in particular — stays fp32.  Parameters, statistics and weight
+// gradients are always fp32.  Kernels are templates on the storage type AT in {float, bf16}.
+typedef __bf16 bf16;
+typedef __bf16 bf16v2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16v4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16v8 __attribute__((ext_vector_type(8)));
+typedef float f32v2 __attribute__((ext_vector_type(2)));
+typedef float f32v4 __attribute__((ext_vector_type(4)));
+typedef float f32v8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float aget(const float* p) { return *p; }
+__device__ __forceinline__ float aget(const bf16* p) { return (float)*p; }
+__device__ __forceinline__ void aput(float* p, float v) { *p = v; }
+__device__ __forceinline__ void aput(bf16* p, float v) { *p = (bf16)v; }
+
+// N consecutive elements <-> N floats (N = 1, 2, 4, 8); the address must be N-element aligned
+template <int N>
+__device__ __forceinline__ void aload(const float* p, float (&v)[N]) {
+  if constexpr (N == 8) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  } else if constexpr (N == 4) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else if constexpr (N == 2) {
+    const float2 t = *reinterpret_cast<const float2*>(p);
+    v[0] = t.x; v[1] = t.y;
+  } else {
+    v[0] = *p;
+  }
+}
+template <int N>
+__device__ __forceinline__ void aload(const bf16* p, float (&v)[N]) {
+  if constexpr (N == 8) {
+    const f32v8 f = __builtin_convertvector(*reinterpret_cast<const bf16v8*>(p), f32v8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = f[i];
+  } else if constexpr (N == 4) {
+    const f32v4 f = __builtin_convertvector(*reinterpret_cast<const bf16v4*>(p), f32v4);
+    v[0] = f[0]; v[1] = f[1]; v[2] = f[2]; v[3] = f[3];
+  } else if constexpr (N == 2) {
+    const f32v2 f = __builtin_convertvector(*reinterpret_cast<const bf16v2*>(p), f32v2);
+    v[0] = f[0]; v[1] = f[1];
+  } else {
+    v[0] = (float)*p;
+  }
+}
+template <int N>
+__device__ __forceinline__ void astore(float* p, const float (&v)[N]) {
+  if constexpr (N == 8) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  } else if constexpr (N == 4) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  } else if constexpr (N == 2) {
+    *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
+  } else {
+    *p = v[0];
+  }
+}
+template <int N>
+__device__ __forceinline__ void astore(bf16* p, const float (&v)[N]) {
+  if constexpr (N == 8) {
+    f32v8 f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = v[i];
+    *reinterpret_cast<bf16v8*>(p) = __builtin_convertvector(f, bf16v8);
+  } else if constexpr (N == 4) {
+    f32v4 f = {v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<bf16v4*>(p) = __builtin_convertvector(f, bf16v4);
+  } else if constexpr (N == 2) {
+    f32v2 f = {v[0], v[1]};
+    *reinterpret_cast<bf16v2*>(p) = __builtin_convertvector(f, bf16v2);
+  } else {
+    *p = (bf16)v[0];
+  }
+}
+
+// 4 consecutive activation elements <-> float4
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const bf16* p) {
+  const f32v4 f = __builtin_convertvector(*reinterpret_cast<const bf16v4*>(p), f32v4);
+  return make_float4(f[0], f[1], f[2], f[3]);
+}
+__device__ __forceinline__ void st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(bf16* p, const float4& v) {
+  const f32v4 f = {v.x, v.y, v.z, v.w};
+  *reinterpret_cast<bf16v4*>(p) = __builtin_convertvector(f, bf16v4);
+}
+
 // erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7): branch-free, 1 rcp + 1 exp + 5 fma —
 // the libm erff costs ~4x more VALU and carries a branch per element.  Used for the exact-erf
 // GELU of the MLP (layers/mlp.py:56); the 1e-4 parity budget dwarfs its error.

@@ -31,8 +31,10 @@ enum { LOAD_PLAIN = 0, LOAD_S2D = 1, LOAD_K3 = 2 };
 enum { EPI_PLAIN = 0, EPI_D2S = 1, EPI_LNBWD = 2 };
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
 
-struct GemmArgs {
-  const float* x[4];   // input sources
+// AT = storage type of the activation tensors (float or bf16, fz_common.h); everything else is fp32
+template <typename AT>
+struct GemmArgsT {
+  const AT* x[4];      // input sources
   int nsrc;            // number of sources
   int src_mode;        // 0: channel concat (x[0]: c0 channels, x[1]: Cin-c0)   1: average of sources
   int c0;
@@ -49,13 +51,13 @@ struct GemmArgs {
   float ln_eps;
   float* stats_out;    // [B][2][Vin] (mean, rstd) or null
   int bact;            // activation applied to the B operand
-  const float* bmul;   // B operand *= act'(bmul) (same shape as the input) or null
+  const AT* bmul;      // B operand *= act'(bmul) (same shape as the input) or null
   int bmul_kind;
   int eact;            // activation applied to the result
-  const float* res;    // residual added in the epilogue (same shape as y) or null
-  const float* emul;   // epilogue multiply by act'(emul) (same shape as y) or null
+  const AT* res;       // residual added in the epilogue (same shape as y) or null
+  const AT* emul;      // epilogue multiply by act'(emul) (same shape as y) or null
   int emul_kind;
-  float* y;
+  AT* y;
   int64_t Ncol;        // columns per sample (= Vin for LOAD_PLAIN, coarse voxels for LOAD_S2D)
   int Ho, Wo;          // coarse H, W (LOAD_S2D columns / EPI_D2S input grid)
   int B;
@@ -64,10 +66,10 @@ struct GemmArgs {
   int ygroups, xtiles; // streaming kernel: > 1 row-block groups -> 1-D XCD-aware grid of xtiles column tiles
   // EPI_LNBWD (M == 32): the result is gl = dL/d(LN output); the epilogue applies the LayerNorm
   // backward in registers: y = rstd*(gl*g - mean_c(gl*g) - n*mean_c(gl*g*n)) + lnb_gadd
-  const float* lnb_x;      // (B, 32, V) LayerNorm input
+  const AT* lnb_x;         // (B, 32, V) LayerNorm input
   const float* lnb_stats;  // (B, 2, V) mean, rstd
   const float* lnb_g;      // (32) gamma
-  const float* lnb_gadd;   // (B, 32, V) gradient added to the result, or null
+  const AT* lnb_gadd;      // (B, 32, V) gradient added to the result, or null
   float* lnb_part;         // [gridDim.x][64] per-workgroup partial (gγ | gβ) sums
 };
 
@@ -96,41 +98,28 @@ __device__ __forceinline__ int a_k(int a, int h) {
   return 2 * a + h;
 }
 
-__device__ __forceinline__ float weight_at(const GemmArgs& p, int m, int k) {
+template <typename AT>
+__device__ __forceinline__ float weight_at(const GemmArgsT<AT>& p, int m, int k) {
   return p.w_t ? p.w[(int64_t)k * p.ldw + m] : p.w[(int64_t)m * p.ldw + k];
 }
 
 // ---- NACC-wide vector access (NACC = 4, 2, 1 consecutive voxels per lane) -------------------
-template <int NACC>
-__device__ __forceinline__ void vload(const float* p, float (&v)[NACC]) {
-  if (NACC == 4) {
-    const float4 t = *reinterpret_cast<const float4*>(p);
-    v[0] = t.x; v[1] = t.y; v[2 % NACC] = t.z; v[3 % NACC] = t.w;
-  } else if (NACC == 2) {
-    const float2 t = *reinterpret_cast<const float2*>(p);
-    v[0] = t.x; v[1 % NACC] = t.y;
-  } else {
-    v[0] = *p;
-  }
-}
-template <int NACC>
-__device__ __forceinline__ void vstore(float* p, const float (&v)[NACC]) {
-  if (NACC == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2 % NACC], v[3 % NACC]);
-  else if (NACC == 2) *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1 % NACC]);
-  else *p = v[0];
-}
+template <int NACC, typename T>
+__device__ __forceinline__ void vload(const T* p, float (&v)[NACC]) { aload<NACC>(p, v); }
+template <int NACC, typename T>
+__device__ __forceinline__ void vstore(T* p, const float (&v)[NACC]) { astore<NACC>(p, v); }
 
 // ---- plain-loader fetch of NACC voxels of channel c -------------------------------------------
 // BRANCH-FREE on purpose: hipcc wraps a conditional load in s_cbranch + s_waitcnt vmcnt(0), which
 // serialises every load of the prefetch ring.  Out-of-range lanes/channels read a clamped (valid)
 // address and are zeroed with a select; the two-source concat picks its pointer with a select.
-template <int NACC, bool BMUL>
-__device__ __forceinline__ void fetch_plain(const GemmArgs& p, int b, int c, int64_t off, bool ok,
+template <int NACC, bool BMUL, typename AT>
+__device__ __forceinline__ void fetch_plain(const GemmArgsT<AT>& p, int b, int c, int64_t off, bool ok,
                                             float (&v)[NACC]) {
   const bool cok = ok && c < p.Cin;
   const int cc = c < p.Cin ? c : p.Cin - 1;
   const bool first = cc < p.c0;
-  const float* base = first ? p.x[0] : p.x[1];
+  const AT* base = first ? p.x[0] : p.x[1];
   const int cs = first ? p.c0 : p.Cin - p.c0;
   const int ci = first ? cc : cc - p.c0;
   const int64_t o = ((int64_t)b * cs + ci) * p.Vin + (ok ? off : 0);
@@ -148,12 +137,12 @@ __device__ __forceinline__ void fetch_plain(const GemmArgs& p, int b, int c, int
 // Streaming-kernel variant: NO select on the loaded values (a select right behind the load makes the
 // scheduler wait for the load it just issued).  The consumer masks / gates when the ring slot is
 // used, PF steps later.  With BMUL the gate operand rides in the upper half of the slot.
-template <int NL, bool BMUL>
-__device__ __forceinline__ void fetch_plain_raw(const GemmArgs& p, int b, int c, int64_t off, bool ok,
+template <int NL, bool BMUL, typename AT>
+__device__ __forceinline__ void fetch_plain_raw(const GemmArgsT<AT>& p, int b, int c, int64_t off, bool ok,
                                                 float (&v)[BMUL ? 2 * NL : NL]) {
   const int cc = c < p.Cin ? c : p.Cin - 1;
   const bool first = cc < p.c0;
-  const float* base = first ? p.x[0] : p.x[1];
+  const AT* base = first ? p.x[0] : p.x[1];
   const int cs = first ? p.c0 : p.Cin - p.c0;
   const int ci = first ? cc : cc - p.c0;
   const int64_t oo = ok ? off : 0;
@@ -172,8 +161,8 @@ __device__ __forceinline__ void fetch_plain_raw(const GemmArgs& p, int b, int c,
 // ---- epilogue for one 32-row block -------------------------------------------------------------
 // acc[q][r]: row (r&3)+8(r>>2)+4h of the block, column group q.  tw = per-row additive constant
 // (LayerNorm β·W term), or null.
-template <int NACC, int EPI, bool S2DCOLS>
-__device__ __forceinline__ void store_block(const GemmArgs& p, const f32x16 (&acc)[NACC], int b, int mrow0,
+template <int NACC, int EPI, bool S2DCOLS, typename AT>
+__device__ __forceinline__ void store_block(const GemmArgsT<AT>& p, const f32x16 (&acc)[NACC], int b, int mrow0,
                                             int64_t ncol, int h, const float* tWblk) {
   if (EPI == EPI_PLAIN) {
 #pragma unroll
@@ -220,7 +209,7 @@ __device__ __forceinline__ void store_block(const GemmArgs& p, const f32x16 (&ac
       const int th = (r0 >> 1) & 1, td = h;
       const float bs = p.bias ? p.bias[o] : 0.f;
       const int64_t obase = ((int64_t)b * Mo + o) * Vf;
-      float* ybase = p.y + obase;
+      AT* ybase = p.y + obase;
       // p.res: a fine-resolution tensor added to the scattered block (the skip-connection gradient
       // joining the down-convolution's input gradient, unet.py:95-99 / autograd's accumulation)
       if (NACC == 4 && (p.Wo & 3) == 0) {
@@ -229,17 +218,15 @@ __device__ __forceinline__ void store_block(const GemmArgs& p, const f32x16 (&ac
         const int ho = (int)(t2 % p.Ho);
         const int dz = (int)(t2 / p.Ho);
         const int64_t fo = ((int64_t)(2 * dz + td) * Hf + (2 * ho + th)) * Wf + 2 * wo;
-        float4 lo4 = make_float4(acc[0][r0] + bs, acc[0][r0 + 1] + bs, acc[1 % NACC][r0] + bs, acc[1 % NACC][r0 + 1] + bs);
-        float4 hi4 = make_float4(acc[2 % NACC][r0] + bs, acc[2 % NACC][r0 + 1] + bs, acc[3 % NACC][r0] + bs,
-                                 acc[3 % NACC][r0 + 1] + bs);
+        float o8[8] = {acc[0][r0] + bs, acc[0][r0 + 1] + bs, acc[1 % NACC][r0] + bs, acc[1 % NACC][r0 + 1] + bs,
+                       acc[2 % NACC][r0] + bs, acc[2 % NACC][r0 + 1] + bs, acc[3 % NACC][r0] + bs, acc[3 % NACC][r0 + 1] + bs};
         if (p.res) {
-          const float4 ra = *reinterpret_cast<const float4*>(p.res + obase + fo);
-          const float4 rb = *reinterpret_cast<const float4*>(p.res + obase + fo + 4);
-          lo4.x += ra.x; lo4.y += ra.y; lo4.z += ra.z; lo4.w += ra.w;
-          hi4.x += rb.x; hi4.y += rb.y; hi4.z += rb.z; hi4.w += rb.w;
+          float r8[8];
+          vload<8>(p.res + obase + fo, r8);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o8[i] += r8[i];
         }
-        *reinterpret_cast<float4*>(ybase + fo) = lo4;
-        *reinterpret_cast<float4*>(ybase + fo + 4) = hi4;
+        vstore<8>(ybase + fo, o8);
       } else {
 #pragma unroll
         for (int q = 0; q < NACC; ++q) {
@@ -249,12 +236,13 @@ __device__ __forceinline__ void store_block(const GemmArgs& p, const f32x16 (&ac
           const int ho = (int)(t2 % p.Ho);
           const int dz = (int)(t2 / p.Ho);
           const int64_t fo = ((int64_t)(2 * dz + td) * Hf + (2 * ho + th)) * Wf + 2 * wo;
-          float2 v2 = make_float2(acc[q][r0] + bs, acc[q][r0 + 1] + bs);
+          float v2[2] = {acc[q][r0] + bs, acc[q][r0 + 1] + bs};
           if (p.res) {
-            const float2 r2 = *reinterpret_cast<const float2*>(p.res + obase + fo);
-            v2.x += r2.x; v2.y += r2.y;
+            float r2[2];
+            vload<2>(p.res + obase + fo, r2);
+            v2[0] += r2[0]; v2[1] += r2[1];
           }
-          *reinterpret_cast<float2*>(ybase + fo) = v2;
+          vstore<2>(ybase + fo, v2);
         }
       }
     }
@@ -274,8 +262,8 @@ __device__ __forceinline__ float half_sum32(float v) {
   return v;
 }
 
-template <int NACC, bool GADD, bool GADD_LDS = false>
-__device__ __forceinline__ void lnbwd_block(const GemmArgs& p, const f32x16 (&acc)[NACC], int b, int64_t ncol,
+template <int NACC, bool GADD, bool GADD_LDS = false, typename AT = float>
+__device__ __forceinline__ void lnbwd_block(const GemmArgsT<AT>& p, const f32x16 (&acc)[NACC], int b, int64_t ncol,
                                             bool col_ok, int lane, int wave, float* red /* [4][64] */,
                                             int64_t part_row, const float* g_lds /* gamma[32] in LDS */,
                                             const float* gadd_lds = nullptr /* [32][32*NACC] tile of lnb_gadd */) {
@@ -379,8 +367,8 @@ __device__ __forceinline__ void lnbwd_block(const GemmArgs& p, const f32x16 (&ac
 // workgroup sequentially with one accumulator set: the input is read from HBM exactly once for
 // all output rows and 10+ KiB per wave are in flight.
 // =================================================================================================
-template <int NSTEP, int EPI, bool BMUL, bool GADD = false>
-__global__ __launch_bounds__(256, ((NSTEP <= 16 && EPI != EPI_LNBWD) ? 3 : 2)) void gemm_resident_kernel(GemmArgs p, int RB) {
+template <int NSTEP, int EPI, bool BMUL, bool GADD = false, typename AT = float>
+__global__ __launch_bounds__(256, ((NSTEP <= 16 && EPI != EPI_LNBWD) ? 3 : 2)) void gemm_resident_kernel(GemmArgsT<AT> p, int RB) {
   extern __shared__ __attribute__((aligned(16))) float lds_a[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, h = lane >> 5;
@@ -536,17 +524,18 @@ __global__ __launch_bounds__(256, ((NSTEP <= 16 && EPI != EPI_LNBWD) ? 3 : 2)) v
 //                           out = LayerNormBackward(W1ᵀ·gz; x1, stats, γ) + g2   (+ dγ, dβ partials)
 // Saves one write + one read of the 64-channel tensor per direction against the unfused layers.
 // =================================================================================================
-struct ChainArgs {
+template <typename AT>
+struct ChainArgsT {
   const float* wB;     // GEMM 2 weights: A[m][k] = wB_t ? wB[k*ldwB + m] : wB[m*ldwB + k]   (m < 32, k < 64)
   int wB_t, ldwB;
   const float* biasB;  // forward: [32] or null
-  float* side;         // (B, 64, V)
+  AT* side;            // (B, 64, V)
 };
 
 // HB = 32-row blocks of the hidden tensor: 2 (mlp_ratio 2, the README model) or 4 (mlp_ratio 4, the
 // BraTS bundle, train.yaml:62)
-template <bool BWD, int NACC, int HB>
-__global__ __launch_bounds__(256, (NACC == 2 && HB == 2) ? 3 : 2) void gemm_chain_kernel(GemmArgs p, ChainArgs c, int ntiles) {
+template <bool BWD, int NACC, int HB, typename AT = float>
+__global__ __launch_bounds__(256, (NACC == 2 && HB == 2) ? 3 : 2) void gemm_chain_kernel(GemmArgsT<AT> p, ChainArgsT<AT> c, int ntiles) {
   constexpr int HID = 32 * HB, N1 = 16 * HB * 64;  // hidden rows; floats of each staged weight block
   __shared__ float As1[N1];
   __shared__ float As2[N1];
@@ -608,7 +597,7 @@ __global__ __launch_bounds__(256, (NACC == 2 && HB == 2) ? 3 : 2) void gemm_chai
     const int bt = t / tiles_per_sample;
     const int64_t ct = ((int64_t)(t % tiles_per_sample) * 4 + wave) * (32 * NACC) + NACC * j;
     const unsigned lo = (unsigned)h * (unsigned)p.Ncol + (unsigned)(ct < p.Ncol ? ct : 0);
-    const float* xb = p.x[0] + (int64_t)bt * 32 * p.Ncol;
+    const AT* xb = p.x[0] + (int64_t)bt * 32 * p.Ncol;
 #pragma unroll
     for (int s = 0; s < 16; ++s) vload<NACC>(xb + (int64_t)(2 * s) * p.Ncol + lo, bv[s]);
   };
@@ -777,8 +766,8 @@ enum { PRO_NONE = 0, PRO_LN = 1, PRO_GELU = 2, PRO_BMUL = 3 };
 // (2 workgroups per CU: 3 or 4 — narrower tiles under tighter launch bounds — measured no faster,
 // an occupancy sweep: the operand traffic of these launches runs at 4.1-5.1 TB/s even with the
 // MFMAs compiled out (tools/debug/gemm_probe7.py), the fp32 MFMA time comes largely on top of it.)
-template <int MB, int NACC, int LOADER, int EPI, int PRO, int KS = 1>
-__global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgs p) {
+template <int MB, int NACC, int LOADER, int EPI, int PRO, int KS = 1, typename AT = float>
+__global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgsT<AT> p) {
   constexpr int TN = 32 * NACC;
   constexpr int NL = (LOADER == LOAD_S2D) ? 4 : NACC;  // floats fetched per load step
   // operand prefetch depth (load steps): narrow tiles are latency-bound (L2 round trip ≈ 500-900
@@ -883,10 +872,12 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgs p) {
       const int cc = c < p.Cin ? c : p.Cin - 1;
       const int zdc = zd < 0 ? 0 : (zd >= p.Di ? p.Di - 1 : zd);
       const int zhc = zh < 0 ? 0 : (zh >= p.Hi ? p.Hi - 1 : zh);
-      const float* row = p.x[0] + ((int64_t)b * p.Cin + cc) * p.Vin + ((int64_t)zdc * p.Hi + zhc) * p.Wi;
-      const float4 t = *reinterpret_cast<const float4*>(row + kw0);
-      const float lft = row[kw0 > 0 ? kw0 - 1 : 0];
-      const float rgt = row[kw0 + 4 < p.Wi ? kw0 + 4 : kw0];
+      const AT* row = p.x[0] + ((int64_t)b * p.Cin + cc) * p.Vin + ((int64_t)zdc * p.Hi + zhc) * p.Wi;
+      float t4[4];
+      vload<4>(row + kw0, t4);
+      const float4 t = make_float4(t4[0], t4[1], t4[2], t4[3]);
+      const float lft = aget(row + (kw0 > 0 ? kw0 - 1 : 0));
+      const float rgt = aget(row + (kw0 + 4 < p.Wi ? kw0 + 4 : kw0));
       const float l0 = kw0 > 0 ? lft : 0.f;
       const float r0 = kw0 + 4 < p.Wi ? rgt : 0.f;
       float o0, o1, o2, o3;
@@ -1139,9 +1130,9 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgs p) {
 
 using namespace fz;
 
-// Flat C view of GemmArgs for the ABI (see include/factorizer_hip.h: fz_gemm_desc).
-extern "C" int fz_gemm(const fz_gemm_desc* d, fz_stream_t stream) {
-  if (!d) return fail(FZ_E_ARG, "fz_gemm: null descriptor");
+// Flat C view of GemmArgsT for the ABI (see include/factorizer_hip.h: fz_gemm_desc).
+template <typename AT>
+static int gemm_launch(const fz_gemm_desc* d, fz_stream_t stream) {
   if (!d->x[0] || !d->w || !d->y) return fail(FZ_E_ARG, "fz_gemm: null pointer");
   if (d->loader < LOAD_PLAIN || d->loader > LOAD_K3) return fail(FZ_E_ARG, "fz_gemm: bad loader");
   if (d->epilogue < EPI_PLAIN || d->epilogue > EPI_LNBWD) return fail(FZ_E_ARG, "fz_gemm: bad epilogue");
@@ -1165,18 +1156,18 @@ extern "C" int fz_gemm(const fz_gemm_desc* d, fz_stream_t stream) {
     return fail(FZ_E_UNSUPPORTED, "fz_gemm: one source, or two sources concatenated along channels");
   if (d->bmul && d->bmul_kind != ACT_RELU) return fail(FZ_E_UNSUPPORTED, "fz_gemm: bmul supports the ReLU gate");
   if (d->B == 0) return FZ_OK;
-  GemmArgs a;
-  for (int i = 0; i < 4; ++i) a.x[i] = d->x[i];
+  GemmArgsT<AT> a;
+  for (int i = 0; i < 4; ++i) a.x[i] = (const AT*)d->x[i];
   a.nsrc = d->nsrc; a.src_mode = d->src_mode; a.c0 = d->c0 > 0 ? d->c0 : d->Cin; a.Cin = d->Cin;
-  a.Vin = d->Vin; a.Di = d->Di; a.Hi = d->Hi; a.Wi = d->Wi; a.bmul = d->bmul; a.bmul_kind = d->bmul_kind;
+  a.Vin = d->Vin; a.Di = d->Di; a.Hi = d->Hi; a.Wi = d->Wi; a.bmul = (const AT*)d->bmul; a.bmul_kind = d->bmul_kind;
   a.w = d->w; a.w_t = d->w_t; a.ldw = d->ldw; a.M = d->M; a.K = d->K;
   a.bias = d->bias; a.ln = d->ln; a.ln_g = d->ln_g; a.ln_b = d->ln_b; a.ln_eps = d->ln_eps;
-  a.stats_out = d->stats_out; a.bact = d->bact; a.eact = d->eact; a.res = d->res; a.emul = d->emul;
-  a.emul_kind = d->emul_kind; a.y = d->y; a.Ncol = d->Ncol; a.Ho = d->Ho; a.Wo = d->Wo; a.B = d->B;
+  a.stats_out = d->stats_out; a.bact = d->bact; a.eact = d->eact; a.res = (const AT*)d->res; a.emul = (const AT*)d->emul;
+  a.emul_kind = d->emul_kind; a.y = (AT*)d->y; a.Ncol = d->Ncol; a.Ho = d->Ho; a.Wo = d->Wo; a.B = d->B;
   { const char* e = getenv("FZ_GEMM_DBG"); a.dbg = e ? atoi(e) : 0; }
   { const char* e = getenv("FZ_GEMM_TILEMAP"); a.tile_map = e ? atoi(e) : 1; }
   a.ygroups = 0; a.xtiles = 0;
-  a.lnb_x = d->lnb_x; a.lnb_stats = d->lnb_stats; a.lnb_g = d->lnb_g; a.lnb_gadd = d->lnb_gadd; a.lnb_part = d->lnb_part;
+  a.lnb_x = (const AT*)d->lnb_x; a.lnb_stats = d->lnb_stats; a.lnb_g = d->lnb_g; a.lnb_gadd = (const AT*)d->lnb_gadd; a.lnb_part = d->lnb_part;
   hipStream_t st = (hipStream_t)stream;
   const int mblocks = (d->M + 31) / 32;
 
@@ -1293,6 +1284,13 @@ extern "C" int fz_gemm(const fz_gemm_desc* d, fz_stream_t stream) {
   return FZ_OK;
 }
 
+extern "C" int fz_gemm(const fz_gemm_desc* d, fz_stream_t stream) {
+  if (!d) return fail(FZ_E_ARG, "fz_gemm: null descriptor");
+  if (d->act_dtype == FZ_STORE_F32) return gemm_launch<float>(d, stream);
+  if (d->act_dtype == FZ_STORE_BF16) return gemm_launch<bf16>(d, stream);
+  return fail(FZ_E_ARG, "fz_gemm: act_dtype must be FZ_STORE_F32 or FZ_STORE_BF16");
+}
+
 extern "C" int64_t fz_gemm_lnbwd_partials(const fz_gemm_desc* d) {
   if (!d) return -1;
   return ((d->Ncol + 511) / 512) * d->B;  // one row per workgroup of the resident kernel
@@ -1314,8 +1312,8 @@ extern "C" int fz_mlp_supported(int C, int H, int64_t V) {
   return (C == 32 && (H == 64 || H == 128) && V > 0 && (V % 4) == 0 && V <= ((int64_t)1 << 27)) ? 1 : 0;
 }
 
-extern "C" int fz_mlp_chain(const fz_mlp_desc* d, fz_stream_t stream) {
-  if (!d) return fail(FZ_E_ARG, "fz_mlp_chain: null descriptor");
+template <typename AT>
+static int mlp_launch(const fz_mlp_desc* d, fz_stream_t stream) {
   if (!fz_mlp_supported(d->C, d->H, d->V)) return fail(FZ_E_UNSUPPORTED, "fz_mlp_chain: needs C == 32, H in {64, 128}, V % 4 == 0");
   if (d->B < 0) return fail(FZ_E_SHAPE, "fz_mlp_chain: negative batch");
   if (!d->in || !d->w1 || !d->w2 || !d->out || !d->z1 || !d->stats)
@@ -1324,9 +1322,9 @@ extern "C" int fz_mlp_chain(const fz_mlp_desc* d, fz_stream_t stream) {
   if (d->mode == 1 && (!d->gz1 || !d->x1 || !d->ln_g || !d->part)) return fail(FZ_E_ARG, "fz_mlp_chain: backward needs gz1, x1, gamma, part");
   if (d->mode != 0 && d->mode != 1) return fail(FZ_E_ARG, "fz_mlp_chain: bad mode");
   if (d->B == 0) return FZ_OK;
-  GemmArgs a = {};
-  ChainArgs c = {};
-  a.x[0] = d->in; a.nsrc = 1; a.c0 = 32; a.Cin = 32; a.Vin = d->V; a.M = d->H; a.K = 32; a.Ncol = d->V; a.B = d->B;
+  GemmArgsT<AT> a = {};
+  ChainArgsT<AT> c = {};
+  a.x[0] = (const AT*)d->in; a.nsrc = 1; a.c0 = 32; a.Cin = 32; a.Vin = d->V; a.M = d->H; a.K = 32; a.Ncol = d->V; a.B = d->B;
   hipStream_t st = (hipStream_t)stream;
   const int ntiles = (int)fz_mlp_partials(d->B, d->V);
   int wgs = d->H == 128 ? 512 : 768;  // resident workgroups (2 or 3 per CU), each walking tiles with a stride of the grid
@@ -1335,20 +1333,27 @@ extern "C" int fz_mlp_chain(const fz_mlp_desc* d, fz_stream_t stream) {
   if (d->mode == 0) {
     a.w = d->w1; a.w_t = 0; a.ldw = 32;              // A1[m][k] = W1[m][k]
     a.bias = d->b1; a.ln = 1; a.ln_g = d->ln_g; a.ln_b = d->ln_b; a.ln_eps = d->ln_eps; a.stats_out = d->stats;
-    a.res = d->in; a.y = d->out;
+    a.res = (const AT*)d->in; a.y = (AT*)d->out;
     c.wB = d->w2; c.wB_t = 0; c.ldwB = d->H;         // A2[m][k] = W2[m][k]
-    c.biasB = d->b2; c.side = d->z1;
+    c.biasB = d->b2; c.side = (AT*)d->z1;
     if (d->H == 128) hipLaunchKernelGGL((gemm_chain_kernel<false, 2, 4>), grid, block, 0, st, a, c, ntiles);
     else hipLaunchKernelGGL((gemm_chain_kernel<false, 2, 2>), grid, block, 0, st, a, c, ntiles);
   } else {
     a.w = d->w2; a.w_t = 1; a.ldw = d->H;            // A1[m = hidden][k = c] = W2[c][hidden]
-    a.emul = d->z1; a.y = d->out;
-    a.lnb_x = d->x1; a.lnb_stats = d->stats; a.lnb_g = d->ln_g; a.lnb_gadd = d->in; a.lnb_part = d->part;
+    a.emul = (const AT*)d->z1; a.y = (AT*)d->out;
+    a.lnb_x = (const AT*)d->x1; a.lnb_stats = d->stats; a.lnb_g = d->ln_g; a.lnb_gadd = (const AT*)d->in; a.lnb_part = d->part;
     c.wB = d->w1; c.wB_t = 1; c.ldwB = 32;           // A2[m = c][k = hidden] = W1[hidden][c]
-    c.side = d->gz1;
+    c.side = (AT*)d->gz1;
     if (d->H == 128) hipLaunchKernelGGL((gemm_chain_kernel<true, 2, 4>), grid, block, 0, st, a, c, ntiles);
     else hipLaunchKernelGGL((gemm_chain_kernel<true, 2, 2>), grid, block, 0, st, a, c, ntiles);
   }
   FZ_LAUNCH_CHECK();
   return FZ_OK;
+}
+
+extern "C" int fz_mlp_chain(const fz_mlp_desc* d, fz_stream_t stream) {
+  if (!d) return fail(FZ_E_ARG, "fz_mlp_chain: null descriptor");
+  if (d->act_dtype == FZ_STORE_F32) return mlp_launch<float>(d, stream);
+  if (d->act_dtype == FZ_STORE_BF16) return mlp_launch<bf16>(d, stream);
+  return fail(FZ_E_ARG, "fz_mlp_chain: act_dtype must be FZ_STORE_F32 or FZ_STORE_BF16");
 }

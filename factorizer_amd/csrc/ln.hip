@@ -12,8 +12,9 @@
 namespace fz {
 
 // y = (x - mean) * rstd * g + b ; stats (B,2,V) optional output
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                                                     const float* __restrict__ bta, float* __restrict__ y,
+template <typename AT>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const AT* __restrict__ x, const float* __restrict__ g,
+                                                     const float* __restrict__ bta, AT* __restrict__ y,
                                                      float* __restrict__ stats, int B, int C, int64_t V,
                                                      float eps) {
   const int64_t nvec = V / 4;
@@ -21,30 +22,30 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int b = (int)(i / nvec);
     const int64_t v = (i % nvec) * 4;
-    const float* xp = x + (int64_t)b * C * V + v;
+    const AT* xp = x + (int64_t)b * C * V + v;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int c = 0; c < C; ++c) {
-      const float4 t = *reinterpret_cast<const float4*>(xp + (int64_t)c * V);
+      const float4 t = ld4(xp + (int64_t)c * V);
       s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
     }
     const float inv = 1.0f / (float)C;
     const float4 mu = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int c = 0; c < C; ++c) {
-      const float4 t = *reinterpret_cast<const float4*>(xp + (int64_t)c * V);
+      const float4 t = ld4(xp + (int64_t)c * V);
       const float dx = t.x - mu.x, dy = t.y - mu.y, dz = t.z - mu.z, dw = t.w - mu.w;
       q.x += dx * dx; q.y += dy * dy; q.z += dz * dz; q.w += dw * dw;
     }
     const float4 rs = make_float4(1.0f / sqrtf(q.x * inv + eps), 1.0f / sqrtf(q.y * inv + eps),
                                   1.0f / sqrtf(q.z * inv + eps), 1.0f / sqrtf(q.w * inv + eps));
-    float* yp = y + (int64_t)b * C * V + v;
+    AT* yp = y + (int64_t)b * C * V + v;
     for (int c = 0; c < C; ++c) {
-      const float4 t = *reinterpret_cast<const float4*>(xp + (int64_t)c * V);
+      const float4 t = ld4(xp + (int64_t)c * V);
       const float gc = g[c], bc = bta[c];
       float4 o;
       o.x = (t.x - mu.x) * rs.x * gc + bc; o.y = (t.y - mu.y) * rs.y * gc + bc;
       o.z = (t.z - mu.z) * rs.z * gc + bc; o.w = (t.w - mu.w) * rs.w * gc + bc;
-      *reinterpret_cast<float4*>(yp + (int64_t)c * V) = o;
+      st4(yp + (int64_t)c * V, o);
     }
     if (stats != nullptr) {
       float* sp = stats + (int64_t)b * 2 * V + v;
@@ -57,10 +58,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // gx = rstd * (gl*g - mean_c(gl*g) - n * mean_c(gl*g*n)) [+ gadd],  n = (x - mean) * rstd
 // CMAX > 0: the kernel also accumulates the affine gradients  gγ_c = Σ gl_c·n_c ,  gβ_c = Σ gl_c
 // in registers (C <= CMAX) and writes one partial row per workgroup: part[blk][2][C].
-template <int CMAX>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ gl, const float* __restrict__ x,
+template <int CMAX, typename AT>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const AT* __restrict__ gl, const AT* __restrict__ x,
                                                      const float* __restrict__ stats, const float* __restrict__ g,
-                                                     const float* __restrict__ gadd, float* __restrict__ gx,
+                                                     const AT* __restrict__ gadd, AT* __restrict__ gx,
                                                      float* __restrict__ part, int B, int C, int64_t V) {
   constexpr int CA = CMAX > 0 ? CMAX : 1;
   float ag[CA], ab[CA];
@@ -77,8 +78,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ g
     const float4 rs = *reinterpret_cast<const float4*>(sp + V);
     float4 m1 = make_float4(0.f, 0.f, 0.f, 0.f), m2 = m1;
     auto pass1 = [&](int c, int ci) {
-      const float4 t = *reinterpret_cast<const float4*>(x + base + (int64_t)c * V);
-      const float4 d = *reinterpret_cast<const float4*>(gl + base + (int64_t)c * V);
+      const float4 t = ld4(x + base + (int64_t)c * V);
+      const float4 d = ld4(gl + base + (int64_t)c * V);
       const float gc = g[c];
       const float nx = (t.x - mu.x) * rs.x, ny = (t.y - mu.y) * rs.y, nz = (t.z - mu.z) * rs.z,
                   nw = (t.w - mu.w) * rs.w;
@@ -101,8 +102,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ g
     m1.x *= inv; m1.y *= inv; m1.z *= inv; m1.w *= inv;
     m2.x *= inv; m2.y *= inv; m2.z *= inv; m2.w *= inv;
     for (int c = 0; c < C; ++c) {
-      const float4 t = *reinterpret_cast<const float4*>(x + base + (int64_t)c * V);
-      const float4 d = *reinterpret_cast<const float4*>(gl + base + (int64_t)c * V);
+      const float4 t = ld4(x + base + (int64_t)c * V);
+      const float4 d = ld4(gl + base + (int64_t)c * V);
       const float gc = g[c];
       float4 o;
       o.x = rs.x * (d.x * gc - m1.x - (t.x - mu.x) * rs.x * m2.x);
@@ -110,10 +111,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ g
       o.z = rs.z * (d.z * gc - m1.z - (t.z - mu.z) * rs.z * m2.z);
       o.w = rs.w * (d.w * gc - m1.w - (t.w - mu.w) * rs.w * m2.w);
       if (gadd != nullptr) {
-        const float4 r = *reinterpret_cast<const float4*>(gadd + base + (int64_t)c * V);
+        const float4 r = ld4(gadd + base + (int64_t)c * V);
         o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
       }
-      *reinterpret_cast<float4*>(gx + base + (int64_t)c * V) = o;
+      st4(gx + base + (int64_t)c * V, o);
     }
   }
   if (CMAX > 0) {
@@ -140,11 +141,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ g
 // Backward for wide tensors (C > 64: the 8^3..32^3 stages).  Lanes = consecutive 4-voxel quads
 // (16-byte accesses stay coalesced: 1 KiB per channel row per wave), the NW waves of a workgroup
 // split the channels; the two per-voxel means are combined through LDS.
-template <int NW>
-__global__ __launch_bounds__(64 * NW) void ln_bwd_split_kernel(const float* __restrict__ gl, const float* __restrict__ x,
+template <int NW, typename AT>
+__global__ __launch_bounds__(64 * NW) void ln_bwd_split_kernel(const AT* __restrict__ gl, const AT* __restrict__ x,
                                                                const float* __restrict__ stats,
                                                                const float* __restrict__ g,
-                                                               const float* __restrict__ gadd, float* __restrict__ gx,
+                                                               const AT* __restrict__ gadd, AT* __restrict__ gx,
                                                                float* __restrict__ part, int B, int C, int64_t V) {
   __shared__ float red[NW][8][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -163,8 +164,8 @@ __global__ __launch_bounds__(64 * NW) void ln_bwd_split_kernel(const float* __re
   const int c0 = wave * cs, c1 = min(C, c0 + cs);
   float m[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int c = c0; c < c1; ++c) {
-    const float4 t = *reinterpret_cast<const float4*>(x + base + (int64_t)c * V);
-    const float4 d = *reinterpret_cast<const float4*>(gl + base + (int64_t)c * V);
+    const float4 t = ld4(x + base + (int64_t)c * V);
+    const float4 d = ld4(gl + base + (int64_t)c * V);
     const float gc = g[c];
     const float nx = (t.x - mu.x) * rs.x, ny = (t.y - mu.y) * rs.y, nz = (t.z - mu.z) * rs.z, nw = (t.w - mu.w) * rs.w;
     const float ax = d.x * gc, ay = d.y * gc, az = d.z * gc, aw = d.w * gc;
@@ -194,8 +195,8 @@ __global__ __launch_bounds__(64 * NW) void ln_bwd_split_kernel(const float* __re
   }
   if (!ok) return;
   for (int c = c0; c < c1; ++c) {
-    const float4 t = *reinterpret_cast<const float4*>(x + base + (int64_t)c * V);
-    const float4 d = *reinterpret_cast<const float4*>(gl + base + (int64_t)c * V);
+    const float4 t = ld4(x + base + (int64_t)c * V);
+    const float4 d = ld4(gl + base + (int64_t)c * V);
     const float gc = g[c];
     float4 o;
     o.x = rs.x * (d.x * gc - mm[0] - (t.x - mu.x) * rs.x * mm[4]);
@@ -203,10 +204,10 @@ __global__ __launch_bounds__(64 * NW) void ln_bwd_split_kernel(const float* __re
     o.z = rs.z * (d.z * gc - mm[2] - (t.z - mu.z) * rs.z * mm[6]);
     o.w = rs.w * (d.w * gc - mm[3] - (t.w - mu.w) * rs.w * mm[7]);
     if (gadd != nullptr) {
-      const float4 r = *reinterpret_cast<const float4*>(gadd + base + (int64_t)c * V);
+      const float4 r = ld4(gadd + base + (int64_t)c * V);
       o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
     }
-    *reinterpret_cast<float4*>(gx + base + (int64_t)c * V) = o;
+    st4(gx + base + (int64_t)c * V, o);
   }
 }
 
@@ -215,11 +216,11 @@ __global__ __launch_bounds__(64 * NW) void ln_bwd_split_kernel(const float* __re
 // All loads of a pass are issued before the first use (no per-channel dependent round trips), the
 // optional added gradient and the affine partials are template flags (no branches in the loops),
 // and for CS <= 16 the slice stays in registers between the two passes (each tensor is read once).
-template <int CS, bool GADD, bool PART>
-__global__ __launch_bounds__(512) void ln_bwd_slice_kernel(const float* __restrict__ gl, const float* __restrict__ x,
+template <int CS, bool GADD, bool PART, typename AT>
+__global__ __launch_bounds__(512) void ln_bwd_slice_kernel(const AT* __restrict__ gl, const AT* __restrict__ x,
                                                            const float* __restrict__ stats,
                                                            const float* __restrict__ g,
-                                                           const float* __restrict__ gadd, float* __restrict__ gx,
+                                                           const AT* __restrict__ gadd, AT* __restrict__ gx,
                                                            float* __restrict__ part, int B, int64_t V) {
   constexpr int NW = 8, C = NW * CS;
   constexpr bool KEEP = CS <= 16;
@@ -244,8 +245,8 @@ __global__ __launch_bounds__(512) void ln_bwd_slice_kernel(const float* __restri
   for (int cb = 0; cb < CS; cb += U) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      t[u] = *reinterpret_cast<const float4*>(x + base + (int64_t)(cb + u) * V);
-      d[u] = *reinterpret_cast<const float4*>(gl + base + (int64_t)(cb + u) * V);
+      t[u] = ld4(x + base + (int64_t)(cb + u) * V);
+      d[u] = ld4(gl + base + (int64_t)(cb + u) * V);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -283,13 +284,13 @@ __global__ __launch_bounds__(512) void ln_bwd_slice_kernel(const float* __restri
     float4 r[GADD ? U : 1];
     if (GADD) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) r[GADD ? u : 0] = *reinterpret_cast<const float4*>(gadd + base + (int64_t)(cb + u) * V);
+      for (int u = 0; u < U; ++u) r[GADD ? u : 0] = ld4(gadd + base + (int64_t)(cb + u) * V);
     }
     if (!KEEP) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        t[u] = *reinterpret_cast<const float4*>(x + base + (int64_t)(cb + u) * V);
-        d[u] = *reinterpret_cast<const float4*>(gl + base + (int64_t)(cb + u) * V);
+        t[u] = ld4(x + base + (int64_t)(cb + u) * V);
+        d[u] = ld4(gl + base + (int64_t)(cb + u) * V);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(512) void ln_bwd_slice_kernel(const float* __restri
         const float4 rr = r[GADD ? u : 0];
         o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
       }
-      if (ok) *reinterpret_cast<float4*>(gx + base + (int64_t)(cb + u) * V) = o;
+      if (ok) st4(gx + base + (int64_t)(cb + u) * V, o);
     }
   }
 }
@@ -335,16 +336,17 @@ __global__ __launch_bounds__(256) void ln_part_reduce_kernel(const float* __rest
 
 // per-channel sums over batch and voxels (bias gradient of the transposed conv, unet.py:123):
 // part[(b*nchunk + chunk)][c] = Σ_{v in chunk} x[b, c, v]
-__global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ x, float* __restrict__ part, int C,
+template <typename AT>
+__global__ __launch_bounds__(256) void rowsum_kernel(const AT* __restrict__ x, float* __restrict__ part, int C,
                                                      int64_t V, int nchunk) {
   __shared__ float red[4];
   const int c = blockIdx.x, chunk = blockIdx.y, b = blockIdx.z;
   const int64_t per = ((V / 4 + nchunk - 1) / nchunk) * 4;
   const int64_t v0 = chunk * per, v1 = min(V, v0 + per);
-  const float* xp = x + ((int64_t)b * C + c) * V;
+  const AT* xp = x + ((int64_t)b * C + c) * V;
   float s = 0.f;
   for (int64_t v = v0 + threadIdx.x * 4; v < v1; v += 1024) {
-    const float4 t = *reinterpret_cast<const float4*>(xp + v);
+    const float4 t = ld4(xp + v);
     s += (t.x + t.y) + (t.z + t.w);
   }
   s = wave_sum(s);
@@ -366,16 +368,24 @@ static unsigned ln_grid(int64_t total) {
   return (unsigned)blocks;
 }
 
-extern "C" int fz_ln_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats, int B,
-                         int C, int64_t V, float eps, fz_stream_t stream) {
+template <typename AT>
+static int ln_fwd_launch(const void* x, const float* gamma, const float* beta, void* y, float* stats, int B, int C,
+                         int64_t V, float eps, fz_stream_t stream) {
+  hipLaunchKernelGGL(ln_fwd_kernel<AT>, dim3(ln_grid(V / 4 * B)), dim3(256), 0, (hipStream_t)stream, (const AT*)x,
+                     gamma, beta, (AT*)y, stats, B, C, V, eps);
+  FZ_LAUNCH_CHECK();
+  return FZ_OK;
+}
+
+extern "C" int fz_ln_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int B,
+                         int C, int64_t V, float eps, int act_dtype, fz_stream_t stream) {
   if (!x || !gamma || !beta || !y) return fail(FZ_E_ARG, "fz_ln_fwd: null pointer");
   if (B < 0 || C < 1 || V < 1) return fail(FZ_E_SHAPE, "fz_ln_fwd: bad sizes");
   if (V % 4) return fail(FZ_E_UNSUPPORTED, "fz_ln_fwd: voxel count must be a multiple of 4");
   if (B == 0) return FZ_OK;
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3(ln_grid(V / 4 * B)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y,
-                     stats, B, C, V, eps);
-  FZ_LAUNCH_CHECK();
-  return FZ_OK;
+  if (act_dtype == FZ_STORE_F32) return ln_fwd_launch<float>(x, gamma, beta, y, stats, B, C, V, eps, stream);
+  if (act_dtype == FZ_STORE_BF16) return ln_fwd_launch<bf16>(x, gamma, beta, y, stats, B, C, V, eps, stream);
+  return fail(FZ_E_ARG, "fz_ln_fwd: bad act_dtype");
 }
 
 // If gparams != NULL and C <= 64 the kernel also produces the affine gradients:
@@ -389,15 +399,14 @@ extern "C" int64_t fz_ln_bwd_workspace_bytes2(int B, int C, int64_t V) {
 }
 extern "C" int64_t fz_ln_bwd_workspace_bytes(int C) { return C <= 64 ? (int64_t)(1024 + 64) * 2 * C * 4 : 0; }
 
-extern "C" int fz_ln_bwd(const float* gl, const float* x, const float* stats, const float* gamma,
-                         const float* gadd, float* gx, float* gparams, void* workspace, int B, int C, int64_t V,
+template <typename AT>
+static int ln_bwd_launch(const void* gl_, const void* x_, const float* stats, const float* gamma,
+                         const void* gadd_, void* gx_, float* gparams, void* workspace, int B, int C, int64_t V,
                          fz_stream_t stream) {
-  if (!gl || !x || !stats || !gamma || !gx) return fail(FZ_E_ARG, "fz_ln_bwd: null pointer");
-  if (B < 0 || C < 1 || V < 1) return fail(FZ_E_SHAPE, "fz_ln_bwd: bad sizes");
-  if (V % 4) return fail(FZ_E_UNSUPPORTED, "fz_ln_bwd: voxel count must be a multiple of 4");
-  if (gparams != nullptr && workspace == nullptr)
-    return fail(FZ_E_ARG, "fz_ln_bwd: fused affine gradients need a workspace (fz_ln_bwd_workspace_bytes2)");
-  if (B == 0) return FZ_OK;
+  const AT* gl = (const AT*)gl_;
+  const AT* x = (const AT*)x_;
+  const AT* gadd = (const AT*)gadd_;
+  AT* gx = (AT*)gx_;
   hipStream_t st = (hipStream_t)stream;
   unsigned grid = ln_grid(V / 4 * B);
   {
@@ -408,7 +417,7 @@ extern "C" int fz_ln_bwd(const float* gl, const float* x, const float* stats, co
       const int64_t quads = (V / 4) * B;
       const unsigned gq = (unsigned)((quads + 63) / 64);
       float* part = gparams ? (float*)workspace : nullptr;
-#define FZ_LNS(CS, GA, PA) hipLaunchKernelGGL((ln_bwd_slice_kernel<CS, GA, PA>), dim3(gq), dim3(512), 0, st, gl, x, stats, gamma, gadd, gx, part, B, V)
+#define FZ_LNS(CS, GA, PA) hipLaunchKernelGGL((ln_bwd_slice_kernel<CS, GA, PA, AT>), dim3(gq), dim3(512), 0, st, gl, x, stats, gamma, gadd, gx, part, B, V)
 #define FZ_LNS_F(CS)                                                                       \
   do {                                                                                     \
     if (gadd) { if (part) FZ_LNS(CS, true, true); else FZ_LNS(CS, true, false); }          \
@@ -427,9 +436,9 @@ extern "C" int fz_ln_bwd(const float* gl, const float* x, const float* stats, co
     if (grid > 1024) grid = 1024;
     float* part = (float*)workspace;
     if (C <= 32)
-      hipLaunchKernelGGL(ln_bwd_kernel<32>, dim3(grid), dim3(256), 0, st, gl, x, stats, gamma, gadd, gx, part, B, C, V);
+      hipLaunchKernelGGL((ln_bwd_kernel<32, AT>), dim3(grid), dim3(256), 0, st, gl, x, stats, gamma, gadd, gx, part, B, C, V);
     else
-      hipLaunchKernelGGL(ln_bwd_kernel<64>, dim3(grid), dim3(256), 0, st, gl, x, stats, gamma, gadd, gx, part, B, C, V);
+      hipLaunchKernelGGL((ln_bwd_kernel<64, AT>), dim3(grid), dim3(256), 0, st, gl, x, stats, gamma, gadd, gx, part, B, C, V);
     FZ_LAUNCH_CHECK();
     hipLaunchKernelGGL(ln_part_reduce_kernel, dim3((2 * C + 31) / 32, 1), dim3(256), 0, st, part, (int)grid, 2 * C,
                        (int)grid, gparams);
@@ -441,9 +450,9 @@ extern "C" int fz_ln_bwd(const float* gl, const float* x, const float* stats, co
     const unsigned gq = (unsigned)((quads + 63) / 64);
     float* part = gparams ? (float*)workspace : nullptr;
     if (C >= 256)
-      hipLaunchKernelGGL(ln_bwd_split_kernel<16>, dim3(gq), dim3(1024), 0, st, gl, x, stats, gamma, gadd, gx, part, B, C, V);
+      hipLaunchKernelGGL((ln_bwd_split_kernel<16, AT>), dim3(gq), dim3(1024), 0, st, gl, x, stats, gamma, gadd, gx, part, B, C, V);
     else
-      hipLaunchKernelGGL(ln_bwd_split_kernel<8>, dim3(gq), dim3(512), 0, st, gl, x, stats, gamma, gadd, gx, part, B, C, V);
+      hipLaunchKernelGGL((ln_bwd_split_kernel<8, AT>), dim3(gq), dim3(512), 0, st, gl, x, stats, gamma, gadd, gx, part, B, C, V);
     FZ_LAUNCH_CHECK();
     if (gparams) {
       float* tmp = part + (int64_t)gq * 2 * C;
@@ -451,11 +460,25 @@ extern "C" int fz_ln_bwd(const float* gl, const float* x, const float* stats, co
     }
     return FZ_OK;
   } else {
-    hipLaunchKernelGGL(ln_bwd_kernel<0>, dim3(grid), dim3(256), 0, st, gl, x, stats, gamma, gadd, gx,
+    hipLaunchKernelGGL((ln_bwd_kernel<0, AT>), dim3(grid), dim3(256), 0, st, gl, x, stats, gamma, gadd, gx,
                        (float*)nullptr, B, C, V);
   }
   FZ_LAUNCH_CHECK();
   return FZ_OK;
+}
+
+extern "C" int fz_ln_bwd(const void* gl, const void* x, const float* stats, const float* gamma,
+                         const void* gadd, void* gx, float* gparams, void* workspace, int B, int C, int64_t V,
+                         int act_dtype, fz_stream_t stream) {
+  if (!gl || !x || !stats || !gamma || !gx) return fail(FZ_E_ARG, "fz_ln_bwd: null pointer");
+  if (B < 0 || C < 1 || V < 1) return fail(FZ_E_SHAPE, "fz_ln_bwd: bad sizes");
+  if (V % 4) return fail(FZ_E_UNSUPPORTED, "fz_ln_bwd: voxel count must be a multiple of 4");
+  if (gparams != nullptr && workspace == nullptr)
+    return fail(FZ_E_ARG, "fz_ln_bwd: fused affine gradients need a workspace (fz_ln_bwd_workspace_bytes2)");
+  if (B == 0) return FZ_OK;
+  if (act_dtype == FZ_STORE_F32) return ln_bwd_launch<float>(gl, x, stats, gamma, gadd, gx, gparams, workspace, B, C, V, stream);
+  if (act_dtype == FZ_STORE_BF16) return ln_bwd_launch<bf16>(gl, x, stats, gamma, gadd, gx, gparams, workspace, B, C, V, stream);
+  return fail(FZ_E_ARG, "fz_ln_bwd: bad act_dtype");
 }
 
 // Two-stage when there are many rows: `tmp` (64 x n floats, may be NULL for rows <= 512) holds the
@@ -486,12 +509,18 @@ extern "C" int fz_rowsum_chunks(int64_t V) {
   return (int)n;
 }
 
-extern "C" int fz_rowsum(const float* x, float* part, float* out, int B, int C, int64_t V, fz_stream_t stream) {
+extern "C" int fz_rowsum(const void* x, float* part, float* out, int B, int C, int64_t V, int act_dtype,
+                         fz_stream_t stream) {
   if (!x || !part || !out) return fail(FZ_E_ARG, "fz_rowsum: null pointer");
   if (B < 1 || C < 1 || V < 4 || (V % 4)) return fail(FZ_E_SHAPE, "fz_rowsum: bad sizes");
   const int nchunk = fz_rowsum_chunks(V);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(rowsum_kernel, dim3(C, nchunk, B), dim3(256), 0, st, x, part, C, V, nchunk);
+  if (act_dtype == FZ_STORE_BF16)
+    hipLaunchKernelGGL(rowsum_kernel<bf16>, dim3(C, nchunk, B), dim3(256), 0, st, (const bf16*)x, part, C, V, nchunk);
+  else if (act_dtype == FZ_STORE_F32)
+    hipLaunchKernelGGL(rowsum_kernel<float>, dim3(C, nchunk, B), dim3(256), 0, st, (const float*)x, part, C, V, nchunk);
+  else
+    return fail(FZ_E_ARG, "fz_rowsum: bad act_dtype");
   FZ_LAUNCH_CHECK();
   hipLaunchKernelGGL(ln_part_reduce_kernel, dim3((C + 31) / 32, 1), dim3(256), 0, st, part, B * nchunk, C, B * nchunk,
                      out);

@@ -4,8 +4,13 @@
 
 namespace fz {
 struct NmfArgs {
-  const float *x, *u0, *v0, *gy, *gu, *gv;
-  float *y, *uo, *vo, *gx;
+  const void *x;            // matrices: storage type of the launcher
+  const float *u0, *v0;
+  const void *gy;
+  const float *gu, *gv;
+  void *y;
+  float *uo, *vo;
+  void *gx;
   int64_t nmat;
   int M, N, T, G, solver;
   float eps;
@@ -19,6 +24,14 @@ int nmf_launch_bwd_r1(const NmfArgs&);
 int nmf_launch_bwd_r2(const NmfArgs&);
 int nmf_launch_bwd_r3(const NmfArgs&);
 int nmf_launch_bwd_r4(const NmfArgs&);
+int nmf_launch_fwd_r1_bf16(const NmfArgs&);
+int nmf_launch_fwd_r2_bf16(const NmfArgs&);
+int nmf_launch_fwd_r3_bf16(const NmfArgs&);
+int nmf_launch_fwd_r4_bf16(const NmfArgs&);
+int nmf_launch_bwd_r1_bf16(const NmfArgs&);
+int nmf_launch_bwd_r2_bf16(const NmfArgs&);
+int nmf_launch_bwd_r3_bf16(const NmfArgs&);
+int nmf_launch_bwd_r4_bf16(const NmfArgs&);
 
 static int hist_floats(int M, int N, int R, int G) {
   int MP, NPL;
@@ -51,15 +64,24 @@ extern "C" int fz_nmf_supported(int M, int N, int R, int T, int Tgrad) {
   return (f > 0 && f * 4 <= 160 * 1024) ? 1 : 0;
 }
 
-extern "C" int fz_nmf_fwd(const float* x, const float* u0, const float* v0, float* y, float* u_out,
+extern "C" int fz_nmf_fwd(const void* x, const float* u0, const float* v0, void* y, float* u_out,
                           float* v_out, int64_t nmat, int M, int N, int R, int T, int solver, float eps,
-                          fz_stream_t stream) {
+                          int act_dtype, fz_stream_t stream) {
   int rc = check_common(nmat, M, N, R, T, solver);
   if (rc != FZ_OK) return rc;
   if (!x || !u0 || !v0 || !y) return fz::fail(FZ_E_ARG, "fz_nmf_fwd: null pointer");
   if (nmat == 0) return FZ_OK;
   fz::NmfArgs a{x, u0, v0, nullptr, nullptr, nullptr, y, u_out, v_out, nullptr, nmat, M, N, T, 0, solver, eps,
                 (hipStream_t)stream};
+  if (act_dtype == FZ_STORE_BF16) {
+    switch (R) {
+      case 1: return fz::nmf_launch_fwd_r1_bf16(a);
+      case 2: return fz::nmf_launch_fwd_r2_bf16(a);
+      case 3: return fz::nmf_launch_fwd_r3_bf16(a);
+      default: return fz::nmf_launch_fwd_r4_bf16(a);
+    }
+  }
+  if (act_dtype != FZ_STORE_F32) return fz::fail(FZ_E_ARG, "fz_nmf_fwd: bad act_dtype");
   switch (R) {
     case 1: return fz::nmf_launch_fwd_r1(a);
     case 2: return fz::nmf_launch_fwd_r2(a);
@@ -68,9 +90,9 @@ extern "C" int fz_nmf_fwd(const float* x, const float* u0, const float* v0, floa
   }
 }
 
-extern "C" int fz_nmf_bwd(const float* x, const float* u0, const float* v0, const float* gy, const float* gu,
-                          const float* gv, float* gx, int64_t nmat, int M, int N, int R, int T, int Tgrad,
-                          int solver, float eps, fz_stream_t stream) {
+extern "C" int fz_nmf_bwd(const void* x, const float* u0, const float* v0, const void* gy, const float* gu,
+                          const float* gv, void* gx, int64_t nmat, int M, int N, int R, int T, int Tgrad,
+                          int solver, float eps, int act_dtype, fz_stream_t stream) {
   int rc = check_common(nmat, M, N, R, T, solver);
   if (rc != FZ_OK) return rc;
   if (!x || !u0 || !v0 || !gx || (!gy && !gu && !gv)) return fz::fail(FZ_E_ARG, "fz_nmf_bwd: null pointer");
@@ -78,6 +100,15 @@ extern "C" int fz_nmf_bwd(const float* x, const float* u0, const float* v0, cons
   int G = Tgrad < 0 ? 0 : (Tgrad > T ? T : Tgrad);
   fz::NmfArgs a{x, u0, v0, gy, gu, gv, nullptr, nullptr, nullptr, gx, nmat, M, N, T, G, solver, eps,
                 (hipStream_t)stream};
+  if (act_dtype == FZ_STORE_BF16) {
+    switch (R) {
+      case 1: return fz::nmf_launch_bwd_r1_bf16(a);
+      case 2: return fz::nmf_launch_bwd_r2_bf16(a);
+      case 3: return fz::nmf_launch_bwd_r3_bf16(a);
+      default: return fz::nmf_launch_bwd_r4_bf16(a);
+    }
+  }
+  if (act_dtype != FZ_STORE_F32) return fz::fail(FZ_E_ARG, "fz_nmf_bwd: bad act_dtype");
   switch (R) {
     case 1: return fz::nmf_launch_bwd_r1(a);
     case 2: return fz::nmf_launch_bwd_r2(a);

@@ -77,12 +77,15 @@ __device__ __forceinline__ bool cf_decode(const CfGeom& q, int64_t mat, int lane
   return true;
 }
 
-__device__ __forceinline__ void cf_load(const float* __restrict__ t, const CfAddr& a, float (&x)[8][8]) {
+// AT = storage type of the channels-first tensors t / out / ga / gt (float or bf16); the wave program
+// and the window accumulation run in fp32 either way
+template <typename AT>
+__device__ __forceinline__ void cf_load(const AT* __restrict__ t, const CfAddr& a, float (&x)[8][8]) {
 #pragma unroll
   for (int dd = 0; dd < 8; ++dd)
 #pragma unroll
     for (int jp = 0; jp < 2; ++jp) {
-      const float4 v = *reinterpret_cast<const float4*>(t + a.base + dd * a.V + a.off[jp]);
+      const float4 v = ld4(t + a.base + dd * a.V + a.off[jp]);
       x[dd][jp * 4 + 0] = v.x; x[dd][jp * 4 + 1] = v.y; x[dd][jp * 4 + 2] = v.z; x[dd][jp * 4 + 3] = v.w;
     }
 }
@@ -127,9 +130,9 @@ __device__ __forceinline__ int64_t cf_logical_block(int xcd_remap) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
 }
 
-template <int R, int SOLVER>
-__global__ __launch_bounds__(1024) void nmf_cf_fwd_kernel(const float* __restrict__ t, const float* __restrict__ u0,
-                                                          const float* __restrict__ v0, float* __restrict__ out,
+template <int R, int SOLVER, typename AT>
+__global__ __launch_bounds__(1024) void nmf_cf_fwd_kernel(const AT* __restrict__ t, const float* __restrict__ u0,
+                                                          const float* __restrict__ v0, AT* __restrict__ out,
                                                           CfGeom q, int64_t nmat, int T, float eps, int xcd_remap) {
   const int lane = threadIdx.x & 63;
   const int64_t mat = cf_logical_block(xcd_remap) * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -146,17 +149,17 @@ __global__ __launch_bounds__(1024) void nmf_cf_fwd_kernel(const float* __restric
   for (int dd = 0; dd < 8; ++dd)
 #pragma unroll
     for (int jp = 0; jp < 2; ++jp) {
-      float* p = out + a.base + dd * a.V + a.off[jp];
+      AT* p = out + a.base + dd * a.V + a.off[jp];
       float4 o;
       if (q.accumulate) {
-        o = *reinterpret_cast<const float4*>(p);
+        o = ld4(p);
         o.x += x[dd][jp * 4 + 0]; o.y += x[dd][jp * 4 + 1]; o.z += x[dd][jp * 4 + 2]; o.w += x[dd][jp * 4 + 3];
       } else {
         o = make_float4(0.0f + x[dd][jp * 4 + 0], 0.0f + x[dd][jp * 4 + 1], 0.0f + x[dd][jp * 4 + 2],
                         0.0f + x[dd][jp * 4 + 3]);
       }
       if (q.divisor > 1) o = cf_divide4(o, dv, dv_pow2);
-      *reinterpret_cast<float4*>(p) = o;
+      st4(p, o);
     }
 }
 
@@ -178,22 +181,24 @@ struct CfTile {
 // HALF (W-axis shift ≡ 2 mod 4, e.g. the production windows [None, 2, 4, 6]): a 16-byte chunk of the
 // shifted run starts 8 bytes into an aligned quad of the tensor and may straddle the cyclic wrap, so
 // it moves as two 8-byte halves with separately wrapped addresses (off2 = offset of voxels +2, +3).
-template <bool HALF>
-__device__ __forceinline__ float4 cf_ld4(const float* p, int64_t o, int64_t o2) {
+template <bool HALF, typename AT>
+__device__ __forceinline__ float4 cf_ld4(const AT* p, int64_t o, int64_t o2) {
   if (HALF) {
-    const float2 a = *reinterpret_cast<const float2*>(p + o);
-    const float2 b = *reinterpret_cast<const float2*>(p + o2);
-    return make_float4(a.x, a.y, b.x, b.y);
+    float a[2], b[2];
+    aload<2>(p + o, a);
+    aload<2>(p + o2, b);
+    return make_float4(a[0], a[1], b[0], b[1]);
   }
-  return *reinterpret_cast<const float4*>(p + o);
+  return ld4(p + o);
 }
-template <bool HALF>
-__device__ __forceinline__ void cf_st4(float* p, int64_t o, int64_t o2, float4 v) {
+template <bool HALF, typename AT>
+__device__ __forceinline__ void cf_st4(AT* p, int64_t o, int64_t o2, float4 v) {
   if (HALF) {
-    *reinterpret_cast<float2*>(p + o) = make_float2(v.x, v.y);
-    *reinterpret_cast<float2*>(p + o2) = make_float2(v.z, v.w);
+    const float a[2] = {v.x, v.y}, b[2] = {v.z, v.w};
+    astore<2>(p + o, a);
+    astore<2>(p + o2, b);
   } else {
-    *reinterpret_cast<float4*>(p + o) = v;
+    st4(p + o, v);
   }
 }
 
@@ -255,11 +260,11 @@ __device__ __forceinline__ void cf_to_owner(float* S, const int (&lidx)[2], int 
   }
 }
 
-template <int R, int SOLVER, int WPB, bool HALF = false>
-__global__ __launch_bounds__(WPB * 64, WPB == 8 ? 2 : (WPB == 4 ? 4 : (WPB == 1 ? 8 : 1))) void nmf_cf_fwd_tile_kernel(const float* __restrict__ t,
+template <int R, int SOLVER, int WPB, bool HALF, typename AT>
+__global__ __launch_bounds__(WPB * 64, WPB == 8 ? 2 : (WPB == 4 ? 4 : (WPB == 1 ? 8 : 1))) void nmf_cf_fwd_tile_kernel(const AT* __restrict__ t,
                                                                    const float* __restrict__ u0,
                                                                    const float* __restrict__ v0,
-                                                                   float* __restrict__ out, CfGeom q, int T, float eps,
+                                                                   AT* __restrict__ out, CfGeom q, int T, float eps,
                                                                    int xcd_remap) {
   using TL = CfTile<WPB>;
   extern __shared__ __attribute__((aligned(16))) float fz_lds_tile[];
@@ -325,10 +330,10 @@ __global__ __launch_bounds__(WPB * 64, WPB == 8 ? 2 : (WPB == 4 ? 4 : (WPB == 1 
 }
 
 // backward: gY = gather_w(ga) / W ; gt (+)= [t > 0] ∘ scatter_w(gX)
-template <int R, int SOLVER>
-__global__ __launch_bounds__(512, 2) void nmf_cf_bwd_kernel(const float* __restrict__ t, const float* __restrict__ u0,
+template <int R, int SOLVER, typename AT>
+__global__ __launch_bounds__(512, 2) void nmf_cf_bwd_kernel(const AT* __restrict__ t, const float* __restrict__ u0,
                                                             const float* __restrict__ v0,
-                                                            const float* __restrict__ ga, float* __restrict__ gt,
+                                                            const AT* __restrict__ ga, AT* __restrict__ gt,
                                                             CfGeom q, int64_t nmat, int T, int G, float eps,
                                                             int relu_gate, int xcd_remap) {
   extern __shared__ __attribute__((aligned(16))) float fz_lds_cf[];
@@ -349,7 +354,7 @@ __global__ __launch_bounds__(512, 2) void nmf_cf_bwd_kernel(const float* __restr
   for (int dd = 0; dd < 8; ++dd)
 #pragma unroll
     for (int jp = 0; jp < 2; ++jp) {
-      float* p = gt + a.base + dd * a.V + a.off[jp];
+      AT* p = gt + a.base + dd * a.V + a.off[jp];
       float r[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -357,19 +362,19 @@ __global__ __launch_bounds__(512, 2) void nmf_cf_bwd_kernel(const float* __restr
         r[e] = (!relu_gate || x[dd][jp * 4 + e] > 0.f) ? gv : 0.f;
       }
       if (q.accumulate) {
-        const float4 o = *reinterpret_cast<const float4*>(p);
+        const float4 o = ld4(p);
         r[0] += o.x; r[1] += o.y; r[2] += o.z; r[3] += o.w;
       }
-      *reinterpret_cast<float4*>(p) = make_float4(r[0], r[1], r[2], r[3]);
+      st4(p, make_float4(r[0], r[1], r[2], r[3]));
     }
 }
 
 // line-coalesced backward: same exchange for t and for the incoming gradient, ReLU gate applied on
 // the owner side before the exchange back, read-modify-write of gt with the coalesced map
-template <int R, int SOLVER, int WPB, bool HALF = false>
+template <int R, int SOLVER, int WPB, bool HALF, typename AT>
 __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : (WPB == 1 ? 8 : 1)) void nmf_cf_bwd_tile_kernel(
-    const float* __restrict__ t, const float* __restrict__ u0, const float* __restrict__ v0,
-    const float* __restrict__ ga, float* __restrict__ gt, CfGeom q, int T, int G, float eps, int relu_gate,
+    const AT* __restrict__ t, const float* __restrict__ u0, const float* __restrict__ v0,
+    const AT* __restrict__ ga, AT* __restrict__ gt, CfGeom q, int T, int G, float eps, int relu_gate,
     int xcd_remap) {
   using TL = CfTile<WPB>;
   extern __shared__ __attribute__((aligned(16))) float fz_lds_cf[];
@@ -468,9 +473,10 @@ extern "C" int fz_nmf_cf_supported(int C, int D, int H, int W, int d, int pd, in
   return per_wave <= 160 * 1024 ? 1 : 0;
 }
 
-extern "C" int fz_nmf_cf_fwd(const float* t, const float* u0, const float* v0, float* out, int B, int C, int D,
-                             int H, int W, const int* shift, int accumulate, int divisor, int R, int T,
-                             int solver, float eps, fz_stream_t stream) {
+template <typename AT>
+static int cf_fwd_launch(const AT* t, const float* u0, const float* v0, AT* out, int B, int C, int D,
+                         int H, int W, const int* shift, int accumulate, int divisor, int R, int T,
+                         int solver, float eps, fz_stream_t stream) {
   CfGeom q;
   int rc = cf_geom(q, B, C, D, H, W, shift, accumulate, divisor);
   if (rc != FZ_OK) return rc;
@@ -499,7 +505,7 @@ extern "C" int fz_nmf_cf_fwd(const float* t, const float* u0, const float* v0, f
     const unsigned nblk = (unsigned)(nmat / twpb);
 #define FZ_CF_TILE(RR, SS, WW, HH)                                                                          \
   do {                                                                                                      \
-    auto kern = nmf_cf_fwd_tile_kernel<RR, SS, WW, HH>;                                                     \
+    auto kern = nmf_cf_fwd_tile_kernel<RR, SS, WW, HH, AT>;                                                   \
     const int lds = CfTile<WW>::STAGE_FLOATS * (int)sizeof(float);                                          \
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(64 * WW), lds, st, t, u0, v0, out, q, T, eps, xr);            \
   } while (0)
@@ -514,16 +520,29 @@ extern "C" int fz_nmf_cf_fwd(const float* t, const float* u0, const float* v0, f
     return FZ_OK;
   }
   dim3 grid((unsigned)((nmat + wpb - 1) / wpb)), block(64 * wpb);
-#define FZ_CF_FWD(RR, SS) hipLaunchKernelGGL((nmf_cf_fwd_kernel<RR, SS>), grid, block, 0, st, t, u0, v0, out, q, nmat, T, eps, xr)
+#define FZ_CF_FWD(RR, SS) hipLaunchKernelGGL((nmf_cf_fwd_kernel<RR, SS, AT>), grid, block, 0, st, t, u0, v0, out, q, nmat, T, eps, xr)
   if (R == 1) { if (solver == FZ_SOLVER_MU) FZ_CF_FWD(1, SOLVER_MU); else FZ_CF_FWD(1, SOLVER_HALS); }
   else { if (solver == FZ_SOLVER_MU) FZ_CF_FWD(2, SOLVER_MU); else FZ_CF_FWD(2, SOLVER_HALS); }
   FZ_LAUNCH_CHECK();
   return FZ_OK;
 }
 
-extern "C" int fz_nmf_cf_bwd(const float* t, const float* u0, const float* v0, const float* ga, float* gt, int B,
-                             int C, int D, int H, int W, const int* shift, int accumulate, int nshift,
-                             int relu_gate, int R, int T, int Tgrad, int solver, float eps, fz_stream_t stream) {
+extern "C" int fz_nmf_cf_fwd(const void* t, const float* u0, const float* v0, void* out, int B, int C, int D,
+                             int H, int W, const int* shift, int accumulate, int divisor, int R, int T,
+                             int solver, float eps, int act_dtype, fz_stream_t stream) {
+  if (act_dtype == FZ_STORE_F32)
+    return cf_fwd_launch<float>((const float*)t, u0, v0, (float*)out, B, C, D, H, W, shift, accumulate, divisor, R, T,
+                                solver, eps, stream);
+  if (act_dtype == FZ_STORE_BF16)
+    return cf_fwd_launch<bf16>((const bf16*)t, u0, v0, (bf16*)out, B, C, D, H, W, shift, accumulate, divisor, R, T,
+                               solver, eps, stream);
+  return fail(FZ_E_ARG, "fz_nmf_cf_fwd: bad act_dtype");
+}
+
+template <typename AT>
+static int cf_bwd_launch(const AT* t, const float* u0, const float* v0, const AT* ga, AT* gt, int B,
+                         int C, int D, int H, int W, const int* shift, int accumulate, int nshift,
+                         int relu_gate, int R, int T, int Tgrad, int solver, float eps, fz_stream_t stream) {
   CfGeom q;
   int rc = cf_geom(q, B, C, D, H, W, shift, accumulate, 1);
   if (rc != FZ_OK) return rc;
@@ -558,7 +577,7 @@ extern "C" int fz_nmf_cf_bwd(const float* t, const float* u0, const float* v0, c
       const unsigned nblk = (unsigned)(nmat / twpb);
 #define FZ_CF_BWD_TILE(RR, SS, WW, HH)                                                                      \
   do {                                                                                                      \
-    auto kern = nmf_cf_bwd_tile_kernel<RR, SS, WW, HH>;                                                     \
+    auto kern = nmf_cf_bwd_tile_kernel<RR, SS, WW, HH, AT>;                                                    \
     if (tlds > 65536)                                                                                       \
       FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                    \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, tlds));                     \
@@ -579,7 +598,7 @@ extern "C" int fz_nmf_cf_bwd(const float* t, const float* u0, const float* v0, c
   dim3 grid((unsigned)((nmat + wpb - 1) / wpb)), block(64 * wpb);
 #define FZ_CF_BWD(RR, SS)                                                                                 \
   do {                                                                                                    \
-    auto kern = nmf_cf_bwd_kernel<RR, SS>;                                                                \
+    auto kern = nmf_cf_bwd_kernel<RR, SS, AT>;                                                          \
     if (lds > 65536)                                                                                      \
       FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                  \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));                    \
@@ -589,4 +608,17 @@ extern "C" int fz_nmf_cf_bwd(const float* t, const float* u0, const float* v0, c
   else { if (solver == FZ_SOLVER_MU) FZ_CF_BWD(2, SOLVER_MU); else FZ_CF_BWD(2, SOLVER_HALS); }
   FZ_LAUNCH_CHECK();
   return FZ_OK;
+}
+
+extern "C" int fz_nmf_cf_bwd(const void* t, const float* u0, const float* v0, const void* ga, void* gt, int B,
+                             int C, int D, int H, int W, const int* shift, int accumulate, int nshift,
+                             int relu_gate, int R, int T, int Tgrad, int solver, float eps, int act_dtype,
+                             fz_stream_t stream) {
+  if (act_dtype == FZ_STORE_F32)
+    return cf_bwd_launch<float>((const float*)t, u0, v0, (const float*)ga, (float*)gt, B, C, D, H, W, shift, accumulate,
+                                nshift, relu_gate, R, T, Tgrad, solver, eps, stream);
+  if (act_dtype == FZ_STORE_BF16)
+    return cf_bwd_launch<bf16>((const bf16*)t, u0, v0, (const bf16*)ga, (bf16*)gt, B, C, D, H, W, shift, accumulate,
+                               nshift, relu_gate, R, T, Tgrad, solver, eps, stream);
+  return fail(FZ_E_ARG, "fz_nmf_cf_bwd: bad act_dtype");
 }

@@ -1,2 +1,3 @@
 #define FZ_R 2
+#define FZ_AT float
 #include "nmf_kernels.inc"

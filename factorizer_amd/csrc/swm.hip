@@ -101,11 +101,12 @@ __global__ __launch_bounds__(256) void swm_fwd_kernel(const char* __restrict__ x
 // ------------------------------------------------------------------------------------------
 // inverse: y (all windows) -> x ;  x = (((0 + z_0) + z_1) + ...) [/ nshift]   (fp32)
 // ------------------------------------------------------------------------------------------
-template <int VE, bool GATE>
-__global__ __launch_bounds__(256) void swm_inv_kernel(const float* __restrict__ y, float* __restrict__ x,
-                                                      const float* __restrict__ gate, SwmGeom q,
+// AT: storage type (float, or bf16 with the window sum / average taken in fp32 and rounded once)
+template <int VE, bool GATE, typename AT>
+__global__ __launch_bounds__(256) void swm_inv_kernel(const AT* __restrict__ y, AT* __restrict__ x,
+                                                      const AT* __restrict__ gate, SwmGeom q,
                                                       int average) {
-  struct alignas(VE * 4) Vf { float e[VE]; };
+  struct Vf { float e[VE]; };
   // block -> (b, hh, g0, g1) of the UNSHIFTED tiling of x
   int bid = blockIdx.x;
   const int g1 = bid % q.G1; bid /= q.G1;
@@ -161,9 +162,11 @@ __global__ __launch_bounds__(256) void swm_inv_kernel(const float* __restrict__ 
         for (int w = 0; w < kMaxShifts; ++w) {
           if (w < q.nshift) {
             const int64_t yi = yrow[w] + (int64_t)dd * P;
-            Vf z = *reinterpret_cast<const Vf*>(y + yi);
+            Vf z;
+            aload<VE>(y + yi, z.e);
             if (GATE) {
-              Vf gt = *reinterpret_cast<const Vf*>(gate + yi);
+              Vf gt;
+              aload<VE>(gate + yi, gt.e);
 #pragma unroll
               for (int e = 0; e < VE; ++e) z.e[e] = gt.e[e] > 0.f ? z.e[e] : 0.f;
             }
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(256) void swm_inv_kernel(const float* __restrict__ 
           for (int e = 0; e < VE; ++e) acc.e[e] = acc.e[e] / nw;
         }
         const int64_t xi = xbase + (int64_t)dd * V3 + (int64_t)zd * HW + xoff;
-        *reinterpret_cast<Vf*>(x + xi) = acc;
+        astore<VE>(x + xi, acc.e);
       }
     }
   }
@@ -187,10 +190,10 @@ __global__ __launch_bounds__(256) void swm_inv_kernel(const float* __restrict__ 
 // nshift windows (the index math of the inverse kernel with loads and stores swapped), so the
 // HBM traffic equals the algorithmic (1 + nshift)·B·C·V·s.  fp32, 16/8/4-byte vectors.
 // ------------------------------------------------------------------------------------------
-template <int VE, bool RELU, bool DIV>
-__global__ __launch_bounds__(256) void swm_fwd_x_kernel(const float* __restrict__ x, float* __restrict__ y, SwmGeom q,
+template <int VE, bool RELU, bool DIV, typename AT>
+__global__ __launch_bounds__(256) void swm_fwd_x_kernel(const AT* __restrict__ x, AT* __restrict__ y, SwmGeom q,
                                                         float divisor) {
-  struct alignas(VE * 4) Vf { float e[VE]; };
+  struct Vf { float e[VE]; };
   int bid = blockIdx.x;
   const int g1 = bid % q.G1; bid /= q.G1;
   const int g0 = bid % q.G0; bid /= q.G0;
@@ -236,7 +239,8 @@ __global__ __launch_bounds__(256) void swm_fwd_x_kernel(const float* __restrict_
         }
       }
       for (int dd = 0; dd < q.d; ++dd) {
-        Vf v = *reinterpret_cast<const Vf*>(x + xbase + (int64_t)dd * V3 + (int64_t)zd * HW + xoff);
+        Vf v;
+        aload<VE>(x + xbase + (int64_t)dd * V3 + (int64_t)zd * HW + xoff, v.e);
         if (RELU || DIV) {
 #pragma unroll
           for (int e = 0; e < VE; ++e) {
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(256) void swm_fwd_x_kernel(const float* __restrict_
         }
 #pragma unroll
         for (int w = 0; w < kMaxShifts; ++w) {
-          if (w < q.nshift) *reinterpret_cast<Vf*>(y + yrow[w] + (int64_t)dd * P) = v;
+          if (w < q.nshift) astore<VE>(y + yrow[w] + (int64_t)dd * P, v.e);
         }
       }
     }
@@ -301,7 +305,6 @@ extern "C" int fz_swm_fwd(const void* x, void* y, int B, int C, int D, int H, in
   if (rc != FZ_OK) return rc;
   if (!x || !y) return fail(FZ_E_ARG, "fz_swm_fwd: null pointer");
   if (elem_bytes != 4 && elem_bytes != 2) return fail(FZ_E_UNSUPPORTED, "fz_swm_fwd: elem_bytes must be 4 or 2");
-  if (elem_bytes == 2 && (relu || div > 1)) return fail(FZ_E_UNSUPPORTED, "fz_swm_fwd: relu/div need fp32");
   if (B == 0) return FZ_OK;
   const int64_t nblk = (int64_t)nshift * B * q.h * q.G0 * q.G1;
   if (nblk > 0x7fffffff) return fail(FZ_E_UNSUPPORTED, "fz_swm_fwd: grid too large");
@@ -311,13 +314,31 @@ extern "C" int fz_swm_fwd(const void* x, void* y, int B, int C, int D, int H, in
   const bool R = relu != 0, Dv = div > 1;
 #define FZ_FWD(ES, VB, RR, DD) \
   hipLaunchKernelGGL((swm_fwd_kernel<ES, VB, RR, DD>), grid, block, 0, st, (const char*)x, (char*)y, q, fdiv)
+  if (elem_bytes == 2 && (R || Dv)) {
+    // 16-bit words with arithmetic asked for: they are bf16 (the mixed-precision activation type)
+    const int ve = pick_ve(q, 4);
+    const int64_t nb2 = (int64_t)B * q.h * q.G0 * q.G1;
+    dim3 grid2((unsigned)nb2);
+#define FZ_FWXB(VE, RR, DD) hipLaunchKernelGGL((swm_fwd_x_kernel<VE, RR, DD, bf16>), grid2, block, 0, st, (const bf16*)x, (bf16*)y, q, fdiv)
+#define FZ_FWXB4(VE)                                 \
+  do {                                               \
+    if (R && Dv) FZ_FWXB(VE, true, true);            \
+    else if (R) FZ_FWXB(VE, true, false);            \
+    else FZ_FWXB(VE, false, true);                   \
+  } while (0)
+    if (ve == 4) FZ_FWXB4(4);
+    else if (ve == 2) FZ_FWXB4(2);
+    else FZ_FWXB4(1);
+    FZ_LAUNCH_CHECK();
+    return FZ_OK;
+  }
   if (elem_bytes == 4) {
     const int ve = pick_ve(q, 4);
     {
       // x-centric single-read kernel (one workgroup per unshifted pencil)
       const int64_t nb2 = (int64_t)B * q.h * q.G0 * q.G1;
       dim3 grid2((unsigned)nb2);
-#define FZ_FWX(VE, RR, DD) hipLaunchKernelGGL((swm_fwd_x_kernel<VE, RR, DD>), grid2, block, 0, st, (const float*)x, (float*)y, q, fdiv)
+#define FZ_FWX(VE, RR, DD) hipLaunchKernelGGL((swm_fwd_x_kernel<VE, RR, DD, float>), grid2, block, 0, st, (const float*)x, (float*)y, q, fdiv)
 #define FZ_FWX4(VE)                                  \
   do {                                               \
     if (R && Dv) FZ_FWX(VE, true, true);             \
@@ -354,24 +375,26 @@ extern "C" int fz_swm_fwd(const void* x, void* y, int B, int C, int D, int H, in
 
 extern "C" int fz_swm_inv(const void* y, void* x, int B, int C, int D, int H, int W, int d, int pd, int ph,
                           int pw, int nshift, const int* shifts, int average, const void* gate,
-                          fz_stream_t stream) {
+                          int act_dtype, fz_stream_t stream) {
   SwmGeom q;
   int rc = make_geom(q, B, C, D, H, W, d, pd, ph, pw, nshift, shifts, "fz_swm_inv");
   if (rc != FZ_OK) return rc;
   if (!x || !y) return fail(FZ_E_ARG, "fz_swm_inv: null pointer");
+  if (act_dtype != FZ_STORE_F32 && act_dtype != FZ_STORE_BF16) return fail(FZ_E_ARG, "fz_swm_inv: bad act_dtype");
   if (B == 0) return FZ_OK;
   const int64_t nblk = (int64_t)B * q.h * q.G0 * q.G1;
   if (nblk > 0x7fffffff) return fail(FZ_E_UNSUPPORTED, "fz_swm_inv: grid too large");
   dim3 grid((unsigned)nblk), block(256);
   hipStream_t st = (hipStream_t)stream;
   const int ve = pick_ve(q, 4);
-#define FZ_INV(VE)                                                                                       \
+#define FZ_INV_T(VE, AT)                                                                                 \
   do {                                                                                                   \
-    if (gate) hipLaunchKernelGGL((swm_inv_kernel<VE, true>), grid, block, 0, st, (const float*)y,        \
-                                 (float*)x, (const float*)gate, q, average);                             \
-    else hipLaunchKernelGGL((swm_inv_kernel<VE, false>), grid, block, 0, st, (const float*)y, (float*)x, \
-                            (const float*)nullptr, q, average);                                          \
+    if (gate) hipLaunchKernelGGL((swm_inv_kernel<VE, true, AT>), grid, block, 0, st, (const AT*)y,       \
+                                 (AT*)x, (const AT*)gate, q, average);                                   \
+    else hipLaunchKernelGGL((swm_inv_kernel<VE, false, AT>), grid, block, 0, st, (const AT*)y, (AT*)x,   \
+                            (const AT*)nullptr, q, average);                                             \
   } while (0)
+#define FZ_INV(VE) do { if (act_dtype == FZ_STORE_BF16) FZ_INV_T(VE, bf16); else FZ_INV_T(VE, float); } while (0)
   if (ve == 4) FZ_INV(4);
   else if (ve == 2) FZ_INV(2);
   else FZ_INV(1);

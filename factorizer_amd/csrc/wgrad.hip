@@ -14,6 +14,8 @@
 // region (row stride 33 → conflict-free column reads), with no workgroup barriers.  Voxel
 // ranges are split over waves and workgroups; partial sums go to a workspace and a second
 // kernel reduces them in a fixed order (bitwise reproducible, no float atomics).
+#include <type_traits>
+
 #include "fz_common.h"
 
 namespace fz {
@@ -39,12 +41,14 @@ __device__ __forceinline__ void split_bf16x8(const float (&x)[8], bf16x8& hi, bf
 
 enum { QL_PLAIN = 0, QL_S2D = 1, QL_K3 = 2 };
 
-struct WgradArgs {
-  const float* p;      // (B, M, Np) output-side gradient rows
+// AT = storage type of the activation tensors p, pmul, q (float or bf16); everything else is fp32
+template <typename AT>
+struct WgradArgsT {
+  const AT* p;         // (B, M, Np) output-side gradient rows
   int M;
-  const float* pmul;   // optional: P *= act'(pmul) (same shape as p)
+  const AT* pmul;      // optional: P *= act'(pmul) (same shape as p)
   int pmul_kind;
-  const float* q[4];   // input sources
+  const AT* q[4];      // input sources
   int nsrc, src_mode, c0;
   int Cin;             // input channels
   int K;               // Q rows: Cin (plain), 8*Cin (s2d), 27*Cin (k3)
@@ -70,9 +74,11 @@ __device__ __forceinline__ float gelu_grad_w(float x) {
 }
 
 // MBP x MBQ blocks of 32x32 outputs per workgroup; 4 waves split the voxel tiles.
-// BF3: split-bf16 products (see wgrad_fast_kernel), opt-in.
-template <int MBP, int MBQ, int QL, bool BF3 = false>
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+// BF: 0 = fp32 MFMAs; 3 = split-bf16 products (see wgrad_fast_kernel), opt-in; 1 = plain bf16 MFMAs
+// (operands rounded to bf16, fp32 accumulation) — the mixed-precision mode, where P and Q are bf16 in HBM
+// anyway and only a prologue (LayerNorm / GELU) result takes one extra rounding.
+template <int MBP, int MBQ, int QL, int BF = 0, typename AT = float>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgsT<AT> a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int PR = 32 * MBP, QR = 32 * MBQ;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -116,7 +122,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     for (int i = 0; i < NP; ++i) {
       const int m = m0 + r0 + 8 * i;
       const int mc = m < a.M ? m : a.M - 1;
-      pv[i] = *reinterpret_cast<const float4*>(a.p + ((int64_t)b * a.M + mc) * a.N + nc);
+      pv[i] = ld4(a.p + ((int64_t)b * a.M + mc) * a.N + nc);
     }
     if (QL == QL_PLAIN) {
 #pragma unroll
@@ -124,14 +130,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         const int k = k0 + r0 + 8 * i;
         const int kc = k < a.K ? k : a.K - 1;
         const bool first = kc < a.c0;
-        const float* base = first ? a.q[0] : a.q[1];
+        const AT* base = first ? a.q[0] : a.q[1];
         const int cs = first ? a.c0 : a.Cin - a.c0;
         const int ci = first ? kc : kc - a.c0;
-        qv[i] = *reinterpret_cast<const float4*>(base + ((int64_t)b * cs + ci) * a.Vq + nc);
+        qv[i] = ld4(base + ((int64_t)b * cs + ci) * a.Vq + nc);
       }
-      const float* st = (a.stats ? a.stats : a.q[0]) + (a.stats ? (int64_t)b * 2 * a.Vq : 0);
-      mu4 = *reinterpret_cast<const float4*>(st + nc);
-      rs4 = *reinterpret_cast<const float4*>(st + (a.stats ? a.Vq : 0) + nc);
+      // (without statistics: a harmless read of the first floats of the partial workspace, never used)
+      const float* st = a.stats ? a.stats + (int64_t)b * 2 * a.Vq + nc : a.part;
+      mu4 = *reinterpret_cast<const float4*>(st);
+      rs4 = *reinterpret_cast<const float4*>(st + (a.stats ? a.Vq : 0));
     }
   };
 
@@ -176,7 +183,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
       for (int i = 0; i < NP; ++i) {
         const int m = m0 + r0 + 8 * i;
         const int mc = m < a.M ? m : a.M - 1;
-        const float4 e = *reinterpret_cast<const float4*>(a.pmul + ((int64_t)b * a.M + mc) * a.N + nc);
+        const float4 e = ld4(a.pmul + ((int64_t)b * a.M + mc) * a.N + nc);
         if (a.pmul_kind == 2) { pv[i].x *= gelu_grad_w(e.x); pv[i].y *= gelu_grad_w(e.y); pv[i].z *= gelu_grad_w(e.z); pv[i].w *= gelu_grad_w(e.w); }
         else { pv[i].x = e.x > 0.f ? pv[i].x : 0.f; pv[i].y = e.y > 0.f ? pv[i].y : 0.f; pv[i].z = e.z > 0.f ? pv[i].z : 0.f; pv[i].w = e.w > 0.f ? pv[i].w : 0.f; }
       }
@@ -199,7 +206,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         const int ho = (int)(t2 % a.Ho);
         const int dz = (int)(t2 / a.Ho);
         const int64_t fo = ((int64_t)(2 * dz + td) * a.H + (2 * ho + th)) * a.W + 2 * wo;
-        const float4 v = *reinterpret_cast<const float4*>(a.q[0] + ((int64_t)b * a.Cin + ci) * a.Vq + fo);
+        const float4 v = ld4(a.q[0] + ((int64_t)b * a.Cin + ci) * a.Vq + fo);
         float* d0 = Qt + (2 * rp) * kStride + 2 * cp;
         float* d1 = d0 + kStride;
         d0[0] = ok ? v.x : 0.f; d1[0] = ok ? v.y : 0.f; d0[1] = ok ? v.z : 0.f; d1[1] = ok ? v.w : 0.f;
@@ -223,13 +230,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         const int zd = dz + kd - 1, zh = hh + kh - 1, zw = w + kw - 1;
         const bool ok = nok && k < a.K && zd >= 0 && zd < a.D && zh >= 0 && zh < a.H && zw >= 0 && zw < a.W;
         const int zdc = min(max(zd, 0), a.D - 1), zhc = min(max(zh, 0), a.H - 1), zwc = min(max(zw, 0), a.W - 1);
-        const float v = a.q[0][((int64_t)b * a.Cin + ci) * a.Vq + ((int64_t)zdc * a.H + zhc) * a.W + zwc];
+        const float v = aget(a.q[0] + ((int64_t)b * a.Cin + ci) * a.Vq + ((int64_t)zdc * a.H + zhc) * a.W + zwc);
         Qt[r * kStride + col] = ok ? v : 0.f;
       }
     }
     if (t + 1 < t_end) issue_loads(t + 1);  // in flight during the MFMA loop below
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (BF3) {
+    if (BF != 0) {
       // ---- 2 K-steps of 16 voxels: lane half h, element e <-> voxel 16·t + 8·h + e ----
 #pragma unroll
       for (int t16 = 0; t16 < 2; ++t16) {
@@ -252,8 +259,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         for (int i = 0; i < MBP; ++i)
 #pragma unroll
           for (int jq = 0; jq < MBQ; ++jq) {
-            acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pm[i], qh[jq], acc[i][jq], 0, 0, 0);
-            acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph[i], qm[jq], acc[i][jq], 0, 0, 0);
+            if (BF == 3) {
+              acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pm[i], qh[jq], acc[i][jq], 0, 0, 0);
+              acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph[i], qm[jq], acc[i][jq], 0, 0, 0);
+            }
             acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph[i], qh[jq], acc[i][jq], 0, 0, 0);
           }
       }
@@ -338,8 +347,8 @@ constexpr int kStrideF = 36;
 // optimizer; the input-gradient / forward GEMMs stay on fp32 MFMAs (errors there chain through ~40 layers).
 // The k index of an MFMA operand element is (lane half, element): ANY assignment of voxels to it is
 // valid as long as both operands use the same one — half h, element e <-> voxel 16·t + 8·h + e of K-step t.
-template <int MBP, int MBQ, int QPRO, bool BF3 = false>
-__global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(WgradArgs a) {
+template <int MBP, int MBQ, int QPRO, int BF = 0, typename AT = float>
+__global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(WgradArgsT<AT> a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int PR = 32 * MBP, QR = 32 * MBQ;
   constexpr int NP = PR / 8, NQ = QR / 8;
@@ -374,17 +383,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(WgradArgs a) {
   auto issue_loads = [&](int64_t t) {
     const int b = (int)(t / tiles_per_sample);
     const int64_t n0 = (t % tiles_per_sample) * kTile;
-    const float* pb = a.p + ((int64_t)b * a.M + m0) * a.N + n0;  // uniform
+    const AT* pb = a.p + ((int64_t)b * a.M + m0) * a.N + n0;  // uniform
 #pragma unroll
-    for (int i = 0; i < NP; ++i) pv[i] = *reinterpret_cast<const float4*>(pb + (int64_t)(8 * i) * a.N + lane_p);
+    for (int i = 0; i < NP; ++i) pv[i] = ld4(pb + (int64_t)(8 * i) * a.N + lane_p);
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
       const int k = k0 + 8 * i;  // first row of this chunk group: uniform (c0 is a multiple of 8)
       const bool first = k < a.c0;
-      const float* base = first ? a.q[0] : a.q[1];
+      const AT* base = first ? a.q[0] : a.q[1];
       const int cs = first ? a.c0 : a.Cin - a.c0;
       const int ci = first ? k : k - a.c0;
-      qv[i] = *reinterpret_cast<const float4*>(base + ((int64_t)b * cs + ci) * a.Vq + n0 + lane_q);
+      qv[i] = ld4(base + ((int64_t)b * cs + ci) * a.Vq + n0 + lane_q);
     }
     if (QPRO == QP_STATS) {
       const float* st = a.stats + (int64_t)b * 2 * a.Vq + n0 + cq * 4;
@@ -418,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(WgradArgs a) {
     for (int i = 0; i < MBP; ++i)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int off = BF3 ? (16 * (e >> 1) + 8 * h + 4 * (e & 1)) : (16 * h + 4 * e);
+        const int off = BF != 0 ? (16 * (e >> 1) + 8 * h + 4 * (e & 1)) : (16 * h + 4 * e);
         const float4 v = *reinterpret_cast<const float4*>(Pt + (i * 32 + c) * kStrideF + off);
         pa[i][4 * e] = v.x; pa[i][4 * e + 1] = v.y; pa[i][4 * e + 2] = v.z; pa[i][4 * e + 3] = v.w;
       }
@@ -426,7 +435,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(WgradArgs a) {
     for (int jq = 0; jq < MBQ; ++jq)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int off = BF3 ? (16 * (e >> 1) + 8 * h + 4 * (e & 1)) : (16 * h + 4 * e);
+        const int off = BF != 0 ? (16 * (e >> 1) + 8 * h + 4 * (e & 1)) : (16 * h + 4 * e);
         const float4 v = *reinterpret_cast<const float4*>(Qt + (jq * 32 + c) * kStrideF + off);
         qb[jq][4 * e] = v.x; qb[jq][4 * e + 1] = v.y; qb[jq][4 * e + 2] = v.z; qb[jq][4 * e + 3] = v.w;
       }
@@ -439,7 +448,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(WgradArgs a) {
       for (int e = 0; e < 16; ++e) ps += pa[i][e];
       psum[i] += ps;
     }
-    if (BF3) {
+    if (BF != 0) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         bf16x8 ph[MBP], pm[MBP], qh[MBQ], qm[MBQ];
@@ -461,8 +470,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(WgradArgs a) {
         for (int i = 0; i < MBP; ++i)
 #pragma unroll
           for (int jq = 0; jq < MBQ; ++jq) {
-            acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pm[i], qh[jq], acc[i][jq], 0, 0, 0);
-            acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph[i], qm[jq], acc[i][jq], 0, 0, 0);
+            if (BF == 3) {
+              acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pm[i], qh[jq], acc[i][jq], 0, 0, 0);
+              acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph[i], qm[jq], acc[i][jq], 0, 0, 0);
+            }
             acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph[i], qh[jq], acc[i][jq], 0, 0, 0);
           }
       }
@@ -703,8 +714,8 @@ extern "C" int64_t fz_wgrad_workspace_bytes(const fz_wgrad_desc* d) {
          (int64_t)sizeof(float);
 }
 
-extern "C" int fz_wgrad(const fz_wgrad_desc* d, void* workspace, fz_stream_t stream) {
-  if (!d || !workspace) return fail(FZ_E_ARG, "fz_wgrad: null descriptor/workspace");
+template <typename AT>
+static int wgrad_launch(const fz_wgrad_desc* d, void* workspace, fz_stream_t stream) {
   if (!d->p || !d->q[0] || !d->gw) return fail(FZ_E_ARG, "fz_wgrad: null pointer");
   if (d->loader < 0 || d->loader > 2) return fail(FZ_E_ARG, "fz_wgrad: bad loader");
   if (d->N % 4 != 0) return fail(FZ_E_UNSUPPORTED, "fz_wgrad: column count must be a multiple of 4");
@@ -717,9 +728,9 @@ extern "C" int fz_wgrad(const fz_wgrad_desc* d, void* workspace, fz_stream_t str
   int tpc;
   const bool fast = use_fast(d);
   const int nchunk = pick_chunks(total_tiles, gy * gz, fast, &tpc);
-  WgradArgs a;
-  a.p = d->p; a.M = d->M; a.pmul = d->pmul; a.pmul_kind = d->pmul_kind;
-  for (int i = 0; i < 4; ++i) a.q[i] = d->q[i];
+  WgradArgsT<AT> a;
+  a.p = (const AT*)d->p; a.M = d->M; a.pmul = (const AT*)d->pmul; a.pmul_kind = d->pmul_kind;
+  for (int i = 0; i < 4; ++i) a.q[i] = (const AT*)d->q[i];
   a.nsrc = d->nsrc; a.src_mode = d->src_mode; a.c0 = d->c0 > 0 ? d->c0 : d->Cin; a.Cin = d->Cin; a.K = d->K;
   a.Vq = d->Vq; a.D = d->D; a.H = d->H; a.W = d->W; a.N = d->N; a.Ho = d->Ho; a.Wo = d->Wo;
   a.stats = d->stats; a.qact = d->qact; a.B = d->B; a.tiles_per_chunk = tpc;
@@ -728,12 +739,14 @@ extern "C" int fz_wgrad(const fz_wgrad_desc* d, void* workspace, fz_stream_t str
   dim3 grid(nchunk, gy, gz), block(256);
   const size_t lds = (size_t)4 * (PR + QR) * kStride * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
+  constexpr bool kBf16 = !std::is_same<AT, float>::value;  // bf16 activations: plain bf16 MFMAs
   int bf3g = 0;
   { const char* e = getenv("FZ_WGRAD_BF3"); if (e) bf3g = atoi(e); }
 #define FZ_WG(MBP, MBQ, QL)                                                                        \
   do {                                                                                             \
-    if (bf3g) hipLaunchKernelGGL((wgrad_kernel<MBP, MBQ, QL, true>), grid, block, lds, st, a);     \
-    else hipLaunchKernelGGL((wgrad_kernel<MBP, MBQ, QL, false>), grid, block, lds, st, a);         \
+    if (kBf16) hipLaunchKernelGGL((wgrad_kernel<MBP, MBQ, QL, 1>), grid, block, lds, st, a);       \
+    else if (bf3g) hipLaunchKernelGGL((wgrad_kernel<MBP, MBQ, QL, 3>), grid, block, lds, st, a);   \
+    else hipLaunchKernelGGL((wgrad_kernel<MBP, MBQ, QL, 0>), grid, block, lds, st, a);             \
   } while (0)
 #define FZ_WG_SHAPES(QL)                                 \
   do {                                                   \
@@ -751,8 +764,9 @@ extern "C" int fz_wgrad(const fz_wgrad_desc* d, void* workspace, fz_stream_t str
     { const char* e = getenv("FZ_WGRAD_BF3"); if (e) bf3 = atoi(e); }
 #define FZ_WGF(MBP, MBQ, QP)                                                                              \
   do {                                                                                                    \
-    if (bf3) hipLaunchKernelGGL((wgrad_fast_kernel<MBP, MBQ, QP, true>), grid, block, ldsz, st, a);       \
-    else hipLaunchKernelGGL((wgrad_fast_kernel<MBP, MBQ, QP, false>), grid, block, ldsz, st, a);          \
+    if (kBf16) hipLaunchKernelGGL((wgrad_fast_kernel<MBP, MBQ, QP, 1>), grid, block, ldsz, st, a);        \
+    else if (bf3) hipLaunchKernelGGL((wgrad_fast_kernel<MBP, MBQ, QP, 3>), grid, block, ldsz, st, a);     \
+    else hipLaunchKernelGGL((wgrad_fast_kernel<MBP, MBQ, QP, 0>), grid, block, ldsz, st, a);              \
   } while (0)
 #define FZ_WGF_SHAPES(QP)                                \
   do {                                                   \
@@ -785,6 +799,13 @@ extern "C" int fz_wgrad(const fz_wgrad_desc* d, void* workspace, fz_stream_t str
   }
   FZ_LAUNCH_CHECK();
   return FZ_OK;
+}
+
+extern "C" int fz_wgrad(const fz_wgrad_desc* d, void* workspace, fz_stream_t stream) {
+  if (!d || !workspace) return fail(FZ_E_ARG, "fz_wgrad: null descriptor/workspace");
+  if (d->act_dtype == FZ_STORE_F32) return wgrad_launch<float>(d, workspace, stream);
+  if (d->act_dtype == FZ_STORE_BF16) return wgrad_launch<bf16>(d, workspace, stream);
+  return fail(FZ_E_ARG, "fz_wgrad: act_dtype must be FZ_STORE_F32 or FZ_STORE_BF16");
 }
 
 // out[e] (+)= Σ_chunks part[chunk][e], fixed order — exposed for kernels that produce their own

@@ -104,6 +104,8 @@ def _swm_fwd_raw(x, geo: Geometry, relu=False, div=1):
         es = 4
     elif x.dtype in (torch.bfloat16, torch.float16):
         es = 2
+        if x.dtype == torch.float16 and (relu or div > 1):
+            raise TypeError("SWMatricize with fused arithmetic: float32 or bfloat16 (float16 only moves bits)")
     else:
         raise TypeError(f"SWMatricize: unsupported dtype {x.dtype}")
     with _dev_guard(x):
@@ -115,14 +117,15 @@ def _swm_fwd_raw(x, geo: Geometry, relu=False, div=1):
 
 
 def _swm_inv_raw(y, geo: Geometry, average=True, gate=None):
-    if y.dtype != torch.float32:
-        raise TypeError("SWMatricize.inverse_forward: float32 only on device")
+    ad = N.act_dtype(y)   # float32, or bfloat16 storage (window sum / average in fp32, rounded once)
+    if gate is not None and gate.dtype != y.dtype:
+        raise TypeError("SWMatricize.inverse_forward: gate and y must have the same dtype")
     B = y.shape[0] // (geo.nshift * geo.h)
     x = torch.empty((B, geo.C, *geo.spatial), dtype=y.dtype, device=y.device)
     with _dev_guard(y):
-        rc = _timed("swm_inv", (1 + geo.nshift) * x.numel() * 4, lambda: N.lib().fz_swm_inv(
+        rc = _timed("swm_inv", (1 + geo.nshift) * x.numel() * y.element_size(), lambda: N.lib().fz_swm_inv(
             y.data_ptr(), x.data_ptr(), B, geo.C, *geo.s3, geo.d, *geo.p3, geo.nshift, geo._carr,
-            int(average), N.ptr(gate), N.stream_ptr(y)))
+            int(average), N.ptr(gate), ad, N.stream_ptr(y)))
     N.check(rc, "fz_swm_inv")
     return x
 
@@ -135,7 +138,7 @@ class SWMForwardFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
-        if gy.dtype != torch.float32:
+        if gy.dtype not in (torch.float32, torch.bfloat16):   # fp16: sum the windows in fp32
             return _swm_inv_raw(gy.float().contiguous(), ctx.geo, average=False).to(gy.dtype), None
         return _swm_inv_raw(gy.contiguous(), ctx.geo, average=False), None
 
@@ -148,6 +151,8 @@ class SWMInverseFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gx):
+        if gx.dtype == torch.float16:
+            return _swm_fwd_raw(gx.float().contiguous(), ctx.geo, div=ctx.geo.nshift).to(gx.dtype), None
         return _swm_fwd_raw(gx.contiguous(), ctx.geo, div=ctx.geo.nshift), None
 
 
@@ -171,12 +176,14 @@ def _nmf_fwd_raw(x, u0, v0, T, solver, eps, want_uv=False):
     y = torch.empty_like(x)
     u = v = None
     if want_uv:
-        u = torch.empty((*x.shape[:-2], M, R), dtype=x.dtype, device=x.device)
-        v = torch.empty((*x.shape[:-2], Nn, R), dtype=x.dtype, device=x.device)
+        # the factors are fp32 whatever the storage type of x (fp32 U/V/Gram/eps)
+        u = torch.empty((*x.shape[:-2], M, R), dtype=torch.float32, device=x.device)
+        v = torch.empty((*x.shape[:-2], Nn, R), dtype=torch.float32, device=x.device)
+    ad = N.act_dtype(x)
     with _dev_guard(x):
-        rc = _timed(f"nmf_fwd_{M}x{Nn}", 2 * x.numel() * 4, lambda: N.lib().fz_nmf_fwd(
+        rc = _timed(f"nmf_fwd_{M}x{Nn}", 2 * x.numel() * x.element_size(), lambda: N.lib().fz_nmf_fwd(
             x.data_ptr(), u0.data_ptr(), v0.data_ptr(), y.data_ptr(), N.ptr(u), N.ptr(v), nmat, M, Nn, R, T,
-            N.SOLVER_ID[solver], eps, N.stream_ptr(x)))
+            N.SOLVER_ID[solver], eps, ad, N.stream_ptr(x)))
     N.check(rc, "fz_nmf_fwd")
     return y, u, v
 
@@ -186,10 +193,15 @@ def _nmf_bwd_raw(x, u0, v0, gy, gu, gv, T, G, solver, eps):
     R = u0.shape[1]
     nmat = x.numel() // (M * Nn)
     gx = torch.empty_like(x)
+    ad = N.act_dtype(x)
+    if gy is not None and gy.dtype != x.dtype:
+        gy = gy.to(x.dtype)
+    if gu is not None:
+        gu, gv = gu.float().contiguous(), gv.float().contiguous()
     with _dev_guard(x):
-        rc = _timed(f"nmf_bwd_{M}x{Nn}", 3 * x.numel() * 4, lambda: N.lib().fz_nmf_bwd(
+        rc = _timed(f"nmf_bwd_{M}x{Nn}", 3 * x.numel() * x.element_size(), lambda: N.lib().fz_nmf_bwd(
             x.data_ptr(), u0.data_ptr(), v0.data_ptr(), N.ptr(gy), N.ptr(gu), N.ptr(gv), gx.data_ptr(), nmat,
-            M, Nn, R, T, G, N.SOLVER_ID[solver], eps, N.stream_ptr(x)))
+            M, Nn, R, T, G, N.SOLVER_ID[solver], eps, ad, N.stream_ptr(x)))
     N.check(rc, "fz_nmf_bwd")
     return gx
 
@@ -267,14 +279,16 @@ class FactCoreFn(torch.autograd.Function):
         B = t.shape[0]
         out = torch.empty_like(t)
         R = u0.shape[1]
-        nb = 2 * 4 * t.numel()
+        es = t.element_size()
+        nb = 2 * es * t.numel()
+        ad = N.act_dtype(t)
         with _dev_guard(t):
             for w, s in enumerate(geo.shifts):
                 arr = (N._i * 3)(*s)
-                rc = _timed(f"nmf_cf_fwd_{geo.C}x" + "x".join(str(v) for v in geo.spatial), nb + (4 * t.numel() if w else 0), lambda: N.lib().fz_nmf_cf_fwd(
+                rc = _timed(f"nmf_cf_fwd_{geo.C}x" + "x".join(str(v) for v in geo.spatial), nb + (es * t.numel() if w else 0), lambda: N.lib().fz_nmf_cf_fwd(
                     t.data_ptr(), u0.data_ptr(), v0.data_ptr(), out.data_ptr(), B, geo.C, *geo.spatial, arr,
                     int(w > 0), geo.nshift if w == geo.nshift - 1 else 1, R, T, N.SOLVER_ID[solver], eps,
-                    N.stream_ptr(t)))
+                    ad, N.stream_ptr(t)))
                 N.check(rc, "fz_nmf_cf_fwd")
         ctx.save_for_backward(t, u0, v0)
         ctx.cfg = (geo, T, G, solver, eps, relu_gate)
@@ -287,16 +301,20 @@ class FactCoreFn(torch.autograd.Function):
         if G <= 0:
             return (torch.zeros_like(t),) + (None,) * 8
         ga = ga.contiguous()
+        if ga.dtype != t.dtype:
+            ga = ga.to(t.dtype)
         gt = torch.empty_like(t)
         B = t.shape[0]
         R = u0.shape[1]
-        nb = 3 * 4 * t.numel()
+        es = t.element_size()
+        nb = 3 * es * t.numel()
+        ad = N.act_dtype(t)
         with _dev_guard(t):
             for w, s in enumerate(geo.shifts):
                 arr = (N._i * 3)(*s)
-                rc = _timed(f"nmf_cf_bwd_{geo.C}x" + "x".join(str(v) for v in geo.spatial), nb + (4 * t.numel() if w else 0), lambda: N.lib().fz_nmf_cf_bwd(
+                rc = _timed(f"nmf_cf_bwd_{geo.C}x" + "x".join(str(v) for v in geo.spatial), nb + (es * t.numel() if w else 0), lambda: N.lib().fz_nmf_cf_bwd(
                     t.data_ptr(), u0.data_ptr(), v0.data_ptr(), ga.data_ptr(), gt.data_ptr(), B, geo.C,
                     *geo.spatial, arr, int(w > 0), geo.nshift, int(relu_gate), R, T, G, N.SOLVER_ID[solver], eps,
-                    N.stream_ptr(t)))
+                    ad, N.stream_ptr(t)))
                 N.check(rc, "fz_nmf_cf_bwd")
         return (gt,) + (None,) * 8

@@ -75,6 +75,8 @@ class PositionalEmbedding(nn.Module):
         nn.init.normal_(self.pos, std=1.0)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.dtype != self.pos.dtype and x.dtype == torch.bfloat16:
+            return x + self.pos.to(x.dtype)   # bf16 activations stay bf16 (no promotion by the fp32 parameter)
         return x + self.pos
 
 

@@ -69,7 +69,18 @@ class DiceBCEFn(torch.autograd.Function):
         return gz, None, None
 
 
+def _fp32_logits(logits, target):
+    """The loss is evaluated in fp32 whatever the storage type of the network's activations (the head of a
+    mixed-precision run emits bf16 logits: one cast of a (B, out_channels, V) tensor)."""
+    if logits.dtype in (torch.bfloat16, torch.float16):
+        logits = logits.float()
+    if target.dtype != logits.dtype:
+        target = target.to(logits.dtype)
+    return logits, target
+
+
 def dice_bce_loss(logits, target, smooth: float = 1e-5):
+    logits, target = _fp32_logits(logits, target)
     planes = logits.shape[0] * logits.shape[1]
     if logits.is_cuda and logits.numel() and logits.dtype == torch.float32 and target.dtype == torch.float32 \
             and (logits.numel() // planes) % 4 == 0:
@@ -135,8 +146,7 @@ def dice_ce_loss(logits, target, smooth: float = 1e-5):
     B, C = logits.shape[:2]
     if C == 1:
         return dice_bce_loss(logits, target, smooth)
-    if target.dtype != logits.dtype:
-        target = target.to(logits.dtype)
+    logits, target = _fp32_logits(logits, target)
     if logits.is_cuda and logits.numel() and logits.dtype == torch.float32 and 2 <= C <= 8 \
             and (logits.numel() // (B * C)) % 4 == 0:
         return DiceCEFn.apply(logits, target, smooth)

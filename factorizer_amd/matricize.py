@@ -98,7 +98,7 @@ class _WindowedMatricize(nn.Module):
             raise ValueError(f"expected (num_shifts*B*{geo.h}, {geo.G}, {geo.d}, {geo.P}), got {tuple(y.shape)}")
         if not y.numel():
             return composed.swm_inverse(y, geo)
-        if y.is_cuda and y.dtype == torch.float32:
+        if y.is_cuda and y.dtype in (torch.float32, torch.bfloat16):
             return Fn.swm_inverse(y, geo)
         if y.is_cuda:
             return Fn.swm_inverse(y.float(), geo).to(y.dtype)

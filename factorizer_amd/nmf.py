@@ -410,7 +410,11 @@ class MatrixFactorization(nn.Module):
         sid = getattr(self.solver, "native_id", None)
         if sid is None or not isinstance(self.init, RandomInit) or self.solver.factor != (0, 1):
             return None
-        if x.dtype != torch.float32 or tuple(x.shape[-2:]) != self.size:
+        # float32, or bfloat16 STORAGE: the kernels then load/store bf16 and factorise in fp32
+        # (u0 / v0 stay the fp32 buffers; SURVEY.md §5, eps at matrix_factorization.py:200,236)
+        if x.dtype not in (torch.float32, torch.bfloat16) or tuple(x.shape[-2:]) != self.size:
+            return None
+        if self.init.u0.dtype != torch.float32:
             return None
         G = min(max(self.num_grad_steps, 0), self.num_iters)
         if not Fn.nmf_supported(self.size[0], self.size[1], self.rank, self.num_iters, G):
@@ -435,8 +439,13 @@ class MatrixFactorization(nn.Module):
         if sid is not None:
             return Fn.nmf_decompose(x, self.init.u0, self.init.v0, self.num_iters,
                                     min(max(self.num_grad_steps, 0), self.num_iters), sid, self.solver.eps)
+        if x.dtype in (torch.bfloat16, torch.float16):
+            # composed path in reduced precision: factorise in fp32 (eps = 1e-16 vanishes in fp16 and the
+            # Gram matrices lose their low bits in bf16), factors are returned in fp32
+            x = x.float()
         with self.context(0):
             u, v = self.init(x)
+            u, v = u.to(x.dtype), v.to(x.dtype)
         for it in range(1, self.num_iters + 1):
             with self.context(it):
                 if self.verbose:
@@ -457,7 +466,7 @@ class MatrixFactorization(nn.Module):
             return Fn.nmf(x, self.init.u0, self.init.v0, self.num_iters,
                           min(max(self.num_grad_steps, 0), self.num_iters), sid, self.solver.eps)
         u, v = self.decompose(x)
-        return self.reconstruct(u, v)
+        return self.reconstruct(u, v).to(x.dtype)
 
 
 class NMF(MatrixFactorization):

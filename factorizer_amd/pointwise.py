@@ -56,7 +56,8 @@ def _gemm(xs, w, y, *, B, Cin, Vin, M, K, Ncol, w_t=False, ldw=None, bias=None, 
     d.y, d.Ncol, d.Ho, d.Wo, d.B = _p(y), Ncol, Ho, Wo, B
     d.loader, d.epilogue = loader, epilogue
     x0 = xs[0]
-    nbytes = 4 * (sum(t.numel() for t in xs) + y.numel() + (res.numel() if res is not None else 0))
+    d.act_dtype = N.act_dtype(x0)
+    nbytes = x0.element_size() * (sum(t.numel() for t in xs) + y.numel() + (res.numel() if res is not None else 0))
     with torch.cuda.device(x0.device):
         rc = Fn._timed(f"{name}_{Cin}->{M}", nbytes,
                        lambda: N.lib().fz_gemm(ctypes.byref(d), N.stream_ptr(x0)))
@@ -76,11 +77,12 @@ def _wgrad(p, qs, gw, *, B, M, Cin, K, Vq, Ncols, gbias=None, pmul=None, pmul_ki
     if ln is not None:
         d.ln_g, d.ln_b = _p(ln[0]), _p(ln[1])
     d.gw, d.gbias, d.accumulate, d.B, d.loader = _p(gw), _p(gbias), int(accumulate), B, loader
+    d.act_dtype = N.act_dtype(p)
     nb = N.lib().fz_wgrad_workspace_bytes(ctypes.byref(d))
     if nb < 0:
         raise N.NativeError("fz_wgrad_workspace_bytes failed")
     ws = torch.empty(max(nb // 4, 1), dtype=torch.float32, device=p.device)
-    nbytes = 4 * (p.numel() + sum(t.numel() for t in qs))
+    nbytes = p.element_size() * (p.numel() + sum(t.numel() for t in qs))
     with torch.cuda.device(p.device):
         rc = Fn._timed(f"{name}_{M}x{K}", nbytes,
                        lambda: N.lib().fz_wgrad(ctypes.byref(d), ws.data_ptr(), N.stream_ptr(p)))
@@ -94,12 +96,12 @@ def _ln_backward(gl, x, stats, ln_w, gadd=None):
     B, C = x.shape[:2]
     V = _vox(x)
     gx = torch.empty_like(x)
-    gpar = torch.empty(2 * C, dtype=x.dtype, device=x.device)
-    ws = torch.empty(max(N.lib().fz_ln_bwd_workspace_bytes2(B, C, V) // 4, 1), dtype=x.dtype, device=x.device)
+    gpar = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+    ws = torch.empty(max(N.lib().fz_ln_bwd_workspace_bytes2(B, C, V) // 4, 1), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        rc = Fn._timed(f"ln_bwd_{C}", 3 * 4 * x.numel(), lambda: N.lib().fz_ln_bwd(
+        rc = Fn._timed(f"ln_bwd_{C}", 3 * x.element_size() * x.numel(), lambda: N.lib().fz_ln_bwd(
             gl.data_ptr(), x.data_ptr(), stats.data_ptr(), ln_w.data_ptr(), _p(gadd), gx.data_ptr(), _p(gpar), _p(ws),
-            B, C, V, N.stream_ptr(x)))
+            B, C, V, N.act_dtype(x), N.stream_ptr(x)))
     N.check(rc, "fz_ln_bwd")
     return gx, gpar[:C], gpar[C:]
 
@@ -122,12 +124,13 @@ def _dgrad_lnbwd(gz, w2, x, stats, ln_w, gadd):
     d.y, d.Ncol, d.B = gx.data_ptr(), V, B
     d.loader, d.epilogue = LOAD_PLAIN, 2
     d.lnb_x, d.lnb_stats, d.lnb_g, d.lnb_gadd = x.data_ptr(), stats.data_ptr(), ln_w.data_ptr(), _p(gadd)
+    d.act_dtype = N.act_dtype(x)
     rows = N.lib().fz_gemm_lnbwd_partials(ctypes.byref(d))
-    part = torch.empty((rows, 64), dtype=x.dtype, device=x.device)
+    part = torch.empty((rows, 64), dtype=torch.float32, device=x.device)
     d.lnb_part = part.data_ptr()
-    gpar = torch.empty(64, dtype=x.dtype, device=x.device)
-    tmp = torch.empty((64, 64), dtype=x.dtype, device=x.device)
-    nbytes = 4 * (gz.numel() + 2 * x.numel() + (gadd.numel() if gadd is not None else 0))
+    gpar = torch.empty(64, dtype=torch.float32, device=x.device)
+    tmp = torch.empty((64, 64), dtype=torch.float32, device=x.device)
+    nbytes = x.element_size() * (gz.numel() + 2 * x.numel() + (gadd.numel() if gadd is not None else 0))
     with torch.cuda.device(x.device):
         rc = Fn._timed(f"dgrad_lnbwd_{Mz}->{C}", nbytes, lambda: N.lib().fz_gemm(ctypes.byref(d), N.stream_ptr(x)))
         N.check(rc, "fz_gemm")
@@ -148,15 +151,16 @@ def _mlp_fwd_chain(x1, ln_w, ln_b, eps, w12, b1, w22, b2):
     V = _vox(x1)
     Hd = w12.shape[0]
     z1 = torch.empty((B, Hd, *x1.shape[2:]), dtype=x1.dtype, device=x1.device)
-    st = torch.empty((B, 2, V), dtype=x1.dtype, device=x1.device)
+    st = torch.empty((B, 2, V), dtype=torch.float32, device=x1.device)
     x2 = torch.empty_like(x1)
     d = N.MlpDesc()
     d.mode, d.inp, d.w1, d.w2, d.b1, d.b2 = 0, x1.data_ptr(), w12.data_ptr(), w22.data_ptr(), _p(b1), _p(b2)
     d.ln_g, d.ln_b, d.ln_eps = ln_w.data_ptr(), ln_b.data_ptr(), float(eps)
     d.stats, d.z1, d.out = st.data_ptr(), z1.data_ptr(), x2.data_ptr()
     d.B, d.C, d.H, d.V = B, C, Hd, V
+    d.act_dtype = N.act_dtype(x1)
     with torch.cuda.device(x1.device):
-        rc = Fn._timed(f"mlp_chain_fwd_{C}", 4 * (2 * x1.numel() + z1.numel()),
+        rc = Fn._timed(f"mlp_chain_fwd_{C}", x1.element_size() * (2 * x1.numel() + z1.numel()),
                        lambda: N.lib().fz_mlp_chain(ctypes.byref(d), N.stream_ptr(x1)))
     N.check(rc, "fz_mlp_chain")
     return x2, z1, st
@@ -170,16 +174,17 @@ def _mlp_bwd_chain(g2, z1, w12, w22, x1, st, ln_w):
     gz1 = torch.empty_like(z1)
     gx1 = torch.empty_like(x1)
     rows = N.lib().fz_mlp_partials(B, V)
-    part = torch.empty((rows, 64), dtype=x1.dtype, device=x1.device)
-    gpar = torch.empty(64, dtype=x1.dtype, device=x1.device)
-    tmp = torch.empty((64, 64), dtype=x1.dtype, device=x1.device)
+    part = torch.empty((rows, 64), dtype=torch.float32, device=x1.device)
+    gpar = torch.empty(64, dtype=torch.float32, device=x1.device)
+    tmp = torch.empty((64, 64), dtype=torch.float32, device=x1.device)
     d = N.MlpDesc()
     d.mode, d.inp, d.w1, d.w2 = 1, g2.data_ptr(), w12.data_ptr(), w22.data_ptr()
     d.ln_g, d.stats, d.z1, d.gz1, d.x1 = ln_w.data_ptr(), st.data_ptr(), z1.data_ptr(), gz1.data_ptr(), x1.data_ptr()
     d.out, d.part = gx1.data_ptr(), part.data_ptr()
     d.B, d.C, d.H, d.V = B, C, Hd, V
+    d.act_dtype = N.act_dtype(x1)
     with torch.cuda.device(x1.device):
-        rc = Fn._timed(f"mlp_chain_bwd_{C}", 4 * (3 * x1.numel() + 2 * z1.numel()),
+        rc = Fn._timed(f"mlp_chain_bwd_{C}", x1.element_size() * (3 * x1.numel() + 2 * z1.numel()),
                        lambda: N.lib().fz_mlp_chain(ctypes.byref(d), N.stream_ptr(x1)))
         N.check(rc, "fz_mlp_chain")
         rc = N.lib().fz_reduce_rows(part.data_ptr(), rows, 64, gpar.data_ptr(), tmp.data_ptr(), N.stream_ptr(x1))
@@ -258,8 +263,20 @@ def join_wgrad_streams():
 
 
 def _native_ok(*ts):
+    """Device tensors the GEMM family takes: activations (5-D, first) fp32 or — mixed precision — bf16, all of
+    one type; parameters (<= 3-D) fp32; voxel count divisible by 4."""
     t0 = ts[0]
-    return t0.is_cuda and t0.numel() > 0 and all(t is None or (t.dtype == torch.float32) for t in ts) and _vox(t0) % 4 == 0
+    if not (t0.is_cuda and t0.numel() > 0 and t0.dtype in (torch.float32, torch.bfloat16) and _vox(t0) % 4 == 0):
+        return False
+    for t in ts[1:]:
+        if t is None:
+            continue
+        if t.dim() >= 4:
+            if t.dtype != t0.dtype:
+                return False
+        elif t.dtype != torch.float32:
+            return False
+    return True
 
 
 # ---- LayerNorm → Linear → [ReLU] -----------------------------------------------------------
@@ -272,7 +289,7 @@ class LNLinearFn(torch.autograd.Function):
         M = w.shape[0]
         w2 = w.reshape(M, C)
         y = torch.empty((B, M, *x.shape[2:]), dtype=x.dtype, device=x.device)
-        stats = torch.empty((B, 2, V), dtype=x.dtype, device=x.device)
+        stats = torch.empty((B, 2, V), dtype=torch.float32, device=x.device)
         _gemm([x], w2, y, B=B, Cin=C, Vin=V, M=M, K=C, Ncol=V, bias=b, ln=(ln_w, ln_b, eps), stats_out=stats,
               eact=ACT["relu" if act == "relu_out" else act], name="ln_linear")
         ctx.save_for_backward(x, stats, ln_w, ln_b, w2, y if act == "relu" else None)
@@ -294,7 +311,7 @@ class LNLinearFn(torch.autograd.Function):
         gx, ggamma, gbeta = _ln_backward(gl, x, stats, ln_w)
         # weight / bias grads: GW = (gy∘gate) · LN(x)ᵀ with the affine folded in the reduce step
         gw = torch.empty_like(w2)
-        gb = torch.empty(M, dtype=x.dtype, device=x.device)
+        gb = torch.empty(M, dtype=torch.float32, device=x.device)
         _wgrad(gy, [x], gw, B=B, M=M, Cin=C, K=C, Vq=V, Ncols=V, gbias=gb, pmul=gate, pmul_kind=ACT["relu"],
                stats=stats, ln=(ln_w, ln_b), name="wgrad_ln_linear")
         return gx, ggamma, gbeta, None, gw.reshape(ctx.wshape), (gb if ctx.has_bias else None), None
@@ -329,7 +346,7 @@ class ActLinearResFn(torch.autograd.Function):
         _gemm([gy], w2, gz, B=B, Cin=M, Vin=V, M=C, K=M, Ncol=V, w_t=True, ldw=C,
               emul=(z if ctx.bact != "none" else None), emul_kind=ACT[ctx.bact], name="linear_dgrad")
         gw = torch.empty_like(w2)
-        gb = torch.empty(M, dtype=z.dtype, device=z.device)
+        gb = torch.empty(M, dtype=torch.float32, device=z.device)
         _wgrad(gy, [z], gw, B=B, M=M, Cin=C, K=C, Vq=V, Ncols=V, gbias=gb, qact=ACT[ctx.bact], name="wgrad_linear")
         return gz, gw.reshape(ctx.wshape), (gb if ctx.has_bias else None), (gy if ctx.has_res else None), None
 
@@ -364,7 +381,7 @@ class CatLinearFn(torch.autograd.Function):
         _gemm([gy], w2, g1, B=B, Cin=M, Vin=V, M=C1, K=M, Ncol=V, w_t=True, ldw=C, name="linear_dgrad")
         _gemm([gy], w2[:, C1:], g2, B=B, Cin=M, Vin=V, M=C2, K=M, Ncol=V, w_t=True, ldw=C, name="linear_dgrad")
         gw = torch.empty_like(w2)
-        gb = torch.empty(M, dtype=gy.dtype, device=gy.device)
+        gb = torch.empty(M, dtype=torch.float32, device=gy.device)
         _wgrad(gy, [x1, x2], gw, B=B, M=M, Cin=C, K=C, Vq=V, Ncols=V, gbias=gb, c0=C1, name="wgrad_cat_linear")
         return g1, g2, gw.reshape(ctx.wshape), (gb if ctx.has_bias else None)
 
@@ -387,11 +404,11 @@ class LayerNormFn(torch.autograd.Function):
         B, C = x.shape[:2]
         V = _vox(x)
         y = torch.empty_like(x)
-        stats = torch.empty((B, 2, V), dtype=x.dtype, device=x.device)
+        stats = torch.empty((B, 2, V), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
-            rc = Fn._timed(f"ln_fwd_{C}", 2 * 4 * x.numel(), lambda: N.lib().fz_ln_fwd(
+            rc = Fn._timed(f"ln_fwd_{C}", 2 * x.element_size() * x.numel(), lambda: N.lib().fz_ln_fwd(
                 x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), B, C, V, eps,
-                N.stream_ptr(x)))
+                N.act_dtype(x), N.stream_ptr(x)))
         N.check(rc, "fz_ln_fwd")
         ctx.save_for_backward(x, stats, w)
         return y
@@ -440,7 +457,7 @@ class ConvK2S2Fn(torch.autograd.Function):
             _gemm([gy], w, gx, B=B, Cin=O, Vin=Vc, M=8 * C, K=O, Ncol=Vc, w_t=True, ldw=8 * C,
                   epilogue=EPI_D2S, Ho=Ho, Wo=Wo, res=g_skip, name="conv_k2s2_dgrad")
         gw = torch.empty_like(w)
-        gb = torch.empty(O, dtype=x.dtype, device=x.device)
+        gb = torch.empty(O, dtype=torch.float32, device=x.device)
         _wgrad(gy, [x], gw, B=B, M=O, Cin=C, K=8 * C, Vq=D * H * W, Ncols=Vc, gbias=gb, loader=LOAD_S2D,
                D=D, H=H, W=W, Ho=Ho, Wo=Wo, name="wgrad_conv_k2s2")
         return gx, gw, (gb if ctx.has_bias else None)
@@ -500,10 +517,11 @@ class TConvK2S2Fn(torch.autograd.Function):
         gb = None
         if ctx.has_bias:
             Vf = 8 * V
-            gb = torch.empty(O, dtype=x.dtype, device=x.device)
-            part = torch.empty(B * N.lib().fz_rowsum_chunks(Vf) * O, dtype=x.dtype, device=x.device)
+            gb = torch.empty(O, dtype=torch.float32, device=x.device)
+            part = torch.empty(B * N.lib().fz_rowsum_chunks(Vf) * O, dtype=torch.float32, device=x.device)
             with torch.cuda.device(x.device):
-                rc = N.lib().fz_rowsum(gy.data_ptr(), part.data_ptr(), gb.data_ptr(), B, O, Vf, N.stream_ptr(x))
+                rc = N.lib().fz_rowsum(gy.data_ptr(), part.data_ptr(), gb.data_ptr(), B, O, Vf, N.act_dtype(gy),
+                                       N.stream_ptr(x))
             N.check(rc, "fz_rowsum")
         return gx, gw, gb
 
@@ -521,8 +539,8 @@ class ConvK3Fn(torch.autograd.Function):
         y = torch.empty((B, O, D, H, W), dtype=x.dtype, device=x.device)
         if C * 27 * 64 * 4 <= 65536:
             with torch.cuda.device(x.device):
-                rc = Fn._timed(f"conv_k3_{C}->{O}", 4 * (x.numel() + y.numel()), lambda: N.lib().fz_conv3_fwd(
-                    x.data_ptr(), w.data_ptr(), _p(b), y.data_ptr(), B, C, O, D, H, W, N.stream_ptr(x)))
+                rc = Fn._timed(f"conv_k3_{C}->{O}", x.element_size() * (x.numel() + y.numel()), lambda: N.lib().fz_conv3_fwd(
+                    x.data_ptr(), w.data_ptr(), _p(b), y.data_ptr(), B, C, O, D, H, W, N.act_dtype(x), N.stream_ptr(x)))
             N.check(rc, "fz_conv3_fwd")
         else:
             _gemm([x], w, y, B=B, Cin=C, Vin=V, M=O, K=27 * C, Ncol=V, bias=b, loader=LOAD_K3, Di=D, Hi=H, Wi=W,
@@ -544,25 +562,25 @@ class ConvK3Fn(torch.autograd.Function):
             _warn_composed("Conv3d(k=3) input gradient", x)
             gx = torch.nn.grad.conv3d_input(x.shape, w, gy, padding=1)
         gw = torch.empty_like(w)
-        gb = torch.empty(O, dtype=x.dtype, device=x.device)
+        gb = torch.empty(O, dtype=torch.float32, device=x.device)
         if W % 32 == 0 and 27 * C <= 128:
             lib = N.lib()
             nchunk = lib.fz_conv3_wgrad_chunks(B, D, H, W)
             K = 27 * C
-            part = torch.empty(nchunk * O * K, dtype=x.dtype, device=x.device)
-            pbias = torch.empty(nchunk * O, dtype=x.dtype, device=x.device)
+            part = torch.empty(nchunk * O * K, dtype=torch.float32, device=x.device)
+            pbias = torch.empty(nchunk * O, dtype=torch.float32, device=x.device)
             with torch.cuda.device(x.device):
                 st = N.stream_ptr(x)
 
                 def run():
                     rc = lib.fz_conv3_wgrad_partials(gy.data_ptr(), x.data_ptr(), part.data_ptr(), pbias.data_ptr(),
-                                                     B, C, O, D, H, W, st)
+                                                     B, C, O, D, H, W, N.act_dtype(x), st)
                     if rc == 0:
                         rc = lib.fz_chunk_reduce(part.data_ptr(), nchunk, O * K, gw.data_ptr(), 0, st)
                     if rc == 0:
                         rc = lib.fz_chunk_reduce(pbias.data_ptr(), nchunk, O, gb.data_ptr(), 0, st)
                     return rc
-                rc = Fn._timed(f"wgrad_conv_k3_{O}x{K}", 4 * (x.numel() + gy.numel()), run)
+                rc = Fn._timed(f"wgrad_conv_k3_{O}x{K}", x.element_size() * (x.numel() + gy.numel()), run)
             N.check(rc, "fz_conv3_wgrad")
         else:
             _wgrad(gy, [x], gw, B=B, M=O, Cin=C, K=27 * C, Vq=V, Ncols=V, gbias=gb, loader=LOAD_K3, D=D, H=H, W=W,
@@ -659,7 +677,7 @@ class FactorizerBlockFn(torch.autograd.Function):
         new = lambda ch: torch.empty((B, ch, *sp), dtype=x.dtype, device=x.device)  # noqa: E731
         # 1. t = relu(in_proj(LN1(x)))
         t = new(C)
-        st1 = torch.empty((B, 2, V), dtype=x.dtype, device=x.device)
+        st1 = torch.empty((B, 2, V), dtype=torch.float32, device=x.device)
         _gemm([x], win2, t, B=B, Cin=C, Vin=V, M=C, K=C, Ncol=V, ln=(n1w, n1b, cfg["eps1"]), stats_out=st1,
               eact=ACT["relu"], name="ln_linear")
         # 2. a = inverse(NMF(matricize(t)))
@@ -679,7 +697,7 @@ class FactorizerBlockFn(torch.autograd.Function):
             x2, z1, st2 = _mlp_fwd_chain(x1, n2w, n2b, cfg["eps2"], w12, b1, w22, b2)
         else:
             z1 = new(Hd)
-            st2 = torch.empty((B, 2, V), dtype=x.dtype, device=x.device)
+            st2 = torch.empty((B, 2, V), dtype=torch.float32, device=x.device)
             _gemm([x1], w12, z1, B=B, Cin=C, Vin=V, M=Hd, K=C, Ncol=V, bias=b1, ln=(n2w, n2b, cfg["eps2"]),
                   stats_out=st2, name="ln_linear")
             x2 = new(C)
@@ -722,12 +740,12 @@ class FactorizerBlockFn(torch.autograd.Function):
             _gemm([g2], w22, gz1, B=B, Cin=C, Vin=V, M=Hd, K=C, Ncol=V, w_t=True, ldw=Hd, emul=z1,
                   emul_kind=ACT["gelu"], name="linear_dgrad")
         gw2 = torch.empty_like(w22)
-        gb2 = torch.empty(C, dtype=dt, device=dev)
+        gb2 = torch.empty(C, dtype=torch.float32, device=dev)
         wgrad(g2, [z1], gw2, B=B, M=C, Cin=Hd, K=Hd, Vq=V, Ncols=V, gbias=gb2, qact=ACT["gelu"], name="wgrad_linear")
         if not chain:
             gx1, gg2, gbt2 = _dgrad_lnbwd(gz1, w12, x1, st2, n2w, g2)      # + residual path of the MLP
         gw1 = torch.empty_like(w12)
-        gb1 = torch.empty(Hd, dtype=dt, device=dev)
+        gb1 = torch.empty(Hd, dtype=torch.float32, device=dev)
         wgrad(gz1, [x1], gw1, B=B, M=Hd, Cin=C, K=C, Vq=V, Ncols=V, gbias=gb1, stats=st2, ln=(n2w, n2b),
                name="wgrad_ln_linear")
         del gz1
@@ -735,7 +753,7 @@ class FactorizerBlockFn(torch.autograd.Function):
         ga = torch.empty_like(a)
         _gemm([gx1], wout2, ga, B=B, Cin=C, Vin=V, M=C, K=C, Ncol=V, w_t=True, ldw=C, name="linear_dgrad")
         gwo = torch.empty_like(wout2)
-        gbo = torch.empty(C, dtype=dt, device=dev)
+        gbo = torch.empty(C, dtype=torch.float32, device=dev)
         wgrad(gx1, [a], gwo, B=B, M=C, Cin=C, K=C, Vq=V, Ncols=V, gbias=gbo, name="wgrad_linear")
         # --- core (gradient arrives gated by [t > 0]) ---
         if G <= 0:

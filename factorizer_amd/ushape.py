@@ -204,8 +204,26 @@ class UNet(nn.Module):
             self.num_deep_supr = 3 if num_deep_supr is True else num_deep_supr
             self.heads = nn.ModuleList(make_head(encoder_width[j], out_channels) for j in range(num_deep_supr))
 
+    @staticmethod
+    def _mixed_precision_input(x):
+        """Mixed precision (BASELINE configs[4]): under ``torch.autocast("cuda", dtype=torch.bfloat16)`` — or when
+        handed a bfloat16 input — every activation of the network is STORED as bf16 while parameters,
+        statistics, accumulation and the whole NMF iteration stay fp32 (include/factorizer_hip.h,
+        FZ_STORE_BF16).  float16 is refused: eps = 1e-16 of the NMF ratios underflows in it and all-zero
+        patches turn into NaN (matrix_factorization.py:200,236)."""
+        if x.is_cuda and torch.is_autocast_enabled():
+            dt = torch.get_autocast_gpu_dtype()
+            if dt == torch.float16:
+                raise RuntimeError("Factorizer under float16 autocast: the NMF eps (1e-16) underflows in fp16; "
+                                   "use torch.autocast('cuda', dtype=torch.bfloat16)")
+            if dt == torch.bfloat16 and x.dtype == torch.float32:
+                x = x.to(torch.bfloat16)
+        if x.dtype == torch.float16:
+            raise RuntimeError("Factorizer on a float16 input: use bfloat16 (or float32) activations")
+        return x
+
     def forward_features(self, x):
-        return self.decoder(self.encoder(self.stem(x)))
+        return self.decoder(self.encoder(self.stem(self._mixed_precision_input(x))))
 
     def forward(self, x):
         feats = self.forward_features(x)

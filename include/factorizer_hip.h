@@ -28,6 +28,15 @@ extern "C" {
 #define FZ_E_HIP (-3)         /* a HIP runtime call failed                      */
 #define FZ_E_ARG (-4)         /* null pointer / bad enum                        */
 
+/* Storage type of ACTIVATION tensors (inputs, outputs, their gradients, saved pre-activations).
+ * FZ_STORE_BF16 is the mixed-precision mode of BASELINE configs[4]: activations live in HBM as bf16,
+ * every kernel converts to fp32 on load and rounds to nearest-even on store; parameters, LayerNorm
+ * statistics, weight gradients and all arithmetic — MFMA accumulation, the NMF factors / Gram
+ * matrices / eps (matrix_factorization.py:200,236) — stay fp32.  Pointers documented as "activation"
+ * below are `void*`: float* or (bf16) uint16_t* according to the call's act_dtype. */
+#define FZ_STORE_F32 0
+#define FZ_STORE_BF16 1
+
 #define FZ_SOLVER_MU 0   /* matrix_factorization.py:232-247 MultiplicativeUpdate        */
 #define FZ_SOLVER_HALS 1 /* matrix_factorization.py:194-229 CoordinateDescent + ReLU    */
 
@@ -47,36 +56,39 @@ int64_t fz_launch_count(void);
  *   x: (B, C, D, H, W)   y: (nshift*B*(C/d), G, d, P),  G=(D/pd)(H/ph)(W/pw), P=pd*ph*pw
  *   y[w*B*h + b*h + hh, g, dd, p] = x[b, hh*d+dd, (g_i*p_i + p_i - s_w,i) mod S_i] * (1/div)
  *   shifts: HOST pointer, nshift*3 ints (0 for an unshifted window).
- *   elem_bytes: 4 (fp32) or 2 (bf16/fp16, moved as opaque 16-bit words; relu/div must be 0/1).
- *   relu: if nonzero apply max(.,0) while moving (fp32 only) — FactMixer.act, factorizer.py:44.
- *   div: if >1 divide by it (fp32 only) — used as the backward of fz_swm_inv.
+ *   elem_bytes: 4 (fp32) or 2 (16-bit words: moved as opaque bits — bf16 or fp16 alike — unless relu/div
+ *               ask for arithmetic, in which case they are taken to be bf16).
+ *   relu: if nonzero apply max(.,0) while moving — FactMixer.act, factorizer.py:44.
+ *   div: if >1 divide by it — used as the backward of fz_swm_inv.
  */
 int fz_swm_fwd(const void* x, void* y, int B, int C, int D, int H, int W, int d, int pd,
                int ph, int pw, int nshift, const int* shifts, int elem_bytes, int relu,
                int div, fz_stream_t stream);
 
 /* Replaces SWMatricize.inverse_forward (operations.py:274-280, 423-434):
- *   x = (((0.0 + z_0) + z_1) + ...) / nshift, z_w = inverse window of chunk w of y (fp32).
+ *   x = (((0.0 + z_0) + z_1) + ...) / nshift, z_w = inverse window of chunk w of y (fp32; with
+ *   act_dtype FZ_STORE_BF16 the sum and the division are fp32 and the result is rounded once).
  *   average: 1 → divide by nshift (the module's forward); 0 → plain sum (backward of fwd).
  *   gate: optional (may be NULL) tensor shaped like y; when given, element e of y counts
  *         only where gate[e] > 0 (fused ReLU backward for the relu=1 forward).
  */
 int fz_swm_inv(const void* y, void* x, int B, int C, int D, int H, int W, int d, int pd,
                int ph, int pw, int nshift, const int* shifts, int average, const void* gate,
-               fz_stream_t stream);
+               int act_dtype, fz_stream_t stream);
 
 /* ---- batched NMF ---------------------------------------------------------------------
  * Replaces MatrixFactorization.forward = decompose (init → T × [update U, update V]) then
  * reconstruct u @ v.mT (matrix_factorization.py:514-546) for solver "mu" (:241-247) or
  * "hals" (:210-229), RandomInit broadcast buffers u0 (M,R), v0 (N,R) (:52-58).
- *   x, y: (nmat, M, N) fp32;  u_out (nmat,M,R) / v_out (nmat,N,R) optional (NULL to skip).
+ *   x, y: (nmat, M, N) activations (act_dtype: fp32, or bf16 storage with the whole factorisation —
+ *   u, v, Gram matrices, eps — in fp32);  u_out (nmat,M,R) / v_out (nmat,N,R) fp32, optional (NULL to skip).
  * Supported natively: M <= 32, N <= 64*floor(64/Mpad) (8x512, 16x256, 32x128 families),
  * 1 <= R <= 4; anything else returns FZ_E_UNSUPPORTED (the Python layer then uses its
  * composed path).
  */
-int fz_nmf_fwd(const float* x, const float* u0, const float* v0, float* y, float* u_out,
+int fz_nmf_fwd(const void* x, const float* u0, const float* v0, void* y, float* u_out,
                float* v_out, int64_t nmat, int M, int N, int R, int T, int solver, float eps,
-               fz_stream_t stream);
+               int act_dtype, fz_stream_t stream);
 
 /* Backward of fz_nmf_fwd w.r.t. x (what autograd does through the unrolled iterations,
  * matrix_factorization.py:522-533; formulas: SURVEY.md Appendix A).  The forward is
@@ -85,9 +97,9 @@ int fz_nmf_fwd(const float* x, const float* u0, const float* v0, float* y, float
  *   gy: (nmat,M,N) grad of y, may be NULL if gu/gv given;  gu (nmat,M,R), gv (nmat,N,R):
  *   optional grads of the decompose() outputs (NULL to skip);  gx: (nmat,M,N) out.
  */
-int fz_nmf_bwd(const float* x, const float* u0, const float* v0, const float* gy,
-               const float* gu, const float* gv, float* gx, int64_t nmat, int M, int N, int R,
-               int T, int Tgrad, int solver, float eps, fz_stream_t stream);
+int fz_nmf_bwd(const void* x, const float* u0, const float* v0, const void* gy,
+               const float* gu, const float* gv, void* gx, int64_t nmat, int M, int N, int R,
+               int T, int Tgrad, int solver, float eps, int act_dtype, fz_stream_t stream);
 
 /* 1 if (M,N,R,T,Tgrad) is covered by the native kernels (fwd and bwd), else 0. */
 int fz_nmf_supported(int M, int N, int R, int T, int Tgrad);
@@ -101,15 +113,18 @@ int fz_nmf_supported(int M, int N, int R, int T, int Tgrad);
  *        window (1 otherwise).
  *   bwd: gt (+)= [t > 0 if relu_gate] * scatter_w(dNMF(gather_w(t); gather_w(ga) / nshift));
  *        call once per window with accumulate = (w > 0).
- * t, out, ga, gt: (B, C, D, H, W) fp32; shift: HOST pointer to 3 ints (W-axis shift % 4 == 0).
+ * t, out, ga, gt: (B, C, D, H, W) activations (act_dtype: fp32, or bf16 storage — the running window sum is
+ * then rounded to bf16 between windows, the factorisation itself stays fp32); shift: HOST pointer to 3 ints
+ * (W-axis shift even).
  */
 int fz_nmf_cf_supported(int C, int D, int H, int W, int d, int pd, int ph, int pw, int R, int T, int Tgrad);
-int fz_nmf_cf_fwd(const float* t, const float* u0, const float* v0, float* out, int B, int C, int D,
+int fz_nmf_cf_fwd(const void* t, const float* u0, const float* v0, void* out, int B, int C, int D,
                   int H, int W, const int* shift, int accumulate, int divisor, int R, int T,
-                  int solver, float eps, fz_stream_t stream);
-int fz_nmf_cf_bwd(const float* t, const float* u0, const float* v0, const float* ga, float* gt, int B,
+                  int solver, float eps, int act_dtype, fz_stream_t stream);
+int fz_nmf_cf_bwd(const void* t, const float* u0, const float* v0, const void* ga, void* gt, int B,
                   int C, int D, int H, int W, const int* shift, int accumulate, int nshift,
-                  int relu_gate, int R, int T, int Tgrad, int solver, float eps, fz_stream_t stream);
+                  int relu_gate, int R, int T, int Tgrad, int solver, float eps, int act_dtype,
+                  fz_stream_t stream);
 
 /* ---- channels-first GEMM family (1x1 layers, k2s2 conv / transposed conv, input grads) ----
  * Out[m, n] = epilogue( sum_k A[m,k] * prologue(In)[k,n] ), n = voxel.  One descriptor drives
@@ -135,7 +150,7 @@ int fz_nmf_cf_bwd(const float* t, const float* u0, const float* v0, const float*
 #define FZ_ACT_GELU 2 /* exact erf GELU, layers/mlp.py:56 */
 
 typedef struct fz_gemm_desc {
-  const float* x[4];   /* input source tensors (B, C_i, Vin)                                   */
+  const void* x[4];    /* activation: input source tensors (B, C_i, Vin)                                */
   int nsrc;            /* number of sources                                                    */
   int src_mode;        /* 0: channel concat of x[0] (c0 ch) and x[1]; 1: average of nsrc sources */
   int c0;              /* channels of x[0] in concat mode (0 = all)                            */
@@ -152,14 +167,14 @@ typedef struct fz_gemm_desc {
   float ln_eps;
   float* stats_out;    /* (B, 2, Vin): mean, rstd of the LN prologue, or NULL                  */
   int bact;            /* activation applied to the input operand                              */
-  const float* bmul;   /* input operand *= act'(bmul) (same shape as the input) or NULL        */
+  const void* bmul;    /* activation: input operand *= act'(bmul) (same shape as the input) or NULL        */
   int bmul_kind;
   int eact;            /* activation applied to the result                                     */
-  const float* res;    /* residual added to the result (same shape as y; with FZ_EPI_D2S: the fine-
+  const void* res;     /* activation: residual added to the result (same shape as y; with FZ_EPI_D2S: the fine-
                           resolution tensor, e.g. the skip-connection gradient) or NULL            */
-  const float* emul;   /* result *= act'(emul) (same shape as y) or NULL                       */
+  const void* emul;    /* activation: result *= act'(emul) (same shape as y) or NULL                       */
   int emul_kind;
-  float* y;
+  void* y;             /* activation */
   int64_t Ncol;        /* columns per sample: Vin (plain) or coarse voxel count (s2d)          */
   int Ho, Wo;          /* coarse H, W (s2d columns / d2s input grid)                           */
   int B;
@@ -167,11 +182,12 @@ typedef struct fz_gemm_desc {
   /* FZ_EPI_LNBWD: LayerNorm input x (B,32,V), saved stats (B,2,V), gamma (32), optional gradient
    * added to the result, and a partial buffer of fz_gemm_lnbwd_partials(desc) x 64 floats that
    * receives per-workgroup (dgamma | dbeta) sums (reduce over rows in order). */
-  const float* lnb_x;
+  const void* lnb_x;      /* activation */
   const float* lnb_stats;
   const float* lnb_g;
-  const float* lnb_gadd;
+  const void* lnb_gadd;   /* activation */
   float* lnb_part;
+  int act_dtype;          /* FZ_STORE_F32 / FZ_STORE_BF16: element type of every "activation" pointer */
 } fz_gemm_desc;
 
 /* number of 64-float partial rows fz_gemm writes to lnb_part for this descriptor */
@@ -193,7 +209,7 @@ int fz_gemm(const fz_gemm_desc* desc, fz_stream_t stream);
  */
 typedef struct fz_mlp_desc {
   int mode;
-  const float* in;    /* mode 0: x1 (B, C, V) ; mode 1: g2 = dL/d(out of the block) (B, C, V)  */
+  const void* in;     /* activation; mode 0: x1 (B, C, V) ; mode 1: g2 = dL/d(out of the block) (B, C, V)  */
   const float* w1;    /* (H, C)                                                              */
   const float* w2;    /* (C, H)                                                              */
   const float* b1;    /* (H) or NULL, mode 0                                                 */
@@ -202,13 +218,14 @@ typedef struct fz_mlp_desc {
   const float* ln_b;  /* (C), mode 0                                                         */
   float ln_eps;
   float* stats;       /* (B, 2, V): written in mode 0, read in mode 1                        */
-  float* z1;          /* (B, H, V): written in mode 0, read in mode 1                        */
-  float* gz1;         /* (B, H, V): written in mode 1                                        */
-  const float* x1;    /* (B, C, V): the LayerNorm input, mode 1                              */
-  float* out;         /* (B, C, V)                                                           */
+  void* z1;           /* activation (B, H, V): written in mode 0, read in mode 1                        */
+  void* gz1;          /* activation (B, H, V): written in mode 1                                        */
+  const void* x1;     /* activation (B, C, V): the LayerNorm input, mode 1                              */
+  void* out;          /* activation (B, C, V)                                                */
   float* part;        /* mode 1: fz_mlp_partials(B, V) x 64 floats                           */
   int B, C, H;
   int64_t V;
+  int act_dtype;      /* FZ_STORE_F32 / FZ_STORE_BF16                                        */
 } fz_mlp_desc;
 
 int fz_mlp_supported(int C, int H, int64_t V);
@@ -226,11 +243,11 @@ int fz_mlp_chain(const fz_mlp_desc* desc, fz_stream_t stream);
 #define FZ_QL_K3 2    /* Q[(c,kd,kh,kw)][n] = in[b,c,d+kd-1,h+kh-1,w+kw-1] (zero pad) */
 
 typedef struct fz_wgrad_desc {
-  const float* p;     /* (B, M, N) output-side gradient                                      */
+  const void* p;      /* activation (B, M, N) output-side gradient                                    */
   int M;
-  const float* pmul;  /* optional: P *= act'(pmul)                                           */
+  const void* pmul;   /* activation, optional: P *= act'(pmul)                                      */
   int pmul_kind;      /* FZ_ACT_RELU / FZ_ACT_GELU                                           */
-  const float* q[4];  /* input sources                                                       */
+  const void* q[4];   /* activation: input sources                                                 */
   int nsrc, src_mode, c0;
   int Cin;            /* input channels                                                      */
   int K;              /* Q rows: Cin / 8*Cin / 27*Cin                                        */
@@ -247,6 +264,7 @@ typedef struct fz_wgrad_desc {
   int accumulate;     /* add into gw/gbias instead of overwriting                            */
   int B;
   int loader;
+  int act_dtype;      /* FZ_STORE_F32 / FZ_STORE_BF16; with bf16 the products run on bf16 MFMAs (fp32 accumulation) */
 } fz_wgrad_desc;
 
 int64_t fz_wgrad_workspace_bytes(const fz_wgrad_desc* desc);
@@ -257,32 +275,33 @@ int fz_wgrad(const fz_wgrad_desc* desc, void* workspace, fz_stream_t stream);
  * bwd: gx = rstd*(gl*gamma - mean_c(gl*gamma) - n*mean_c(gl*gamma*n)) [+ gadd]; the parameter
  * gradients come from the same pass (C <= 64) or from fz_wgrad (diag of P=gl, Q=normalised x).
  */
-int fz_ln_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats, int B,
-              int C, int64_t V, float eps, fz_stream_t stream);
+int fz_ln_fwd(const void* x /* activation */, const float* gamma, const float* beta, void* y /* activation */,
+              float* stats, int B, int C, int64_t V, float eps, int act_dtype, fz_stream_t stream);
 /* gparams (optional): [gamma grad (C) | beta grad (C)] computed in the same pass; needs a
  * workspace of fz_ln_bwd_workspace_bytes2(B, C, V). */
 int64_t fz_ln_bwd_workspace_bytes(int C);                        /* C <= 64 */
 int64_t fz_ln_bwd_workspace_bytes2(int B, int C, int64_t V);     /* any C   */
-int fz_ln_bwd(const float* gl, const float* x, const float* stats, const float* gamma,
-              const float* gadd, float* gx, float* gparams, void* workspace, int B, int C, int64_t V,
-              fz_stream_t stream);
+int fz_ln_bwd(const void* gl, const void* x, const float* stats, const float* gamma,
+              const void* gadd, void* gx /* gl, x, gadd, gx: activations */, float* gparams, void* workspace,
+              int B, int C, int64_t V, int act_dtype, fz_stream_t stream);
 
 /* ---- stem: Conv3d(kernel 3, padding 1) (factorizer/factorizer.py:145-149 → unet.py:231,261) ----
  * fwd: y = conv3d(x, w) [+ bias]; needs even C_in, W % 4 == 0.
  * wgrad: per-workgroup partial sums part[nchunk][M][27*C_in], part_bias[nchunk][M]
  * (nchunk = fz_conv3_wgrad_chunks), reduced in a fixed order by fz_chunk_reduce; needs
  * W % 32 == 0 and 27*C_in <= 128. */
-int fz_conv3_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int M, int D,
-                 int H, int W, fz_stream_t stream);
+int fz_conv3_fwd(const void* x /* activation */, const float* w, const float* bias, void* y /* activation */,
+                 int B, int Cin, int M, int D, int H, int W, int act_dtype, fz_stream_t stream);
 int fz_conv3_wgrad_chunks(int B, int D, int H, int W);
-int fz_conv3_wgrad_partials(const float* gy, const float* x, float* part, float* part_bias, int B, int Cin,
-                            int M, int D, int H, int W, fz_stream_t stream);
+int fz_conv3_wgrad_partials(const void* gy, const void* x /* activations */, float* part, float* part_bias, int B,
+                            int Cin, int M, int D, int H, int W, int act_dtype, fz_stream_t stream);
 int fz_chunk_reduce(const float* part, int nchunk, int64_t n, float* out, int accumulate, fz_stream_t stream);
 
 /* out[c] = sum over batch and voxels of x[b,c,v] (bias gradient of ConvTranspose3d, unet.py:123);
  * part: workspace of B * fz_rowsum_chunks(V) * C floats. */
 int fz_rowsum_chunks(int64_t V);
-int fz_rowsum(const float* x, float* part, float* out, int B, int C, int64_t V, fz_stream_t stream);
+int fz_rowsum(const void* x /* activation */, float* part, float* out, int B, int C, int64_t V, int act_dtype,
+              fz_stream_t stream);
 
 /* ---- fused soft-Dice + BCE-with-logits loss (training step; the form of the bundle's
  * DiceCELoss(sigmoid=True, squared_pred=True), model_zoo/factorizer_brats23/configs/train.yaml:67-70).

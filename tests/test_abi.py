@@ -50,8 +50,17 @@ def test_host_side_argument_checks(built_lib):
     assert lib.fz_nmf_supported(8, 512, 2, 10, 10) == 1
     assert lib.fz_nmf_supported(16, 262144, 1, 5, 5) == 0
     assert lib.fz_nmf_supported(8, 512, 5, 5, 5) == 0
-    rc = lib.fz_nmf_fwd(None, None, None, None, None, None, 4, 8, 512, 9, 5, 1, 1e-16, None)
+    rc = lib.fz_nmf_fwd(None, None, None, None, None, None, 4, 8, 512, 9, 5, 1, 1e-16, 0, None)
     assert rc == -2
+    # storage type of the activations (FZ_STORE_F32 / FZ_STORE_BF16): anything else is refused by the host code
+    d = _native.GemmDesc()
+    d.act_dtype = 7
+    assert lib.fz_gemm(ctypes.byref(d), None) == -4 and b"act_dtype" in lib.fz_last_error_string()
+    w = _native.WgradDesc()
+    w.act_dtype = 7
+    assert lib.fz_wgrad(ctypes.byref(w), ctypes.c_void_p(8), None) == -4
+    rc = lib.fz_swm_inv(ctypes.c_void_p(8), ctypes.c_void_p(8), 1, 8, 8, 8, 8, 8, 8, 8, 8, 1, sh, 1, None, 5, None)
+    assert rc == -4 and b"act_dtype" in lib.fz_last_error_string()
 
 
 def test_missing_library_fails_loudly(monkeypatch):
