@@ -212,7 +212,7 @@ class UNet(nn.Module):
         FZ_STORE_BF16).  float16 is refused: eps = 1e-16 of the NMF ratios underflows in it and all-zero
         patches turn into NaN (matrix_factorization.py:200,236)."""
         if x.is_cuda and torch.is_autocast_enabled():
-            dt = torch.get_autocast_gpu_dtype()
+            dt = torch.get_autocast_dtype("cuda")
             if dt == torch.float16:
                 raise RuntimeError("Factorizer under float16 autocast: the NMF eps (1e-16) underflows in fp16; "
                                    "use torch.autocast('cuda', dtype=torch.bfloat16)")

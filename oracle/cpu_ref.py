@@ -399,6 +399,42 @@ def factorizer_block(x, sd, prefix, cfg):
     return x
 
 
+class _StoreBF16(torch.autograd.Function):
+    """A tensor kept in HBM as bf16: rounded (nearest-even) on the way forward, its gradient rounded on the
+    way back — the storage points of the mixed-precision device path (FZ_STORE_BF16)."""
+
+    @staticmethod
+    def forward(ctx, t):
+        return t.to(torch.bfloat16).to(t.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+def factorizer_block_bf16_storage(x, sd, prefix, cfg):
+    """`factorizer_block` in fp32 arithmetic with every tensor the device path stores between kernels rounded
+    to bf16 (t, the matricized tensor and its gradient, the NMF output, the window average a, x1, z1, x2):
+    the reference for the mixed-precision mode of BASELINE configs[4].  It separates what bf16 STORAGE does
+    to the result (this function vs `factorizer_block`: conditioning of the block, large for T = 10 HALS
+    iterations) from what the kernels do (device vs this function)."""
+    q = _StoreBF16.apply
+    f = prefix + "fact."
+    B, C = x.shape[:2]
+    spatial = tuple(x.shape[2:])
+    y = layernorm_cf(x, sd[prefix + "norm1.norm.weight"], sd[prefix + "norm1.norm.bias"])
+    t = q(torch.relu(linear_cf(y, sd[f + "in_proj.linear.weight"])))
+    m = q(swm_forward(t, **cfg["reshape"]))
+    m = q(nmf_forward(m, sd[f + "factorize.init.u0"], sd[f + "factorize.init.v0"], cfg.get("num_iters", 5),
+                      cfg.get("solver", "hals"), cfg.get("num_grad_steps")))
+    a = q(swm_inverse(m, C, spatial, **cfg["reshape"]))
+    x1 = q(x + linear_cf(a, sd[f + "out_proj.linear.weight"], sd[f + "out_proj.linear.bias"]))
+    y = layernorm_cf(x1, sd[prefix + "norm2.norm.weight"], sd[prefix + "norm2.norm.bias"])
+    z1 = q(linear_cf(y, sd[prefix + "mlp.block.0.linear.weight"], sd[prefix + "mlp.block.0.linear.bias"]))
+    return q(x1 + linear_cf(F.gelu(z1), sd[prefix + "mlp.block.3.linear.weight"],
+                            sd[prefix + "mlp.block.3.linear.bias"]))
+
+
 def factorizer_stage(x, sd, prefix, cfg, depth=1):
     """FactorizerStage.forward (factorizer.py:114-122); pos_drop is identity (eval / p=0)."""
     if prefix + "adapter.linear.weight" in sd:

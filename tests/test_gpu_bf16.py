@@ -4,10 +4,14 @@ SURVEY.md §5: eps = 1e-16 of matrix_factorization.py:200,236 underflows in fp16
 factors and Gram matrices never leave fp32).
 
 Reference for every comparison: the fp32 CPU oracle / ATen evaluated on the SAME bf16-rounded inputs.
-Tolerances are stated in units of the bf16 rounding step u = 2^-9 (round-to-nearest-even relative error
-of one store): a kernel that only rounds its OUTPUT must be within 1 u of max|ref| (plus the fp32 noise
-floor); a chain of n stored tensors is held to n·u — the worst case of errors adding coherently through maps
-of unit gain — with n counted in each test."""
+Tolerances are stated in units of the bf16 unit roundoff u = 2^-8 (8 significand bits, round to nearest
+even: the relative error of one store): a kernel that only rounds its OUTPUT must be within 1 u of max|ref|
+(plus the fp32 noise floor); a chain of n stored tensors is held to n·u — the worst case of errors adding
+coherently through maps of unit gain — with n counted in each test.  Where the map between two stored
+tensors is NOT of unit gain (the gradient through T = 10 rank-2 HALS iterations amplifies a perturbation of
+its input ~35x), the reference is the oracle with the same storage roundings inserted
+(oracle.cpu_ref.factorizer_block_bf16_storage), and the distance of THAT to the plain fp32 oracle is
+recorded next to the device's."""
 import warnings
 
 import pytest
@@ -25,7 +29,7 @@ from oracle import cpu_ref as O
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 BF = torch.bfloat16
-U = 2.0 ** -9   # bf16 unit roundoff (8 significand bits, RNE)
+U = 2.0 ** -8   # bf16 unit roundoff (8 significand bits, RNE)
 
 
 def rb(t):
@@ -37,7 +41,7 @@ def close(what, got, ref, n_stores, extra=0.0):
     """max|got − ref| ≤ n_stores · u · max|ref|"""
     assert got.dtype in (BF, torch.float32)
     return P.close(what, got.float(), ref, rel=n_stores * U, floor=1e-6, extra=extra,
-                   why=f"bf16 storage: {n_stores} stored tensor(s) x u = 2^-9 between input and this result")
+                   why=f"bf16 storage: {n_stores} stored tensor(s) x u = 2^-8 between input and this result")
 
 
 def _lin_cpu(x, w, b=None):
@@ -168,7 +172,8 @@ def test_swm_and_nmf_bf16_storage():
         x[0, :8, :5, :6, :5] = 0                          # a patch of zeros: the eps path (NaN in fp16)
         xc = x.clone().requires_grad_(True)
         mc = m(xc)
-        yc = m.inverse_forward(O.nmf_forward(mc, nmf.init.u0, nmf.init.v0, T, solver))
+        u0, v0 = nmf.init.u0.clone(), nmf.init.v0.clone()
+        yc = m.inverse_forward(O.nmf_forward(mc, u0, v0, T, solver))
         ga = rb(torch.rand_like(yc))
         (gxc,) = torch.autograd.grad(yc, xc, ga)
         nd = nmf.to(DEV)
@@ -188,7 +193,7 @@ def test_swm_and_nmf_bf16_storage():
         close(f"{S} gx", gxd, gxc, 3)
         u, v = nd.decompose(md)
         assert u.dtype == torch.float32 and v.dtype == torch.float32                 # factors never leave fp32
-        uo, vo = O.nmf_decompose(mc.detach(), nmf.init.u0, nmf.init.v0, T, solver)
+        uo, vo = O.nmf_decompose(mc.detach(), u0, v0, T, solver)
         P.close(f"{S} u (fp32 internals)", u, uo)
         P.close(f"{S} v (fp32 internals)", v, vo)
 
@@ -203,7 +208,7 @@ def test_fused_core_bf16_matches_modular_bf16():
         nmf = ft.NMF(size=(8, 512), rank=R, num_iters=4, init="uniform", solver=solver)
         t = rb(torch.rand(2, C, *S))
         tc = t.clone().requires_grad_(True)
-        ac = m.inverse_forward(O.nmf_forward(m(tc), nmf.init.u0, nmf.init.v0, 4, solver))
+        ac = m.inverse_forward(O.nmf_forward(m(tc), nmf.init.u0.clone(), nmf.init.v0.clone(), 4, solver))
         ga = rb(torch.rand_like(ac))
         (gtc,) = torch.autograd.grad(ac, tc, ga)
         W = m.geometry.nshift
@@ -218,24 +223,31 @@ def test_fused_core_bf16_matches_modular_bf16():
 
 
 # ---------------------------------------------------------------- BASELINE configs[4] ---------------------
-def _block_bf16_vs_fp32_oracle(C, S, reshape_kw, nmf_kw, mlp_ratio=2, B=2):
+def _block_bf16_vs_fp32_oracle(C, S, reshape_kw, nmf_kw, mlp_ratio=2, B=2, grad_vs="fp32"):
+    """Device (bf16 storage) against (a) the fp32 oracle and (b) the oracle with the same storage roundings
+    inserted, all on the same bf16-rounded input.  grad_vs: which of the two the GRADIENTS are held to."""
     torch.manual_seed(0)
     blk = ft.FactorizerBlock(channels=C, spatial_size=S, norm=ft.LayerNorm, reshape=(ft.SWMatricize, reshape_kw),
                              act=nn.ReLU, factorize=ft.NMF, init="uniform", mlp_ratio=mlp_ratio, dropout=0.0, **nmf_kw)
     sd = {k: v.clone() for k, v in blk.state_dict().items()}
     x = rb(torch.rand(B, C, *S))
     gy = rb(torch.rand_like(x))
-    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if not k.endswith(("u0", "v0"))}
-    full = dict(sd)
-    full.update(params)
-    xo = x.clone().requires_grad_(True)
     cfg = dict(reshape=reshape_kw, num_iters=nmf_kw["num_iters"], solver=nmf_kw["solver"])
-    yo = O.factorizer_block(xo, full, "", cfg)
-    go = torch.autograd.grad(yo, [xo] + list(params.values()), gy)
+
+    def oracle(fn):
+        params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if not k.endswith(("u0", "v0"))}
+        full = dict(sd)
+        full.update(params)
+        xo = x.clone().requires_grad_(True)
+        yo = fn(xo, full, "", cfg)
+        return yo.detach(), torch.autograd.grad(yo, [xo] + list(params.values()), gy), list(params.keys())
+
+    yo, go, pnames = oracle(O.factorizer_block)
+    ye, ge, _ = oracle(O.factorizer_block_bf16_storage)
     blk = blk.to(DEV)
     xd = x.to(DEV, BF).requires_grad_(True)
     names = [k for k, _ in blk.named_parameters()]
-    assert names == list(params.keys())
+    assert names == pnames
     n0 = _native.launch_count()
     with warnings.catch_warnings():
         warnings.simplefilter("error", RuntimeWarning)       # no composed fallback on this configuration
@@ -244,13 +256,23 @@ def _block_bf16_vs_fp32_oracle(C, S, reshape_kw, nmf_kw, mlp_ratio=2, B=2):
     torch.cuda.synchronize()
     assert _native.launch_count() > n0 and yd.dtype == BF and gd[0].dtype == BF
     assert torch.isfinite(yd.float()).all()
-    # forward: t, a (W windows), x1, z1, x2 are stored in bf16 between kernels
-    close("y", yd, yo, 8)
-    # backward: 9 more stored gradients (gz1, gx1, ga, gym, gm, gt, gx + the rounded forward tensors they use)
-    close("gx", gd[0], go[0], 16)
-    for k, a, b in zip(names, gd[1:], go[1:]):
+    # forward: t, ym, a, x1, z1, x2 are stored in bf16 between kernels (6 stores + the W-window accumulate)
+    # (measured: 1.2 u against either oracle — the roundings mostly do not add coherently)
+    close("y vs fp32 oracle", yd, yo, 4)
+    close("y vs storage-emulating oracle", yd, ye, 4)
+
+    def rel(a, b):
+        return ((a.float().cpu() - b).abs().max() / (b.abs().max() + 1e-30)).item()
+    P.note("storage_effect_on_gx (emulating oracle vs fp32 oracle) / device vs fp32 / device vs emulating",
+           emul_vs_fp32=rel(ge[0], go[0]), device_vs_fp32=rel(gd[0], go[0]), device_vs_emul=rel(gd[0], ge[0]),
+           rank=nmf_kw["rank"], num_iters=nmf_kw["num_iters"])
+    gref = go if grad_vs == "fp32" else ge
+    # backward: 7 more stored gradients (gz1, gx1, ga, gym, gm, gt, gx) on top of the rounded forward tensors;
+    # measured 1-2 u, held to 4 u
+    close(f"gx vs {grad_vs} oracle", gd[0], gref[0], 4)
+    for k, a, b in zip(names, gd[1:], gref[1:]):
         assert a.dtype == torch.float32, k
-        close("grad:" + k, a, b, 16)
+        close(f"grad:{k} vs {grad_vs} oracle", a, b, 4)
     return yd
 
 
@@ -258,8 +280,11 @@ def test_block_cfg5_bf16_rank2_t10():
     """BASELINE configs[4] block: anisotropic patch (5,6,5) (p = 8 does not divide 160x192x160, SURVEY headline 5),
     HALS rank 2, 10 iterations, bf16 activations / fp32 NMF internals, at reduced extent, forward and backward
     with every parameter gradient, against the fp32 oracle on the same (bf16-rounded) input."""
+    # gradients against the storage-emulating oracle: bf16 storage of the NMF input alone moves gx by ~13 % of
+    # its maximum at R = 2, T = 10 (measured on the CPU oracle: emul_vs_fp32 in the recorded note; 4 % at
+    # T = 5, 0.3 % at R = 1) — a property of the configuration, not of the kernels
     _block_bf16_vs_fp32_oracle(32, (10, 12, 20), dict(head_dim=8, patch_size=(5, 6, 5)),
-                               dict(rank=2, num_iters=10, solver="hals"))
+                               dict(rank=2, num_iters=10, solver="hals"), grad_vs="storage-emulating")
 
 
 def test_block_cfg2_bf16_fused_core():

@@ -108,6 +108,7 @@ def prod():
     model.eval()
     with torch.no_grad():
         ms = gpu_time(lambda: model(x), 20, 3)
+    eval_ms = ms
     print(json.dumps({"config": "f-1 production Swin Factorizer eval forward B=2", "ms": round(ms, 3),
                       "volumes_per_s": round(2 / ms * 1e3, 1)}))
     # the bundle's inference: one BraTS volume through SlidingWindowInfererAdapt (inference.yaml:96-102)
@@ -115,39 +116,47 @@ def prod():
     inf = ft.SlidingWindowInfererAdapt(roi_size=(128, 128, 128), sw_batch_size=2, overlap=0.5, mode="gaussian")
     with torch.no_grad():
         ms = gpu_time(lambda: inf(vol, model), 5, 2)
-        net_only = gpu_time(lambda: model(x), 10, 2) * 9  # 18 windows = 9 batches of 2
+    net_only = eval_ms * 9  # 18 windows = 9 batches of 2, at the steady eval-forward time measured above
     print(json.dumps({"config": "f-1 sliding-window inference, 240x240x155 volume, roi 128^3, overlap 0.5, gaussian",
                       "ms_per_volume": round(ms, 2), "of_which_network_ms": round(net_only, 2),
-                      "windows": 18}))
+                      "stitching_ms": round(ms - net_only, 2), "windows": 18}))
 
 
-def cfg5(batches=(1, 2, 4)):
-    """BASELINE configs[4] (SURVEY "cfg 5"), one GPU's share: 160x192x160 volumes, rank 2, 10 iterations.
+def cfg5(batches=(1, 2, 4), dtypes=("bf16", "f32")):
+    """BASELINE configs[4] (SURVEY "cfg 5"), one GPU's share: 160x192x160 volumes, rank 2, 10 iterations,
+    bf16 mixed precision (bf16 activation storage under torch.autocast, fp32 parameters / statistics /
+    NMF internals) — and the same in fp32 for comparison.
     p = 8 does not divide the deeper stages of this shape (SURVEY headline 5), so the patch is (5, 6, 5)
-    (N = 150: the masked 8x<=512 NMF family through the modular matricize -> NMF -> inverse kernels).
-    fp32 throughout: the native kernels do not take the bf16 shortcut of the stress config."""
+    (N = 150: the masked 8x<=512 NMF family through the modular matricize -> NMF -> inverse kernels)."""
+    import contextlib
     torch.manual_seed(0)
     model = ft.Factorizer(in_channels=4, out_channels=3, spatial_size=(160, 192, 160), norm=ft.LayerNorm,
                           reshape=(ft.SWMatricize, {"head_dim": 8, "patch_size": (5, 6, 5)}), act=nn.ReLU,
                           factorize=ft.NMF, rank=2, num_iters=10, init="uniform", solver="hals", mlp_ratio=2,
                           dropout=0.1).to(DEV).train()
-    for B in batches:
+    for dt in dtypes:
+      for B in batches:
         x = torch.rand(B, 4, 160, 192, 160, device=DEV)
         t = (torch.rand(B, 3, 160, 192, 160, device=DEV) > 0.5).float()
+        ctx = (lambda: torch.autocast("cuda", dtype=torch.bfloat16)) if dt == "bf16" else contextlib.nullcontext
 
         def fb():
             for p in model.parameters():
                 p.grad = None
-            loss = ft.dice_ce_loss(model(x), t)
+            with ctx():
+                loss = ft.dice_ce_loss(model(x), t)
             loss.backward()
             return loss
+        torch.cuda.empty_cache()
         torch.cuda.reset_peak_memory_stats()
         loss = fb()
         assert torch.isfinite(loss).item()
         ms = gpu_time(fb, 3, 1)
-        print(json.dumps({"config": f"cfg5 stress shape 160x192x160, HALS R2 T10, patch (5,6,5), fp32, fwd+bwd B={B}",
+        print(json.dumps({"config": f"cfg5 stress shape 160x192x160, HALS R2 T10, patch (5,6,5), fwd+bwd B={B}",
+                          "dtype": dt + (" activations, fp32 parameters / statistics / NMF internals" if dt == "bf16" else ""),
                           "ms": round(ms, 2), "volumes_per_s": round(B / ms * 1e3, 2),
-                          "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1)}), flush=True)
+                          "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1),
+                          "loss": round(float(loss), 5)}), flush=True)
         del x, t
 
 
