@@ -158,6 +158,41 @@ __device__ __forceinline__ float wave_sum(float v) {
   v += dpp_take<0x143, 0xc>(v);  // row_bcast31 into rows 2,3
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+
+// ---- EIGHT wave64 sums at once (v[i] <- all-lanes total of v[i], uniform) ---------------------------
+// A multi-value butterfly: every exchange stage halves the number of live registers instead of folding
+// each value separately, so 8 sums cost 18 vector ops + 8 readlanes (8 independent wave_sum calls: 48
+// dependent DPP adds, each behind a VALU->DPP wait state, + 8 readlanes).  The NMF wave program spends a
+// third of its VALU instructions in such reductions (X·V, gY·V, X·ga: 8 rows at a time).
+//   distance 32: v_permlane32_swap (v[k] | v[k+4])  -> 4 registers, halves hold 2 values
+//   distance 16: v_permlane16_swap                  -> 2 registers, 16-lane rows hold 4 values each
+//   distance  8: select + row_ror:8                 -> 1 register, 8-lane groups hold the 8 values
+//   distance 1, 2, 4: quad_perm / row_half_mirror   -> every lane of group i holds total i (lane 8i read back)
+// Order of the additions per value: x[j]+x[j+32] ; +[j+16] ; +[j+8] ; xor 1 ; xor 2 ; half-mirror
+// (tests/emul/emul.cpp mirrors it).
+typedef unsigned fz_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void wave_sum8(float (&v)[8], int lane) {
+  float y[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const fz_u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[k]), __float_as_uint(v[k + 4]), false, false);
+    y[k] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  float z[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const fz_u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(y[k]), __float_as_uint(y[k + 2]), false, false);
+    z[k] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  const bool hi8 = (lane & 8) != 0;
+  const float keep = hi8 ? z[1] : z[0], give = hi8 ? z[0] : z[1];
+  float w = keep + dpp_take<0x128, 0xf>(give);  // row_ror:8: lane l takes lane l ^ 8 of its row
+  w += dpp_take<0xB1, 0xf>(w);                  // quad_perm [1,0,3,2]
+  w += dpp_take<0x4E, 0xf>(w);                  // quad_perm [2,3,0,1]
+  w += dpp_take<0x141, 0xf>(w);                 // row_half_mirror
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w), 8 * i));
+}
 #endif
 
 }  // namespace fz

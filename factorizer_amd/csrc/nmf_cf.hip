@@ -38,6 +38,7 @@ struct CfWave {
     return (((jp * 4 + (lane >> 4)) * 8 + ((lane >> 1) & 7)) * 8) + (lane & 1) * 4 + e;
   }
   __device__ __forceinline__ float sum(float v) const { return wave_sum(v); }
+  __device__ __forceinline__ void sum8(float (&v)[8]) const { wave_sum8(v, lane); }
   __device__ __forceinline__ void st_priv(float* base, int idx, float v) const { base[idx * 64 + lane] = v; }
   __device__ __forceinline__ float ld_priv(const float* base, int idx) const { return base[idx * 64 + lane]; }
   __device__ __forceinline__ void st_uni(float* base, int idx, float v) const {

@@ -40,6 +40,25 @@ FZ_HD float fz_relu(float v) { return v > 0.f ? v : 0.f; }
 // gate(w, g) = g where w > 0 else 0  (ReLU mask taken from the forward value)
 FZ_HD float fz_gate(float w, float g) { return w > 0.f ? g : 0.f; }
 
+// ---- wave totals of K independent per-lane partial sums, eight at a time where K allows -----------
+template <int K, class W, class F>
+FZ_HD void sum_all(W& w, F (&acc)[K]) {
+  if constexpr (K % 8 == 0) {
+#pragma unroll
+    for (int k0 = 0; k0 < K; k0 += 8) {
+      F t[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t[i] = acc[k0 + i];
+      w.sum8(t);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[k0 + i] = t[i];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = w.sum(acc[k]);
+  }
+}
+
 // ---- one half-step on K independent rows of a factor:  w' = update(w; a, b) ------------
 template <int K, int R, int SOLVER, class F>
 FZ_HD void update_rows(F (&w)[K][R], const F (&a)[K][R], const F (&b)[R][R], float eps) {
@@ -182,14 +201,19 @@ FZ_HD void nmf_step(W& w, const typename W::F (&x)[M][NPL], typename W::F (&u)[M
     F a[M][R];
     F b[R][R];
 #pragma unroll
-    for (int m = 0; m < M; ++m)
+    for (int r = 0; r < R; ++r) {
+      F col[M];
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
+      for (int m = 0; m < M; ++m) {
         F acc = x[m][0] * v[0][r];
 #pragma unroll
         for (int j = 1; j < NPL; ++j) acc = acc + x[m][j] * v[j][r];
-        a[m][r] = w.sum(acc);
+        col[m] = acc;
       }
+      sum_all<M, W, F>(w, col);
+#pragma unroll
+      for (int m = 0; m < M; ++m) a[m][r] = col[m];
+    }
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -305,15 +329,22 @@ FZ_HD void nmf_backward_wave(W& w, const float* u0, const float* v0,
     for (int s = 0; s < G; ++s) nmf_step<M, NPL, R, SOLVER, W>(w, x, u, v, mreal, eps, &h, s);
     // output layer  y = u_T v_Tᵀ :  gu = gY v_T ,  gv = gYᵀ u_T
 #pragma unroll
-    for (int m = 0; m < M; ++m)
+    for (int r = 0; r < R; ++r) {
+      F col[M];
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
+      for (int m = 0; m < M; ++m) {
         F acc = g[m][0] * v[0][r];
 #pragma unroll
         for (int j = 1; j < NPL; ++j) acc = acc + g[m][j] * v[j][r];
-        gu[m][r] = w.sum(acc);
+        col[m] = acc;
+      }
+      sum_all<M, W, F>(w, col);
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        gu[m][r] = col[m];
         if (gu_ext != nullptr && m < mreal) gu[m][r] = gu[m][r] + w.ld_uni_global(gu_ext, m * R + r);
       }
+    }
 #pragma unroll
     for (int j = 0; j < NPL; ++j)
 #pragma unroll
@@ -392,14 +423,19 @@ FZ_HD void nmf_backward_wave(W& w, const float* u0, const float* v0,
 #pragma unroll
       for (int q = 0; q < R; ++q) gb[r][q] = w.sum(gb[r][q]);
 #pragma unroll
-    for (int m = 0; m < M; ++m)
+    for (int r = 0; r < R; ++r) {
+      F col[M];
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        F acc = gu[m][r] + w.sum(gup[m][r]);
+      for (int m = 0; m < M; ++m) col[m] = gup[m][r];
+      sum_all<M, W, F>(w, col);
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        F acc = gu[m][r] + col[m];
 #pragma unroll
         for (int q = 0; q < R; ++q) acc = acc + un[m][q] * (gb[q][r] + gb[r][q]);
         gu[m][r] = acc;
       }
+    }
 
     // ---- undo the U-update: u_{s+1} = upd(x; u_s, v_s) ----
     F bs[R][R];

@@ -45,6 +45,19 @@ struct EmuWave {
     float tot = (r3 + r2) + (r1 + r0);
     return F(tot);
   }
+  // eight sums at once: the device's multi-value butterfly (fz_common.h wave_sum8) adds, per value,
+  // x[j]+x[j+32] ; +[j+16] ; +[j+8] ; xor 1 ; xor 2 ; half-mirror
+  void sum8(F (&v)[8]) const {
+    for (int i = 0; i < 8; ++i) {
+      float f32[32], f16[16], f8[8], g[8], h[8];
+      for (int j = 0; j < 32; ++j) f32[j] = v[i].a[j] + v[i].a[j + 32];
+      for (int j = 0; j < 16; ++j) f16[j] = f32[j] + f32[j + 16];
+      for (int j = 0; j < 8; ++j) f8[j] = f16[j] + f16[j + 8];
+      for (int j = 0; j < 8; ++j) g[j] = f8[j] + f8[j ^ 1];
+      for (int j = 0; j < 8; ++j) h[j] = g[j] + g[j ^ 2];
+      v[i] = F(h[0] + h[7]);
+    }
+  }
   void st_priv(float* base, int idx, const F& v) const { std::memcpy(base + idx * 64, v.a, 256); }
   F ld_priv(const float* base, int idx) const { F r; std::memcpy(r.a, base + idx * 64, 256); return r; }
   void st_uni(float* base, int idx, const F& v) const { base[idx] = v.a[0]; }
