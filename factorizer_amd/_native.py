@@ -127,6 +127,11 @@ class WgradDesc(_c.Structure):
 
 
 _SIGS.update({
+    "fz_gnmf_supported": ([_i, _i64, _i, _i, _i], _i),
+    "fz_gnmf_workspace_bytes": ([_i64, _i, _i64, _i, _i, _i], _i64),
+    "fz_gnmf_launches": ([_i, _i, _i], _i),
+    "fz_gnmf_fwd": ([_vp] * 6 + [_i64, _i, _i64, _i, _i, _i, _f, _vp, _vp], _i),
+    "fz_gnmf_bwd": ([_vp] * 7 + [_i64, _i, _i64, _i, _i, _i, _i, _f, _vp, _vp], _i),
     "fz_nmf_cf_supported": ([_i] * 11, _i),
     "fz_nmf_cf_fwd": ([_vp] * 4 + [_i] * 5 + [_c.POINTER(_i)] + [_i] * 5 + [_f, _i, _vp], _i),
     "fz_nmf_cf_bwd": ([_vp] * 5 + [_i] * 5 + [_c.POINTER(_i)] + [_i] * 7 + [_f, _i, _vp], _i),

@@ -85,7 +85,8 @@ class FactorizerBlock(nn.Module):
         if not (isinstance(f.reshape, SWMatricize) and isinstance(mf, MatrixFactorization)):
             return False
         t_like = x.new_empty((1, *f.reshape.output_size[1:]))
-        return mf._native_solver(t_like) is not None and len(f.reshape.geometry.spatial) <= 3
+        # (wave-resident NMF family only: the block's hand-chained backward calls those kernels directly)
+        return mf._native_solver(t_like) is not None and not mf._wide and len(f.reshape.geometry.spatial) <= 3
 
     def _core_cfg(self):
         """(grad steps, solver id) if matricize→NMF→inverse can run as the fused channels-first

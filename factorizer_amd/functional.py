@@ -260,6 +260,97 @@ def nmf_decompose(x, u0, v0, T, G, solver, eps=1e-16):
     return NMFDecomposeFn.apply(x, u0, v0, T, G, solver, eps)
 
 
+# ---- split-N NMF: matrices too wide for one wavefront (csrc/nmf_global.hip) -------
+def gnmf_supported(M, N_, R, T, G) -> bool:
+    return bool(N.lib().fz_gnmf_supported(int(M), int(N_), int(R), int(T), int(G)))
+
+
+def _gnmf_ws(x, nmat, M, Nn, R, T, backward):
+    nb = N.lib().fz_gnmf_workspace_bytes(nmat, M, Nn, R, T, int(backward))
+    if nb < 0:
+        raise N.NativeError("fz_gnmf_workspace_bytes failed")
+    return torch.empty(max(nb // 4, 1), dtype=torch.float32, device=x.device)
+
+
+def _gnmf_fwd_raw(x, u0, v0, T, solver, eps, want_uv=False):
+    M, Nn = x.shape[-2:]
+    R = u0.shape[1]
+    nmat = x.numel() // (M * Nn)
+    y = torch.empty_like(x)
+    u = v = None
+    if want_uv:
+        u = torch.empty((*x.shape[:-2], M, R), dtype=x.dtype, device=x.device)
+        v = torch.empty((*x.shape[:-2], Nn, R), dtype=x.dtype, device=x.device)
+    ws = _gnmf_ws(x, nmat, M, Nn, R, T, False)
+    with _dev_guard(x):
+        rc = _timed(f"gnmf_fwd_{M}x{Nn}", 2 * x.numel() * 4, lambda: N.lib().fz_gnmf_fwd(
+            x.data_ptr(), u0.data_ptr(), v0.data_ptr(), y.data_ptr(), N.ptr(u), N.ptr(v), nmat, M, Nn, R, T,
+            N.SOLVER_ID[solver], eps, ws.data_ptr(), N.stream_ptr(x)))
+    N.check(rc, "fz_gnmf_fwd")
+    return y, u, v
+
+
+def _gnmf_bwd_raw(x, u0, v0, gy, gu, gv, T, G, solver, eps):
+    M, Nn = x.shape[-2:]
+    R = u0.shape[1]
+    nmat = x.numel() // (M * Nn)
+    gx = torch.empty_like(x)
+    ws = _gnmf_ws(x, nmat, M, Nn, R, T, True)
+    with _dev_guard(x):
+        rc = _timed(f"gnmf_bwd_{M}x{Nn}", 3 * x.numel() * 4, lambda: N.lib().fz_gnmf_bwd(
+            x.data_ptr(), u0.data_ptr(), v0.data_ptr(), N.ptr(gy), N.ptr(gu), N.ptr(gv), gx.data_ptr(), nmat, M, Nn,
+            R, T, G, N.SOLVER_ID[solver], eps, ws.data_ptr(), N.stream_ptr(x)))
+    N.check(rc, "fz_gnmf_bwd")
+    return gx
+
+
+class GNMFFn(torch.autograd.Function):
+    """y = u_T v_Tᵀ for matrices whose columns are split over workgroups."""
+
+    @staticmethod
+    def forward(ctx, x, u0, v0, T, G, solver, eps):
+        x, u0, v0 = x.contiguous(), u0.contiguous(), v0.contiguous()
+        y, _, _ = _gnmf_fwd_raw(x, u0, v0, T, solver, eps)
+        ctx.save_for_backward(x, u0, v0)
+        ctx.cfg = (T, G, solver, eps)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, u0, v0 = ctx.saved_tensors
+        T, G, solver, eps = ctx.cfg
+        if G <= 0:
+            return torch.zeros_like(x), None, None, None, None, None, None
+        return _gnmf_bwd_raw(x, u0, v0, gy.contiguous(), None, None, T, G, solver, eps), None, None, None, None, None, None
+
+
+class GNMFDecomposeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, u0, v0, T, G, solver, eps):
+        x, u0, v0 = x.contiguous(), u0.contiguous(), v0.contiguous()
+        _, u, v = _gnmf_fwd_raw(x, u0, v0, T, solver, eps, want_uv=True)
+        ctx.save_for_backward(x, u0, v0)
+        ctx.cfg = (T, G, solver, eps)
+        return u, v
+
+    @staticmethod
+    def backward(ctx, gu, gv):
+        x, u0, v0 = ctx.saved_tensors
+        T, G, solver, eps = ctx.cfg
+        if G <= 0:
+            return torch.zeros_like(x), None, None, None, None, None, None
+        gx = _gnmf_bwd_raw(x, u0, v0, None, gu.contiguous(), gv.contiguous(), T, G, solver, eps)
+        return gx, None, None, None, None, None, None
+
+
+def gnmf(x, u0, v0, T, G, solver, eps=1e-16):
+    return GNMFFn.apply(x, u0, v0, T, G, solver, eps)
+
+
+def gnmf_decompose(x, u0, v0, T, G, solver, eps=1e-16):
+    return GNMFDecomposeFn.apply(x, u0, v0, T, G, solver, eps)
+
+
 # ---- fused FactMixer core on channels-first tensors ------------------------------------------
 def nmf_cf_supported(geo: Geometry, R, T, G) -> bool:
     if len(geo.spatial) != 3 or any(s[2] % 2 for s in geo.shifts):  # odd W-axis shifts: modular kernels

@@ -84,9 +84,19 @@ class _WindowedMatricize(nn.Module):
             raise ValueError(f"expected input of shape (B, {', '.join(map(str, self.input_size[1:]))}), "
                              f"got {tuple(x.shape)}")
 
+    def _is_view(self) -> bool:
+        """One unshifted window over a 1-patch grid — the reference's default FactMixer reshape
+        Matricize(num_heads=1, grid_size=1) (factorizer.py:17) and every `grid_size=1` form: the rearrangement
+        'b (h d) (g p).. -> (b h) (g..) d (p..)' moves nothing, so it is a view, not a kernel."""
+        geo = self.geometry
+        return geo.nshift == 1 and geo.G == 1 and not any(geo.shifts[0])
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         self._check_input(x)
         x = x.as_subclass(torch.Tensor)
+        if self._is_view() and x.is_contiguous():
+            geo = self.geometry
+            return x.view(x.shape[0] * geo.h, 1, geo.d, geo.P)
         if x.is_cuda and x.numel():
             return Fn.swm_forward(x, self.geometry)
         return composed.swm_forward(x, self.geometry)
@@ -96,6 +106,9 @@ class _WindowedMatricize(nn.Module):
         geo = self.geometry
         if y.shape[0] % (geo.nshift * geo.h) or tuple(y.shape[1:]) != (geo.G, geo.d, geo.P):
             raise ValueError(f"expected (num_shifts*B*{geo.h}, {geo.G}, {geo.d}, {geo.P}), got {tuple(y.shape)}")
+        if self._is_view() and y.is_contiguous():
+            # ((0.0 + z_0)) / 1 of operations.py:426-433 is the identity on the values
+            return y.view(y.shape[0] // geo.h, geo.C, *geo.spatial)
         if not y.numel():
             return composed.swm_inverse(y, geo)
         if y.is_cuda and y.dtype in (torch.float32, torch.bfloat16):

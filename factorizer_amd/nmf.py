@@ -401,10 +401,13 @@ class MatrixFactorization(nn.Module):
         self.init = partialize(_parse_init(init))(size=self.size, rank=rank)
         self.solver = partialize(_parse_solver(solver))(size=self.size, rank=rank)
         self.verbose = verbose
+        self._wide = False
 
     # -- which path -------------------------------------------------------------------
     def _native_solver(self, x: Tensor):
-        """Solver id if this call is covered by the gfx950 kernels, else None."""
+        """Solver id if this call is covered by the gfx950 kernels, else None; `self._wide` then says which
+        family: the wave-resident kernels (False) or the split-N kernels for wide matrices (True)."""
+        self._wide = False
         if not x.is_cuda or self.verbose or not x.numel():
             return None
         sid = getattr(self.solver, "native_id", None)
@@ -418,6 +421,11 @@ class MatrixFactorization(nn.Module):
             return None
         G = min(max(self.num_grad_steps, 0), self.num_iters)
         if not Fn.nmf_supported(self.size[0], self.size[1], self.rank, self.num_iters, G):
+            # wider than one wavefront can hold (global Matricize, num_heads= forms): the split-N kernels
+            if x.dtype == torch.float32 and Fn.gnmf_supported(self.size[0], self.size[1], self.rank, self.num_iters, G) \
+                    and x.numel() // (self.size[0] * self.size[1]) <= 65535:
+                self._wide = True
+                return sid
             composed.warn_once(
                 f"nmf{self.size}{self.rank}",
                 f"NMF size={self.size} rank={self.rank} is outside the native kernel families; "
@@ -437,8 +445,9 @@ class MatrixFactorization(nn.Module):
         x = x.as_subclass(Tensor)
         sid = self._native_solver(x)
         if sid is not None:
-            return Fn.nmf_decompose(x, self.init.u0, self.init.v0, self.num_iters,
-                                    min(max(self.num_grad_steps, 0), self.num_iters), sid, self.solver.eps)
+            fn = Fn.gnmf_decompose if self._wide else Fn.nmf_decompose
+            return fn(x, self.init.u0, self.init.v0, self.num_iters,
+                      min(max(self.num_grad_steps, 0), self.num_iters), sid, self.solver.eps)
         if x.dtype in (torch.bfloat16, torch.float16):
             # composed path in reduced precision: factorise in fp32 (eps = 1e-16 vanishes in fp16 and the
             # Gram matrices lose their low bits in bf16), factors are returned in fp32
@@ -463,8 +472,9 @@ class MatrixFactorization(nn.Module):
         x = x.as_subclass(Tensor)
         sid = self._native_solver(x)
         if sid is not None:
-            return Fn.nmf(x, self.init.u0, self.init.v0, self.num_iters,
-                          min(max(self.num_grad_steps, 0), self.num_iters), sid, self.solver.eps)
+            fn = Fn.gnmf if self._wide else Fn.nmf
+            return fn(x, self.init.u0, self.init.v0, self.num_iters,
+                      min(max(self.num_grad_steps, 0), self.num_iters), sid, self.solver.eps)
         u, v = self.decompose(x)
         return self.reconstruct(u, v).to(x.dtype)
 

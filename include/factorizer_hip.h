@@ -104,6 +104,24 @@ int fz_nmf_bwd(const void* x, const float* u0, const float* v0, const void* gy,
 /* 1 if (M,N,R,T,Tgrad) is covered by the native kernels (fwd and bwd), else 0. */
 int fz_nmf_supported(int M, int N, int R, int T, int Tgrad);
 
+/* ---- split-N NMF: matrices too wide for one wavefront ----------------------------
+ * The reference's default FactMixer reshape Matricize(num_heads=1, grid_size=1) (factorizer/factorizer.py:17;
+ * tests/test_factorizer.py:25: one 16 x 262 144 matrix) and `num_heads=` forms with M != 8
+ * (tests/test_factorizer.py:123).  Same semantics and argument meaning as fz_nmf_fwd / fz_nmf_bwd
+ * (matrix_factorization.py:514-546; backward: SURVEY.md Appendix A), fp32, 1 <= M <= 64, any N, 1 <= R <= 4;
+ * the columns are split over workgroups, cross-workgroup sums are two-stage and fixed-order (no float atomics:
+ * bitwise reproducible).  One call issues fz_gnmf_launches(T, Tgrad, backward) kernels (2T+1 forward).
+ * workspace: fz_gnmf_workspace_bytes(nmat, M, N, R, T, backward) bytes of device memory, caller-owned. */
+int fz_gnmf_supported(int M, int64_t N, int R, int T, int Tgrad);
+int64_t fz_gnmf_workspace_bytes(int64_t nmat, int M, int64_t N, int R, int T, int backward);
+int fz_gnmf_launches(int T, int Tgrad, int backward);
+int fz_gnmf_fwd(const float* x, const float* u0, const float* v0, float* y, float* u_out, float* v_out,
+                int64_t nmat, int M, int64_t N, int R, int T, int solver, float eps, void* workspace,
+                fz_stream_t stream);
+int fz_gnmf_bwd(const float* x, const float* u0, const float* v0, const float* gy, const float* gu,
+                const float* gv, float* gx, int64_t nmat, int M, int64_t N, int R, int T, int Tgrad, int solver,
+                float eps, void* workspace, fz_stream_t stream);
+
 /* ---- FactMixer core on channels-first tensors (hot shape: head_dim 8, patch 8x8x8) -----------
  * One launch per shift window performs SWMatricize.forward → NMF.forward →
  * SWMatricize.inverse_forward (factorizer.py:41-50; operations.py:417-434;

@@ -276,7 +276,8 @@ def test_nmf_full_size_properties():
 
 
 def test_nmf_unsupported_shape_uses_composed_path_with_warning():
-    nmf = ft.NMF(size=(8, 1200), rank=2, num_iters=2, init="uniform", solver="hals").to(DEV)
+    # rank 5 is outside both native families (wave-resident and split-N: R <= 4)
+    nmf = ft.NMF(size=(8, 1200), rank=5, num_iters=2, init="uniform", solver="hals").to(DEV)
     x = torch.rand(3, 8, 1200, device=DEV)
     with pytest.warns(RuntimeWarning):
         y = nmf(x)

@@ -1,0 +1,159 @@
+"""-m gpu: split-N NMF (csrc/nmf_global.hip) — matrices whose columns are spread over
+workgroups: the reference's default FactMixer reshape Matricize(num_heads=1, grid_size=1)
+(factorizer/factorizer.py:17; tests/test_factorizer.py:14-110: x (1,16,64^3) -> one 16 x 262 144 matrix, MU
+rank 1) and `num_heads=8` forms with M != 8 (tests/test_factorizer.py:123), against the CPU oracle; launch
+counts asserted."""
+import warnings
+
+import pytest
+import torch
+from torch import nn
+
+import factorizer_amd as ft
+import parity as P
+from factorizer_amd import _native
+from factorizer_amd import functional as Fn
+from oracle import cpu_ref as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _run(M, N, R, T, solver, lead=(2,), G=None, zero=True):
+    torch.manual_seed(M * 1000 + N + R)
+    x = torch.rand(*lead, M, N)
+    if zero:
+        x[(0,) * len(lead)][:, : min(N, 40)] = 0
+    u0, v0 = torch.rand(M, R), torch.rand(N, R)
+    gy = torch.rand_like(x)
+    nmf = ft.NMF(size=(M, N), rank=R, num_iters=T, num_grad_steps=G, init="uniform", solver=solver)
+    nmf.load_state_dict({"init.u0": u0, "init.v0": v0})
+    nd = nmf.to(DEV)
+    xd = x.to(DEV).requires_grad_(True)
+    Gs = T if G is None else G
+    lib = _native.lib()
+    n0 = _native.launch_count()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        y = nd(xd)
+    torch.cuda.synchronize()
+    assert _native.launch_count() - n0 == lib.fz_gnmf_launches(T, Gs, 0) == (2 * T + 1 if T else 1)
+    n1 = _native.launch_count()
+    (gx,) = torch.autograd.grad(y, xd, gy.to(DEV))
+    torch.cuda.synchronize()
+    if Gs > 0:
+        assert _native.launch_count() - n1 == lib.fz_gnmf_launches(T, Gs, 1) == (2 * T + 1) + 2 * Gs + 1
+    yo = O.nmf_forward(x, u0, v0, T, solver, G)
+    gx64 = O.nmf_backward(x.double(), u0.double(), v0.double(), gy.double(), T, solver, G).float()
+    gxo = O.nmf_backward(x, u0, v0, gy, T, solver, G)
+    tag = f"{M}x{N} R{R} T{T} {solver}"
+    P.close(f"y {tag}", y, yo)
+    kink = (gxo - gx64).abs().max().item()      # the fp32 oracle's own distance to fp64
+    P.close(f"gx {tag} (vs fp64 oracle)", gx, gx64, extra=kink)
+    assert (y >= 0).all()
+    return nd, xd, y
+
+
+@pytest.mark.parametrize("solver", ["mu", "hals"])
+@pytest.mark.parametrize("M,N,R", [(16, 4096, 1), (8, 1200, 2), (16, 3000, 3), (24, 2048, 4), (40, 1030, 2), (64, 1024, 1),
+                                   (5, 777, 2)])
+def test_wide_nmf_vs_oracle(solver, M, N, R):
+    """N a multiple of 4 (16-byte column vectors) and not (scalar columns: 777, 1030 % 4 != 0 → 1030 % 4 = 2);
+    M <= 16 (matrix rows resident in registers) and M > 16 (streamed twice); ragged last slab; a block of zeros."""
+    _run(M, N, R, 4, solver)
+
+
+def test_wide_nmf_grad_steps_and_decompose():
+    nd, xd, _ = _run(16, 2048, 2, 5, "hals", G=2)
+    _run(16, 2048, 1, 3, "mu", G=1)
+    u, v = nd.decompose(xd)
+    uo, vo = O.nmf_decompose(xd.detach().cpu(), nd.init.u0.cpu(), nd.init.v0.cpu(), 5, "hals")
+    P.close("u", u, uo)
+    P.close("v", v, vo)
+    gu, gv = torch.rand_like(u), torch.rand_like(v)
+    (gxd,) = torch.autograd.grad([u, v], xd, [gu, gv])
+    xc = xd.detach().cpu().requires_grad_(True)
+    nc = ft.NMF(size=(16, 2048), rank=2, num_iters=5, num_grad_steps=2, init="uniform", solver="hals")
+    nc.load_state_dict({"init.u0": nd.init.u0.cpu(), "init.v0": nd.init.v0.cpu()})
+    uc, vc = nc.decompose(xc)
+    (gxc,) = torch.autograd.grad([uc, vc], xc, [gu.cpu(), gv.cpu()])
+    P.close("gx from (gu, gv)", gxd, gxc)
+
+
+def test_reference_test_config_global_matricize():
+    """tests/test_factorizer.py:14-47 of the reference: FactMixer(16 -> 16, 64^3, reshape=(Matricize, {num_heads: 1,
+    grid_size: 1}), NMF rank 1, 5 iterations, MU) on x (1, 16, 64^3): ONE 16 x 262 144 matrix.  The matricize is a
+    view, the NMF runs in 2T + 1 = 11 launches forward; against the oracle, and the time / bandwidth reported."""
+    torch.manual_seed(0)
+    S = (64, 64, 64)
+    mixer = ft.FactMixer(in_channels=16, out_channels=16, spatial_size=S, reshape=(ft.Matricize, {"num_heads": 1, "grid_size": 1}),
+                         act=nn.ReLU, factorize=ft.NMF, rank=1, num_iters=5, num_grad_steps=None, init="uniform",
+                         solver="mu", dropout=0.0)
+    sd = {k: v.clone() for k, v in mixer.state_dict().items()}
+    x = torch.rand(1, 16, *S)
+    gy = torch.rand_like(x)
+    # oracle: in_proj -> relu -> (view as 16 x 262144) -> NMF -> out_proj
+    xo = x.clone().requires_grad_(True)
+    t = torch.relu(O.linear_cf(xo, sd["in_proj.linear.weight"]))
+    m = O.nmf_forward(t.reshape(1, 1, 16, -1), sd["factorize.init.u0"], sd["factorize.init.v0"], 5, "mu")
+    yo = O.linear_cf(m.reshape(1, 16, *S), sd["out_proj.linear.weight"], sd["out_proj.linear.bias"])
+    (gxo,) = torch.autograd.grad(yo, xo, gy)
+    mixer = mixer.to(DEV)
+    xd = x.to(DEV).requires_grad_(True)
+    assert mixer.reshape._is_view() and mixer.reshape.output_size == (None, 1, 16, 64 ** 3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        yd = mixer(xd)
+        (gxd,) = torch.autograd.grad(yd, xd, gy.to(DEV))
+    P.close("FactMixer y", yd, yo)
+    P.close("FactMixer gx", gxd, gxo)
+    # timing of the NMF alone (forward, then forward+backward)
+    nmf = mixer.factorize
+    td = torch.rand(1, 1, 16, 64 ** 3, device=DEV, requires_grad=True)
+    gm = torch.rand_like(td)
+
+    def timeit(fn, n=20):
+        for _ in range(3):
+            fn()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(n):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / n
+    with torch.no_grad():
+        f_ms = timeit(lambda: nmf(td))
+    fb_ms = timeit(lambda: torch.autograd.grad(nmf(td), td, gm))
+    nbytes = td.numel() * 4
+    # the kernels read X twice per iteration + once for the first partials, and write Y: (2T + 2) passes
+    P.note("wide_nmf_16x262144_mu_r1_t5", fwd_ms=f_ms, fwd_bwd_ms=fb_ms, launches_fwd=11,
+           fwd_traffic_GBps=(2 * 5 + 2) * nbytes / (f_ms * 1e-3) / 1e9,
+           algorithmic_GBps=2 * nbytes / (f_ms * 1e-3) / 1e9)
+
+
+def test_num_heads_8_block_m_not_8():
+    """tests/test_factorizer.py:123 form: SWMatricize(num_heads=8, patch_size=4) at C = 32 -> head_dim 4 (M = 4,
+    N = 64: the wave-resident masked family) and a `num_heads` form whose matrix is too wide for a wave:
+    Matricize(num_heads=2, grid_size=1) at C = 32, 16^3 -> M = 16, N = 4096 (split-N kernels) inside a block."""
+    for reshape, S in (((ft.SWMatricize, {"num_heads": 8, "patch_size": 4}), (8, 8, 8)),
+                       ((ft.Matricize, {"num_heads": 2, "grid_size": 1}), (16, 16, 16))):
+        torch.manual_seed(1)
+        blk = ft.FactorizerBlock(channels=32, spatial_size=S, norm=ft.LayerNorm, reshape=reshape, act=nn.ReLU,
+                                 factorize=ft.NMF, rank=1, num_iters=5, init="uniform", solver="hals", mlp_ratio=2,
+                                 dropout=0.0)
+        x = torch.rand(2, 32, *S)
+        gy = torch.rand_like(x)
+        xc = x.clone().requires_grad_(True)
+        yc = blk(xc)                                    # composed CPU path (pinned against the reference goldens)
+        (gxc,) = torch.autograd.grad(yc, xc, gy)
+        blk = blk.to(DEV)
+        xd = x.to(DEV).requires_grad_(True)
+        n0 = _native.launch_count()
+        with warnings.catch_warnings():
+            warnings.simplefilter("error", RuntimeWarning)
+            yd = blk(xd)
+            (gxd,) = torch.autograd.grad(yd, xd, gy.to(DEV))
+        assert _native.launch_count() > n0
+        P.close(f"{reshape[1]} y", yd, yc)
+        P.close(f"{reshape[1]} gx", gxd, gxc)
