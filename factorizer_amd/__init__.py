@@ -19,5 +19,6 @@ from .parallel import FlatGradSync
 from .inference import SlidingWindowInferer, SlidingWindowInfererAdapt, sliding_window_inference
 from .ushape import (Factorizer, Same, UNet, UNetDecoder, UNetDecoderBlock, UNetEncoder,
                    UNetEncoderBlock, UNetStage)
+from .deconver import Deconv, DeconvInitializer, DeconvMixer, Deconver, DeconverBlock, DeconverStage, Stem
 
 __version__ = "0.1.0"

@@ -260,6 +260,84 @@ def g8():
     npz("g8_solvers", **arrs)
 
 
+# ---- G9: Deconver family (factorization/deconvolution.py:60-260, deconver.py:9-230) --------
+def g9():
+    arrs = {}
+
+    def grads(mod, x, y, tag):
+        torch.manual_seed(5)
+        gy = torch.rand_like(y)
+        names = [k for k, _ in mod.named_parameters()]
+        gs = torch.autograd.grad(y, [x] + list(mod.parameters()), gy, allow_unused=True)
+        arrs[f"{tag}:gy"], arrs[f"{tag}:gx"] = gy, gs[0]
+        for k, g in zip(names, gs[1:]):
+            if g is not None:
+                arrs[f"{tag}:grad:{k}"] = g
+
+    # Deconv: the reference's own test shape (tests/test_deconver.py:16-40) and variants
+    for tag, S, kw in [
+        ("deconv2d_src", (1, 20, 12, 12), dict(channels=20, ratio=2, groups=5, kernel_size=(3, 3), num_iters=3)),
+        ("deconv2d_both", (2, 20, 12, 12), dict(channels=20, ratio=2, groups=5, kernel_size=(3, 3), update_source=True,
+                                               update_filter=True, num_iters=3)),
+        ("deconv3d_dw", (2, 8, 6, 6, 8), dict(channels=8, ratio=2, groups=-1, kernel_size=(3, 3, 3), num_iters=2)),
+        ("deconv3d_g1_k5", (1, 8, 6, 6, 8), dict(channels=8, ratio=1, groups=1, kernel_size=(5, 3, 3), num_iters=2,
+                                                  num_grad_iters=1)),
+    ]:
+        torch.manual_seed(0)
+        m = ft.Deconv(**kw)
+        torch.manual_seed(1)
+        x = torch.rand(*S, requires_grad=True)
+        y = m(x)
+        for k, v in sd_arrays(m, f"{tag}:sd:").items():
+            arrs[k] = v
+        arrs[f"{tag}:x"], arrs[f"{tag}:y"] = x, y
+        grads(m, x, y, tag)
+        with torch.no_grad():
+            s, h = m.fit(x)
+            arrs[f"{tag}:fit_s"], arrs[f"{tag}:fit_h"] = s, h
+            arrs[f"{tag}:recon"] = m.reconstruct(s, h)
+            arrs[f"{tag}:loss"] = m.loss(*[t for t in (m.split_channels(x), m.split_channels(s), m.split_channels(h))]) \
+                if m.groups != 1 else m.loss(x, s, h)
+    # DeconverBlock / DeconverStage (tests/test_deconver.py:76-120)
+    torch.manual_seed(0)
+    blk = ft.DeconverBlock(channels=16, kernel_size=(3, 3), num_iters=3, num_grad_iters=1, mlp_ratio=3)
+    torch.manual_seed(1)
+    x = torch.rand(2, 16, 12, 12, requires_grad=True)
+    y = blk(x)
+    for k, v in sd_arrays(blk, "block2d:sd:").items():
+        arrs[k] = v
+    arrs["block2d:x"], arrs["block2d:y"] = x, y
+    grads(blk, x, y, "block2d")
+    torch.manual_seed(0)
+    st = ft.DeconverStage(in_channels=8, out_channels=16, depth=2, kernel_size=(3, 3, 3), num_iters=2, mlp_ratio=2)
+    torch.manual_seed(1)
+    x = torch.rand(1, 8, 6, 6, 8, requires_grad=True)
+    y = st(x)
+    for k, v in sd_arrays(st, "stage3d:sd:").items():
+        arrs[k] = v
+    arrs["stage3d:x"], arrs["stage3d:y"] = x, y
+    grads(st, x, y, "stage3d")
+    # tiny Deconver models, 2-D (tests/test_deconver.py:122-160 form with groups=-1; its ratio 0.5 gives round(0.5) = 0 source channels and cannot run: ratio 1 here) and 3-D
+    for tag, S, kw in [
+        ("model2d", (1, 4, 16, 16), dict(spatial_dims=2, encoder_width=(8, 16, 32), encoder_depth=(1, 1, 1), strides=(1, 2, 2),
+                                         decoder_depth=(1, 1), act=nn.ReLU, groups=-1, ratio=1, kernel_size=(3, 3),
+                                         num_iters=3, num_grad_iters=1, mlp_ratio=2, dropout=0.0)),
+        ("model3d", (1, 4, 8, 8, 8), dict(spatial_dims=3, encoder_width=(8, 16), encoder_depth=(1, 1), strides=(1, 2),
+                                          decoder_depth=(1,), act=nn.ReLU, groups=4, ratio=2, kernel_size=(3, 3, 3),
+                                          num_iters=2, mlp_ratio=2, dropout=0.0)),
+    ]:
+        torch.manual_seed(0)
+        model = ft.Deconver(in_channels=4, out_channels=3, **kw).eval()
+        torch.manual_seed(1)
+        x = torch.rand(*S, requires_grad=True)
+        y = model(x)
+        for k, v in sd_arrays(model, f"{tag}:sd:").items():
+            arrs[k] = v
+        arrs[f"{tag}:x"], arrs[f"{tag}:y"] = x, y
+        grads(model, x, y, tag)
+    npz("g9_deconver", **arrs)
+
+
 if __name__ == "__main__":
     g1()
     g2_g4()
