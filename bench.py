@@ -167,6 +167,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch-per-gpu", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
+                    help="f32 (the reference's precision: the headline line) or bf16 = torch.autocast(bfloat16): bf16 "
+                         "activation storage, fp32 parameters / statistics / accumulation / NMF internals (BASELINE configs[4] mode)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group and run the hook-launched bucket all-reduces and "
                          "finish() even with one rank (the N = 1 line then executes the N > 1 code path)")
@@ -219,9 +222,13 @@ def main():
     x = torch.rand(B, 4, 128, 128, 128, device=dev)
     target = (torch.rand(B, 3, 128, 128, 128, device=dev) > 0.5).float()
 
+    import contextlib
+    amp = (lambda: torch.autocast("cuda", dtype=torch.bfloat16)) if args.dtype == "bf16" else contextlib.nullcontext
+
     def step():
         sync.zero_grad()
-        loss = ft.dice_ce_loss(model(x), target)   # the recipe's DiceCELoss(sigmoid, squared_pred), train.yaml:67-70
+        with amp():
+            loss = ft.dice_ce_loss(model(x), target)   # the recipe's DiceCELoss(sigmoid, squared_pred), train.yaml:67-70
         loss.backward()
         scale = sync.finish(average=False)          # SUM stays in the buffer; 1/world is applied by the optimizer kernel
         opt.step(grad_scale=scale)
@@ -310,7 +317,10 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if args.dtype == "f32" else "bf16",
+            "dtype_note": ("fp32 throughout (the reference runs amp: false, train.yaml:34)" if args.dtype == "f32" else
+                           "torch.autocast(bfloat16): bf16 activation storage; parameters, LayerNorm statistics, MFMA "
+                           "accumulation, weight gradients and the NMF iteration (U, V, Gram, eps) fp32"),
             "data": "synthetic",
             "config": {"workload": "Swin Factorizer (in4,out3,128^3,widths 32-512,d8,p8,HALS R1 T5) "
                                    "training step fwd+bwd+AdamW (BASELINE configs[3])",
