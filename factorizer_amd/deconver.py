@@ -18,9 +18,10 @@ Evaluation here: every operator is a grouped ``F.conv{1,2,3}d``.  While the filt
 (``update_filter=False``, the default: h = relu(h0) is a parameter) the G groups are the convolution's groups;
 once they depend on the sample the batch is folded into the groups.  Hᵀx + ε does not depend on s, so it is
 computed once per call, not once per iteration.  The 1×1 projections, LayerNorm and MLP around the mixer run
-the native GEMM-family kernels on device (factorizer_amd/pointwise.py); the grouped correlations themselves
-are framework convolutions on the tensor's device (announced once by a RuntimeWarning: no hand-written gfx950
-kernel exists for them yet — DESIGN.md §7).
+the native GEMM-family kernels on device (factorizer_amd/pointwise.py); H, Hᵀ and their input gradients run
+the native grouped-correlation kernel (csrc/deconv.hip: fp32, ≤ 16 channels per group, cubic or square 3/5/7
+kernels; iterations without gradient fuse the update and the division into its epilogue).  The filter gradient
+and `update_filter`'s lag correlations are framework convolutions on device, announced once by a RuntimeWarning.
 """
 from __future__ import annotations
 
@@ -33,6 +34,7 @@ import torch.nn.functional as F
 from torch import Tensor, nn
 
 from . import composed, convs
+from . import functional as Fn
 from .layers import MLP, LayerNorm, Linear
 from .nmf import relative_error
 from .ushape import UNet
@@ -136,11 +138,23 @@ class Deconv(nn.Module):
         return (h + self.eps) / (h.sum([d for d in range(h.ndim) if d not in (0, 2)], keepdim=True) + self.eps)
 
     # ---- operators ------------------------------------------------------------------------------------
-    def _H(self, s: Tensor, hg: Tensor) -> Tensor:
-        return _gcorr(s, hg, self.padding)
+    def _corr(self, inp: Tensor, wg: Tensor, add_eps: float = 0.0) -> Tensor:
+        """grouped correlation (+ eps): the native gfx950 kernel (csrc/deconv.hip) on device where it applies"""
+        if Fn.gcorr_supported(inp, wg):
+            return Fn.gcorr(inp, wg, add_eps)
+        if inp.is_cuda and inp.numel():
+            composed.warn_once(f"deconv{tuple(inp.shape[1:])}{tuple(wg.shape)}",
+                               f"Deconv: grouped correlation {tuple(wg.shape)} on {tuple(inp.shape)} ({inp.dtype}) is outside "
+                               "the native kernel set (fp32, <= 16 channels per group, cubic / square 3-5-7 kernels); "
+                               "using framework convolutions on device")
+        out = _gcorr(inp, wg, self.padding)
+        return out + add_eps if add_eps else out
 
-    def _Ht(self, r: Tensor, hg: Tensor) -> Tensor:
-        return _gcorr(r, _adjoint_filters(hg), self.padding)
+    def _H(self, s: Tensor, hg: Tensor) -> Tensor:
+        return self._corr(s, hg)
+
+    def _Ht(self, r: Tensor, hg: Tensor, add_eps: float = 0.0) -> Tensor:
+        return self._corr(r, _adjoint_filters(hg), add_eps)
 
     def context(self, it: int):
         return torch.no_grad() if it < self.num_iters - self.num_grad_iters + 1 else nullcontext()
@@ -157,12 +171,22 @@ class Deconv(nn.Module):
                 if self.update_source:
                     key = torch.is_grad_enabled()
                     if self.update_filter or key not in shared_num:
-                        num = self._Ht(x, hg) + self.eps
+                        num = self._Ht(x, hg, self.eps)
                         shared_num[key] = num
                     else:
                         num = shared_num[key]
-                    s = s * num / (self._Ht(self._H(s, hg), hg) + self.eps)
+                    r = self._H(s, hg)
+                    hT = _adjoint_filters(hg)
+                    no_grad_needed = not (torch.is_grad_enabled() and (s.requires_grad or num.requires_grad
+                                                                       or r.requires_grad or hT.requires_grad))
+                    if no_grad_needed and Fn.gcorr_supported(r, hT):
+                        s = Fn.gcorr_mu_update(s, num, r, hT, self.eps)      # update + division fused in the kernel
+                    else:
+                        s = s * num / self._corr(r, hT, self.eps)
                 if self.update_filter:
+                    if x.is_cuda and x.numel():
+                        composed.warn_once("deconv_update_h", "Deconv(update_filter=True): the lag correlations of the "
+                                           "filter update are framework convolutions on device")
                     num_h = _lag_corr(s, x, G, self.padding) + self.eps
                     den_h = _lag_corr(s, self._H(s, hg), G, self.padding) + self.eps
                     ratio = (num_h / den_h).reshape(x.shape[0], self.channels, self.source_channels, *self.kernel_size)
@@ -173,9 +197,6 @@ class Deconv(nn.Module):
         s, h = self.init(x)
         if not self.update_filter:
             h = h[:1]          # shared by the batch
-        if x.is_cuda and x.numel():
-            composed.warn_once(f"deconv{tuple(x.shape[1:])}", "Deconv: the grouped correlations of the multiplicative "
-                               "updates run as framework convolutions on device (no native gfx950 kernel yet)")
         return s, h
 
     # ---- API (deconvolution.py:176-260) ---------------------------------------------------------------

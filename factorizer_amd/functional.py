@@ -409,3 +409,82 @@ class FactCoreFn(torch.autograd.Function):
                     ad, N.stream_ptr(t)))
                 N.check(rc, "fz_nmf_cf_bwd")
         return (gt,) + (None,) * 8
+
+
+# ---- grouped "same" cross-correlation of the Deconver family (csrc/deconv.hip) --------------
+def _k3(w):
+    """kernel dims of a (Bw, G, Co, Ci, *k) filter bank as (kd, kh, kw) with 2-D layers as depth 1"""
+    k = tuple(w.shape[4:])
+    return (1,) * (3 - len(k)) + k
+
+
+def gcorr_supported(inp, w) -> bool:
+    if not (inp.is_cuda and inp.numel() and inp.dtype == torch.float32 and w.dtype == torch.float32):
+        return False
+    if inp.dim() not in (4, 5) or w.dim() != inp.dim() + 2 or w.shape[0] not in (1, inp.shape[0]):
+        return False
+    return bool(N.lib().fz_gcorr_supported(int(w.shape[3]), int(w.shape[2]), *_k3(w)))
+
+
+def _gcorr_raw(inp, w, add_eps=0.0, mul_a=None, mul_b=None):
+    B = inp.shape[0]
+    Bw, G, Co, Ci = w.shape[:4]
+    sp = tuple(inp.shape[2:])
+    D, H, W = (1,) * (3 - len(sp)) + sp
+    out = torch.empty((B, G * Co, *sp), dtype=inp.dtype, device=inp.device)
+    kd, kh, kw = _k3(w)
+    with _dev_guard(inp):
+        rc = _timed(f"gcorr_{Ci}->{Co}_k{kd}{kh}{kw}", 4 * (inp.numel() + out.numel() * (3 if mul_a is not None else 1)),
+                    lambda: N.lib().fz_gcorr(inp.data_ptr(), w.data_ptr(), out.data_ptr(), N.ptr(mul_a), N.ptr(mul_b), B, G,
+                                             Ci, Co, D, H, W, kd, kh, kw, int(Bw != 1), float(add_eps),
+                                             N.stream_ptr(inp)))
+    N.check(rc, "fz_gcorr")
+    return out
+
+
+def adjoint_filters(w):
+    """(Bw, G, Co, Ci, *k) → (Bw, G, Ci, Co, *k), spatially flipped: correlation with it is the adjoint operator"""
+    return torch.flip(w.transpose(2, 3), dims=tuple(range(4, w.ndim))).contiguous()
+
+
+class GCorrFn(torch.autograd.Function):
+    """out = corr(inp, w) + add_eps, native forward and input gradient; the filter gradient (a reduction over all
+    voxels: lag-correlation of inp with the output gradient) is a framework op, announced once."""
+
+    @staticmethod
+    def forward(ctx, inp, w, add_eps):
+        inp, w = inp.contiguous(), w.contiguous()
+        ctx.save_for_backward(inp, w)
+        return _gcorr_raw(inp, w, add_eps)
+
+    @staticmethod
+    def backward(ctx, gout):
+        inp, w = ctx.saved_tensors
+        gout = gout.contiguous()
+        ginp = gw = None
+        if ctx.needs_input_grad[0]:
+            ginp = _gcorr_raw(gout, adjoint_filters(w))
+        if ctx.needs_input_grad[1]:
+            from .composed import warn_once
+            warn_once("gcorr_wgrad", "Deconv: the filter gradient of the grouped correlation is a framework op on device")
+            B = inp.shape[0]
+            Bw, G, Co, Ci = w.shape[:4]
+            nd = inp.dim() - 2
+            fn = {1: torch.nn.grad.conv1d_weight, 2: torch.nn.grad.conv2d_weight, 3: torch.nn.grad.conv3d_weight}[nd]
+            pad = tuple(k // 2 for k in w.shape[4:])
+            if Bw == 1:
+                gw = fn(inp, (G * Co, Ci, *w.shape[4:]), gout, padding=pad, groups=G).reshape(w.shape)
+            else:
+                gw = fn(inp.reshape(1, B * G * Ci, *inp.shape[2:]), (B * G * Co, Ci, *w.shape[4:]),
+                        gout.reshape(1, B * G * Co, *gout.shape[2:]), padding=pad, groups=B * G).reshape(w.shape)
+        return ginp, gw, None
+
+
+def gcorr(inp, w, add_eps=0.0):
+    return GCorrFn.apply(inp, w, add_eps)
+
+
+def gcorr_mu_update(s, num, r, wT, eps):
+    """s ∘ num / (corr(r, wT) + eps) in one launch — for iterations that carry no gradient (inference, or the
+    leading `num_iters − num_grad_iters` iterations of deconvolution.py:158-166)."""
+    return _gcorr_raw(r.contiguous(), wT.contiguous(), eps, s.contiguous(), num.contiguous())

@@ -321,6 +321,19 @@ int fz_rowsum_chunks(int64_t V);
 int fz_rowsum(const void* x /* activation */, float* part, float* out, int B, int C, int64_t V, int act_dtype,
               fz_stream_t stream);
 
+/* ---- grouped "same" cross-correlation of the Deconver family ----------------------------
+ * The one operator of the reference's blind-deconvolution updates (factorizer/factorization/deconvolution.py:
+ * 21-40 `conv`, 136-156 `update_s`): out[b, g*Co+o, v] = sum_i sum_t in[b, g*Ci+i, v+t-p] * w[b or 0, g, o, i, t],
+ * zero padding p = k/2 — used as H, as H^T (channel-transposed, flipped filters) and for input gradients.
+ *   in (B, G*Ci, D, H, W); w (Bw, G, Co, Ci, kd, kh, kw), Bw = B if w_batched else 1; out (B, G*Co, D, H, W); fp32.
+ *   mul_a, mul_b: both NULL -> out = corr + add_eps; both given (shape of out) -> the fused multiplicative update
+ *   out = mul_a * mul_b / (corr + add_eps)  (s * (H^T x + eps) / (H^T H s + eps)).
+ * Supported: Co <= 16 per group, cubic 3/5/7 kernels, or depth-1 square 3/5/7 kernels (2-D layers as D = 1). */
+int fz_gcorr_supported(int Ci, int Co, int kd, int kh, int kw);
+int fz_gcorr(const float* in, const float* w, float* out, const float* mul_a, const float* mul_b, int B, int G,
+             int Ci, int Co, int D, int H, int W, int kd, int kh, int kw, int w_batched, float add_eps,
+             fz_stream_t stream);
+
 /* ---- fused soft-Dice + BCE-with-logits loss (training step; the form of the bundle's
  * DiceCELoss(sigmoid=True, squared_pred=True), model_zoo/factorizer_brats23/configs/train.yaml:67-70).
  * sums: part (planes, fz_dice_bce_chunks(V), 4) = {sum p*t, sum p^2, sum t^2, sum bce} per (b,c) plane.

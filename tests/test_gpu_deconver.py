@@ -15,6 +15,7 @@ DEV = "cuda:0"
 
 @pytest.mark.parametrize("tag", sorted(MODELS))
 def test_deconver_model_on_device(golden, tag):
+    import warnings
     g = golden("g9_deconver")
     model = ft.Deconver(in_channels=4, out_channels=3, **MODELS[tag]).eval()
     model.load_state_dict(g.case(f"{tag}:sd"))
@@ -22,18 +23,60 @@ def test_deconver_model_on_device(golden, tag):
     x = g[f"{tag}:x"].to(DEV).requires_grad_(True)
     composed._warned.clear()
     n0 = _native.launch_count()
-    with pytest.warns(RuntimeWarning, match="Deconv: the grouped correlations"):
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)     # the forward is native end to end
         y = model(x)
+        with torch.no_grad():
+            y_inf = model(x)                               # inference: update + division fused into the kernel
     names = [k for k, _ in model.named_parameters()]
-    grads = torch.autograd.grad(y, [x] + list(model.parameters()), g[f"{tag}:gy"].to(DEV), allow_unused=True)
+    with pytest.warns(RuntimeWarning, match="filter gradient"):
+        grads = torch.autograd.grad(y, [x] + list(model.parameters()), g[f"{tag}:gy"].to(DEV), allow_unused=True)
     torch.cuda.synchronize()
-    assert _native.launch_count() > n0, "the dense sub-layers did not run the native kernels"
+    assert _native.launch_count() > n0
     P.close("y", y, g[f"{tag}:y"])
-    P.close("gx", grads[0], g[f"{tag}:gx"], rel=2e-4, why="reference goldens of this tiny model agree with the CPU path to 2e-4 only")
+    P.close("y (no_grad: fused update epilogue)", y_inf, g[f"{tag}:y"])
+    why = "tiny-model goldens: the reference's own CPU evaluation orders agree to 2e-4 only (tests/test_deconver_cpu.py)"
+    P.close("gx", grads[0], g[f"{tag}:gx"], rel=2e-4, why=why)
     for k, gr in zip(names, grads[1:]):
         key = f"{tag}:grad:{k}"
         if key in g.z:
-            P.close("grad:" + k, gr, g[key], rel=2e-4, why="as gx")
+            P.close("grad:" + k, gr, g[key], rel=2e-4, why=why)
+
+
+@pytest.mark.parametrize("nd,k,G,Ci,Co,S,batched", [
+    (3, 3, 8, 16, 4, (6, 9, 70), False), (3, 3, 2, 3, 5, (4, 4, 64), True), (3, 5, 1, 2, 16, (5, 6, 20), False),
+    (3, 7, 3, 1, 1, (9, 5, 33), False), (2, 3, 5, 8, 4, (12, 12), False), (2, 5, 2, 4, 2, (10, 70), True),
+    (2, 7, 4, 2, 8, (9, 31), False)])
+def test_grouped_correlation_kernel(nd, k, G, Ci, Co, S, batched):
+    """csrc/deconv.hip against F.conv{2,3}d: forward, the fused multiplicative-update epilogue, the input gradient
+    (native, through the adjoint filters) and the filter gradient; ragged tiles, per-sample filters."""
+    import torch.nn.functional as F
+    from factorizer_amd import functional as Fn
+    torch.manual_seed(nd * 100 + k)
+    B = 2
+    x = torch.rand(B, G * Ci, *S)
+    w = torch.rand(B if batched else 1, G, Co, Ci, *([k] * nd)) / (Ci * k ** nd) ** 0.5
+    conv = F.conv3d if nd == 3 else F.conv2d
+    xc, wc = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    if batched:
+        yc = conv(xc.reshape(1, B * G * Ci, *S), wc.reshape(B * G * Co, Ci, *([k] * nd)), padding=k // 2, groups=B * G)
+        yc = yc.reshape(B, G * Co, *S)
+    else:
+        yc = conv(xc, wc.reshape(G * Co, Ci, *([k] * nd)), padding=k // 2, groups=G)
+    gy = torch.rand_like(yc)
+    gxc, gwc = torch.autograd.grad(yc, [xc, wc], gy)
+    xd, wd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    assert Fn.gcorr_supported(xd, wd)
+    n0 = _native.launch_count()
+    yd = Fn.gcorr(xd, wd, 0.0)
+    gxd, gwd = torch.autograd.grad(yd, [xd, wd], gy.to(DEV))
+    assert _native.launch_count() - n0 == 2          # forward + input gradient (the filter gradient is a framework op)
+    P.close("y", yd, yc)
+    P.close("gx", gxd, gxc)
+    P.close("gw", gwd, gwc)
+    a, b = torch.rand_like(yc), torch.rand_like(yc)
+    fused = Fn.gcorr_mu_update(a.to(DEV), b.to(DEV), xd.detach(), wd.detach(), 1e-3)
+    P.close("fused a*b/(corr+eps)", fused, a * b / (yc.detach() + 1e-3))
 
 
 @pytest.mark.parametrize("tag", sorted(DECONV))
