@@ -20,6 +20,6 @@ python3 tools/pmc_sq.py $OUT/pmc_sq.json $S1 $S2 > $OUT/pmc_sq.md 2> $OUT/pmc_sq
 python3 tools/pmc_traffic.py $F $W > $OUT/pmc_traffic.json 2> $OUT/pmc_traffic.err
 python3 tools/prof_summary.py $(find $OUT/trace -name "*kernel_stats.csv" | head -1) 40 > $OUT/kernel_stats.md 2> $OUT/kernel_stats.err
 # keep the merged-back payload small: drop the raw per-dispatch csv of the counter passes (tens of MB)
-find $OUT -name "*counter_collection.csv" -size +8M -delete
+find $OUT -name "*counter_collection.csv" -size +6M -delete
 find $OUT -name "*kernel_trace.csv" -size +8M -delete
 ls -la $OUT
