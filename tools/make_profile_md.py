@@ -15,15 +15,15 @@ def main():
     agg = collections.defaultdict(list)
     for r in rows:
         n = r["Kernel_Name"]
-        if any(s in n for s in ("nmf_cf_bwd_tile", "nmf_cf_fwd_tile", "gemm_chain")):
+        if any(s in n for s in ("nmf_cf_bwd_tile", "nmf_cf_fwd_tile", "gemm_chain", "gn_fwd", "gemm_resident")):
             key = (n.split("(")[0].replace("void ", ""), int(r["Grid_Size_X"]))
             agg[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     pmc = json.load(open(pmc_path))
     b = json.load(open(bench_path))
     r = b["roofline"]
     out = [f"# {title}\n",
-           "`rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline` "
-           "(6 steps under the profiler; summary by `tools/prof_summary.py`).\n", notes + "\n", tab,
+           "`rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline` "
+           "(`tools/profile_round.sh`: 5 steps under the profiler; summary by `tools/prof_summary.py`).\n", notes + "\n", tab,
            "\n## Launch duration by grid size (kernel trace) — the stage-0 launches are the ones `bench.py` reports\n",
            "| kernel | grid (threads) | launches | avg us |\n|---|---|---|---|"]
     for k, v in sorted(agg.items()):
@@ -33,17 +33,18 @@ def main():
                f"{r['avg_launch_ms'] * 1e3:.1f} us, {r['achieved']:.0f} GB/s of algorithmic bytes "
                f"({r['algorithmic_bytes_per_launch'] / 1e9:.3f} GB per launch) = {r['frac']:.3f} of 8 TB/s.\n")
     out.append("## HBM traffic per launch from PMC counters (separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes, "
-               "FETCH_SIZE x2 per the gfx950 correction; `tools/pmc_traffic.py` -> `r01_pmc_traffic.json`; stage-0 launches)\n")
+               "FETCH_SIZE x2 per the gfx950 correction; `tools/pmc_traffic.py` -> `r02_pmc_traffic.json`; stage-0 launches)\n")
     out.append("| kernel | fetch (corrected) MB | write MB | traffic MB | algorithmic MB |\n|---|---|---|---|---|")
-    alg = {"fz::nmf_cf_bwd_tile_kernel<1, 1, 4, false>": (3.5 * 536.87, " (avg over the 2 windows)"),
-           "fz::nmf_cf_fwd_tile_kernel<1, 1, 8, false>": (2.5 * 536.87, " (avg over the 2 windows)"),
-           "fz::gemm_chain_kernel<true, 2, 2>": (7 * 536.87, ""), "fz::gemm_chain_kernel<false, 2, 2>": (4 * 536.87, "")}
+    alg = {"fz::nmf_cf_bwd_tile_kernel<1, 1, 4, false, float>": (3.5 * 536.87, " (avg over the 2 windows)"),
+           "fz::nmf_cf_fwd_tile_kernel<1, 1, 8, false, float>": (2.5 * 536.87, " (avg over the 2 windows)"),
+           "fz::gemm_chain_kernel<true, 2, 2, float>": (7 * 536.87, ""), "fz::gemm_chain_kernel<false, 2, 2, float>": (4 * 536.87, "")}
     for k, (a, note) in alg.items():
         if k in pmc:
             v = pmc[k]
             out.append(f"| `{k}` | {v['fetch_bytes_corrected'] / 1e6:.0f} | {v['write_bytes'] / 1e6:.0f} | "
                        f"{v['traffic_bytes'] / 1e6:.0f} | {a:.0f}{note} |")
-    out.append("\nFull bench line of that run: `profiles/r01_bench_n1.json`.\n")
+    out.append("\nFull bench line of that run: `profiles/r02_bench_n1.json`; SQ counters (VALU / MFMA / LDS / wait shares) of the same "
+               "command: `profiles/r02_p2_pmc_sq.md`.\n")
     print("\n".join(out))
 
 
