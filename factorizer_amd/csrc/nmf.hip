@@ -38,6 +38,7 @@ static int hist_floats(int M, int N, int R, int G) {
   // same order as launch_shape (nmf_kernels.inc): the smallest register footprint that holds the matrix
   if (M <= 8 && N <= 64) { MP = 8; NPL = 1; }
   else if (M <= 8 && N <= 128) { MP = 8; NPL = 2; }
+  else if (M <= 8 && N <= 192) { MP = 8; NPL = 3; }
   else if (M <= 8 && N <= 256) { MP = 8; NPL = 4; }
   else if (M <= 8 && N <= 512) { MP = 8; NPL = 8; }
   else if (M <= 16 && N <= 64) { MP = 16; NPL = 1; }

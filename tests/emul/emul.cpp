@@ -141,6 +141,7 @@ extern "C" int emu_nmf_fwd(const float* x, const float* u0, const float* v0, flo
                            int64_t nmat, int M, int N, int R, int T, int solver, float eps) {
   if (M <= 8 && N <= 64) { DISPATCH_R(run_fwd, 8, 1, x, u0, v0, y, uo, vo, nmat, M, N, T, eps) }
   if (M <= 8 && N <= 128) { DISPATCH_R(run_fwd, 8, 2, x, u0, v0, y, uo, vo, nmat, M, N, T, eps) }
+  if (M <= 8 && N <= 192) { DISPATCH_R(run_fwd, 8, 3, x, u0, v0, y, uo, vo, nmat, M, N, T, eps) }
   if (M <= 8 && N <= 256) { DISPATCH_R(run_fwd, 8, 4, x, u0, v0, y, uo, vo, nmat, M, N, T, eps) }
   if (M <= 8 && N <= 512) { DISPATCH_R(run_fwd, 8, 8, x, u0, v0, y, uo, vo, nmat, M, N, T, eps) }
   if (M <= 16 && N <= 64) { DISPATCH_R(run_fwd, 16, 1, x, u0, v0, y, uo, vo, nmat, M, N, T, eps) }
@@ -155,6 +156,7 @@ extern "C" int emu_nmf_bwd(const float* x, const float* u0, const float* v0, con
                            int solver, float eps) {
   if (M <= 8 && N <= 64) { DISPATCH_R(run_bwd, 8, 1, x, u0, v0, gy, gu, gv, gx, nmat, M, N, T, G, eps) }
   if (M <= 8 && N <= 128) { DISPATCH_R(run_bwd, 8, 2, x, u0, v0, gy, gu, gv, gx, nmat, M, N, T, G, eps) }
+  if (M <= 8 && N <= 192) { DISPATCH_R(run_bwd, 8, 3, x, u0, v0, gy, gu, gv, gx, nmat, M, N, T, G, eps) }
   if (M <= 8 && N <= 256) { DISPATCH_R(run_bwd, 8, 4, x, u0, v0, gy, gu, gv, gx, nmat, M, N, T, G, eps) }
   if (M <= 8 && N <= 512) { DISPATCH_R(run_bwd, 8, 8, x, u0, v0, gy, gu, gv, gx, nmat, M, N, T, G, eps) }
   if (M <= 16 && N <= 64) { DISPATCH_R(run_bwd, 16, 1, x, u0, v0, gy, gu, gv, gx, nmat, M, N, T, G, eps) }
