@@ -129,6 +129,8 @@ class WgradDesc(_c.Structure):
 _SIGS.update({
     "fz_gcorr_supported": ([_i] * 5, _i),
     "fz_gcorr": ([_vp] * 5 + [_i] * 11 + [_f, _vp], _i),
+    "fz_gcorr_wgrad_workspace_bytes": ([_i] * 10, _i64),
+    "fz_gcorr_wgrad": ([_vp] * 4 + [_i] * 11 + [_vp], _i),
     "fz_gnmf_supported": ([_i, _i64, _i, _i, _i], _i),
     "fz_gnmf_workspace_bytes": ([_i64, _i, _i64, _i, _i, _i], _i64),
     "fz_gnmf_launches": ([_i, _i, _i], _i),

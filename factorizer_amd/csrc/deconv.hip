@@ -110,6 +110,131 @@ __global__ __launch_bounds__(256) void gcorr_kernel(GcArgs a) {
   }
 }
 
+
+// ---- filter gradient -------------------------------------------------------------------------------
+//   gw[bw, g, o, i, τ] = Σ_b Σ_v  gout[b, g·Co + o, v] · in[b, g·Ci + i, v + τ − p]     (b = bw when the filters are per sample)
+// — the lag-correlation of the input with the output gradient, a reduction over all voxels.  The reference gets it
+// from autograd through F.conv{2,3}d (deconvolution.py:21-40).  Two deterministic stages, no float atomics:
+//   1. one workgroup per (sample, group, input channel, chunk of voxel tiles): the gout tile (all Co channels) and
+//      the input tile (+ halo) sit in LDS; a work item is one (o, kd, kh) filter row × one slice of the tile's voxel
+//      quads and accumulates the KW taps of that row; slices are added through LDS in slice order, chunks of tiles
+//      in registers; the per-chunk sums go to the caller's workspace;
+//   2. `gcorr_wgrad_finish_kernel` adds chunks (and samples, for shared filters) in index order.
+struct GcwArgs {
+  const float* in;    // (B, G·Ci, D, H, W)
+  const float* gout;  // (B, G·Co, D, H, W)
+  float* part;        // (B, G, nchunks, Co, Ci, KD·KH·KW)
+  int B, G, Ci, Co, D, H, W;
+  int tiles_d, tiles_h, tiles_w, nchunks, tiles_per_chunk;
+};
+
+constexpr int kGoStride = kTD * kTH * kTW + 4;   // gout tile row stride (floats): rows of different o on different banks
+
+template <int CO, int KD, int KH, int KW>
+__global__ __launch_bounds__(256) void gcorr_wgrad_kernel(GcwArgs a) {
+  constexpr int PD = KD / 2, PH = KH / 2, PW = KW / 2;
+  constexpr int LD = kTD + 2 * PD, LH = kTH + 2 * PH, LW = kTW + 2 * PW;
+  constexpr int LWS = LW + 1;
+  constexpr int P = CO * KD * KH;                       // filter rows
+  constexpr int S = P >= 256 ? 1 : 256 / P;             // voxel-quad slices per row
+  constexpr int NI = (P * S + 255) / 256;               // work items per thread
+  constexpr int NR = P * KW;                            // sums per (input channel, chunk)
+  constexpr int NS = (NR + 255) / 256;
+  constexpr int NQ = kTD * kTH * kTW / 4;               // voxel quads per tile
+  extern __shared__ __attribute__((aligned(16))) float fz_lds_gcw[];
+  float* go = fz_lds_gcw;                               // [CO][kGoStride]
+  float* tile = go + CO * kGoStride;                    // [LD][LH][LWS]
+  float* red = tile + LD * LH * LWS;                    // [S][NR]
+  const int tid = threadIdx.x;
+  const int chunk = blockIdx.x;
+  const int g = blockIdx.y / a.Ci, ci = blockIdx.y % a.Ci, b = blockIdx.z;
+  const int64_t V = (int64_t)a.D * a.H * a.W;
+  const float* inc = a.in + (((int64_t)b * a.G + g) * a.Ci + ci) * V;
+  const float* gob = a.gout + ((int64_t)b * a.G + g) * a.Co * V;
+  const int ntiles = a.tiles_d * a.tiles_h * a.tiles_w;
+
+  float tot[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) tot[s] = 0.f;
+
+  const int t_lo = chunk * a.tiles_per_chunk;
+  const int t_hi = min(ntiles, t_lo + a.tiles_per_chunk);
+  for (int t = t_lo; t < t_hi; ++t) {
+    const int twi = t % a.tiles_w, thi = (t / a.tiles_w) % a.tiles_h, tdi = t / (a.tiles_w * a.tiles_h);
+    const int d0 = tdi * kTD, h0 = thi * kTH, w0 = twi * kTW;
+    __syncthreads();   // the previous tile's sweep and reduction are done with go / tile / red
+    for (int idx = tid; idx < CO * kTD * kTH * kTW; idx += 256) {
+      const int lw = idx % kTW, lh = (idx / kTW) % kTH, ld = (idx / (kTW * kTH)) % kTD, o = idx / (kTW * kTH * kTD);
+      const int zd = d0 + ld, zh = h0 + lh, zw = w0 + lw;
+      const bool ok = o < a.Co && zd < a.D && zh < a.H && zw < a.W;
+      go[o * kGoStride + (ld * kTH + lh) * kTW + lw] = ok ? gob[(int64_t)o * V + ((int64_t)zd * a.H + zh) * a.W + zw] : 0.f;
+    }
+    for (int idx = tid; idx < LD * LH * LW; idx += 256) {
+      const int lw = idx % LW, lh = (idx / LW) % LH, ld = idx / (LW * LH);
+      const int zd = d0 + ld - PD, zh = h0 + lh - PH, zw = w0 + lw - PW;
+      const bool ok = zd >= 0 && zd < a.D && zh >= 0 && zh < a.H && zw >= 0 && zw < a.W;
+      tile[(ld * LH + lh) * LWS + lw] = ok ? inc[((int64_t)zd * a.H + zh) * a.W + zw] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < NI; ++n) {
+      const int item = tid + 256 * n;
+      if (item < P * S) {
+        const int pr = item / S, sl = item % S;
+        const int kh = pr % KH, kd = (pr / KH) % KD, o = pr / (KH * KD);
+        float acc[KW];
+#pragma unroll
+        for (int kw = 0; kw < KW; ++kw) acc[kw] = 0.f;
+        for (int q = sl; q < NQ; q += S) {
+          const int tw = q % (kTW / 4), th = (q / (kTW / 4)) % kTH, td = q / (kTW / 4 * kTH);
+          const float4 g4 = *reinterpret_cast<const float4*>(go + o * kGoStride + q * 4);
+          const float* rp = tile + ((td + kd) * LH + (th + kh)) * LWS + tw * 4;
+          float row[4 + KW - 1];
+#pragma unroll
+          for (int e = 0; e < 4 + KW - 1; ++e) row[e] = rp[e];
+#pragma unroll
+          for (int kw = 0; kw < KW; ++kw)
+            acc[kw] = acc[kw] + g4.x * row[kw] + g4.y * row[kw + 1] + g4.z * row[kw + 2] + g4.w * row[kw + 3];
+        }
+#pragma unroll
+        for (int kw = 0; kw < KW; ++kw) red[sl * NR + pr * KW + kw] = acc[kw];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int r = tid + 256 * s;
+      if (r < NR) {
+        float v = 0.f;
+        for (int sl = 0; sl < S; ++sl) v += red[sl * NR + r];
+        tot[s] += v;
+      }
+    }
+  }
+  constexpr int K3 = KD * KH * KW;
+  float* pp = a.part + (((int64_t)b * a.G + g) * a.nchunks + chunk) * a.Co * a.Ci * K3;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int r = tid + 256 * s;
+    if (r < NR) {
+      const int o = r / K3, tau = r % K3;
+      if (o < a.Co) pp[((int64_t)o * a.Ci + ci) * K3 + tau] = tot[s];
+    }
+  }
+}
+
+// gw[bw, g, e] = Σ_{b ∈ samples of bw} Σ_chunk part[b, g, chunk, e], ascending b then chunk
+__global__ void gcorr_wgrad_finish_kernel(const float* part, float* gw, int B, int G, int nchunks, int E, int w_batched) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n = (int64_t)(w_batched ? B : 1) * G * E;
+  if (i >= n) return;
+  const int e = (int)(i % E), g = (int)((i / E) % G), bw = (int)(i / ((int64_t)E * G));
+  float v = 0.f;
+  for (int b = w_batched ? bw : 0; b < (w_batched ? bw + 1 : B); ++b)
+    for (int c = 0; c < nchunks; ++c) v += part[(((int64_t)b * G + g) * nchunks + c) * E + e];
+  gw[i] = v;
+}
+
 }  // namespace fz
 
 using namespace fz;
@@ -152,6 +277,69 @@ extern "C" int fz_gcorr(const float* in, const float* w, float* out, const float
   } else {
     if (kw == 3) FZ_GC_CO(3, 3, 3); else if (kw == 5) FZ_GC_CO(5, 5, 5); else FZ_GC_CO(7, 7, 7);
   }
+  FZ_LAUNCH_CHECK();
+  return FZ_OK;
+}
+
+static int gcw_chunks(int B, int G, int Ci, int ntiles) {
+  // enough workgroups to fill the chip (≈ 4 per CU), never more than one per tile
+  const int64_t per = (int64_t)B * G * Ci;
+  int64_t nc = (1024 + per - 1) / per;
+  if (nc < 1) nc = 1;
+  if (nc > ntiles) nc = ntiles;
+  return (int)nc;
+}
+
+extern "C" int64_t fz_gcorr_wgrad_workspace_bytes(int B, int G, int Ci, int Co, int D, int H, int W, int kd, int kh, int kw) {
+  if (B < 1 || G < 1 || Ci < 1 || Co < 1 || D < 1 || H < 1 || W < 1) return 0;
+  const int ntiles = ((D + kTD - 1) / kTD) * ((H + kTH - 1) / kTH) * ((W + kTW - 1) / kTW);
+  return (int64_t)B * G * gcw_chunks(B, G, Ci, ntiles) * Co * Ci * kd * kh * kw * (int64_t)sizeof(float);
+}
+
+// Filter gradient of fz_gcorr: gw (Bw, G, Co, Ci, kd, kh, kw) from in (B, G·Ci, D, H, W) and gout (B, G·Co, D, H, W);
+// ws: fz_gcorr_wgrad_workspace_bytes(...) bytes.  fp32.
+extern "C" int fz_gcorr_wgrad(const float* in, const float* gout, float* gw, void* ws, int B, int G, int Ci, int Co, int D,
+                              int H, int W, int kd, int kh, int kw, int w_batched, fz_stream_t stream) {
+  if (!in || !gout || !gw || !ws) return fail(FZ_E_ARG, "fz_gcorr_wgrad: null pointer");
+  if (B < 1 || G < 1 || D < 1 || H < 1 || W < 1) return fail(FZ_E_SHAPE, "fz_gcorr_wgrad: bad sizes");
+  if (!fz_gcorr_supported(Ci, Co, kd, kh, kw))
+    return fail(FZ_E_UNSUPPORTED, "fz_gcorr_wgrad: needs <= 16 output channels per group and a 3/5/7 cubic (or depth-1 square) kernel");
+  if ((int64_t)G * Ci > 65535 || B > 65535) return fail(FZ_E_UNSUPPORTED, "fz_gcorr_wgrad: more than 65535 (group, channel) pairs / samples");
+  GcwArgs a{in, gout, (float*)ws, B, G, Ci, Co, D, H, W, (D + kTD - 1) / kTD, (H + kTH - 1) / kTH, (W + kTW - 1) / kTW, 0, 0};
+  const int ntiles = a.tiles_d * a.tiles_h * a.tiles_w;
+  a.nchunks = gcw_chunks(B, G, Ci, ntiles);
+  a.tiles_per_chunk = (ntiles + a.nchunks - 1) / a.nchunks;
+  dim3 grid((unsigned)a.nchunks, (unsigned)(G * Ci), (unsigned)B), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define FZ_GCW(CO_, KD_, KH_, KW_)                                                                                        \
+  do {                                                                                                                    \
+    constexpr int P_ = CO_ * KD_ * KH_, S_ = P_ >= 256 ? 1 : 256 / P_;                                                    \
+    constexpr int lds_ = (CO_ * kGoStride + (kTD + 2 * (KD_ / 2)) * (kTH + 2 * (KH_ / 2)) * (kTW + 2 * (KW_ / 2) + 1) +    \
+                          S_ * P_ * KW_) * (int)sizeof(float);                                                            \
+    static_assert(lds_ <= 160 * 1024, "gcorr_wgrad: tile exceeds LDS");                                                   \
+    auto kern = gcorr_wgrad_kernel<CO_, KD_, KH_, KW_>;                                                                   \
+    if (lds_ > 65536)                                                                                                     \
+      FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_)); \
+    hipLaunchKernelGGL(kern, grid, block, lds_, st, a);                                                                   \
+  } while (0)
+#define FZ_GCW_CO(KD_, KH_, KW_)                  \
+  do {                                            \
+    if (Co <= 1) FZ_GCW(1, KD_, KH_, KW_);        \
+    else if (Co <= 2) FZ_GCW(2, KD_, KH_, KW_);   \
+    else if (Co <= 4) FZ_GCW(4, KD_, KH_, KW_);   \
+    else if (Co <= 8) FZ_GCW(8, KD_, KH_, KW_);   \
+    else FZ_GCW(16, KD_, KH_, KW_);               \
+  } while (0)
+  if (kd == 1) {
+    if (kw == 3) FZ_GCW_CO(1, 3, 3); else if (kw == 5) FZ_GCW_CO(1, 5, 5); else FZ_GCW_CO(1, 7, 7);
+  } else {
+    if (kw == 3) FZ_GCW_CO(3, 3, 3); else if (kw == 5) FZ_GCW_CO(5, 5, 5); else FZ_GCW_CO(7, 7, 7);
+  }
+  FZ_LAUNCH_CHECK();
+  const int E = Co * Ci * kd * kh * kw;
+  const int64_t n = (int64_t)(w_batched ? B : 1) * G * E;
+  hipLaunchKernelGGL(gcorr_wgrad_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)ws, gw, B, G,
+                     a.nchunks, E, w_batched ? 1 : 0);
   FZ_LAUNCH_CHECK();
   return FZ_OK;
 }

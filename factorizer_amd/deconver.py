@@ -20,8 +20,9 @@ once they depend on the sample the batch is folded into the groups.  Hᵀx + ε 
 computed once per call, not once per iteration.  The 1×1 projections, LayerNorm and MLP around the mixer run
 the native GEMM-family kernels on device (factorizer_amd/pointwise.py); H, Hᵀ and their input gradients run
 the native grouped-correlation kernel (csrc/deconv.hip: fp32, ≤ 16 channels per group, cubic or square 3/5/7
-kernels; iterations without gradient fuse the update and the division into its epilogue).  The filter gradient
-and `update_filter`'s lag correlations are framework convolutions on device, announced once by a RuntimeWarning.
+kernels; iterations without gradient fuse the update and the division into its epilogue); the filter gradient and
+`update_filter`'s lag correlations — the same reduction over all voxels — run `fz_gcorr_wgrad` (deterministic
+two-stage sums).  Shapes outside that set use framework convolutions on device, announced once by a RuntimeWarning.
 """
 from __future__ import annotations
 
@@ -150,6 +151,16 @@ class Deconv(nn.Module):
         out = _gcorr(inp, wg, self.padding)
         return out + add_eps if add_eps else out
 
+    def _lags(self, s: Tensor, x: Tensor) -> Tensor:
+        """corr(s, x) over the lags of the kernel support → (B, G, C/G, K, *kernel): fz_gcorr_wgrad on device"""
+        if Fn.lag_corr_supported(s, x, self.groups, self.kernel_size):
+            return Fn.lag_corr(s, x, self.groups, self.kernel_size)
+        if x.is_cuda and x.numel():
+            composed.warn_once("deconv_update_h", "Deconv(update_filter=True): lag correlations outside the native kernel "
+                               "set (fp32, <= 16 channels per group, cubic / square 3-5-7 kernels); using framework "
+                               "convolutions on device")
+        return _lag_corr(s, x, self.groups, self.padding)
+
     def _H(self, s: Tensor, hg: Tensor) -> Tensor:
         return self._corr(s, hg)
 
@@ -161,7 +172,6 @@ class Deconv(nn.Module):
 
     def _iterate(self, x: Tensor, s: Tensor, h: Tensor):
         """x (B, C, *S), s (B, G·K, *S), h (Bw, C, K, *k) → (s, h) after num_iters updates."""
-        G = self.groups
         shared_num = {}   # Hᵀx + ε is the same in every iteration while h is fixed: one per autograd mode
         for it in range(1, self.num_iters + 1):
             with self.context(it):
@@ -184,11 +194,8 @@ class Deconv(nn.Module):
                     else:
                         s = s * num / self._corr(r, hT, self.eps)
                 if self.update_filter:
-                    if x.is_cuda and x.numel():
-                        composed.warn_once("deconv_update_h", "Deconv(update_filter=True): the lag correlations of the "
-                                           "filter update are framework convolutions on device")
-                    num_h = _lag_corr(s, x, G, self.padding) + self.eps
-                    den_h = _lag_corr(s, self._H(s, hg), G, self.padding) + self.eps
+                    num_h = self._lags(s, x) + self.eps
+                    den_h = self._lags(s, self._H(s, hg)) + self.eps
                     ratio = (num_h / den_h).reshape(x.shape[0], self.channels, self.source_channels, *self.kernel_size)
                     h = h * ratio
         return s, h

@@ -423,7 +423,11 @@ def gcorr_supported(inp, w) -> bool:
         return False
     if inp.dim() not in (4, 5) or w.dim() != inp.dim() + 2 or w.shape[0] not in (1, inp.shape[0]):
         return False
-    return bool(N.lib().fz_gcorr_supported(int(w.shape[3]), int(w.shape[2]), *_k3(w)))
+    if not N.lib().fz_gcorr_supported(int(w.shape[3]), int(w.shape[2]), *_k3(w)):
+        return False
+    if torch.is_grad_enabled() and inp.requires_grad:      # the input gradient is the adjoint correlation: Co ↔ Ci
+        return bool(N.lib().fz_gcorr_supported(int(w.shape[2]), int(w.shape[3]), *_k3(w)))
+    return True
 
 
 def _gcorr_raw(inp, w, add_eps=0.0, mul_a=None, mul_b=None):
@@ -447,9 +451,28 @@ def adjoint_filters(w):
     return torch.flip(w.transpose(2, 3), dims=tuple(range(4, w.ndim))).contiguous()
 
 
+def _gcorr_wgrad_raw(inp, gout, w_shape):
+    """gw (Bw, G, Co, Ci, *k) of out = corr(inp, w): fz_gcorr_wgrad (deterministic two-stage reduction)"""
+    B = inp.shape[0]
+    Bw, G, Co, Ci = w_shape[:4]
+    sp = tuple(inp.shape[2:])
+    D, H, W = (1,) * (3 - len(sp)) + sp
+    ks = tuple(w_shape[4:])
+    kd, kh, kw = (1,) * (3 - len(ks)) + ks
+    gw = torch.empty(tuple(w_shape), dtype=torch.float32, device=inp.device)
+    nb = N.lib().fz_gcorr_wgrad_workspace_bytes(B, G, Ci, Co, D, H, W, kd, kh, kw)
+    ws = torch.empty(max(nb // 4, 1), dtype=torch.float32, device=inp.device)
+    with _dev_guard(inp):
+        rc = _timed(f"gcorr_wgrad_{Ci}->{Co}_k{kd}{kh}{kw}", 4 * (inp.numel() + gout.numel()),
+                    lambda: N.lib().fz_gcorr_wgrad(inp.data_ptr(), gout.data_ptr(), gw.data_ptr(), ws.data_ptr(), B, G, Ci, Co,
+                                                   D, H, W, kd, kh, kw, int(Bw != 1), N.stream_ptr(inp)))
+    N.check(rc, "fz_gcorr_wgrad")
+    return gw
+
+
 class GCorrFn(torch.autograd.Function):
-    """out = corr(inp, w) + add_eps, native forward and input gradient; the filter gradient (a reduction over all
-    voxels: lag-correlation of inp with the output gradient) is a framework op, announced once."""
+    """out = corr(inp, w) + add_eps: native forward, input gradient (the adjoint correlation) and filter gradient
+    (the lag-correlation of inp with the output gradient, fz_gcorr_wgrad)."""
 
     @staticmethod
     def forward(ctx, inp, w, add_eps):
@@ -465,19 +488,44 @@ class GCorrFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             ginp = _gcorr_raw(gout, adjoint_filters(w))
         if ctx.needs_input_grad[1]:
-            from .composed import warn_once
-            warn_once("gcorr_wgrad", "Deconv: the filter gradient of the grouped correlation is a framework op on device")
-            B = inp.shape[0]
-            Bw, G, Co, Ci = w.shape[:4]
-            nd = inp.dim() - 2
-            fn = {1: torch.nn.grad.conv1d_weight, 2: torch.nn.grad.conv2d_weight, 3: torch.nn.grad.conv3d_weight}[nd]
-            pad = tuple(k // 2 for k in w.shape[4:])
-            if Bw == 1:
-                gw = fn(inp, (G * Co, Ci, *w.shape[4:]), gout, padding=pad, groups=G).reshape(w.shape)
-            else:
-                gw = fn(inp.reshape(1, B * G * Ci, *inp.shape[2:]), (B * G * Co, Ci, *w.shape[4:]),
-                        gout.reshape(1, B * G * Co, *gout.shape[2:]), padding=pad, groups=B * G).reshape(w.shape)
+            gw = _gcorr_wgrad_raw(inp, gout, w.shape)
         return ginp, gw, None
+
+
+class LagCorrFn(torch.autograd.Function):
+    """L[b, g, c, k, τ] = Σ_v x[b, g·C + c, v] · s[b, g·K + k, v + τ − p] — the lag correlations of the filter update
+    (deconvolution.py:43-50 `sconv`, :150-156 `update_h`).  The same reduction as the filter gradient of the grouped
+    correlation (fz_gcorr_wgrad); its own gradients are two grouped correlations with gL as per-sample filters."""
+
+    @staticmethod
+    def forward(ctx, s, x, G, ksize):
+        s, x = s.contiguous(), x.contiguous()
+        ctx.save_for_backward(s, x)
+        B = s.shape[0]
+        return _gcorr_wgrad_raw(s, x, (B, G, x.shape[1] // G, s.shape[1] // G, *ksize))
+
+    @staticmethod
+    def backward(ctx, gL):
+        s, x = ctx.saved_tensors
+        gL = gL.contiguous()
+        gs = gx = None
+        if ctx.needs_input_grad[0]:
+            gs = _gcorr_raw(x, adjoint_filters(gL))
+        if ctx.needs_input_grad[1]:
+            gx = _gcorr_raw(s, gL)
+        return gs, gx, None, None
+
+
+def lag_corr_supported(s, x, G, ksize) -> bool:
+    if not (s.is_cuda and s.numel() and s.dtype == torch.float32 and x.dtype == torch.float32 and s.dim() in (4, 5)):
+        return False
+    K, C = s.shape[1] // G, x.shape[1] // G
+    k3 = (1,) * (3 - len(ksize)) + tuple(int(k) for k in ksize)
+    return bool(N.lib().fz_gcorr_supported(K, C, *k3)) and bool(N.lib().fz_gcorr_supported(C, K, *k3))
+
+
+def lag_corr(s, x, G, ksize):
+    return LagCorrFn.apply(s, x, G, tuple(int(k) for k in ksize))
 
 
 def gcorr(inp, w, add_eps=0.0):

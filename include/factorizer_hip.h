@@ -333,6 +333,12 @@ int fz_gcorr_supported(int Ci, int Co, int kd, int kh, int kw);
 int fz_gcorr(const float* in, const float* w, float* out, const float* mul_a, const float* mul_b, int B, int G,
              int Ci, int Co, int D, int H, int W, int kd, int kh, int kw, int w_batched, float add_eps,
              fz_stream_t stream);
+/* Filter gradient of fz_gcorr (what autograd derives through F.conv{2,3}d in the reference, deconvolution.py:21-40):
+ * gw[bw, g, o, i, t] = sum_b sum_v gout[b, g*Co+o, v] * in[b, g*Ci+i, v+t-p]  (b = bw for per-sample filters).
+ * Deterministic two-stage reduction; ws: fz_gcorr_wgrad_workspace_bytes(...) bytes of caller workspace. */
+int64_t fz_gcorr_wgrad_workspace_bytes(int B, int G, int Ci, int Co, int D, int H, int W, int kd, int kh, int kw);
+int fz_gcorr_wgrad(const float* in, const float* gout, float* gw, void* ws, int B, int G, int Ci, int Co, int D, int H,
+                   int W, int kd, int kh, int kw, int w_batched, fz_stream_t stream);
 
 /* ---- fused soft-Dice + BCE-with-logits loss (training step; the form of the bundle's
  * DiceCELoss(sigmoid=True, squared_pred=True), model_zoo/factorizer_brats23/configs/train.yaml:67-70).

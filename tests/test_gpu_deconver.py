@@ -1,6 +1,7 @@
 """-m gpu: the Deconver family on device against the reference goldens (g9): the 1x1 projections,
 LayerNorm, MLP, stem / k2s2 convolutions run the native GEMM-family kernels; the grouped correlations of the
-multiplicative updates are framework convolutions on device and say so (RuntimeWarning) — asserted here."""
+multiplicative updates, their input gradients, filter gradients and the lag correlations of the filter update run
+csrc/deconv.hip — no framework fallback (a RuntimeWarning would fail the tests)."""
 import pytest
 import torch
 
@@ -24,13 +25,15 @@ def test_deconver_model_on_device(golden, tag):
     composed._warned.clear()
     n0 = _native.launch_count()
     with warnings.catch_warnings():
-        warnings.simplefilter("error", RuntimeWarning)     # the forward is native end to end
+        warnings.simplefilter("error", RuntimeWarning)     # forward and backward are native end to end
         y = model(x)
         with torch.no_grad():
             y_inf = model(x)                               # inference: update + division fused into the kernel
-    names = [k for k, _ in model.named_parameters()]
-    with pytest.warns(RuntimeWarning, match="filter gradient"):
-        grads = torch.autograd.grad(y, [x] + list(model.parameters()), g[f"{tag}:gy"].to(DEV), allow_unused=True)
+        names = [k for k, _ in model.named_parameters()]
+        gy = g[f"{tag}:gy"].to(DEV)
+        pgrads = torch.autograd.grad(model(x.detach()), list(model.parameters()), gy, allow_unused=True)
+    # (the gradient w.r.t. the network INPUT goes through the stem's k3 input gradient, a framework op that says so)
+    grads = torch.autograd.grad(y, [x], gy) + pgrads
     torch.cuda.synchronize()
     assert _native.launch_count() > n0
     P.close("y", y, g[f"{tag}:y"])
@@ -70,7 +73,7 @@ def test_grouped_correlation_kernel(nd, k, G, Ci, Co, S, batched):
     n0 = _native.launch_count()
     yd = Fn.gcorr(xd, wd, 0.0)
     gxd, gwd = torch.autograd.grad(yd, [xd, wd], gy.to(DEV))
-    assert _native.launch_count() - n0 == 2          # forward + input gradient (the filter gradient is a framework op)
+    assert _native.launch_count() - n0 == 4          # forward, input gradient, filter gradient (sweep + finish)
     P.close("y", yd, yc)
     P.close("gx", gxd, gxc)
     P.close("gw", gwd, gwc)
@@ -93,3 +96,39 @@ def test_deconv_layer_on_device(golden, tag):
     with torch.no_grad():
         s, h = m.fit(x)
         P.close("reconstruct", m.reconstruct(s, h), g[f"{tag}:recon"])
+
+
+@pytest.mark.parametrize("nd,k,G,K,C,S", [(3, 3, 2, 3, 4, (5, 6, 70)), (3, 5, 1, 2, 3, (4, 9, 20)), (2, 3, 4, 2, 2, (12, 66)),
+                                          (2, 7, 1, 1, 5, (9, 31)), (3, 7, 2, 2, 1, (3, 5, 9))])
+def test_lag_correlation_kernel(nd, k, G, K, C, S):
+    """Fn.lag_corr (fz_gcorr_wgrad as a forward op + two grouped correlations as its gradients) against the framework
+    restatement of deconvolution.py:43-50,150-156 on CPU, values and both gradients."""
+    from factorizer_amd import functional as Fn
+    from factorizer_amd.deconver import _lag_corr
+    torch.manual_seed(7 * nd + k)
+    B = 2
+    s, x = torch.rand(B, G * K, *S), torch.rand(B, G * C, *S)
+    sc, xc = s.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    Lc = _lag_corr(sc, xc, G, (k // 2,) * nd)
+    gL = torch.rand_like(Lc)
+    gsc, gxc = torch.autograd.grad(Lc, [sc, xc], gL)
+    sd, xd = s.to(DEV).requires_grad_(True), x.to(DEV).requires_grad_(True)
+    assert Fn.lag_corr_supported(sd, xd, G, (k,) * nd)
+    Ld = Fn.lag_corr(sd, xd, G, (k,) * nd)
+    gsd, gxd = torch.autograd.grad(Ld, [sd, xd], gL.to(DEV))
+    P.close("L", Ld, Lc)
+    P.close("gs", gsd, gsc)
+    P.close("gx", gxd, gxc)
+
+
+def test_gcorr_wgrad_is_deterministic_and_chunked():
+    """several voxel tiles per workgroup chunk (the per-chunk register sums) and run-to-run bit equality"""
+    from factorizer_amd import functional as Fn
+    torch.manual_seed(3)
+    B, G, Ci, Co, S = 2, 8, 16, 2, (8, 8, 130)            # 256 (sample, group, channel) triples -> 4 chunks of 3 tiles
+    x, gy = torch.rand(B, G * Ci, *S), torch.rand(B, G * Co, *S)
+    ref = torch.nn.grad.conv3d_weight(x.double(), (G * Co, Ci, 3, 3, 3), gy.double(), padding=1, groups=G).reshape(1, G, Co, Ci, 3, 3, 3)
+    a = Fn._gcorr_wgrad_raw(x.to(DEV), gy.to(DEV), (1, G, Co, Ci, 3, 3, 3))
+    b = Fn._gcorr_wgrad_raw(x.to(DEV), gy.to(DEV), (1, G, Co, Ci, 3, 3, 3))
+    assert torch.equal(a, b)
+    P.close("gw, 16640 voxels per filter tap", a, ref.float())
