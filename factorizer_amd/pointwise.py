@@ -558,9 +558,16 @@ class ConvK3Fn(torch.autograd.Function):
         V = D * H * W
         gx = None
         if ctx.needs_input_grad[0]:
-            # not on the training path (the stem's input is data); composed from ATen, and said so
-            _warn_composed("Conv3d(k=3) input gradient", x)
-            gx = torch.nn.grad.conv3d_input(x.shape, w, gy, padding=1)
+            # not on the training path (the stem's input is data): the adjoint is the same k3 correlation with the
+            # channel-transposed, spatially flipped filters — the generic tap loader of the GEMM family
+            if O % 2 == 0 and W % 4 == 0:
+                wt = torch.flip(w, dims=(2, 3, 4)).transpose(0, 1).contiguous()
+                gx = torch.empty_like(x)
+                _gemm([gy], wt, gx, B=B, Cin=O, Vin=V, M=C, K=27 * O, Ncol=V, loader=LOAD_K3, Di=D, Hi=H, Wi=W,
+                      name="conv_k3_dgrad")
+            else:
+                _warn_composed("Conv3d(k=3) input gradient", x)
+                gx = torch.nn.grad.conv3d_input(x.shape, w, gy, padding=1)
         gw = torch.empty_like(w)
         gb = torch.empty(O, dtype=torch.float32, device=x.device)
         if W % 32 == 0 and 27 * C <= 128:

@@ -143,7 +143,7 @@ def test_convs_bf16_storage():
         md = type(mod)(mod.in_channels, mod.out_channels, mod.kernel_size, stride=mod.stride, padding=mod.padding,
                        bias=mod.bias is not None).to(DEV)
         md.load_state_dict(mod.state_dict())
-        stem = name == "stem_k3"   # the stem's input is data: its input gradient is not a native kernel
+        stem = name == "stem_k3"   # the stem's input is data: its input gradient is not part of the training step
         xd = x.to(DEV, BF).requires_grad_(not stem)
         n0 = _native.launch_count()
         with warnings.catch_warnings():

@@ -31,9 +31,7 @@ def test_deconver_model_on_device(golden, tag):
             y_inf = model(x)                               # inference: update + division fused into the kernel
         names = [k for k, _ in model.named_parameters()]
         gy = g[f"{tag}:gy"].to(DEV)
-        pgrads = torch.autograd.grad(model(x.detach()), list(model.parameters()), gy, allow_unused=True)
-    # (the gradient w.r.t. the network INPUT goes through the stem's k3 input gradient, a framework op that says so)
-    grads = torch.autograd.grad(y, [x], gy) + pgrads
+        grads = torch.autograd.grad(y, [x] + list(model.parameters()), gy, allow_unused=True)
     torch.cuda.synchronize()
     assert _native.launch_count() > n0
     P.close("y", y, g[f"{tag}:y"])

@@ -373,7 +373,7 @@ def _fallback_cases():
 
 def _stem_gx():
     x = torch.randn(1, 4, 4, 4, 8, device=DEV, requires_grad=True)
-    w = torch.randn(8, 4, 3, 3, 3, device=DEV)
+    w = torch.randn(7, 4, 3, 3, 3, device=DEV)            # odd C_out: outside the tap loader of the adjoint GEMM
     (gx,) = torch.autograd.grad(PW.ConvK3Fn.apply(x, w, None).sum(), x)
     return gx
 
@@ -387,6 +387,26 @@ def test_every_composed_device_branch_warns(name):
     with pytest.warns(RuntimeWarning, match="composed framework ops|outside the native kernel set"):
         out = _fallback_cases()[name]()
     assert torch.isfinite(out.float()).all()
+
+
+@pytest.mark.parametrize("B,C,O,S", [(2, 4, 32, (8, 8, 16)), (1, 2, 8, (4, 6, 8)), (1, 4, 6, (5, 3, 12))])
+def test_stem_input_gradient_native(B, C, O, S):
+    """Conv3d(k3, p1) input gradient = the k3 correlation of gy with the channel-transposed, flipped filters through the
+    tap loader of the GEMM family (no framework op, no warning)."""
+    import warnings
+    torch.manual_seed(O)
+    x, w = torch.randn(B, C, *S), torch.randn(O, C, 3, 3, 3) / (27 * C) ** 0.5
+    xc = x.clone().requires_grad_(True)
+    yc = F.conv3d(xc, w, None, padding=1)
+    gy = torch.randn_like(yc)
+    (gxc,) = torch.autograd.grad(yc, xc, gy)
+    xd = x.to(DEV).requires_grad_(True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        yd = PW.ConvK3Fn.apply(xd, w.to(DEV), None)
+        (gxd,) = torch.autograd.grad(yd, xd, gy.to(DEV))
+    _cmp(yd, yc, "y")
+    _cmp(gxd, gxc, "gx")
 
 
 def test_odd_channel_stem_runs_native():
