@@ -115,7 +115,8 @@ class GemmDesc(_c.Structure):
 class MlpDesc(_c.Structure):
     _fields_ = [("mode", _i), ("inp", _vp), ("w1", _vp), ("w2", _vp), ("b1", _vp), ("b2", _vp), ("ln_g", _vp),
                 ("ln_b", _vp), ("ln_eps", _f), ("stats", _vp), ("z1", _vp), ("gz1", _vp), ("x1", _vp), ("out", _vp),
-                ("part", _vp), ("B", _i), ("C", _i), ("H", _i), ("V", _i64), ("act_dtype", _i)]
+                ("part", _vp), ("B", _i), ("C", _i), ("H", _i), ("V", _i64), ("act_dtype", _i), ("wpart", _vp),
+                ("gw1", _vp), ("gb1", _vp), ("gw2", _vp), ("gb2", _vp)]
 
 
 class WgradDesc(_c.Structure):
@@ -148,6 +149,8 @@ _SIGS.update({
     "fz_sw_finalize": ([_vp, _vp, _i, _i64, _vp], _i),
     "fz_mlp_supported": ([_i, _i, _i64], _i),
     "fz_mlp_partials": ([_i, _i64], _i64),
+    "fz_mlp_wgrad_rows": ([_i, _i64], _i),
+    "fz_mlp_wgrad_workspace_bytes": ([_i, _i64], _i64),
     "fz_mlp_chain": ([_c.POINTER(MlpDesc), _vp], _i),
     "fz_wgrad": ([_c.POINTER(WgradDesc), _vp, _vp], _i),
     "fz_wgrad_workspace_bytes": ([_c.POINTER(WgradDesc)], _i64),

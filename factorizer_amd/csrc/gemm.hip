@@ -749,6 +749,399 @@ __global__ __launch_bounds__(256, (NACC == 2 && HB == 2) ? 3 : 2) void gemm_chai
 }
 
 // =================================================================================================
+// MLP backward chain WITH the two weight gradients (C = 32, hidden 64): the unfused step reads g2 and z1
+// again for dW2 = g2 ⊗ gelu(z1) and writes + re-reads gz1 for dW1 = gz1 ⊗ LN(x1) — 13 plane-sets of traffic per
+// block (7 chain + 3 + 3) where 5 suffice (g2, z1 ×2, x1 in; gx1 out).  A weight gradient reduces over VOXELS, so
+// its MFMA operands need the channel on the lane axis; everything in the chain has the voxel there.  Each wave
+// turns its tile through wave-private LDS ([channel][voxel] rows, stride 68 ≡ 4 (mod 64): the 64 (channel16, k4)
+// lanes of a v_mfma_f32_16x16x4_f32 operand read hit 64 banks):
+//   Bf  32 x 64: g2 (operand of dW2) during the first pass, then LN-normalised x1 (operand of dW1, and the
+//                LayerNorm backward reads it back in the accumulator layout);
+//   T   16 x 64: one 16-channel block of gelu(z1) (pass A) resp. gz1 (pass B) at a time.
+// The (dW2 | dW1 | db2 | db1) sums stay in registers across the tiles of the persistent workgroup, are added
+// over its four waves through LDS at the end and leave as one row of `wpart` per workgroup;
+// chain_wg_finish_kernel adds the rows in index order (no float atomics) and applies the LayerNorm affine to dW1.
+// 13 KB of LDS per wave + 64 accumulator registers: two workgroups per CU (the plain chain runs three).
+// =================================================================================================
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kTS = 68;                       // LDS row stride of the transposable tiles (floats)
+constexpr int kWgRow = 2048 + 2048 + 32 + 64; // floats of one wpart row: dW2 [32][64] | S1 [64][32] | db2 | db1
+
+// gelu(x) and gelu'(x) with ONE exponential: erf(x/√2) by Abramowitz-Stegun 7.1.26 (fast_erf, fz_common.h) needs
+// exp(−x²/2), which is also the Gaussian density of gelu'
+__device__ __forceinline__ void gelu_both(float x, float& g, float& dg) {
+  const float ax = fabsf(x) * 0.70710678118654752f;
+  const float E = __expf(-0.5f * x * x);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float r = 1.0f - poly * E;                       // erf(|x|/√2)
+  const float cdf = 0.5f * (1.0f + (x < 0.f ? -r : r));
+  g = x * cdf;
+  dg = cdf + x * (0.3989422804014327f * E);
+}
+
+template <typename AT>
+__global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT> p, ChainArgsT<AT> c, int ntiles, float* wpart) {
+  constexpr int NACC = 2, HB = 2, HID = 64, N1 = 16 * HB * 64;
+  constexpr int kWave = 48 * kTS;             // floats of one wave's (Bf | T) region
+  extern __shared__ __attribute__((aligned(16))) float fz_lds_cw[];
+  float* As1 = fz_lds_cw;
+  float* As2 = As1 + N1;
+  float* tB = As2 + N1;                       // gamma[32]
+  float* red = tB + 32;                       // [4][64]
+  float* R = red + 256;                       // 4 wave regions
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int l16 = lane & 15, k4 = lane >> 4;
+  float* Bf = R + wave * kWave;
+  float* T = Bf + 32 * kTS;
+  const int tiles_per_sample = (int)((p.Ncol + 128 * NACC - 1) / (128 * NACC));
+
+  for (int base = threadIdx.x; base < 2 * N1; base += 256 * 8) {
+    float tmp[8];
+#pragma unroll
+    for (int uu = 0; uu < 8; ++uu) {
+      const int idx = base + uu * 256;
+      float wv;
+      if (idx < N1) {
+        const int l = idx & 63, rb = (idx >> 6) % HB, a = idx / (64 * HB);
+        wv = weight_at(p, rb * 32 + (l & 31), 2 * a + (l >> 5));
+      } else {
+        const int i2 = idx - N1;
+        const int l = i2 & 63, s2 = i2 >> 6;
+        const int r = s2 & 15, rb = s2 >> 4;
+        const int k = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), m = l & 31;
+        wv = c.wB_t ? c.wB[(int64_t)k * c.ldwB + m] : c.wB[(int64_t)m * c.ldwB + k];
+      }
+      tmp[uu] = wv;
+    }
+#pragma unroll
+    for (int uu = 0; uu < 8; ++uu) {
+      const int idx = base + uu * 256;
+      if (idx < N1) As1[idx] = tmp[uu]; else As2[idx - N1] = tmp[uu];
+    }
+  }
+  if (threadIdx.x < 32) tB[threadIdx.x] = p.lnb_g[threadIdx.x];
+
+  f32x4 dW2[2][4], dW1[4][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b4 = 0; b4 < 4; ++b4)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) { dW2[a][b4][v] = 0.f; dW1[b4][a][v] = 0.f; }
+  float db2[2] = {0.f, 0.f}, db1[4] = {0.f, 0.f, 0.f, 0.f};
+
+  int tile = blockIdx.x;
+  float bv[16][NACC];
+  auto fetch_tile = [&](int t) {
+    const int bt = t / tiles_per_sample;
+    const int64_t ct = ((int64_t)(t % tiles_per_sample) * 4 + wave) * (32 * NACC) + NACC * j;
+    const unsigned lo = (unsigned)h * (unsigned)p.Ncol + (unsigned)(ct < p.Ncol ? ct : 0);
+    const AT* xb = p.x[0] + (int64_t)bt * 32 * p.Ncol;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) vload<NACC>(xb + (int64_t)(2 * s) * p.Ncol + lo, bv[s]);
+  };
+  fetch_tile(tile);
+  __syncthreads();
+
+  for (; tile < ntiles; tile += gridDim.x) {
+    asm volatile("" ::: "memory");   // keep loop-invariant LDS reads out of VGPRs (see gemm_chain_kernel)
+    const int b = tile / tiles_per_sample;
+    const int64_t col_off = ((int64_t)(tile % tiles_per_sample) * 4 + wave) * (32 * NACC) + NACC * j;
+    const bool col_ok = col_off < p.Ncol;
+    const int64_t nc = col_ok ? col_off : 0;
+    const unsigned lane_row = (unsigned)(4 * h) * (unsigned)p.Ncol + (unsigned)nc;
+    const unsigned lane_par = (unsigned)h * (unsigned)p.Ncol + (unsigned)nc;
+    const int64_t sample = (int64_t)b * 32 * p.Ncol;
+
+    // ---- Bf <- g2 (lanes past the last column contribute zero to the voxel sums) ----
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+      *reinterpret_cast<float2*>(Bf + (2 * s + h) * kTS + 2 * j) = make_float2(col_ok ? bv[s][0] : 0.f, col_ok ? bv[s][1] : 0.f);
+
+    // ---- GEMM 1: gh = W2ᵀ g2 ----
+    f32x16 acc1[HB][NACC];
+#pragma unroll
+    for (int rb = 0; rb < HB; ++rb)
+#pragma unroll
+      for (int q = 0; q < NACC; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[rb][q][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+      for (int rb = 0; rb < HB; ++rb) {
+        const float av = As1[(s * HB + rb) * 64 + lane];
+#pragma unroll
+        for (int q = 0; q < NACC; ++q) acc1[rb][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[s][q], acc1[rb][q], 0, 0, 0);
+        if (rb == HB - 1 && (s & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+      }
+    // (the next tile's operand is requested after GEMM 2: its 32 registers would otherwise be live next to the 64
+    // gz1 accumulators and the 64 weight-gradient accumulators; the epilogue and the other resident waves cover
+    // the round trip)
+
+    // ---- pass A: 16 hidden channels at a time: gz1 = gh ∘ gelu'(z1) (kept in acc1); gelu(z1) -> T; dW2 += g2 ⊗ gelu(z1) ----
+#pragma unroll
+    for (int g8 = 0; g8 < 4; ++g8) {
+      // (compiler-only fence: the g2 operand reads below are the same for every group — left alone they are read once
+      // and kept in 32 registers across all four)
+      asm volatile("" ::: "memory");
+      float e[8][NACC];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int rr = g8 * 8 + i, rb = rr >> 4, r = rr & 15;
+        const int rbase = rb * 32 + (r & 3) + 8 * (r >> 2);
+        vload<NACC>(p.emul + ((int64_t)b * HID + rbase) * p.Ncol + lane_row, e[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int rr = g8 * 8 + i, rb = rr >> 4, r = rr & 15;
+        float gl[NACC];
+#pragma unroll
+        for (int q = 0; q < NACC; ++q) {
+          float dg;
+          gelu_both(e[i][q], gl[q], dg);
+          float gz = acc1[rb][q][r] * dg;
+          // pin the product HERE: its only readers are pass B and GEMM 2, and the optimiser otherwise sinks the
+          // gelu' evaluation (and with it the liveness of all 64 z1 values) down to them
+          asm volatile("" : "+v"(gz));
+          acc1[rb][q][r] = gz;
+        }
+        const int loc = (i & 3) + 8 * (i >> 2) + 4 * h;
+        *reinterpret_cast<float2*>(T + loc * kTS + 2 * j) = make_float2(col_ok ? gl[0] : 0.f, col_ok ? gl[1] : 0.f);
+      }
+#pragma unroll
+      for (int tc = 0; tc < 2; ++tc) {   // 8 voxel quads at a time: 24 LDS operands in flight, then 16 MFMAs
+        float bq[8], a0[8], a1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int t = tc * 8 + u;
+          bq[u] = T[l16 * kTS + 4 * t + k4];
+          a0[u] = Bf[l16 * kTS + 4 * t + k4];
+          a1[u] = Bf[(16 + l16) * kTS + 4 * t + k4];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          dW2[0][g8] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u], bq[u], dW2[0][g8], 0, 0, 0);
+          dW2[1][g8] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u], bq[u], dW2[1][g8], 0, 0, 0);
+        }
+        if (g8 == 0) {   // db2 = Σ_v g2 from the operands of the first group (pinned: the optimiser otherwise postpones
+                         // the sums — and keeps the operands alive — to the end of the tile)
+          db2[0] += ((a0[0] + a0[1]) + (a0[2] + a0[3])) + ((a0[4] + a0[5]) + (a0[6] + a0[7]));
+          db2[1] += ((a1[0] + a1[1]) + (a1[2] + a1[3])) + ((a1[4] + a1[5]) + (a1[6] + a1[7]));
+          asm volatile("" : "+v"(db2[0]), "+v"(db2[1]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- Bf <- LN-normalised x1 ----
+    const float* sp = p.lnb_stats + (int64_t)b * 2 * p.Ncol;
+    float mu[NACC], rs[NACC];
+    vload<NACC>(sp + nc, mu);
+    vload<NACC>(sp + p.Ncol + nc, rs);
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      float xv[8][NACC];
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) vload<NACC>(p.lnb_x + sample + (int64_t)(2 * (hf * 8 + s8)) * p.Ncol + lane_par, xv[s8]);
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8)
+        *reinterpret_cast<float2*>(Bf + (2 * (hf * 8 + s8) + h) * kTS + 2 * j) =
+            make_float2(col_ok ? (xv[s8][0] - mu[0]) * rs[0] : 0.f, col_ok ? (xv[s8][1] - mu[1]) * rs[1] : 0.f);
+    }
+
+    // ---- pass B: gz1 block -> T; S1 += gz1 ⊗ x̂, db1 += Σ gz1 ----
+#pragma unroll
+    for (int g8 = 0; g8 < 4; ++g8) {
+      asm volatile("" ::: "memory");   // as in pass A: re-read the x̂ operands per group instead of holding 32 registers
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int rr = g8 * 8 + i, rb = rr >> 4, r = rr & 15;
+        const int loc = (i & 3) + 8 * (i >> 2) + 4 * h;
+        *reinterpret_cast<float2*>(T + loc * kTS + 2 * j) = make_float2(col_ok ? acc1[rb][0][r] : 0.f, col_ok ? acc1[rb][1][r] : 0.f);
+      }
+#pragma unroll
+      for (int tc = 0; tc < 2; ++tc) {
+        float aq[8], b0[8], b1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int t = tc * 8 + u;
+          aq[u] = T[l16 * kTS + 4 * t + k4];
+          b0[u] = Bf[l16 * kTS + 4 * t + k4];
+          b1[u] = Bf[(16 + l16) * kTS + 4 * t + k4];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          dW1[g8][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[u], b0[u], dW1[g8][0], 0, 0, 0);
+          dW1[g8][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[u], b1[u], dW1[g8][1], 0, 0, 0);
+        }
+        db1[g8] += ((aq[0] + aq[1]) + (aq[2] + aq[3])) + ((aq[4] + aq[5]) + (aq[6] + aq[7]));
+        asm volatile("" : "+v"(db1[g8]));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- GEMM 2: gl = W1ᵀ gz1 straight from the accumulators ----
+    f32x16 acc2[NACC];
+#pragma unroll
+    for (int q = 0; q < NACC; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[q][r] = 0.f;
+#pragma unroll
+    for (int rb = 0; rb < HB; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float av = As2[(rb * 16 + r) * 64 + lane];
+#pragma unroll
+        for (int q = 0; q < NACC; ++q) acc2[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, acc1[rb][q][r], acc2[q], 0, 0, 0);
+        if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+    fetch_tile(tile + gridDim.x < ntiles ? tile + gridDim.x : tile);
+
+    // ---- LayerNorm backward + residual gradient (x̂ from Bf in the accumulator layout, g2 re-read: L2 / MALL) ----
+    float m1[NACC] = {0.f, 0.f}, m2[NACC] = {0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+      const float gc = tB[row];
+      const float2 xh = *reinterpret_cast<const float2*>(Bf + row * kTS + 2 * j);
+      const float a0 = acc2[0][r] * gc, a1 = acc2[1][r] * gc;
+      m1[0] += a0; m1[1] += a1;
+      m2[0] += a0 * xh.x; m2[1] += a1 * xh.y;
+    }
+#pragma unroll
+    for (int q = 0; q < NACC; ++q) {
+      m1[q] = (m1[q] + __shfl_xor(m1[q], 32, 64)) * (1.0f / 32.0f);
+      m2[q] = (m2[q] + __shfl_xor(m2[q], 32, 64)) * (1.0f / 32.0f);
+    }
+#pragma unroll
+    for (int r8 = 0; r8 < 2; ++r8) {      // 8 rows at a time: 8 residual loads in flight, then 8 rows out
+      float ga[8][NACC];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = r8 * 8 + i;
+        vload<NACC>(p.lnb_gadd + sample + (int64_t)((r & 3) + 8 * (r >> 2)) * p.Ncol + lane_row, ga[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = r8 * 8 + i;
+        const int rbase = (r & 3) + 8 * (r >> 2);
+        const int row = rbase + 4 * h;
+        const float gc = tB[row];
+        const float2 xh = *reinterpret_cast<const float2*>(Bf + row * kTS + 2 * j);
+        float v[NACC];
+        v[0] = rs[0] * (acc2[0][r] * gc - m1[0] - xh.x * m2[0]) + ga[i][0];
+        v[1] = rs[1] * (acc2[1][r] * gc - m1[1] - xh.y * m2[1]) + ga[i][1];
+        if (col_ok) vstore<NACC>(p.y + sample + (int64_t)rbase * p.Ncol + lane_row, v);
+        float sg = col_ok ? acc2[0][r] * xh.x + acc2[1][r] * xh.y : 0.f;
+        float sb = col_ok ? acc2[0][r] + acc2[1][r] : 0.f;
+        sg = half_sum32(sg);
+        sb = half_sum32(sb);
+        if ((lane & 31) == 31) {
+          red[wave * 64 + row] = sg;
+          red[wave * 64 + 32 + row] = sb;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int e = threadIdx.x;
+      p.lnb_part[(int64_t)tile * 64 + e] = (red[e] + red[64 + e]) + (red[128 + e] + red[192 + e]);
+    }
+    __syncthreads();
+  }
+
+  // ---- the workgroup's (dW2 | S1 | db2 | db1) row: add the four waves through LDS, waves in index order ----
+  float* row = wpart + (int64_t)blockIdx.x * kWgRow;
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) R[(wave * 32 + (a * 4 + cb) * 4 + v) * 64 + lane] = dW2[a][cb][v];
+  __syncthreads();
+  for (int e = threadIdx.x; e < 2048; e += 256) {
+    const int idx = e >> 6, l = e & 63;
+    const int a = idx >> 4, cb = (idx >> 2) & 3, v = idx & 3;
+    const float t = (R[e] + R[2048 + e]) + (R[4096 + e] + R[6144 + e]);
+    row[(16 * a + 4 * (l >> 4) + v) * 64 + 16 * cb + (l & 15)] = t;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) R[(wave * 32 + (cb * 2 + kh) * 4 + v) * 64 + lane] = dW1[cb][kh][v];
+  __syncthreads();
+  for (int e = threadIdx.x; e < 2048; e += 256) {
+    const int idx = e >> 6, l = e & 63;
+    const int cb = idx >> 3, kh = (idx >> 2) & 1, v = idx & 3;
+    const float t = (R[e] + R[2048 + e]) + (R[4096 + e] + R[6144 + e]);
+    row[2048 + (16 * cb + 4 * (l >> 4) + v) * 32 + 16 * kh + (l & 15)] = t;
+  }
+  __syncthreads();
+  R[(wave * 6 + 0) * 64 + lane] = db2[0];
+  R[(wave * 6 + 1) * 64 + lane] = db2[1];
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb) R[(wave * 6 + 2 + cb) * 64 + lane] = db1[cb];
+  __syncthreads();
+  if (threadIdx.x < 96) {
+    const int e = threadIdx.x, slot = e >> 4, i16 = e & 15;   // slots 0,1: db2 halves; 2..5: db1 blocks
+    float t = 0.f;
+    for (int w = 0; w < 4; ++w)
+      for (int kk = 0; kk < 4; ++kk) t += R[(w * 6 + slot) * 64 + kk * 16 + i16];
+    row[4096 + e] = t;
+  }
+}
+
+// gw2 = Σ rows dW2;  gb2, gb1 likewise;  gw1[c][k] = γ[k]·Σ S1[c][k] + β[k]·gb1[c]   (z1 = W1·(γ x̂ + β) + b1).
+// 256 threads = 16 elements x 16 row slices; slices walk the rows with stride 16 and are added in slice order.
+__global__ __launch_bounds__(256) void chain_wg_finish_kernel(const float* wpart, int rows, const float* ln_g, const float* ln_b,
+                                                              float* gw1, float* gb1, float* gw2, float* gb2) {
+  __shared__ float s[16][17];
+  __shared__ float sb1[64];
+  const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  auto total = [&](int e) {
+    float t = 0.f;
+    for (int r = sl; r < rows; r += 16) t += wpart[(int64_t)r * kWgRow + e];
+    return t;
+  };
+  // every block also needs db1 of the rows it scales: blocks over S1 recompute the 16-row slice sums of their db1 entry
+  const int e = blockIdx.x * 16 + el;
+  s[sl][el] = e < kWgRow ? total(e) : 0.f;
+  __syncthreads();
+  float v = 0.f;
+  if (sl == 0) {
+    for (int q = 0; q < 16; ++q) v += s[q][el];
+  }
+  const bool is_s1 = e >= 2048 && e < 4096;
+  if (is_s1) {   // uniform per block: 16 consecutive elements of one S1 row c
+    __syncthreads();
+    const int cidx = (blockIdx.x * 16 - 2048) / 32;
+    if (el == 0) s[sl][0] = total(4096 + 32 + cidx);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+      for (int q = 0; q < 16; ++q) t += s[q][0];
+      sb1[0] = t;
+    }
+    __syncthreads();
+  }
+  if (sl != 0 || e >= kWgRow) return;
+  if (e < 2048) gw2[e] = v;
+  else if (e < 4096) { const int k = (e - 2048) & 31; gw1[e - 2048] = ln_g[k] * v + ln_b[k] * sb1[0]; }
+  else if (e < 4096 + 32) gb2[e - 4096] = v;
+  else gb1[e - 4096 - 32] = v;
+}
+
+// =================================================================================================
 // Kernel B — streaming operand with a PF-deep register prefetch ring, any K, all loaders.
 // NACC = consecutive voxels per lane (4/2/1 → 128/64/32-column wave tiles): small tiles give the
 // deep, narrow stages (8^3..32^3 voxels, C = 128..512) enough workgroups to fill 256 CUs.
@@ -1308,6 +1701,17 @@ extern "C" int64_t fz_mlp_partials(int B, int64_t V) {
   return ((V + tw - 1) / tw) * (int64_t)B;
 }
 
+// rows of `wpart` (fz_mlp_desc mode 2): one per resident workgroup (two per CU), kWgRow floats each
+extern "C" int fz_mlp_wgrad_rows(int B, int64_t V) {
+  const int64_t nt = fz_mlp_partials(B, V);
+  int wgs = 512;
+  { const char* e = getenv("FZ_MLP_WG_WGS"); if (e && atoi(e) > 0) wgs = atoi(e); }
+  return (int)(nt < wgs ? nt : wgs);
+}
+extern "C" int64_t fz_mlp_wgrad_workspace_bytes(int B, int64_t V) {
+  return (int64_t)fz_mlp_wgrad_rows(B, V) * kWgRow * (int64_t)sizeof(float);
+}
+
 extern "C" int fz_mlp_supported(int C, int H, int64_t V) {
   return (C == 32 && (H == 64 || H == 128) && V > 0 && (V % 4) == 0 && V <= ((int64_t)1 << 27)) ? 1 : 0;
 }
@@ -1320,8 +1724,20 @@ static int mlp_launch(const fz_mlp_desc* d, fz_stream_t stream) {
     return fail(FZ_E_ARG, "fz_mlp_chain: null pointer");
   if (d->mode == 0 && (!d->ln_g || !d->ln_b)) return fail(FZ_E_ARG, "fz_mlp_chain: forward needs the LayerNorm affine");
   if (d->mode == 1 && (!d->gz1 || !d->x1 || !d->ln_g || !d->part)) return fail(FZ_E_ARG, "fz_mlp_chain: backward needs gz1, x1, gamma, part");
-  if (d->mode != 0 && d->mode != 1) return fail(FZ_E_ARG, "fz_mlp_chain: bad mode");
-  if (d->B == 0) return FZ_OK;
+  if (d->mode == 2 && (!d->x1 || !d->ln_g || !d->ln_b || !d->part || !d->wpart || !d->gw1 || !d->gb1 || !d->gw2 || !d->gb2))
+    return fail(FZ_E_ARG, "fz_mlp_chain: backward with weight gradients needs x1, gamma, beta, part, wpart, gw1, gb1, gw2, gb2");
+  if (d->mode == 2 && d->H != 64) return fail(FZ_E_UNSUPPORTED, "fz_mlp_chain: the fused weight gradients need H == 64");
+  if (d->mode < 0 || d->mode > 2) return fail(FZ_E_ARG, "fz_mlp_chain: bad mode");
+  if (d->B == 0) {
+    if (d->mode == 2) {   // no voxels: the sums are empty
+      hipStream_t s0 = (hipStream_t)stream;
+      FZ_HIP_OK(hipMemsetAsync(d->gw1, 0, sizeof(float) * 64 * 32, s0));
+      FZ_HIP_OK(hipMemsetAsync(d->gw2, 0, sizeof(float) * 64 * 32, s0));
+      FZ_HIP_OK(hipMemsetAsync(d->gb1, 0, sizeof(float) * 64, s0));
+      FZ_HIP_OK(hipMemsetAsync(d->gb2, 0, sizeof(float) * 32, s0));
+    }
+    return FZ_OK;
+  }
   GemmArgsT<AT> a = {};
   ChainArgsT<AT> c = {};
   a.x[0] = (const AT*)d->in; a.nsrc = 1; a.c0 = 32; a.Cin = 32; a.Vin = d->V; a.M = d->H; a.K = 32; a.Ncol = d->V; a.B = d->B;
@@ -1338,6 +1754,21 @@ static int mlp_launch(const fz_mlp_desc* d, fz_stream_t stream) {
     c.biasB = d->b2; c.side = (AT*)d->z1;
     if (d->H == 128) hipLaunchKernelGGL((gemm_chain_kernel<false, 2, 4>), grid, block, 0, st, a, c, ntiles);
     else hipLaunchKernelGGL((gemm_chain_kernel<false, 2, 2>), grid, block, 0, st, a, c, ntiles);
+  } else if (d->mode == 2) {
+    a.w = d->w2; a.w_t = 1; a.ldw = d->H;
+    a.emul = (const AT*)d->z1; a.y = (AT*)d->out;
+    a.lnb_x = (const AT*)d->x1; a.lnb_stats = d->stats; a.lnb_g = d->ln_g; a.lnb_gadd = (const AT*)d->in; a.lnb_part = d->part;
+    c.wB = d->w1; c.wB_t = 1; c.ldwB = 32;
+    const int rows = fz_mlp_wgrad_rows(d->B, d->V);
+    constexpr int lds = (2 * 2048 + 32 + 256 + 4 * 48 * kTS) * (int)sizeof(float);
+    auto kern = gemm_chain_bwd_wg_kernel<AT>;
+    FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)rows), block, lds, st, a, c, ntiles, (float*)d->wpart);
+    FZ_LAUNCH_CHECK();
+    hipLaunchKernelGGL(chain_wg_finish_kernel, dim3(kWgRow / 16), dim3(256), 0, st, (const float*)d->wpart, rows, d->ln_g, d->ln_b,
+                       d->gw1, d->gb1, d->gw2, d->gb2);
+    FZ_LAUNCH_CHECK();
+    return FZ_OK;
   } else {
     a.w = d->w2; a.w_t = 1; a.ldw = d->H;            // A1[m = hidden][k = c] = W2[c][hidden]
     a.emul = (const AT*)d->z1; a.y = (AT*)d->out;

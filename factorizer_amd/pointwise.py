@@ -192,6 +192,43 @@ def _mlp_bwd_chain(g2, z1, w12, w22, x1, st, ln_w):
     return gz1, gx1, gpar[:32], gpar[32:]
 
 
+def _mlp_wgrad_fused_ok(C, Hd, V):
+    """the chain backward that also forms dW1, db1, dW2, db2 (csrc/gemm.hip gemm_chain_bwd_wg_kernel): hidden 64"""
+    return _mlp_chain_ok(C, Hd, V) and Hd == 64 and os.environ.get("FZ_MLP_FUSED_WGRAD", "1") != "0"
+
+
+def _mlp_bwd_chain_wgrad(g2, z1, w12, w22, x1, st, ln_w, ln_b):
+    """(gx1, gγ, gβ, gw1, gb1, gw2, gb2) in ONE pass over (g2, z1, x1): gz1 never reaches HBM."""
+    B, C = x1.shape[:2]
+    V = _vox(x1)
+    Hd = w12.shape[0]
+    dev = x1.device
+    gx1 = torch.empty_like(x1)
+    rows = N.lib().fz_mlp_partials(B, V)
+    part = torch.empty((rows, 64), dtype=torch.float32, device=dev)
+    gpar = torch.empty(64, dtype=torch.float32, device=dev)
+    tmp = torch.empty((64, 64), dtype=torch.float32, device=dev)
+    wpart = torch.empty(N.lib().fz_mlp_wgrad_workspace_bytes(B, V) // 4, dtype=torch.float32, device=dev)
+    gw1 = torch.empty((Hd, C), dtype=torch.float32, device=dev)
+    gw2 = torch.empty((C, Hd), dtype=torch.float32, device=dev)
+    gb1 = torch.empty(Hd, dtype=torch.float32, device=dev)
+    gb2 = torch.empty(C, dtype=torch.float32, device=dev)
+    d = N.MlpDesc()
+    d.mode, d.inp, d.w1, d.w2 = 2, g2.data_ptr(), w12.data_ptr(), w22.data_ptr()
+    d.ln_g, d.ln_b, d.stats, d.z1, d.x1 = ln_w.data_ptr(), ln_b.data_ptr(), st.data_ptr(), z1.data_ptr(), x1.data_ptr()
+    d.out, d.part, d.wpart = gx1.data_ptr(), part.data_ptr(), wpart.data_ptr()
+    d.gw1, d.gb1, d.gw2, d.gb2 = gw1.data_ptr(), gb1.data_ptr(), gw2.data_ptr(), gb2.data_ptr()
+    d.B, d.C, d.H, d.V = B, C, Hd, V
+    d.act_dtype = N.act_dtype(x1)
+    with torch.cuda.device(dev):
+        rc = Fn._timed(f"mlp_chain_bwd_wgrad_{C}", x1.element_size() * (3 * x1.numel() + z1.numel()),
+                       lambda: N.lib().fz_mlp_chain(ctypes.byref(d), N.stream_ptr(x1)))
+        N.check(rc, "fz_mlp_chain")
+        rc = N.lib().fz_reduce_rows(part.data_ptr(), rows, 64, gpar.data_ptr(), tmp.data_ptr(), N.stream_ptr(x1))
+        N.check(rc, "fz_reduce_rows")
+    return gx1, gpar[:32], gpar[32:], gw1, gb1, gw2, gb2
+
+
 _SIDE = {}
 
 
@@ -740,22 +777,26 @@ class FactorizerBlockFn(torch.autograd.Function):
 
         # --- MLP ---
         chain = _mlp_chain_ok(C, Hd, V)
-        if chain:
-            gz1, gx1, gg2, gbt2 = _mlp_bwd_chain(g2, z1, w12, w22, x1, st2, n2w)   # + residual path of the MLP
+        if _mlp_wgrad_fused_ok(C, Hd, V):
+            # input-gradient chain + both weight gradients in one pass over (g2, z1, x1)
+            gx1, gg2, gbt2, gw1, gb1, gw2, gb2 = _mlp_bwd_chain_wgrad(g2, z1, w12, w22, x1, st2, n2w, n2b)
         else:
-            gz1 = torch.empty_like(z1)
-            _gemm([g2], w22, gz1, B=B, Cin=C, Vin=V, M=Hd, K=C, Ncol=V, w_t=True, ldw=Hd, emul=z1,
-                  emul_kind=ACT["gelu"], name="linear_dgrad")
-        gw2 = torch.empty_like(w22)
-        gb2 = torch.empty(C, dtype=torch.float32, device=dev)
-        wgrad(g2, [z1], gw2, B=B, M=C, Cin=Hd, K=Hd, Vq=V, Ncols=V, gbias=gb2, qact=ACT["gelu"], name="wgrad_linear")
-        if not chain:
-            gx1, gg2, gbt2 = _dgrad_lnbwd(gz1, w12, x1, st2, n2w, g2)      # + residual path of the MLP
-        gw1 = torch.empty_like(w12)
-        gb1 = torch.empty(Hd, dtype=torch.float32, device=dev)
-        wgrad(gz1, [x1], gw1, B=B, M=Hd, Cin=C, K=C, Vq=V, Ncols=V, gbias=gb1, stats=st2, ln=(n2w, n2b),
-               name="wgrad_ln_linear")
-        del gz1
+            if chain:
+                gz1, gx1, gg2, gbt2 = _mlp_bwd_chain(g2, z1, w12, w22, x1, st2, n2w)   # + residual path of the MLP
+            else:
+                gz1 = torch.empty_like(z1)
+                _gemm([g2], w22, gz1, B=B, Cin=C, Vin=V, M=Hd, K=C, Ncol=V, w_t=True, ldw=Hd, emul=z1,
+                      emul_kind=ACT["gelu"], name="linear_dgrad")
+            gw2 = torch.empty_like(w22)
+            gb2 = torch.empty(C, dtype=torch.float32, device=dev)
+            wgrad(g2, [z1], gw2, B=B, M=C, Cin=Hd, K=Hd, Vq=V, Ncols=V, gbias=gb2, qact=ACT["gelu"], name="wgrad_linear")
+            if not chain:
+                gx1, gg2, gbt2 = _dgrad_lnbwd(gz1, w12, x1, st2, n2w, g2)      # + residual path of the MLP
+            gw1 = torch.empty_like(w12)
+            gb1 = torch.empty(Hd, dtype=torch.float32, device=dev)
+            wgrad(gz1, [x1], gw1, B=B, M=Hd, Cin=C, K=C, Vq=V, Ncols=V, gbias=gb1, stats=st2, ln=(n2w, n2b),
+                   name="wgrad_ln_linear")
+            del gz1
         # --- out_proj ---
         ga = torch.empty_like(a)
         _gemm([gx1], wout2, ga, B=B, Cin=C, Vin=V, M=C, K=C, Ncol=V, w_t=True, ldw=C, name="linear_dgrad")

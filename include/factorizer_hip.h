@@ -224,6 +224,10 @@ int fz_gemm(const fz_gemm_desc* desc, fz_stream_t stream);
  *           out = LayerNormBackward(W1ᵀ·gz1; x1, stats, gamma) + in ; part receives
  *           fz_mlp_partials(B, V) rows of 64 floats (dgamma | dbeta partial sums, reduce with
  *           fz_reduce_rows)
+ *   mode 2  (H = 64) mode 1 WITH the two weight gradients and bias gradients of the MLP, gz1 never reaching
+ *           HBM: gw2 (C, H) = sum_v in[.,v] gelu(z1[.,v])^T, gb2 (C) = sum_v in, gb1 (H) = sum_v gz1,
+ *           gw1 (H, C) = sum_v gz1 (ln_g * xhat + ln_b)^T.  wpart: fz_mlp_wgrad_workspace_bytes(B, V) bytes of
+ *           caller workspace (one row of partial sums per resident workgroup, added in row order).
  */
 typedef struct fz_mlp_desc {
   int mode;
@@ -244,10 +248,17 @@ typedef struct fz_mlp_desc {
   int B, C, H;
   int64_t V;
   int act_dtype;      /* FZ_STORE_F32 / FZ_STORE_BF16                                        */
+  void* wpart;        /* mode 2: workspace, fz_mlp_wgrad_workspace_bytes(B, V)                */
+  float* gw1;         /* mode 2: (H, C)                                                      */
+  float* gb1;         /* mode 2: (H)                                                         */
+  float* gw2;         /* mode 2: (C, H)                                                      */
+  float* gb2;         /* mode 2: (C)                                                         */
 } fz_mlp_desc;
 
 int fz_mlp_supported(int C, int H, int64_t V);
 int64_t fz_mlp_partials(int B, int64_t V);
+int fz_mlp_wgrad_rows(int B, int64_t V);
+int64_t fz_mlp_wgrad_workspace_bytes(int B, int64_t V);
 int fz_mlp_chain(const fz_mlp_desc* desc, fz_stream_t stream);
 
 /* ---- weight gradients of the GEMM family ------------------------------------------------

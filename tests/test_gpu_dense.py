@@ -310,6 +310,49 @@ def test_mlp_chain_kernel(B, S, Hd):
     _cmp(gb, lb.grad, "dbeta")
 
 
+@pytest.mark.parametrize("bf", [False, True])
+@pytest.mark.parametrize("B,S", [(2, (8, 8, 8)), (1, (6, 4, 5)), (2, (16, 16, 12)), (3, (32, 32, 40))])
+def test_mlp_chain_backward_with_weight_gradients(B, S, bf):
+    """fz_mlp_chain mode 2 (gemm_chain_bwd_wg_kernel): the input-gradient chain AND dW1, db1, dW2, db2 of the MLP from
+    one pass over (g2, z1, x1) — transposed MFMA operands through wave-private LDS, sums carried across the tiles of
+    the persistent workgroups, rows added in order.  Against CPU autograd of x + fc2(gelu(fc1(LN(x)))); V = 120
+    covers a ragged tile, (3, 32·32·40) several tiles per workgroup.  Run twice: bit-identical."""
+    torch.manual_seed(11)
+    C, Hd = 32, 64
+    rnd = (lambda t: t.bfloat16().float()) if bf else (lambda t: t)
+    x = rnd(torch.randn(B, C, *S) * 2 + 0.5)
+    ln_w, ln_b = torch.rand(C) + 0.5, torch.randn(C) * 0.1
+    w1, b1 = torch.randn(Hd, C) * 0.2, torch.randn(Hd) * 0.1
+    w2, b2 = torch.randn(C, Hd) * 0.2, torch.randn(C) * 0.1
+    g2 = rnd(torch.randn(B, C, *S))
+    dt = torch.bfloat16 if bf else torch.float32
+    d = lambda t: t.to(DEV).contiguous()  # noqa: E731
+    xd, g2d = d(x).to(dt), d(g2).to(dt)
+    x2, z1, st = PW._mlp_fwd_chain(xd, d(ln_w), d(ln_b), 1e-5, d(w1), d(b1), d(w2), d(b2))
+    xc = x.clone().requires_grad_(True)
+    prm = [t.clone().requires_grad_(True) for t in (ln_w, ln_b, w1, b1, w2, b2)]
+    xn = F.layer_norm(xc.movedim(1, -1), (C,), prm[0], prm[1], 1e-5).movedim(-1, 1)
+    z1c = _lin_cpu(xn, prm[2].unsqueeze(-1), prm[3])
+    if bf:
+        # the backward reads the STORED pre-activation (bf16): give the CPU graph exactly those values (a bf16 tie
+        # broken the other way is 2^-8 of one addend, far above the bound on the voxel sums)
+        z1c = z1c + (z1.float().cpu().reshape(z1c.shape) - z1c.detach())
+    yc = xc + _lin_cpu(F.gelu(z1c), prm[4].unsqueeze(-1), prm[5])
+    gxc, ggc, gbc, gw1c, gb1c, gw2c, gb2c = torch.autograd.grad(yc, [xc] + prm, g2)
+    assert PW._mlp_wgrad_fused_ok(C, Hd, x[0, 0].numel())
+    n0 = _native.launch_count()
+    out = PW._mlp_bwd_chain_wgrad(g2d, z1, d(w1), d(w2), xd, st, d(ln_w), d(ln_b))
+    assert _native.launch_count() - n0 >= 2
+    out2 = PW._mlp_bwd_chain_wgrad(g2d, z1, d(w1), d(w2), xd, st, d(ln_w), d(ln_b))
+    for a, b in zip(out, out2):
+        assert torch.equal(a, b)
+    names = ("gx1", "dgamma", "dbeta", "gw1", "gb1", "gw2", "gb2")
+    refs = (gxc, ggc, gbc, gw1c, gb1c, gw2c, gb2c)
+    why = "bf16 activation storage: gx1 is rounded once on store (2^-9 relative)" if bf else None
+    for n, a, r in zip(names, out, refs):
+        _cmp(a.float(), r, n, rtol=(4e-3 if n == "gx1" else 1e-4) if bf else 1e-4, why=why if (bf and n == "gx1") else None)
+
+
 def test_flat_adamw_kernel_matches_torch():
     """fz_adamw_step (csrc/optim.hip) against torch.optim.AdamW on the CPU: 5 steps over a 1 000 003-element
     buffer (odd length: vector body + scalar tail), lr 1e-4 / wd 1e-5 of train.yaml:72-76."""
