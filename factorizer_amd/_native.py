@@ -119,6 +119,12 @@ class MlpDesc(_c.Structure):
                 ("gw1", _vp), ("gb1", _vp), ("gw2", _vp), ("gb2", _vp)]
 
 
+class GemmDwDesc(_c.Structure):
+    _fields_ = [("g", _vp), ("q", _vp), ("w", _vp), ("ln", _i), ("stats", _vp), ("ln_g", _vp), ("ln_b", _vp), ("gadd", _vp),
+                ("y", _vp), ("part", _vp), ("wpart", _vp), ("gw", _vp), ("gb", _vp), ("B", _i), ("C", _i), ("V", _i64),
+                ("act_dtype", _i)]
+
+
 class WgradDesc(_c.Structure):
     _fields_ = [("p", _vp), ("M", _i), ("pmul", _vp), ("pmul_kind", _i), ("q", _vp * 4), ("nsrc", _i),
                 ("src_mode", _i), ("c0", _i), ("Cin", _i), ("K", _i), ("Vq", _i64), ("D", _i), ("H", _i),
@@ -150,6 +156,9 @@ _SIGS.update({
     "fz_mlp_supported": ([_i, _i, _i64], _i),
     "fz_mlp_partials": ([_i, _i64], _i64),
     "fz_mlp_wgrad_rows": ([_i, _i64], _i),
+    "fz_gemm_dw_rows": ([_i, _i64], _i),
+    "fz_gemm_dw_workspace_bytes": ([_i, _i64], _i64),
+    "fz_gemm_dw": ([_c.POINTER(GemmDwDesc), _vp], _i),
     "fz_mlp_wgrad_workspace_bytes": ([_i, _i64], _i64),
     "fz_mlp_chain": ([_c.POINTER(MlpDesc), _vp], _i),
     "fz_wgrad": ([_c.POINTER(WgradDesc), _vp, _vp], _i),

@@ -1142,6 +1142,281 @@ __global__ __launch_bounds__(256) void chain_wg_finish_kernel(const float* wpart
 }
 
 // =================================================================================================
+// Input gradient AND weight gradient of a 32 -> 32 layer in one pass (C = 32: in_proj behind LayerNorm, out_proj):
+//   y  = Wᵀ g                                   (LNB: then the LayerNorm backward on the accumulators, + gadd)
+//   dW = Σ_v g[m][v] · q[k][v],  db = Σ_v g     (LNB: q = LN-normalised x; the affine is applied by the finish kernel)
+// Unfused, the weight-gradient launch reads g and q a second time (2 of the 6 resp. 4 plane-sets of the pair).  Both
+// MFMA operands of dW come straight from memory in [channel][voxel] order, so each wave parks its g tile and its q
+// tile in LDS (stride kTS) and reads them back with the channel on the lane axis — no register transposes.
+// Persistent workgroups (two per CU), sums carried in registers across tiles, one wpart row per workgroup.
+// =================================================================================================
+constexpr int kDwRow = 1024 + 32;   // floats of one wpart row: dW [32][32] | db [32]
+
+template <typename AT>
+struct DwArgsT {
+  const AT* g;        // (B, 32, V) gradient of the layer output
+  const AT* q;        // (B, 32, V) layer input (LNB: the LayerNorm input)
+  const float* w;     // (32, 32) forward weight W[m][k]
+  const float* stats; // LNB: (B, 2, V)
+  const float* ln_g;  // LNB: gamma
+  const AT* gadd;     // LNB: (B, 32, V) added to y, or null
+  AT* y;              // (B, 32, V)
+  float* part;        // LNB: [ntiles][64] (dgamma | dbeta) partial rows
+  float* wpart;       // [gridDim.x][kDwRow]
+  int64_t V;
+  int B;
+};
+
+template <bool LNB, typename AT>
+__global__ __launch_bounds__(256, 2) void gemm_dw_kernel(DwArgsT<AT> p, int ntiles) {
+  constexpr int NACC = 2;
+  constexpr int kWave = 64 * kTS;             // floats of one wave's (Gb | Qb) region
+  extern __shared__ __attribute__((aligned(16))) float fz_lds_dw[];
+  float* As = fz_lds_dw;                      // [16][64] operand order: A[m][k] = W[k][m]
+  float* tB = As + 1024;                      // gamma[32]
+  float* red = tB + 32;                       // [4][64]
+  float* R = red + 256;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int l16 = lane & 15, k4 = lane >> 4;
+  float* Gb = R + wave * kWave;
+  float* Qb = Gb + 32 * kTS;
+  const int tiles_per_sample = (int)((p.V + 128 * NACC - 1) / (128 * NACC));
+
+  for (int idx = threadIdx.x; idx < 1024; idx += 256) {
+    const int l = idx & 63, a = idx >> 6;
+    As[idx] = p.w[(int64_t)(2 * a + (l >> 5)) * 32 + (l & 31)];   // A[m = l&31][k = 2a + h] = W[k][m]
+  }
+  if (LNB && threadIdx.x < 32) tB[threadIdx.x] = p.ln_g[threadIdx.x];
+
+  f32x4 dW[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) dW[a][b2][v] = 0.f;
+  float db[2] = {0.f, 0.f};
+
+  int tile = blockIdx.x;
+  float bv[16][NACC];
+  auto fetch_tile = [&](int t) {
+    const int bt = t / tiles_per_sample;
+    const int64_t ct = ((int64_t)(t % tiles_per_sample) * 4 + wave) * (32 * NACC) + NACC * j;
+    const unsigned lo = (unsigned)h * (unsigned)p.V + (unsigned)(ct < p.V ? ct : 0);
+    const AT* xb = p.g + (int64_t)bt * 32 * p.V;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) vload<NACC>(xb + (int64_t)(2 * s) * p.V + lo, bv[s]);
+  };
+  fetch_tile(tile);
+  __syncthreads();
+
+  for (; tile < ntiles; tile += gridDim.x) {
+    asm volatile("" ::: "memory");
+    const int b = tile / tiles_per_sample;
+    const int64_t col_off = ((int64_t)(tile % tiles_per_sample) * 4 + wave) * (32 * NACC) + NACC * j;
+    const bool col_ok = col_off < p.V;
+    const int64_t nc = col_ok ? col_off : 0;
+    const unsigned lane_row = (unsigned)(4 * h) * (unsigned)p.V + (unsigned)nc;
+    const unsigned lane_par = (unsigned)h * (unsigned)p.V + (unsigned)nc;
+    const int64_t sample = (int64_t)b * 32 * p.V;
+
+    // ---- q tile -> Qb (LNB: normalised), in two halves of 8 loads ----
+    float mu[NACC] = {0.f, 0.f}, rs[NACC] = {1.f, 1.f};
+    if (LNB) {
+      const float* sp = p.stats + (int64_t)b * 2 * p.V;
+      vload<NACC>(sp + nc, mu);
+      vload<NACC>(sp + p.V + nc, rs);
+    }
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      float xv[8][NACC];
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) vload<NACC>(p.q + sample + (int64_t)(2 * (hf * 8 + s8)) * p.V + lane_par, xv[s8]);
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8)
+        *reinterpret_cast<float2*>(Qb + (2 * (hf * 8 + s8) + h) * kTS + 2 * j) =
+            make_float2(col_ok ? (xv[s8][0] - mu[0]) * rs[0] : 0.f, col_ok ? (xv[s8][1] - mu[1]) * rs[1] : 0.f);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- g tile -> Gb ----
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+      *reinterpret_cast<float2*>(Gb + (2 * s + h) * kTS + 2 * j) = make_float2(col_ok ? bv[s][0] : 0.f, col_ok ? bv[s][1] : 0.f);
+
+    // ---- y = Wᵀ g ----
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int q = 0; q < NACC; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const float av = As[s * 64 + lane];
+#pragma unroll
+      for (int q = 0; q < NACC; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[s][q], acc[q], 0, 0, 0);
+    }
+    fetch_tile(tile + gridDim.x < ntiles ? tile + gridDim.x : tile);
+
+    // ---- dW += g ⊗ q, db += Σ g ----
+#pragma unroll
+    for (int tc = 0; tc < 2; ++tc) {
+      float a0[8], a1[8], b0[8], b1[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = tc * 8 + u;
+        a0[u] = Gb[l16 * kTS + 4 * t + k4];
+        a1[u] = Gb[(16 + l16) * kTS + 4 * t + k4];
+        b0[u] = Qb[l16 * kTS + 4 * t + k4];
+        b1[u] = Qb[(16 + l16) * kTS + 4 * t + k4];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        dW[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u], b0[u], dW[0][0], 0, 0, 0);
+        dW[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u], b1[u], dW[0][1], 0, 0, 0);
+        dW[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u], b0[u], dW[1][0], 0, 0, 0);
+        dW[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u], b1[u], dW[1][1], 0, 0, 0);
+      }
+      db[0] += ((a0[0] + a0[1]) + (a0[2] + a0[3])) + ((a0[4] + a0[5]) + (a0[6] + a0[7]));
+      db[1] += ((a1[0] + a1[1]) + (a1[2] + a1[3])) + ((a1[4] + a1[5]) + (a1[6] + a1[7]));
+      asm volatile("" : "+v"(db[0]), "+v"(db[1]));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    if (!LNB) {
+      if (col_ok) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rbase = (r & 3) + 8 * (r >> 2);
+          float v[NACC] = {acc[0][r], acc[1][r]};
+          vstore<NACC>(p.y + sample + (int64_t)rbase * p.V + lane_row, v);
+        }
+      }
+    } else {
+      float m1[NACC] = {0.f, 0.f}, m2[NACC] = {0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float gc = tB[row];
+        const float2 xh = *reinterpret_cast<const float2*>(Qb + row * kTS + 2 * j);
+        const float a0 = acc[0][r] * gc, a1 = acc[1][r] * gc;
+        m1[0] += a0; m1[1] += a1;
+        m2[0] += a0 * xh.x; m2[1] += a1 * xh.y;
+      }
+#pragma unroll
+      for (int q = 0; q < NACC; ++q) {
+        m1[q] = (m1[q] + __shfl_xor(m1[q], 32, 64)) * (1.0f / 32.0f);
+        m2[q] = (m2[q] + __shfl_xor(m2[q], 32, 64)) * (1.0f / 32.0f);
+      }
+#pragma unroll
+      for (int r8 = 0; r8 < 2; ++r8) {
+        float ga[8][NACC];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int r = r8 * 8 + i;
+          if (p.gadd != nullptr) vload<NACC>(p.gadd + sample + (int64_t)((r & 3) + 8 * (r >> 2)) * p.V + lane_row, ga[i]);
+          else ga[i][0] = ga[i][1] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int r = r8 * 8 + i;
+          const int rbase = (r & 3) + 8 * (r >> 2);
+          const int row = rbase + 4 * h;
+          const float gc = tB[row];
+          const float2 xh = *reinterpret_cast<const float2*>(Qb + row * kTS + 2 * j);
+          float v[NACC];
+          v[0] = rs[0] * (acc[0][r] * gc - m1[0] - xh.x * m2[0]) + ga[i][0];
+          v[1] = rs[1] * (acc[1][r] * gc - m1[1] - xh.y * m2[1]) + ga[i][1];
+          if (col_ok) vstore<NACC>(p.y + sample + (int64_t)rbase * p.V + lane_row, v);
+          float sg = col_ok ? acc[0][r] * xh.x + acc[1][r] * xh.y : 0.f;
+          float sb = col_ok ? acc[0][r] + acc[1][r] : 0.f;
+          sg = half_sum32(sg);
+          sb = half_sum32(sb);
+          if ((lane & 31) == 31) {
+            red[wave * 64 + row] = sg;
+            red[wave * 64 + 32 + row] = sb;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __syncthreads();
+      if (threadIdx.x < 64) {
+        const int e = threadIdx.x;
+        p.part[(int64_t)tile * 64 + e] = (red[e] + red[64 + e]) + (red[128 + e] + red[192 + e]);
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- workgroup row: (dW | db), waves added in index order ----
+  float* row = p.wpart + (int64_t)blockIdx.x * kDwRow;
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) R[(wave * 16 + (a * 2 + b2) * 4 + v) * 64 + lane] = dW[a][b2][v];
+  __syncthreads();
+  for (int e = threadIdx.x; e < 1024; e += 256) {
+    const int idx = e >> 6, l = e & 63;
+    const int a = idx >> 3, b2 = (idx >> 2) & 1, v = idx & 3;
+    const float t = (R[e] + R[1024 + e]) + (R[2048 + e] + R[3072 + e]);
+    row[(16 * a + 4 * (l >> 4) + v) * 32 + 16 * b2 + (l & 15)] = t;
+  }
+  __syncthreads();
+  R[(wave * 2 + 0) * 64 + lane] = db[0];
+  R[(wave * 2 + 1) * 64 + lane] = db[1];
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const int e = threadIdx.x, slot = e >> 4, i16 = e & 15;
+    float t = 0.f;
+    for (int w = 0; w < 4; ++w)
+      for (int kk = 0; kk < 4; ++kk) t += R[(w * 2 + slot) * 64 + kk * 16 + i16];
+    row[1024 + e] = t;
+  }
+}
+
+// gw[m][k] = (ln ? γ[k]·S[m][k] + β[k]·sg[m] : S[m][k]),  gb[m] = sg[m] (when wanted); rows added in slice order
+__global__ __launch_bounds__(256) void dw_finish_kernel(const float* wpart, int rows, const float* ln_g, const float* ln_b,
+                                                        float* gw, float* gb) {
+  __shared__ float s[16][17];
+  __shared__ float sm;
+  const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  auto total = [&](int e) {
+    float t = 0.f;
+    for (int r = sl; r < rows; r += 16) t += wpart[(int64_t)r * kDwRow + e];
+    return t;
+  };
+  const int e = blockIdx.x * 16 + el;      // kDwRow = 66 x 16
+  s[sl][el] = total(e);
+  __syncthreads();
+  float v = 0.f;
+  if (sl == 0)
+    for (int q = 0; q < 16; ++q) v += s[q][el];
+  const bool is_w = e < 1024;              // uniform per block
+  if (is_w && ln_g != nullptr) {
+    __syncthreads();
+    const int m = (blockIdx.x * 16) / 32;
+    if (el == 0) s[sl][0] = total(1024 + m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+      for (int q = 0; q < 16; ++q) t += s[q][0];
+      sm = t;
+    }
+    __syncthreads();
+  }
+  if (sl != 0) return;
+  if (is_w) {
+    const int k = e & 31;
+    gw[e] = ln_g != nullptr ? ln_g[k] * v + ln_b[k] * sm : v;
+  } else if (gb != nullptr) {
+    gb[e - 1024] = v;
+  }
+}
+
+// =================================================================================================
 // Kernel B — streaming operand with a PF-deep register prefetch ring, any K, all loaders.
 // NACC = consecutive voxels per lane (4/2/1 → 128/64/32-column wave tiles): small tiles give the
 // deep, narrow stages (8^3..32^3 voxels, C = 128..512) enough workgroups to fill 256 CUs.
@@ -1780,6 +2055,54 @@ static int mlp_launch(const fz_mlp_desc* d, fz_stream_t stream) {
   }
   FZ_LAUNCH_CHECK();
   return FZ_OK;
+}
+
+extern "C" int fz_gemm_dw_rows(int B, int64_t V);
+template <typename AT>
+static int gemm_dw_launch(const fz_gemm_dw_desc* d, fz_stream_t stream) {
+  DwArgsT<AT> a;
+  a.g = (const AT*)d->g; a.q = (const AT*)d->q; a.w = d->w; a.stats = d->stats; a.ln_g = d->ln_g; a.gadd = (const AT*)d->gadd;
+  a.y = (AT*)d->y; a.part = d->part; a.wpart = (float*)d->wpart; a.V = d->V; a.B = d->B;
+  const int ntiles = (int)fz_mlp_partials(d->B, d->V);
+  const int rows = fz_gemm_dw_rows(d->B, d->V);
+  constexpr int lds = (1024 + 32 + 256 + 4 * 64 * kTS) * (int)sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  if (d->ln) {
+    auto kern = gemm_dw_kernel<true, AT>;
+    FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)rows), dim3(256), lds, st, a, ntiles);
+  } else {
+    auto kern = gemm_dw_kernel<false, AT>;
+    FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)rows), dim3(256), lds, st, a, ntiles);
+  }
+  FZ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(dw_finish_kernel, dim3(kDwRow / 16), dim3(256), 0, st, (const float*)d->wpart, rows,
+                     d->ln ? d->ln_g : (const float*)nullptr, d->ln_b, d->gw, d->gb);
+  FZ_LAUNCH_CHECK();
+  return FZ_OK;
+}
+
+extern "C" int fz_gemm_dw_rows(int B, int64_t V) {
+  const int64_t nt = fz_mlp_partials(B, V);
+  int wgs = 512;
+  { const char* e = getenv("FZ_GEMM_DW_WGS"); if (e && atoi(e) > 0) wgs = atoi(e); }
+  return (int)(nt < wgs ? nt : wgs);
+}
+extern "C" int64_t fz_gemm_dw_workspace_bytes(int B, int64_t V) {
+  return (int64_t)fz_gemm_dw_rows(B, V) * kDwRow * (int64_t)sizeof(float);
+}
+
+extern "C" int fz_gemm_dw(const fz_gemm_dw_desc* d, fz_stream_t stream) {
+  if (!d) return fail(FZ_E_ARG, "fz_gemm_dw: null descriptor");
+  if (!d->g || !d->q || !d->w || !d->y || !d->wpart || !d->gw) return fail(FZ_E_ARG, "fz_gemm_dw: null pointer");
+  if (d->ln && (!d->stats || !d->ln_g || !d->ln_b || !d->part)) return fail(FZ_E_ARG, "fz_gemm_dw: the LayerNorm form needs stats, gamma, beta, part");
+  if (!d->ln && d->gadd) return fail(FZ_E_UNSUPPORTED, "fz_gemm_dw: gadd only with the LayerNorm backward");
+  if (d->C != 32) return fail(FZ_E_UNSUPPORTED, "fz_gemm_dw: needs C == 32");
+  if (d->B < 1 || d->V < 1 || d->V % 4 != 0 || d->V > ((int64_t)1 << 27)) return fail(FZ_E_UNSUPPORTED, "fz_gemm_dw: needs B >= 1, V % 4 == 0, V <= 2^27");
+  if (d->act_dtype == FZ_STORE_F32) return gemm_dw_launch<float>(d, stream);
+  if (d->act_dtype == FZ_STORE_BF16) return gemm_dw_launch<bf16>(d, stream);
+  return fail(FZ_E_ARG, "fz_gemm_dw: act_dtype must be FZ_STORE_F32 or FZ_STORE_BF16");
 }
 
 extern "C" int fz_mlp_chain(const fz_mlp_desc* d, fz_stream_t stream) {

@@ -139,6 +139,44 @@ def _dgrad_lnbwd(gz, w2, x, stats, ln_w, gadd):
     return gx, gpar[:32], gpar[32:]
 
 
+def _dw_fused_ok(C, V):
+    """input gradient + weight gradient of a 32 -> 32 layer in one pass (csrc/gemm.hip gemm_dw_kernel)"""
+    return C == 32 and V % 4 == 0 and V <= (1 << 27) and os.environ.get("FZ_DW_FUSED", "1") != "0"
+
+
+def _gemm_dw(g, w2, q, ln=None, stats=None, gadd=None, want_bias=False, name="dgrad_wgrad"):
+    """y = Wᵀ g [→ LayerNorm backward + gadd], gw = Σ_v g ⊗ in, gb = Σ_v g — fz_gemm_dw.  ln = (γ, β) or None.
+    Returns (y, gw, gb or None, gγ, gβ) (gγ, gβ None without ln)."""
+    B, C = q.shape[:2]
+    V = _vox(q)
+    dev = q.device
+    y = torch.empty_like(q)
+    gw = torch.empty((C, C), dtype=torch.float32, device=dev)
+    gb = torch.empty(C, dtype=torch.float32, device=dev) if want_bias else None
+    wpart = torch.empty(N.lib().fz_gemm_dw_workspace_bytes(B, V) // 4, dtype=torch.float32, device=dev)
+    d = N.GemmDwDesc()
+    d.g, d.q, d.w, d.y = g.data_ptr(), q.data_ptr(), w2.data_ptr(), y.data_ptr()
+    d.wpart, d.gw, d.gb = wpart.data_ptr(), gw.data_ptr(), _p(gb)
+    d.B, d.C, d.V, d.act_dtype = B, C, V, N.act_dtype(q)
+    part = gpar = None
+    if ln is not None:
+        rows = N.lib().fz_mlp_partials(B, V)
+        part = torch.empty((rows, 64), dtype=torch.float32, device=dev)
+        gpar = torch.empty(64, dtype=torch.float32, device=dev)
+        tmp = torch.empty((64, 64), dtype=torch.float32, device=dev)
+        d.ln, d.stats, d.ln_g, d.ln_b, d.gadd, d.part = 1, stats.data_ptr(), ln[0].data_ptr(), ln[1].data_ptr(), _p(gadd), part.data_ptr()
+    nbytes = q.element_size() * (3 * q.numel() + (gadd.numel() if gadd is not None else 0))
+    with torch.cuda.device(dev):
+        rc = Fn._timed(f"{name}_{C}", nbytes, lambda: N.lib().fz_gemm_dw(ctypes.byref(d), N.stream_ptr(q)))
+        N.check(rc, "fz_gemm_dw")
+        if ln is not None:
+            rc = N.lib().fz_reduce_rows(part.data_ptr(), rows, 64, gpar.data_ptr(), tmp.data_ptr(), N.stream_ptr(q))
+            N.check(rc, "fz_reduce_rows")
+    if ln is not None:
+        return y, gw, gb, gpar[:32], gpar[32:]
+    return y, gw, gb, None, None
+
+
 def _mlp_chain_ok(C, Hd, V):
     return os.environ.get("FZ_MLP_CHAIN", "1") != "0" and bool(N.lib().fz_mlp_supported(C, Hd, V))
 
@@ -798,11 +836,15 @@ class FactorizerBlockFn(torch.autograd.Function):
                    name="wgrad_ln_linear")
             del gz1
         # --- out_proj ---
-        ga = torch.empty_like(a)
-        _gemm([gx1], wout2, ga, B=B, Cin=C, Vin=V, M=C, K=C, Ncol=V, w_t=True, ldw=C, name="linear_dgrad")
-        gwo = torch.empty_like(wout2)
-        gbo = torch.empty(C, dtype=torch.float32, device=dev)
-        wgrad(gx1, [a], gwo, B=B, M=C, Cin=C, K=C, Vq=V, Ncols=V, gbias=gbo, name="wgrad_linear")
+        dw = _dw_fused_ok(C, V)
+        if dw:
+            ga, gwo, gbo, _, _ = _gemm_dw(gx1, wout2, a, want_bias=True, name="dgrad_wgrad")
+        else:
+            ga = torch.empty_like(a)
+            _gemm([gx1], wout2, ga, B=B, Cin=C, Vin=V, M=C, K=C, Ncol=V, w_t=True, ldw=C, name="linear_dgrad")
+            gwo = torch.empty_like(wout2)
+            gbo = torch.empty(C, dtype=torch.float32, device=dev)
+            wgrad(gx1, [a], gwo, B=B, M=C, Cin=C, K=C, Vq=V, Ncols=V, gbias=gbo, name="wgrad_linear")
         # --- core (gradient arrives gated by [t > 0]) ---
         if G <= 0:
             gt = torch.zeros_like(t)
@@ -819,9 +861,12 @@ class FactorizerBlockFn(torch.autograd.Function):
             del gm
         del ga
         # --- in_proj + LN1 ---
-        gx, gg1, gbt1 = _dgrad_lnbwd(gt, win2, x, st1, n1w, gx1)        # + residual path of the mixer
-        gwi = torch.empty_like(win2)
-        wgrad(gt, [x], gwi, B=B, M=C, Cin=C, K=C, Vq=V, Ncols=V, stats=st1, ln=(n1w, n1b), name="wgrad_ln_linear")
+        if dw:
+            gx, gwi, _, gg1, gbt1 = _gemm_dw(gt, win2, x, ln=(n1w, n1b), stats=st1, gadd=gx1, name="dgrad_lnbwd_wgrad")
+        else:
+            gx, gg1, gbt1 = _dgrad_lnbwd(gt, win2, x, st1, n1w, gx1)        # + residual path of the mixer
+            gwi = torch.empty_like(win2)
+            wgrad(gt, [x], gwi, B=B, M=C, Cin=C, K=C, Vq=V, Ncols=V, stats=st1, ln=(n1w, n1b), name="wgrad_ln_linear")
         if side is not None:
             if _LateJoin.enabled:
                 _LateJoin.keep.extend(keep)

@@ -255,6 +255,35 @@ typedef struct fz_mlp_desc {
   float* gb2;         /* mode 2: (C)                                                         */
 } fz_mlp_desc;
 
+/* ---- input gradient AND weight gradient of a 32 -> 32 1x1 layer in one pass (in_proj behind LayerNorm, out_proj;
+ * factorizer.py:38,53 + norm.py:29-34 as autograd sees them):
+ *   y = W^T g                                  (ln: then LayerNormBackward(.; q, stats, ln_g) + gadd; part receives
+ *                                               fz_mlp_partials(B, V) rows of (dgamma | dbeta) sums)
+ *   gw (32, 32) = sum_v g[m,v] * in[k,v]       (ln: in = ln_g * xhat(q) + ln_b, the LayerNorm output)
+ *   gb (32)     = sum_v g[m,v]                 (optional)
+ * wpart: fz_gemm_dw_workspace_bytes(B, V) bytes of caller workspace; rows are added in index order. */
+typedef struct fz_gemm_dw_desc {
+  const void* g;       /* activation (B, 32, V): gradient of the layer output                 */
+  const void* q;       /* activation (B, 32, V): layer input (ln: the LayerNorm input)        */
+  const float* w;      /* (32, 32) forward weight                                             */
+  int ln;
+  const float* stats;  /* ln: (B, 2, V) mean, rstd                                            */
+  const float* ln_g;   /* ln: (32)                                                            */
+  const float* ln_b;   /* ln: (32)                                                            */
+  const void* gadd;    /* ln: activation (B, 32, V) added to y, or NULL                       */
+  void* y;             /* activation (B, 32, V)                                               */
+  float* part;         /* ln: fz_mlp_partials(B, V) x 64 floats                               */
+  void* wpart;
+  float* gw;           /* (32, 32)                                                            */
+  float* gb;           /* (32) or NULL                                                        */
+  int B, C;
+  int64_t V;
+  int act_dtype;
+} fz_gemm_dw_desc;
+int fz_gemm_dw_rows(int B, int64_t V);
+int64_t fz_gemm_dw_workspace_bytes(int B, int64_t V);
+int fz_gemm_dw(const fz_gemm_dw_desc* desc, fz_stream_t stream);
+
 int fz_mlp_supported(int C, int H, int64_t V);
 int64_t fz_mlp_partials(int B, int64_t V);
 int fz_mlp_wgrad_rows(int B, int64_t V);

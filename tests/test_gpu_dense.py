@@ -353,6 +353,61 @@ def test_mlp_chain_backward_with_weight_gradients(B, S, bf):
         _cmp(a.float(), r, n, rtol=(4e-3 if n == "gx1" else 1e-4) if bf else 1e-4, why=why if (bf and n == "gx1") else None)
 
 
+@pytest.mark.parametrize("bf", [False, True])
+@pytest.mark.parametrize("ln", [False, True])
+@pytest.mark.parametrize("B,S", [(2, (8, 8, 8)), (1, (6, 4, 5)), (3, (32, 32, 40))])
+def test_gemm_dw_kernel(B, S, ln, bf):
+    """fz_gemm_dw (gemm_dw_kernel): input gradient and weight (+ bias) gradient of a 32 -> 32 layer from one pass —
+    out_proj form (y = Wᵀg, gw = Σ g ⊗ a, gb = Σ g) and in_proj form (LayerNorm backward on the accumulators + added
+    gradient, gw against the LayerNorm OUTPUT γ x̂ + β, dγ / dβ).  Against CPU autograd; ragged tile (V = 120);
+    several tiles per persistent workgroup; bit-identical when repeated."""
+    torch.manual_seed(17 + B)
+    C = 32
+    rnd = (lambda t: t.bfloat16().float()) if bf else (lambda t: t)
+    x = rnd(torch.randn(B, C, *S) * 1.5 + 0.3)
+    g = rnd(torch.randn(B, C, *S))
+    gadd = rnd(torch.randn(B, C, *S))
+    w = torch.randn(C, C) * 0.2
+    ln_w, ln_b = torch.rand(C) + 0.5, torch.randn(C) * 0.1
+    xc, wc = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    lw, lb = ln_w.clone().requires_grad_(True), ln_b.clone().requires_grad_(True)
+    if ln:
+        inp = F.layer_norm(xc.movedim(1, -1), (C,), lw, lb, 1e-5).movedim(-1, 1)
+        yc = _lin_cpu(inp, wc.unsqueeze(-1), None)
+        gxc, gwc, ggc, gbc = torch.autograd.grad(yc, [xc, wc, lw, lb], g)
+        gxc = gxc + gadd
+    else:
+        bc = torch.zeros(C, requires_grad=True)
+        yc = _lin_cpu(xc, wc.unsqueeze(-1), bc)
+        gxc, gwc, gbias_c = torch.autograd.grad(yc, [xc, wc, bc], g)
+    dt = torch.bfloat16 if bf else torch.float32
+    d = lambda t: t.to(DEV).contiguous()  # noqa: E731
+    xd, gd, gaddd = d(x).to(dt), d(g).to(dt), d(gadd).to(dt)
+    V = x[0, 0].numel()
+    assert PW._dw_fused_ok(C, V)
+    n0 = _native.launch_count()
+    if ln:
+        mean = xd.float().mean(1, keepdim=True)
+        rstd = (xd.float().var(1, unbiased=False, keepdim=True) + 1e-5).rsqrt()
+        st = torch.cat([mean, rstd], 1).reshape(B, 2, V).contiguous()
+        run = lambda: PW._gemm_dw(gd, d(w), xd, ln=(d(ln_w), d(ln_b)), stats=st, gadd=gaddd)  # noqa: E731
+    else:
+        run = lambda: PW._gemm_dw(gd, d(w), xd, want_bias=True)  # noqa: E731
+    y, gw, gb, gg, gbt = run()
+    assert _native.launch_count() - n0 >= 2
+    y2, gw2, gb2, gg2, gbt2 = run()
+    assert torch.equal(y, y2) and torch.equal(gw, gw2)
+    why = "bf16 activation storage: y is rounded once on store (2^-9 relative)" if bf else None
+    _cmp(y.float(), gxc, "y", rtol=4e-3 if bf else 1e-4, why=why)
+    _cmp(gw, gwc, "gw")
+    if ln:
+        _cmp(gg, ggc, "dgamma")
+        _cmp(gbt, gbc, "dbeta")
+    else:
+        _cmp(gb, gbias_c, "gb")
+        assert torch.equal(gb, gb2)
+
+
 def test_flat_adamw_kernel_matches_torch():
     """fz_adamw_step (csrc/optim.hip) against torch.optim.AdamW on the CPU: 5 steps over a 1 000 003-element
     buffer (odd length: vector body + scalar tail), lr 1e-4 / wd 1e-5 of train.yaml:72-76."""
