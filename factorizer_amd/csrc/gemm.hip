@@ -860,6 +860,29 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
     for (int s = 0; s < 16; ++s)
       *reinterpret_cast<float2*>(Bf + (2 * s + h) * kTS + 2 * j) = make_float2(col_ok ? bv[s][0] : 0.f, col_ok ? bv[s][1] : 0.f);
 
+    // Every global operand of the tile is requested one phase AHEAD of its use (two waves per SIMD cannot hide a
+    // memory round trip per phase): z1 block g+1 during block g, x1 during the last z1 block, the residual rows before
+    // GEMM 2.
+    float e[2][8][NACC];
+    auto fetch_z1 = [&](int g8, float (&dst)[8][NACC]) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int rr = g8 * 8 + i, rb = rr >> 4, r = rr & 15;
+        const int rbase = rb * 32 + (r & 3) + 8 * (r >> 2);
+        vload<NACC>(p.emul + ((int64_t)b * HID + rbase) * p.Ncol + lane_row, dst[i]);
+      }
+    };
+    float xv[2][8][NACC];
+    auto fetch_x1 = [&](int hf, float (&dst)[8][NACC]) {
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) vload<NACC>(p.lnb_x + sample + (int64_t)(2 * (hf * 8 + s8)) * p.Ncol + lane_par, dst[s8]);
+    };
+    const float* sp = p.lnb_stats + (int64_t)b * 2 * p.Ncol;
+    float mu[NACC], rs[NACC];
+    vload<NACC>(sp + nc, mu);
+    vload<NACC>(sp + p.Ncol + nc, rs);
+    fetch_z1(0, e[0]);
+
     // ---- GEMM 1: gh = W2ᵀ g2 ----
     f32x16 acc1[HB][NACC];
 #pragma unroll
@@ -887,13 +910,8 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
       // (compiler-only fence: the g2 operand reads below are the same for every group — left alone they are read once
       // and kept in 32 registers across all four)
       asm volatile("" ::: "memory");
-      float e[8][NACC];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int rr = g8 * 8 + i, rb = rr >> 4, r = rr & 15;
-        const int rbase = rb * 32 + (r & 3) + 8 * (r >> 2);
-        vload<NACC>(p.emul + ((int64_t)b * HID + rbase) * p.Ncol + lane_row, e[i]);
-      }
+      if (g8 < 3) fetch_z1(g8 + 1, e[(g8 + 1) & 1]);
+      else { fetch_x1(0, xv[0]); fetch_x1(1, xv[1]); }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int rr = g8 * 8 + i, rb = rr >> 4, r = rr & 15;
@@ -901,7 +919,7 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
 #pragma unroll
         for (int q = 0; q < NACC; ++q) {
           float dg;
-          gelu_both(e[i][q], gl[q], dg);
+          gelu_both(e[g8 & 1][i][q], gl[q], dg);
           float gz = acc1[rb][q][r] * dg;
           // pin the product HERE: its only readers are pass B and GEMM 2, and the optimiser otherwise sinks the
           // gelu' evaluation (and with it the liveness of all 64 z1 values) down to them
@@ -937,21 +955,13 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
       __builtin_amdgcn_sched_barrier(0);
     }
 
-    // ---- Bf <- LN-normalised x1 ----
-    const float* sp = p.lnb_stats + (int64_t)b * 2 * p.Ncol;
-    float mu[NACC], rs[NACC];
-    vload<NACC>(sp + nc, mu);
-    vload<NACC>(sp + p.Ncol + nc, rs);
+    // ---- Bf <- LN-normalised x1 (requested during the last z1 block) ----
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-      float xv[8][NACC];
-#pragma unroll
-      for (int s8 = 0; s8 < 8; ++s8) vload<NACC>(p.lnb_x + sample + (int64_t)(2 * (hf * 8 + s8)) * p.Ncol + lane_par, xv[s8]);
+    for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
       for (int s8 = 0; s8 < 8; ++s8)
         *reinterpret_cast<float2*>(Bf + (2 * (hf * 8 + s8) + h) * kTS + 2 * j) =
-            make_float2(col_ok ? (xv[s8][0] - mu[0]) * rs[0] : 0.f, col_ok ? (xv[s8][1] - mu[1]) * rs[1] : 0.f);
-    }
+            make_float2(col_ok ? (xv[hf][s8][0] - mu[0]) * rs[0] : 0.f, col_ok ? (xv[hf][s8][1] - mu[1]) * rs[1] : 0.f);
 
     // ---- pass B: gz1 block -> T; S1 += gz1 ⊗ x̂, db1 += Σ gz1 ----
 #pragma unroll
@@ -984,6 +994,12 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+
+    // residual rows (g2 again: L2 / MALL), requested before GEMM 2
+    float ga[2][8][NACC];
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      vload<NACC>(p.lnb_gadd + sample + (int64_t)((r & 3) + 8 * (r >> 2)) * p.Ncol + lane_row, ga[r >> 3][r & 7]);
 
     // ---- GEMM 2: gl = W1ᵀ gz1 straight from the accumulators ----
     f32x16 acc2[NACC];
@@ -1019,13 +1035,7 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
       m2[q] = (m2[q] + __shfl_xor(m2[q], 32, 64)) * (1.0f / 32.0f);
     }
 #pragma unroll
-    for (int r8 = 0; r8 < 2; ++r8) {      // 8 rows at a time: 8 residual loads in flight, then 8 rows out
-      float ga[8][NACC];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int r = r8 * 8 + i;
-        vload<NACC>(p.lnb_gadd + sample + (int64_t)((r & 3) + 8 * (r >> 2)) * p.Ncol + lane_row, ga[i]);
-      }
+    for (int r8 = 0; r8 < 2; ++r8) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int r = r8 * 8 + i;
@@ -1034,8 +1044,8 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
         const float gc = tB[row];
         const float2 xh = *reinterpret_cast<const float2*>(Bf + row * kTS + 2 * j);
         float v[NACC];
-        v[0] = rs[0] * (acc2[0][r] * gc - m1[0] - xh.x * m2[0]) + ga[i][0];
-        v[1] = rs[1] * (acc2[1][r] * gc - m1[1] - xh.y * m2[1]) + ga[i][1];
+        v[0] = rs[0] * (acc2[0][r] * gc - m1[0] - xh.x * m2[0]) + ga[r8][i][0];
+        v[1] = rs[1] * (acc2[1][r] * gc - m1[1] - xh.y * m2[1]) + ga[r8][i][1];
         if (col_ok) vstore<NACC>(p.y + sample + (int64_t)rbase * p.Ncol + lane_row, v);
         float sg = col_ok ? acc2[0][r] * xh.x + acc2[1][r] * xh.y : 0.f;
         float sb = col_ok ? acc2[0][r] + acc2[1][r] : 0.f;
