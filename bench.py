@@ -35,6 +35,11 @@ from factorizer_amd import functional as Fn  # noqa: E402
 from factorizer_amd.parallel import FlatGradSync  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+FP32_MFMA_PEAK_TFLOPS = 157.3   # dense fp32 matrix peak, /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32, 256 CUs)
+# fp32 MFMA flop per ALGORITHMIC byte of the fused kernels whose arithmetic intensity is above the fp32 ridge
+# (157.3 TFLOP/s / 8 TB/s = 19.7 flop/B).  mlp_chain_bwd_wgrad (C = 32, hidden 64): per voxel 2 input-gradient GEMMs
+# + 2 weight-gradient GEMMs of 2*32*64 flop each = 16 384 flop over 5 planes of 32 channels * 4 B = 640 B.
+MFMA_FLOP_PER_BYTE = {"mlp_chain_bwd_wgrad_": 16384 / 640}
 
 # HBM traffic per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
 # passes of this same command, FETCH_SIZE doubled per the gfx950 correction of
@@ -48,6 +53,9 @@ PMC_TRAFFIC = os.path.join(ROOT, "profiles", os.environ.get("FZ_PMC_TRAFFIC", "r
 PMC_KERNEL = {"nmf_cf_bwd_32x128x128x128": "fz::nmf_cf_bwd_tile_kernel<",
               "nmf_cf_fwd_32x128x128x128": "fz::nmf_cf_fwd_tile_kernel<",
               "mlp_chain_bwd_32": "fz::gemm_chain_kernel<true",
+              "mlp_chain_bwd_wgrad_32": "fz::gemm_chain_bwd_wg_kernel<",
+              "dgrad_lnbwd_wgrad_32": "fz::gemm_dw_kernel<true",
+              "dgrad_wgrad_32": "fz::gemm_dw_kernel<false",
               "mlp_chain_fwd_32": "fz::gemm_chain_kernel<false"}
 
 
@@ -292,8 +300,17 @@ def main():
             avg_ms = a["ms"] / a["calls"]
             gbs = a["bytes"] / a["calls"] / (avg_ms * 1e-3) / 1e9
             traffic, traffic_source = pmc_traffic(name)
-            roof = {"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+            # which roof binds: the one with the larger minimum time for this launch's algorithmic work
+            fpb = next((v for k, v in MFMA_FLOP_PER_BYTE.items() if name.startswith(k)), 0.0)
+            tflops = fpb * gbs / 1e3
+            if fpb * HBM_PEAK_GBS / 1e3 > FP32_MFMA_PEAK_TFLOPS:     # arithmetic intensity above the fp32 ridge
+                head = {"bound": "mfma", "kernel": name, "achieved": round(tflops, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(tflops / FP32_MFMA_PEAK_TFLOPS, 4),
+                        "flop_per_algorithmic_byte": fpb, "hbm_GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)}
+            else:
+                head = {"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
+            roof = {**head, "traffic": traffic,
                     "traffic_source": traffic_source,
                     "avg_launch_ms": round(avg_ms, 4), "launches": a["calls"],
                     "algorithmic_bytes_per_launch": a["bytes"] // a["calls"],
