@@ -749,6 +749,297 @@ __global__ __launch_bounds__(256, (NACC == 2 && HB == 2) ? 3 : 2) void gemm_chai
 }
 
 // =================================================================================================
+// MLP chain for C = 64, hidden 128 (stage 1 of the README model): the same two chained GEMMs as gemm_chain_kernel,
+// with the hidden tensor produced and consumed in TWO passes of 64 rows — 64 accumulator registers for the pass,
+// 64 for the 64-row result that GEMM 2 accumulates over both passes, 64 for the operand tile — so the chain still
+// fits 256 VGPRs at two workgroups per CU with 8-byte lane loads.  Weights of both GEMMs (2 x 32 KB) sit in LDS in
+// operand order; the residual (forward) / added gradient and the LayerNorm input (backward) are re-read in the
+// accumulator layout (L2 / MALL) instead of being stashed.
+//   forward : z = W1·LN(x1) + b1 -> side ; out = x1 + W2·gelu(z) + b2          5 plane-sets against 7 unfused
+//   backward: gz = (W2ᵀ g2) ∘ gelu'(z) -> side ; out = LNbwd(W1ᵀ gz) + g2      8 against 12 (+ dγ, dβ partial rows)
+// =================================================================================================
+template <bool BWD, typename AT>
+__global__ __launch_bounds__(256, 2) void gemm_chain64_kernel(GemmArgsT<AT> p, ChainArgsT<AT> c, int ntiles) {
+  constexpr int NACC = 2, C = 64, HID = 128;
+  extern __shared__ __attribute__((aligned(16))) float fz_lds_c64[];
+  float* As1 = fz_lds_c64;            // [32 steps][4 row blocks][64]
+  float* As2 = As1 + 8192;            // [4 x 16 (rb, r) steps][2 row blocks][64]
+  float* tW = As2 + 8192;             // [128]
+  float* tB = tW + 128;               // [64]
+  float* red = tB + 64;               // [4][128]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int tiles_per_sample = (int)((p.Ncol + 128 * NACC - 1) / (128 * NACC));
+
+  for (int base = threadIdx.x; base < 16384; base += 256 * 8) {
+    float tmp[8];
+#pragma unroll
+    for (int uu = 0; uu < 8; ++uu) {
+      const int idx = base + uu * 256;
+      float wv;
+      if (idx < 8192) {
+        const int l = idx & 63, rb = (idx >> 6) & 3, a = idx >> 8;
+        const int m = rb * 32 + (l & 31), k = 2 * a + (l >> 5);
+        wv = weight_at(p, m, k);
+        if (!BWD) wv *= p.ln_g[k];
+      } else {
+        const int i2 = idx - 8192;
+        const int l = i2 & 63, mb = (i2 >> 6) & 1, s2 = i2 >> 7;
+        const int r = s2 & 15, rb = s2 >> 4;
+        const int k = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), m = mb * 32 + (l & 31);
+        wv = c.wB_t ? c.wB[(int64_t)k * c.ldwB + m] : c.wB[(int64_t)m * c.ldwB + k];
+      }
+      tmp[uu] = wv;
+    }
+#pragma unroll
+    for (int uu = 0; uu < 8; ++uu) fz_lds_c64[base + uu * 256] = tmp[uu];
+  }
+  if (BWD) {
+    if (threadIdx.x < C) tB[threadIdx.x] = p.lnb_g[threadIdx.x];
+  } else {
+    for (int r = threadIdx.x; r < HID; r += blockDim.x) {
+      float t = 0.f;
+      for (int k = 0; k < C; ++k) t += weight_at(p, r, k) * p.ln_b[k];
+      tW[r] = t + (p.bias ? p.bias[r] : 0.f);
+      if (r < C) tB[r] = c.biasB ? c.biasB[r] : 0.f;
+    }
+  }
+
+  int tile = blockIdx.x;
+  float bv[32][NACC];
+  auto fetch_tile = [&](int t) {
+    const int bt = t / tiles_per_sample;
+    const int64_t ct = ((int64_t)(t % tiles_per_sample) * 4 + wave) * (32 * NACC) + NACC * j;
+    const unsigned lo = (unsigned)h * (unsigned)p.Ncol + (unsigned)(ct < p.Ncol ? ct : 0);
+    const AT* xb = p.x[0] + (int64_t)bt * C * p.Ncol;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) vload<NACC>(xb + (int64_t)(2 * s) * p.Ncol + lo, bv[s]);
+  };
+  fetch_tile(tile);
+  __syncthreads();
+
+  for (; tile < ntiles; tile += gridDim.x) {
+    asm volatile("" ::: "memory");
+    const int b = tile / tiles_per_sample;
+    const int64_t col_off = ((int64_t)(tile % tiles_per_sample) * 4 + wave) * (32 * NACC) + NACC * j;
+    const bool col_ok = col_off < p.Ncol;
+    const int64_t nc = col_ok ? col_off : 0;
+    const unsigned lane_row = (unsigned)(4 * h) * (unsigned)p.Ncol + (unsigned)nc;
+
+    if (!BWD) {
+      float mu[NACC], rs[NACC];
+#pragma unroll
+      for (int e = 0; e < NACC; ++e) {
+        float t = 0.f;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) t += bv[s][e];
+        t += __shfl_xor(t, 32, 64);
+        mu[e] = t / 64.0f;
+      }
+#pragma unroll
+      for (int e = 0; e < NACC; ++e) {
+        float t = 0.f;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+          const float d = bv[s][e] - mu[e];
+          t += d * d;
+        }
+        t += __shfl_xor(t, 32, 64);
+        rs[e] = 1.0f / sqrtf(t / 64.0f + p.ln_eps);
+      }
+#pragma unroll
+      for (int s = 0; s < 32; ++s)
+#pragma unroll
+        for (int e = 0; e < NACC; ++e) bv[s][e] = (bv[s][e] - mu[e]) * rs[e];
+      if (p.stats_out != nullptr && h == 0 && col_ok) {
+        float* so = p.stats_out + (int64_t)b * 2 * p.Vin;
+        vstore<NACC>(so + col_off, mu);
+        vstore<NACC>(so + p.Vin + col_off, rs);
+      }
+    }
+
+    f32x16 acc2[2][NACC];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int q = 0; q < NACC; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[mb][q][r] = 0.f;
+
+#pragma unroll
+    for (int p2 = 0; p2 < 2; ++p2) {
+      // ---- GEMM 1, hidden rows 64·p2 .. 64·p2 + 63 ----
+      f32x16 acc1[2][NACC];
+#pragma unroll
+      for (int rbl = 0; rbl < 2; ++rbl)
+#pragma unroll
+        for (int q = 0; q < NACC; ++q)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc1[rbl][q][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 32; ++s) {
+#pragma unroll
+        for (int rbl = 0; rbl < 2; ++rbl) {
+          const float av = As1[(s * 4 + 2 * p2 + rbl) * 64 + lane];
+#pragma unroll
+          for (int q = 0; q < NACC; ++q) acc1[rbl][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[s][q], acc1[rbl][q], 0, 0, 0);
+        }
+        if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+      if (p2 == 1) fetch_tile(tile + gridDim.x < ntiles ? tile + gridDim.x : tile);   // the operand tile is consumed
+
+      // ---- hidden rows: transform in registers, copy to HBM for the other pass ----
+      if (!BWD) {
+#pragma unroll
+        for (int rbl = 0; rbl < 2; ++rbl)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int rbase = (2 * p2 + rbl) * 32 + (r & 3) + 8 * (r >> 2);
+            const float add = tW[rbase + 4 * h];
+            float v[NACC];
+#pragma unroll
+            for (int q = 0; q < NACC; ++q) v[q] = acc1[rbl][q][r] + add;
+            if (col_ok) vstore<NACC>(c.side + ((int64_t)b * HID + rbase) * p.Ncol + lane_row, v);
+#pragma unroll
+            for (int q = 0; q < NACC; ++q) acc1[rbl][q][r] = gelu_f(v[q]);
+          }
+      } else {
+#pragma unroll
+        for (int g8 = 0; g8 < 4; ++g8) {
+          float e[8][NACC];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int rr = g8 * 8 + i, rbl = rr >> 4, r = rr & 15;
+            const int rbase = (2 * p2 + rbl) * 32 + (r & 3) + 8 * (r >> 2);
+            vload<NACC>(p.emul + ((int64_t)b * HID + rbase) * p.Ncol + lane_row, e[i]);
+          }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int rr = g8 * 8 + i, rbl = rr >> 4, r = rr & 15;
+            const int rbase = (2 * p2 + rbl) * 32 + (r & 3) + 8 * (r >> 2);
+            float v[NACC];
+#pragma unroll
+            for (int q = 0; q < NACC; ++q) v[q] = acc1[rbl][q][r] * gelu_grad_f(e[i][q]);
+            if (col_ok) vstore<NACC>(c.side + ((int64_t)b * HID + rbase) * p.Ncol + lane_row, v);
+#pragma unroll
+            for (int q = 0; q < NACC; ++q) acc1[rbl][q][r] = v[q];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+
+      // ---- GEMM 2 += (64 result rows) x (these 64 hidden rows), straight from the accumulators ----
+#pragma unroll
+      for (int rbl = 0; rbl < 2; ++rbl)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#pragma unroll
+          for (int mb = 0; mb < 2; ++mb) {
+            const float av = As2[(((2 * p2 + rbl) * 16 + r) * 2 + mb) * 64 + lane];
+#pragma unroll
+            for (int q = 0; q < NACC; ++q) acc2[mb][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, acc1[rbl][q][r], acc2[mb][q], 0, 0, 0);
+          }
+          if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    const int64_t sample = (int64_t)b * C * p.Ncol;
+    if (!BWD) {
+      // out = acc2 + b2 + x1 (residual re-read in the accumulator layout), 8 rows at a time
+#pragma unroll
+      for (int g8 = 0; g8 < 4; ++g8) {
+        float e[8][NACC];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int rr = g8 * 8 + i, mb = rr >> 4, r = rr & 15;
+          vload<NACC>(p.res + sample + (int64_t)(mb * 32 + (r & 3) + 8 * (r >> 2)) * p.Ncol + lane_row, e[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int rr = g8 * 8 + i, mb = rr >> 4, r = rr & 15;
+          const int rbase = mb * 32 + (r & 3) + 8 * (r >> 2);
+          const float add = tB[rbase + 4 * h];
+          float v[NACC];
+#pragma unroll
+          for (int q = 0; q < NACC; ++q) v[q] = acc2[mb][q][r] + add + e[i][q];
+          if (col_ok) vstore<NACC>(p.y + sample + (int64_t)rbase * p.Ncol + lane_row, v);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      // LayerNorm backward over the 64 channels of this lane's voxels (rows (mb, r, h)) + added gradient
+      const float* sp = p.lnb_stats + (int64_t)b * 2 * p.Ncol;
+      float mu[NACC], rs[NACC];
+      vload<NACC>(sp + nc, mu);
+      vload<NACC>(sp + p.Ncol + nc, rs);
+      float xs[32][NACC];
+      float m1[NACC] = {0.f, 0.f}, m2[NACC] = {0.f, 0.f};
+#pragma unroll
+      for (int g8 = 0; g8 < 4; ++g8) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int rr = g8 * 8 + i, mb = rr >> 4, r = rr & 15;
+          vload<NACC>(p.lnb_x + sample + (int64_t)(mb * 32 + (r & 3) + 8 * (r >> 2)) * p.Ncol + lane_row, xs[rr]);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int rr = g8 * 8 + i, mb = rr >> 4, r = rr & 15;
+          const float gc = tB[mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+#pragma unroll
+          for (int q = 0; q < NACC; ++q) {
+            const float av = acc2[mb][q][r] * gc;
+            xs[rr][q] = (xs[rr][q] - mu[q]) * rs[q];
+            m1[q] += av;
+            m2[q] += av * xs[rr][q];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int q = 0; q < NACC; ++q) {
+        m1[q] = (m1[q] + __shfl_xor(m1[q], 32, 64)) * (1.0f / 64.0f);
+        m2[q] = (m2[q] + __shfl_xor(m2[q], 32, 64)) * (1.0f / 64.0f);
+      }
+#pragma unroll
+      for (int g8 = 0; g8 < 4; ++g8) {
+        float ga[8][NACC];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int rr = g8 * 8 + i, mb = rr >> 4, r = rr & 15;
+          vload<NACC>(p.lnb_gadd + sample + (int64_t)(mb * 32 + (r & 3) + 8 * (r >> 2)) * p.Ncol + lane_row, ga[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int rr = g8 * 8 + i, mb = rr >> 4, r = rr & 15;
+          const int rbase = mb * 32 + (r & 3) + 8 * (r >> 2);
+          const int row = rbase + 4 * h;
+          const float gc = tB[row];
+          float v[NACC];
+#pragma unroll
+          for (int q = 0; q < NACC; ++q) v[q] = rs[q] * (acc2[mb][q][r] * gc - m1[q] - xs[rr][q] * m2[q]) + ga[i][q];
+          if (col_ok) vstore<NACC>(p.y + sample + (int64_t)rbase * p.Ncol + lane_row, v);
+          float sg = col_ok ? acc2[mb][0][r] * xs[rr][0] + acc2[mb][1][r] * xs[rr][1] : 0.f;
+          float sb = col_ok ? acc2[mb][0][r] + acc2[mb][1][r] : 0.f;
+          sg = half_sum32(sg);
+          sb = half_sum32(sb);
+          if ((lane & 31) == 31) {
+            red[wave * 128 + row] = sg;
+            red[wave * 128 + 64 + row] = sb;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+      if (threadIdx.x < 128) {
+        const int e = threadIdx.x;
+        p.lnb_part[(int64_t)tile * 128 + e] = (red[e] + red[128 + e]) + (red[256 + e] + red[384 + e]);
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// =================================================================================================
 // MLP backward chain WITH the two weight gradients (C = 32, hidden 64): the unfused step reads g2 and z1
 // again for dW2 = g2 ⊗ gelu(z1) and writes + re-reads gz1 for dW1 = gz1 ⊗ LN(x1) — 13 plane-sets of traffic per
 // block (7 chain + 3 + 3) where 5 suffice (g2, z1 ×2, x1 in; gx1 out).  A weight gradient reduces over VOXELS, so
@@ -1998,12 +2289,14 @@ extern "C" int64_t fz_mlp_wgrad_workspace_bytes(int B, int64_t V) {
 }
 
 extern "C" int fz_mlp_supported(int C, int H, int64_t V) {
-  return (C == 32 && (H == 64 || H == 128) && V > 0 && (V % 4) == 0 && V <= ((int64_t)1 << 27)) ? 1 : 0;
+  const bool shape = (C == 32 && (H == 64 || H == 128)) || (C == 64 && H == 128);
+  return (shape && V > 0 && (V % 4) == 0 && V <= ((int64_t)1 << 27)) ? 1 : 0;
 }
 
 template <typename AT>
 static int mlp_launch(const fz_mlp_desc* d, fz_stream_t stream) {
-  if (!fz_mlp_supported(d->C, d->H, d->V)) return fail(FZ_E_UNSUPPORTED, "fz_mlp_chain: needs C == 32, H in {64, 128}, V % 4 == 0");
+  if (!fz_mlp_supported(d->C, d->H, d->V)) return fail(FZ_E_UNSUPPORTED, "fz_mlp_chain: needs (C, H) in {(32, 64), (32, 128), (64, 128)}, V % 4 == 0");
+  if (d->C == 64 && d->mode == 2) return fail(FZ_E_UNSUPPORTED, "fz_mlp_chain: the fused weight gradients need C == 32, H == 64");
   if (d->B < 0) return fail(FZ_E_SHAPE, "fz_mlp_chain: negative batch");
   if (!d->in || !d->w1 || !d->w2 || !d->out || !d->z1 || !d->stats)
     return fail(FZ_E_ARG, "fz_mlp_chain: null pointer");
@@ -2028,6 +2321,34 @@ static int mlp_launch(const fz_mlp_desc* d, fz_stream_t stream) {
   a.x[0] = (const AT*)d->in; a.nsrc = 1; a.c0 = 32; a.Cin = 32; a.Vin = d->V; a.M = d->H; a.K = 32; a.Ncol = d->V; a.B = d->B;
   hipStream_t st = (hipStream_t)stream;
   const int ntiles = (int)fz_mlp_partials(d->B, d->V);
+  if (d->C == 64) {
+    if (d->mode == 1 && !d->in) return fail(FZ_E_ARG, "fz_mlp_chain: null pointer");
+    a.x[0] = (const AT*)d->in; a.nsrc = 1; a.c0 = 64; a.Cin = 64; a.Vin = d->V; a.M = 128; a.K = 64; a.Ncol = d->V; a.B = d->B;
+    int wgs64 = 512;
+    { const char* e = getenv("FZ_MLP_WGS"); if (e) wgs64 = atoi(e); }
+    dim3 grid64((unsigned)(ntiles < wgs64 ? ntiles : wgs64));
+    constexpr int lds64 = (8192 + 8192 + 128 + 64 + 512) * (int)sizeof(float);
+    if (d->mode == 0) {
+      a.w = d->w1; a.w_t = 0; a.ldw = 64;
+      a.bias = d->b1; a.ln = 1; a.ln_g = d->ln_g; a.ln_b = d->ln_b; a.ln_eps = d->ln_eps; a.stats_out = d->stats;
+      a.res = (const AT*)d->in; a.y = (AT*)d->out;
+      c.wB = d->w2; c.wB_t = 0; c.ldwB = 128; c.biasB = d->b2; c.side = (AT*)d->z1;
+      auto kern = gemm_chain64_kernel<false, AT>;
+      FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds64));
+      hipLaunchKernelGGL(kern, grid64, dim3(256), lds64, st, a, c, ntiles);
+    } else {
+      a.w = d->w2; a.w_t = 1; a.ldw = 128;             // A1[m = hidden][k = c] = W2[c][hidden]
+      a.emul = (const AT*)d->z1; a.y = (AT*)d->out;
+      a.lnb_x = (const AT*)d->x1; a.lnb_stats = d->stats; a.lnb_g = d->ln_g; a.lnb_gadd = (const AT*)d->in; a.lnb_part = d->part;
+      c.wB = d->w1; c.wB_t = 1; c.ldwB = 64;           // A2[m = c][k = hidden] = W1[hidden][c]
+      c.side = (AT*)d->gz1;
+      auto kern = gemm_chain64_kernel<true, AT>;
+      FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds64));
+      hipLaunchKernelGGL(kern, grid64, dim3(256), lds64, st, a, c, ntiles);
+    }
+    FZ_LAUNCH_CHECK();
+    return FZ_OK;
+  }
   int wgs = d->H == 128 ? 512 : 768;  // resident workgroups (2 or 3 per CU), each walking tiles with a stride of the grid
   { const char* e = getenv("FZ_MLP_WGS"); if (e) wgs = atoi(e); }
   dim3 grid((unsigned)(ntiles < wgs ? ntiles : wgs)), block(256);

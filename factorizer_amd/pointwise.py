@@ -212,9 +212,9 @@ def _mlp_bwd_chain(g2, z1, w12, w22, x1, st, ln_w):
     gz1 = torch.empty_like(z1)
     gx1 = torch.empty_like(x1)
     rows = N.lib().fz_mlp_partials(B, V)
-    part = torch.empty((rows, 64), dtype=torch.float32, device=x1.device)
-    gpar = torch.empty(64, dtype=torch.float32, device=x1.device)
-    tmp = torch.empty((64, 64), dtype=torch.float32, device=x1.device)
+    part = torch.empty((rows, 2 * C), dtype=torch.float32, device=x1.device)
+    gpar = torch.empty(2 * C, dtype=torch.float32, device=x1.device)
+    tmp = torch.empty((64, 2 * C), dtype=torch.float32, device=x1.device)
     d = N.MlpDesc()
     d.mode, d.inp, d.w1, d.w2 = 1, g2.data_ptr(), w12.data_ptr(), w22.data_ptr()
     d.ln_g, d.stats, d.z1, d.gz1, d.x1 = ln_w.data_ptr(), st.data_ptr(), z1.data_ptr(), gz1.data_ptr(), x1.data_ptr()
@@ -225,9 +225,9 @@ def _mlp_bwd_chain(g2, z1, w12, w22, x1, st, ln_w):
         rc = Fn._timed(f"mlp_chain_bwd_{C}", x1.element_size() * (3 * x1.numel() + 2 * z1.numel()),
                        lambda: N.lib().fz_mlp_chain(ctypes.byref(d), N.stream_ptr(x1)))
         N.check(rc, "fz_mlp_chain")
-        rc = N.lib().fz_reduce_rows(part.data_ptr(), rows, 64, gpar.data_ptr(), tmp.data_ptr(), N.stream_ptr(x1))
+        rc = N.lib().fz_reduce_rows(part.data_ptr(), rows, 2 * C, gpar.data_ptr(), tmp.data_ptr(), N.stream_ptr(x1))
         N.check(rc, "fz_reduce_rows")
-    return gz1, gx1, gpar[:32], gpar[32:]
+    return gz1, gx1, gpar[:C], gpar[C:]
 
 
 def _mlp_wgrad_fused_ok(C, Hd, V):

@@ -216,7 +216,8 @@ int fz_reduce_rows(const float* part, int64_t rows, int n, float* out, float* tm
 
 int fz_gemm(const fz_gemm_desc* desc, fz_stream_t stream);
 
-/* ---- MLP chain (C = 32, hidden H = 64 or 128): two GEMMs, hidden tensor stays in the accumulators
+/* ---- MLP chain ((C, H) = (32, 64), (32, 128) or (64, 128)): two GEMMs, hidden tensor stays in the accumulators
+ * (modes 0 and 1; part rows are 2*C floats: dgamma | dbeta)
  * Replaces per FactorizerBlock (factorizer.py:76, layers/mlp.py:54-63, layers/norm.py:29-34):
  *   mode 0  out = in + W2·gelu(W1·LN(in) + b1) + b2 ; z1 = W1·LN(in) + b1 and stats (mean, rstd)
  *           are written for the backward

@@ -272,15 +272,16 @@ def test_dice_ce_loss_fused(C):
     assert abs(ft.DiceCELoss(sigmoid=True, squared_pred=True)(zd, t.to(DEV)).item() - ld.item()) == 0.0
 
 
-@pytest.mark.parametrize("Hd", [64, 128])
+@pytest.mark.parametrize("C,Hd", [(32, 64), (32, 128), (64, 128)])
 @pytest.mark.parametrize("B,S", [(2, (8, 8, 8)), (1, (6, 4, 5)), (2, (16, 16, 12))])
-def test_mlp_chain_kernel(B, S, Hd):
+def test_mlp_chain_kernel(B, S, C, Hd):
     """fz_mlp_chain (csrc/gemm.hip gemm_chain_kernel) against the layer-by-layer CPU composition
     x + fc2(gelu(fc1(LN(x)))) (factorizer.py:76, mlp.py:54-60, norm.py:29-34): forward, the saved
     pre-activation / statistics, and the backward chain (gz1, gx1, dγ, dβ).  V = 120 and 3072 cover
     partial column tiles."""
     torch.manual_seed(3)
-    C = 32  # hidden 64 = mlp_ratio 2 (README), 128 = mlp_ratio 4 (BraTS bundle, train.yaml:62)
+    # C = 32: hidden 64 = mlp_ratio 2 (README), 128 = mlp_ratio 4 (BraTS bundle, train.yaml:62); C = 64, hidden 128 =
+    # stage 1 of the README model (gemm_chain64_kernel: the hidden tensor in two passes of 64 rows)
     x = torch.randn(B, C, *S) * 2 + 0.5
     ln_w, ln_b = torch.rand(C) + 0.5, torch.randn(C) * 0.1
     w1, b1 = torch.randn(Hd, C) * 0.2, torch.randn(Hd) * 0.1
