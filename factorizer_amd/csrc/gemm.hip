@@ -2197,7 +2197,9 @@ static int gemm_launch(const fz_gemm_desc* d, fz_stream_t stream) {
     if (wgs(nacc, MBsel) < 512 && MBsel == 2) MBsel = 1;
     if (narrow_ok) {
       if (wgs(nacc, MBsel) < 256) nacc = 2;
-      if (wgs(nacc, MBsel) < 256) nacc = 1;
+      // (when even 32-voxel tiles cannot give one workgroup per CU — the 8^3 bottleneck — stay with 64-voxel tiles and
+      // let the K-split below fill the chip: 8-byte lane loads; 512->1024 at 2 x 8^3: 33 against 43 us, tools/debug/gemm_deep.py)
+      if (wgs(nacc, MBsel) < 256 && !(wgs(1, MBsel) < 256 && d->K >= 256)) nacc = 1;
       const char* e = getenv("FZ_GEMM_CFG");  // diagnostics: "<nacc><mb>", e.g. 42
       if (e && e[0] && e[1]) { nacc = e[0] - '0'; MBsel = e[1] - '0'; if (MBsel == 2 && (nacc != 4 || mblocks < 2)) MBsel = 1; }
     }
