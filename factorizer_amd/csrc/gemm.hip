@@ -1056,7 +1056,7 @@ __global__ __launch_bounds__(256, 2) void gemm_chain64_kernel(GemmArgsT<AT> p, C
 // =================================================================================================
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kTS = 68;                       // LDS row stride of the transposable tiles (floats)
-constexpr int kWgRow = 2048 + 2048 + 32 + 64; // floats of one wpart row: dW2 [32][64] | S1 [64][32] | db2 | db1
+constexpr int kWgRow = 2048 + 2048 + 32 + 64 + 64; // floats of one wpart row: dW2 [32][64] | S1 [64][32] | db2 | db1 | dγ | dβ
 
 // gelu(x) and gelu'(x) with ONE exponential: erf(x/√2) by Abramowitz-Stegun 7.1.26 (fast_erf, fz_common.h) needs
 // exp(−x²/2), which is also the Gaussian density of gelu'
@@ -1122,6 +1122,7 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
 #pragma unroll
       for (int v = 0; v < 4; ++v) { dW2[a][b4][v] = 0.f; dW1[b4][a][v] = 0.f; }
   float db2[2] = {0.f, 0.f}, db1[4] = {0.f, 0.f, 0.f, 0.f};
+  float gln = 0.f;   // threads 0..63: running (dγ | dβ) sum of this workgroup's tiles, tiles in walking order
 
   int tile = blockIdx.x;
   float bv[16][NACC];
@@ -1352,12 +1353,12 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
     __syncthreads();
     if (threadIdx.x < 64) {
       const int e = threadIdx.x;
-      p.lnb_part[(int64_t)tile * 64 + e] = (red[e] + red[64 + e]) + (red[128 + e] + red[192 + e]);
+      gln += (red[e] + red[64 + e]) + (red[128 + e] + red[192 + e]);
     }
     __syncthreads();
   }
 
-  // ---- the workgroup's (dW2 | S1 | db2 | db1) row: add the four waves through LDS, waves in index order ----
+  // ---- the workgroup's (dW2 | S1 | db2 | db1 | dγ | dβ) row: add the four waves through LDS, waves in index order ----
   float* row = wpart + (int64_t)blockIdx.x * kWgRow;
   __syncthreads();
 #pragma unroll
@@ -1400,12 +1401,13 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
       for (int kk = 0; kk < 4; ++kk) t += R[(w * 6 + slot) * 64 + kk * 16 + i16];
     row[4096 + e] = t;
   }
+  if (threadIdx.x < 64) row[4096 + 96 + threadIdx.x] = gln;
 }
 
 // gw2 = Σ rows dW2;  gb2, gb1 likewise;  gw1[c][k] = γ[k]·Σ S1[c][k] + β[k]·gb1[c]   (z1 = W1·(γ x̂ + β) + b1).
 // 256 threads = 16 elements x 16 row slices; slices walk the rows with stride 16 and are added in slice order.
 __global__ __launch_bounds__(256) void chain_wg_finish_kernel(const float* wpart, int rows, const float* ln_g, const float* ln_b,
-                                                              float* gw1, float* gb1, float* gw2, float* gb2) {
+                                                              float* gw1, float* gb1, float* gw2, float* gb2, float* gln) {
   __shared__ float s[16][17];
   __shared__ float sb1[64];
   const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
@@ -1439,7 +1441,8 @@ __global__ __launch_bounds__(256) void chain_wg_finish_kernel(const float* wpart
   if (e < 2048) gw2[e] = v;
   else if (e < 4096) { const int k = (e - 2048) & 31; gw1[e - 2048] = ln_g[k] * v + ln_b[k] * sb1[0]; }
   else if (e < 4096 + 32) gb2[e - 4096] = v;
-  else gb1[e - 4096 - 32] = v;
+  else if (e < 4096 + 96) gb1[e - 4096 - 32] = v;
+  else gln[e - 4096 - 96] = v;          // dγ (32) | dβ (32)
 }
 
 // =================================================================================================
@@ -1451,7 +1454,7 @@ __global__ __launch_bounds__(256) void chain_wg_finish_kernel(const float* wpart
 // tile in LDS (stride kTS) and reads them back with the channel on the lane axis — no register transposes.
 // Persistent workgroups (two per CU), sums carried in registers across tiles, one wpart row per workgroup.
 // =================================================================================================
-constexpr int kDwRow = 1024 + 32;   // floats of one wpart row: dW [32][32] | db [32]
+constexpr int kDwRow = 1024 + 32 + 64;   // floats of one wpart row: dW [32][32] | db [32] | dγ [32] | dβ [32] (LNB)
 
 template <typename AT>
 struct DwArgsT {
@@ -1462,7 +1465,6 @@ struct DwArgsT {
   const float* ln_g;  // LNB: gamma
   const AT* gadd;     // LNB: (B, 32, V) added to y, or null
   AT* y;              // (B, 32, V)
-  float* part;        // LNB: [ntiles][64] (dgamma | dbeta) partial rows
   float* wpart;       // [gridDim.x][kDwRow]
   int64_t V;
   int B;
@@ -1498,6 +1500,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_kernel(DwArgsT<AT> p, int ntil
 #pragma unroll
       for (int v = 0; v < 4; ++v) dW[a][b2][v] = 0.f;
   float db[2] = {0.f, 0.f};
+  float gln = 0.f;   // threads 0..63 (LNB): running (dγ | dβ) sum of this workgroup's tiles
 
   int tile = blockIdx.x;
   float bv[16][NACC];
@@ -1643,7 +1646,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_kernel(DwArgsT<AT> p, int ntil
       __syncthreads();
       if (threadIdx.x < 64) {
         const int e = threadIdx.x;
-        p.part[(int64_t)tile * 64 + e] = (red[e] + red[64 + e]) + (red[128 + e] + red[192 + e]);
+        gln += (red[e] + red[64 + e]) + (red[128 + e] + red[192 + e]);
       }
       __syncthreads();
     }
@@ -1676,11 +1679,12 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_kernel(DwArgsT<AT> p, int ntil
       for (int kk = 0; kk < 4; ++kk) t += R[(w * 2 + slot) * 64 + kk * 16 + i16];
     row[1024 + e] = t;
   }
+  if (threadIdx.x < 64) row[1024 + 32 + threadIdx.x] = gln;
 }
 
 // gw[m][k] = (ln ? γ[k]·S[m][k] + β[k]·sg[m] : S[m][k]),  gb[m] = sg[m] (when wanted); rows added in slice order
 __global__ __launch_bounds__(256) void dw_finish_kernel(const float* wpart, int rows, const float* ln_g, const float* ln_b,
-                                                        float* gw, float* gb) {
+                                                        float* gw, float* gb, float* gln) {
   __shared__ float s[16][17];
   __shared__ float sm;
   const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
@@ -1689,7 +1693,7 @@ __global__ __launch_bounds__(256) void dw_finish_kernel(const float* wpart, int 
     for (int r = sl; r < rows; r += 16) t += wpart[(int64_t)r * kDwRow + e];
     return t;
   };
-  const int e = blockIdx.x * 16 + el;      // kDwRow = 66 x 16
+  const int e = blockIdx.x * 16 + el;      // kDwRow = 70 x 16
   s[sl][el] = total(e);
   __syncthreads();
   float v = 0.f;
@@ -1712,8 +1716,10 @@ __global__ __launch_bounds__(256) void dw_finish_kernel(const float* wpart, int 
   if (is_w) {
     const int k = e & 31;
     gw[e] = ln_g != nullptr ? ln_g[k] * v + ln_b[k] * sm : v;
-  } else if (gb != nullptr) {
-    gb[e - 1024] = v;
+  } else if (e < 1024 + 32) {
+    if (gb != nullptr) gb[e - 1024] = v;
+  } else if (gln != nullptr) {
+    gln[e - 1024 - 32] = v;
   }
 }
 
@@ -2304,8 +2310,8 @@ static int mlp_launch(const fz_mlp_desc* d, fz_stream_t stream) {
     return fail(FZ_E_ARG, "fz_mlp_chain: null pointer");
   if (d->mode == 0 && (!d->ln_g || !d->ln_b)) return fail(FZ_E_ARG, "fz_mlp_chain: forward needs the LayerNorm affine");
   if (d->mode == 1 && (!d->gz1 || !d->x1 || !d->ln_g || !d->part)) return fail(FZ_E_ARG, "fz_mlp_chain: backward needs gz1, x1, gamma, part");
-  if (d->mode == 2 && (!d->x1 || !d->ln_g || !d->ln_b || !d->part || !d->wpart || !d->gw1 || !d->gb1 || !d->gw2 || !d->gb2))
-    return fail(FZ_E_ARG, "fz_mlp_chain: backward with weight gradients needs x1, gamma, beta, part, wpart, gw1, gb1, gw2, gb2");
+  if (d->mode == 2 && (!d->x1 || !d->ln_g || !d->ln_b || !d->gln || !d->wpart || !d->gw1 || !d->gb1 || !d->gw2 || !d->gb2))
+    return fail(FZ_E_ARG, "fz_mlp_chain: backward with weight gradients needs x1, gamma, beta, gln, wpart, gw1, gb1, gw2, gb2");
   if (d->mode == 2 && d->H != 64) return fail(FZ_E_UNSUPPORTED, "fz_mlp_chain: the fused weight gradients need H == 64");
   if (d->mode < 0 || d->mode > 2) return fail(FZ_E_ARG, "fz_mlp_chain: bad mode");
   if (d->B == 0) {
@@ -2315,6 +2321,7 @@ static int mlp_launch(const fz_mlp_desc* d, fz_stream_t stream) {
       FZ_HIP_OK(hipMemsetAsync(d->gw2, 0, sizeof(float) * 64 * 32, s0));
       FZ_HIP_OK(hipMemsetAsync(d->gb1, 0, sizeof(float) * 64, s0));
       FZ_HIP_OK(hipMemsetAsync(d->gb2, 0, sizeof(float) * 32, s0));
+      FZ_HIP_OK(hipMemsetAsync(d->gln, 0, sizeof(float) * 64, s0));
     }
     return FZ_OK;
   }
@@ -2374,7 +2381,7 @@ static int mlp_launch(const fz_mlp_desc* d, fz_stream_t stream) {
     hipLaunchKernelGGL(kern, dim3((unsigned)rows), block, lds, st, a, c, ntiles, (float*)d->wpart);
     FZ_LAUNCH_CHECK();
     hipLaunchKernelGGL(chain_wg_finish_kernel, dim3(kWgRow / 16), dim3(256), 0, st, (const float*)d->wpart, rows, d->ln_g, d->ln_b,
-                       d->gw1, d->gb1, d->gw2, d->gb2);
+                       d->gw1, d->gb1, d->gw2, d->gb2, d->gln);
     FZ_LAUNCH_CHECK();
     return FZ_OK;
   } else {
@@ -2395,7 +2402,7 @@ template <typename AT>
 static int gemm_dw_launch(const fz_gemm_dw_desc* d, fz_stream_t stream) {
   DwArgsT<AT> a;
   a.g = (const AT*)d->g; a.q = (const AT*)d->q; a.w = d->w; a.stats = d->stats; a.ln_g = d->ln_g; a.gadd = (const AT*)d->gadd;
-  a.y = (AT*)d->y; a.part = d->part; a.wpart = (float*)d->wpart; a.V = d->V; a.B = d->B;
+  a.y = (AT*)d->y; a.wpart = (float*)d->wpart; a.V = d->V; a.B = d->B;
   const int ntiles = (int)fz_mlp_partials(d->B, d->V);
   const int rows = fz_gemm_dw_rows(d->B, d->V);
   constexpr int lds = (1024 + 32 + 256 + 4 * 64 * kTS) * (int)sizeof(float);
@@ -2411,7 +2418,7 @@ static int gemm_dw_launch(const fz_gemm_dw_desc* d, fz_stream_t stream) {
   }
   FZ_LAUNCH_CHECK();
   hipLaunchKernelGGL(dw_finish_kernel, dim3(kDwRow / 16), dim3(256), 0, st, (const float*)d->wpart, rows,
-                     d->ln ? d->ln_g : (const float*)nullptr, d->ln_b, d->gw, d->gb);
+                     d->ln ? d->ln_g : (const float*)nullptr, d->ln_b, d->gw, d->gb, d->ln ? d->gln : (float*)nullptr);
   FZ_LAUNCH_CHECK();
   return FZ_OK;
 }
@@ -2429,7 +2436,7 @@ extern "C" int64_t fz_gemm_dw_workspace_bytes(int B, int64_t V) {
 extern "C" int fz_gemm_dw(const fz_gemm_dw_desc* d, fz_stream_t stream) {
   if (!d) return fail(FZ_E_ARG, "fz_gemm_dw: null descriptor");
   if (!d->g || !d->q || !d->w || !d->y || !d->wpart || !d->gw) return fail(FZ_E_ARG, "fz_gemm_dw: null pointer");
-  if (d->ln && (!d->stats || !d->ln_g || !d->ln_b || !d->part)) return fail(FZ_E_ARG, "fz_gemm_dw: the LayerNorm form needs stats, gamma, beta, part");
+  if (d->ln && (!d->stats || !d->ln_g || !d->ln_b || !d->gln)) return fail(FZ_E_ARG, "fz_gemm_dw: the LayerNorm form needs stats, gamma, beta, gln");
   if (!d->ln && d->gadd) return fail(FZ_E_UNSUPPORTED, "fz_gemm_dw: gadd only with the LayerNorm backward");
   if (d->C != 32) return fail(FZ_E_UNSUPPORTED, "fz_gemm_dw: needs C == 32");
   if (d->B < 1 || d->V < 1 || d->V % 4 != 0 || d->V > ((int64_t)1 << 27)) return fail(FZ_E_UNSUPPORTED, "fz_gemm_dw: needs B >= 1, V % 4 == 0, V <= 2^27");

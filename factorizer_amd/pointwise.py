@@ -158,20 +158,14 @@ def _gemm_dw(g, w2, q, ln=None, stats=None, gadd=None, want_bias=False, name="dg
     d.g, d.q, d.w, d.y = g.data_ptr(), q.data_ptr(), w2.data_ptr(), y.data_ptr()
     d.wpart, d.gw, d.gb = wpart.data_ptr(), gw.data_ptr(), _p(gb)
     d.B, d.C, d.V, d.act_dtype = B, C, V, N.act_dtype(q)
-    part = gpar = None
+    gpar = None
     if ln is not None:
-        rows = N.lib().fz_mlp_partials(B, V)
-        part = torch.empty((rows, 64), dtype=torch.float32, device=dev)
         gpar = torch.empty(64, dtype=torch.float32, device=dev)
-        tmp = torch.empty((64, 64), dtype=torch.float32, device=dev)
-        d.ln, d.stats, d.ln_g, d.ln_b, d.gadd, d.part = 1, stats.data_ptr(), ln[0].data_ptr(), ln[1].data_ptr(), _p(gadd), part.data_ptr()
+        d.ln, d.stats, d.ln_g, d.ln_b, d.gadd, d.gln = 1, stats.data_ptr(), ln[0].data_ptr(), ln[1].data_ptr(), _p(gadd), gpar.data_ptr()
     nbytes = q.element_size() * (3 * q.numel() + (gadd.numel() if gadd is not None else 0))
     with torch.cuda.device(dev):
         rc = Fn._timed(f"{name}_{C}", nbytes, lambda: N.lib().fz_gemm_dw(ctypes.byref(d), N.stream_ptr(q)))
         N.check(rc, "fz_gemm_dw")
-        if ln is not None:
-            rc = N.lib().fz_reduce_rows(part.data_ptr(), rows, 64, gpar.data_ptr(), tmp.data_ptr(), N.stream_ptr(q))
-            N.check(rc, "fz_reduce_rows")
     if ln is not None:
         return y, gw, gb, gpar[:32], gpar[32:]
     return y, gw, gb, None, None
@@ -242,10 +236,7 @@ def _mlp_bwd_chain_wgrad(g2, z1, w12, w22, x1, st, ln_w, ln_b):
     Hd = w12.shape[0]
     dev = x1.device
     gx1 = torch.empty_like(x1)
-    rows = N.lib().fz_mlp_partials(B, V)
-    part = torch.empty((rows, 64), dtype=torch.float32, device=dev)
     gpar = torch.empty(64, dtype=torch.float32, device=dev)
-    tmp = torch.empty((64, 64), dtype=torch.float32, device=dev)
     wpart = torch.empty(N.lib().fz_mlp_wgrad_workspace_bytes(B, V) // 4, dtype=torch.float32, device=dev)
     gw1 = torch.empty((Hd, C), dtype=torch.float32, device=dev)
     gw2 = torch.empty((C, Hd), dtype=torch.float32, device=dev)
@@ -254,7 +245,7 @@ def _mlp_bwd_chain_wgrad(g2, z1, w12, w22, x1, st, ln_w, ln_b):
     d = N.MlpDesc()
     d.mode, d.inp, d.w1, d.w2 = 2, g2.data_ptr(), w12.data_ptr(), w22.data_ptr()
     d.ln_g, d.ln_b, d.stats, d.z1, d.x1 = ln_w.data_ptr(), ln_b.data_ptr(), st.data_ptr(), z1.data_ptr(), x1.data_ptr()
-    d.out, d.part, d.wpart = gx1.data_ptr(), part.data_ptr(), wpart.data_ptr()
+    d.out, d.gln, d.wpart = gx1.data_ptr(), gpar.data_ptr(), wpart.data_ptr()
     d.gw1, d.gb1, d.gw2, d.gb2 = gw1.data_ptr(), gb1.data_ptr(), gw2.data_ptr(), gb2.data_ptr()
     d.B, d.C, d.H, d.V = B, C, Hd, V
     d.act_dtype = N.act_dtype(x1)
@@ -262,8 +253,6 @@ def _mlp_bwd_chain_wgrad(g2, z1, w12, w22, x1, st, ln_w, ln_b):
         rc = Fn._timed(f"mlp_chain_bwd_wgrad_{C}", x1.element_size() * (3 * x1.numel() + z1.numel()),
                        lambda: N.lib().fz_mlp_chain(ctypes.byref(d), N.stream_ptr(x1)))
         N.check(rc, "fz_mlp_chain")
-        rc = N.lib().fz_reduce_rows(part.data_ptr(), rows, 64, gpar.data_ptr(), tmp.data_ptr(), N.stream_ptr(x1))
-        N.check(rc, "fz_reduce_rows")
     return gx1, gpar[:32], gpar[32:], gw1, gb1, gw2, gb2
 
 

@@ -254,12 +254,13 @@ typedef struct fz_mlp_desc {
   float* gb1;         /* mode 2: (H)                                                         */
   float* gw2;         /* mode 2: (C, H)                                                      */
   float* gb2;         /* mode 2: (C)                                                         */
+  float* gln;         /* mode 2: (2*C) dgamma | dbeta of the LayerNorm (part is not used)    */
 } fz_mlp_desc;
 
 /* ---- input gradient AND weight gradient of a 32 -> 32 1x1 layer in one pass (in_proj behind LayerNorm, out_proj;
  * factorizer.py:38,53 + norm.py:29-34 as autograd sees them):
- *   y = W^T g                                  (ln: then LayerNormBackward(.; q, stats, ln_g) + gadd; part receives
- *                                               fz_mlp_partials(B, V) rows of (dgamma | dbeta) sums)
+ *   y = W^T g                                  (ln: then LayerNormBackward(.; q, stats, ln_g) + gadd; gln receives
+ *                                               dgamma | dbeta)
  *   gw (32, 32) = sum_v g[m,v] * in[k,v]       (ln: in = ln_g * xhat(q) + ln_b, the LayerNorm output)
  *   gb (32)     = sum_v g[m,v]                 (optional)
  * wpart: fz_gemm_dw_workspace_bytes(B, V) bytes of caller workspace; rows are added in index order. */
@@ -273,7 +274,7 @@ typedef struct fz_gemm_dw_desc {
   const float* ln_b;   /* ln: (32)                                                            */
   const void* gadd;    /* ln: activation (B, 32, V) added to y, or NULL                       */
   void* y;             /* activation (B, 32, V)                                               */
-  float* part;         /* ln: fz_mlp_partials(B, V) x 64 floats                               */
+  float* gln;          /* ln: (64) dgamma | dbeta                                             */
   void* wpart;
   float* gw;           /* (32, 32)                                                            */
   float* gb;           /* (32) or NULL                                                        */
