@@ -1044,8 +1044,9 @@ __global__ __launch_bounds__(256, 2) void gemm_chain64_kernel(GemmArgsT<AT> p, C
 // again for dW2 = g2 ⊗ gelu(z1) and writes + re-reads gz1 for dW1 = gz1 ⊗ LN(x1) — 13 plane-sets of traffic per
 // block (7 chain + 3 + 3) where 5 suffice (g2, z1 ×2, x1 in; gx1 out).  A weight gradient reduces over VOXELS, so
 // its MFMA operands need the channel on the lane axis; everything in the chain has the voxel there.  Each wave
-// turns its tile through wave-private LDS ([channel][voxel] rows, stride 68 ≡ 4 (mod 64): the 64 (channel16, k4)
-// lanes of a v_mfma_f32_16x16x4_f32 operand read hit 64 banks):
+// turns its tile through wave-private LDS ([channel][voxel] rows, stride 66 ≡ 2 (mod 32): ds_read_b32 banks are
+// (a/4) mod 32 per 32-lane half, and the (channel16, k4 ∈ {0,1} resp. {2,3}) lanes of a v_mfma_f32_16x16x4_f32 operand
+// read then hit 32 different banks; the 8-byte tile writes / accumulator-layout reads are conflict-free at any stride):
 //   Bf  32 x 64: g2 (operand of dW2) during the first pass, then LN-normalised x1 (operand of dW1, and the
 //                LayerNorm backward reads it back in the accumulator layout);
 //   T   16 x 64: one 16-channel block of gelu(z1) (pass A) resp. gz1 (pass B) at a time.
@@ -1055,7 +1056,7 @@ __global__ __launch_bounds__(256, 2) void gemm_chain64_kernel(GemmArgsT<AT> p, C
 // 13 KB of LDS per wave + 64 accumulator registers: two workgroups per CU (the plain chain runs three).
 // =================================================================================================
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int kTS = 68;                       // LDS row stride of the transposable tiles (floats)
+constexpr int kTS = 66;                       // LDS row stride of the transposable tiles (floats): ≡ 2 (mod 32), even
 constexpr int kWgRow = 2048 + 2048 + 32 + 64 + 64; // floats of one wpart row: dW2 [32][64] | S1 [64][32] | db2 | db1 | dγ | dβ
 
 // gelu(x) and gelu'(x) with ONE exponential: erf(x/√2) by Abramowitz-Stegun 7.1.26 (fast_erf, fz_common.h) needs
