@@ -758,7 +758,9 @@ __global__ __launch_bounds__(256, (NACC == 2 && HB == 2) ? 3 : 2) void gemm_chai
 //   forward : z = W1·LN(x1) + b1 -> side ; out = x1 + W2·gelu(z) + b2          5 plane-sets against 7 unfused
 //   backward: gz = (W2ᵀ g2) ∘ gelu'(z) -> side ; out = LNbwd(W1ᵀ gz) + g2      8 against 12 (+ dγ, dβ partial rows)
 // =================================================================================================
-template <bool BWD, typename AT>
+// SINGLE (BWD only): ONE 64 -> 64 input-gradient GEMM (in_proj of a C = 64 block) in front of the same LayerNorm-backward
+// epilogue — fz_gemm with EPI_LNBWD and M = K = 64: the pre-LayerNorm gradient never reaches HBM.
+template <bool BWD, typename AT, bool SINGLE = false>
 __global__ __launch_bounds__(256, 2) void gemm_chain64_kernel(GemmArgsT<AT> p, ChainArgsT<AT> c, int ntiles) {
   constexpr int NACC = 2, C = 64, HID = 128;
   extern __shared__ __attribute__((aligned(16))) float fz_lds_c64[];
@@ -771,13 +773,16 @@ __global__ __launch_bounds__(256, 2) void gemm_chain64_kernel(GemmArgsT<AT> p, C
   const int j = lane & 31, h = lane >> 5;
   const int tiles_per_sample = (int)((p.Ncol + 128 * NACC - 1) / (128 * NACC));
 
-  for (int base = threadIdx.x; base < 16384; base += 256 * 8) {
+  for (int base = threadIdx.x; base < (SINGLE ? 4096 : 16384); base += 256 * 8) {
     float tmp[8];
 #pragma unroll
     for (int uu = 0; uu < 8; ++uu) {
       const int idx = base + uu * 256;
       float wv;
-      if (idx < 8192) {
+      if (SINGLE) {   // A[m = mb*32 + (l & 31)][k = 2a + (l >> 5)], [32 steps][2 row blocks][64]
+        const int l = idx & 63, mb = (idx >> 6) & 1, a = idx >> 7;
+        wv = weight_at(p, mb * 32 + (l & 31), 2 * a + (l >> 5));
+      } else if (idx < 8192) {
         const int l = idx & 63, rb = (idx >> 6) & 3, a = idx >> 8;
         const int m = rb * 32 + (l & 31), k = 2 * a + (l >> 5);
         wv = weight_at(p, m, k);
@@ -866,8 +871,21 @@ __global__ __launch_bounds__(256, 2) void gemm_chain64_kernel(GemmArgsT<AT> p, C
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[mb][q][r] = 0.f;
 
+    if (SINGLE) {
 #pragma unroll
-    for (int p2 = 0; p2 < 2; ++p2) {
+      for (int s = 0; s < 32; ++s) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+          const float av = As1[(s * 2 + mb) * 64 + lane];
+#pragma unroll
+          for (int q = 0; q < NACC; ++q) acc2[mb][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[s][q], acc2[mb][q], 0, 0, 0);
+        }
+        if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+      fetch_tile(tile + gridDim.x < ntiles ? tile + gridDim.x : tile);
+    }
+#pragma unroll
+    for (int p2 = 0; p2 < (SINGLE ? 0 : 2); ++p2) {
       // ---- GEMM 1, hidden rows 64·p2 .. 64·p2 + 63 ----
       f32x16 acc1[2][NACC];
 #pragma unroll
@@ -2112,9 +2130,10 @@ static int gemm_launch(const fz_gemm_desc* d, fz_stream_t stream) {
   if (!d->x[0] || !d->w || !d->y) return fail(FZ_E_ARG, "fz_gemm: null pointer");
   if (d->loader < LOAD_PLAIN || d->loader > LOAD_K3) return fail(FZ_E_ARG, "fz_gemm: bad loader");
   if (d->epilogue < EPI_PLAIN || d->epilogue > EPI_LNBWD) return fail(FZ_E_ARG, "fz_gemm: bad epilogue");
-  if (d->epilogue == EPI_LNBWD && (d->M != 32 || (d->K != 32 && d->K != 64) || d->loader != LOAD_PLAIN || !d->lnb_x || !d->lnb_stats ||
+  const bool lnb64 = d->epilogue == EPI_LNBWD && d->M == 64 && d->K == 64 && d->nsrc == 1 && !d->bmul;
+  if (d->epilogue == EPI_LNBWD && ((!lnb64 && (d->M != 32 || (d->K != 32 && d->K != 64))) || d->loader != LOAD_PLAIN || !d->lnb_x || !d->lnb_stats ||
                                    !d->lnb_g || !d->lnb_part || d->bias || d->res || d->emul || d->eact || d->ln))
-    return fail(FZ_E_UNSUPPORTED, "fz_gemm: LayerNorm-backward epilogue needs M == 32, K <= 64, plain loader");
+    return fail(FZ_E_UNSUPPORTED, "fz_gemm: LayerNorm-backward epilogue needs M == 32 (K = 32 or 64) or M == K == 64, plain loader");
   if (d->epilogue == EPI_LNBWD && d->Ncol > ((int64_t)1 << 27)) return fail(FZ_E_UNSUPPORTED, "fz_gemm: LayerNorm-backward epilogue: more than 2^27 voxels per sample");
   if (d->B < 0 || d->Cin < 1 || d->M < 1 || d->K < 1) return fail(FZ_E_SHAPE, "fz_gemm: sizes must be positive");
   if ((d->K & 1) && (d->loader != LOAD_PLAIN || d->ln))
@@ -2146,6 +2165,18 @@ static int gemm_launch(const fz_gemm_desc* d, fz_stream_t stream) {
   a.lnb_x = (const AT*)d->lnb_x; a.lnb_stats = d->lnb_stats; a.lnb_g = d->lnb_g; a.lnb_gadd = (const AT*)d->lnb_gadd; a.lnb_part = d->lnb_part;
   hipStream_t st = (hipStream_t)stream;
   const int mblocks = (d->M + 31) / 32;
+  if (lnb64) {   // 64 -> 64 input gradient + LayerNorm backward over 64 channels: gemm_chain64_kernel, SINGLE form
+    if (d->Ncol % 4 != 0) return fail(FZ_E_UNSUPPORTED, "fz_gemm: voxel count must be a multiple of 4");
+    if (!d->lnb_gadd) return fail(FZ_E_UNSUPPORTED, "fz_gemm: the 64-channel LayerNorm-backward epilogue needs the added gradient");
+    ChainArgsT<AT> c = {};
+    const int ntiles = (int)fz_mlp_partials(d->B, d->Ncol);
+    constexpr int lds64 = (8192 + 8192 + 128 + 64 + 512) * (int)sizeof(float);
+    auto kern = gemm_chain64_kernel<true, AT, true>;
+    FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds64));
+    hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles < 512 ? ntiles : 512)), dim3(256), lds64, st, a, c, ntiles);
+    FZ_LAUNCH_CHECK();
+    return FZ_OK;
+  }
 
   // ---- Kernel A: whole operand in registers (K <= 64, plain loader) ----
   // measured (tools/debug/gemm_probe5.py): the register-resident kernel wins for K <= 32, the
@@ -2271,7 +2302,8 @@ extern "C" int fz_gemm(const fz_gemm_desc* d, fz_stream_t stream) {
 
 extern "C" int64_t fz_gemm_lnbwd_partials(const fz_gemm_desc* d) {
   if (!d) return -1;
-  return ((d->Ncol + 511) / 512) * d->B;  // one row per workgroup of the resident kernel
+  if (d->M == 64) return fz_mlp_partials(d->B, d->Ncol);   // 256-voxel tiles, rows of 128 floats
+  return ((d->Ncol + 511) / 512) * d->B;  // one row per workgroup of the resident kernel (rows of 64 floats)
 }
 
 // MLP chain for C = 32, hidden 64 (see gemm_chain_kernel).  Replaces, per FactorizerBlock,

@@ -108,11 +108,12 @@ def _ln_backward(gl, x, stats, ln_w, gadd=None):
 
 def _dgrad_lnbwd(gz, w2, x, stats, ln_w, gadd):
     """gx = LayerNormBackward(W2ᵀ·gz; x, stats, γ) + gadd and (gγ, gβ), in ONE kernel when the
-    LayerNorm width is 32 (csrc/gemm.hip EPI_LNBWD: gl never leaves the accumulators)."""
+    LayerNorm width is 32, or 64 with a 64-channel gradient (csrc/gemm.hip EPI_LNBWD: gl never leaves the accumulators)."""
     B, C = x.shape[:2]
     V = _vox(x)
     Mz = gz.shape[1]
-    if C != 32 or Mz > 64 or Mz % 2:
+    fused64 = C == 64 and Mz == 64 and gadd is not None and V % 4 == 0 and os.environ.get("FZ_LNBWD64", "1") != "0"
+    if not fused64 and (C != 32 or Mz > 64 or Mz % 2):
         gl = torch.empty_like(x)
         _gemm([gz], w2, gl, B=B, Cin=Mz, Vin=V, M=C, K=Mz, Ncol=V, w_t=True, ldw=C, name="linear_dgrad")
         return _ln_backward(gl, x, stats, ln_w, gadd=gadd)
@@ -126,17 +127,17 @@ def _dgrad_lnbwd(gz, w2, x, stats, ln_w, gadd):
     d.lnb_x, d.lnb_stats, d.lnb_g, d.lnb_gadd = x.data_ptr(), stats.data_ptr(), ln_w.data_ptr(), _p(gadd)
     d.act_dtype = N.act_dtype(x)
     rows = N.lib().fz_gemm_lnbwd_partials(ctypes.byref(d))
-    part = torch.empty((rows, 64), dtype=torch.float32, device=x.device)
+    part = torch.empty((rows, 2 * C), dtype=torch.float32, device=x.device)
     d.lnb_part = part.data_ptr()
-    gpar = torch.empty(64, dtype=torch.float32, device=x.device)
-    tmp = torch.empty((64, 64), dtype=torch.float32, device=x.device)
+    gpar = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+    tmp = torch.empty((64, 2 * C), dtype=torch.float32, device=x.device)
     nbytes = x.element_size() * (gz.numel() + 2 * x.numel() + (gadd.numel() if gadd is not None else 0))
     with torch.cuda.device(x.device):
         rc = Fn._timed(f"dgrad_lnbwd_{Mz}->{C}", nbytes, lambda: N.lib().fz_gemm(ctypes.byref(d), N.stream_ptr(x)))
         N.check(rc, "fz_gemm")
-        rc = N.lib().fz_reduce_rows(part.data_ptr(), rows, 64, gpar.data_ptr(), tmp.data_ptr(), N.stream_ptr(x))
+        rc = N.lib().fz_reduce_rows(part.data_ptr(), rows, 2 * C, gpar.data_ptr(), tmp.data_ptr(), N.stream_ptr(x))
         N.check(rc, "fz_reduce_rows")
-    return gx, gpar[:32], gpar[32:]
+    return gx, gpar[:C], gpar[C:]
 
 
 def _dw_fused_ok(C, V):

@@ -197,9 +197,10 @@ typedef struct fz_gemm_desc {
   int Ho, Wo;          /* coarse H, W (s2d columns / d2s input grid)                           */
   int B;
   int loader, epilogue;
-  /* FZ_EPI_LNBWD: LayerNorm input x (B,32,V), saved stats (B,2,V), gamma (32), optional gradient
-   * added to the result, and a partial buffer of fz_gemm_lnbwd_partials(desc) x 64 floats that
-   * receives per-workgroup (dgamma | dbeta) sums (reduce over rows in order). */
+  /* FZ_EPI_LNBWD (M = 32 with K = 32 or 64; or M = K = 64 with the added gradient): LayerNorm input x (B,M,V),
+   * saved stats (B,2,V), gamma (M), gradient added to the result (optional for M = 32), and a partial buffer of
+   * fz_gemm_lnbwd_partials(desc) x 2*M floats that receives per-workgroup (dgamma | dbeta) sums (reduce over
+   * rows in order). */
   const void* lnb_x;      /* activation */
   const float* lnb_stats;
   const float* lnb_g;

@@ -409,6 +409,33 @@ def test_gemm_dw_kernel(B, S, ln, bf):
         assert torch.equal(gb, gb2)
 
 
+@pytest.mark.parametrize("C,Mz", [(32, 32), (32, 64), (64, 64)])
+@pytest.mark.parametrize("B,S", [(2, (8, 8, 8)), (1, (6, 4, 5)), (2, (16, 32, 40))])
+def test_dgrad_lnbwd_kernel(B, S, C, Mz):
+    """fz_gemm with the LayerNorm-backward epilogue: gx = LNbwd(Wᵀ gz; x, stats, γ) + gadd, dγ, dβ — the resident kernel
+    (LayerNorm width 32) and the SINGLE form of gemm_chain64_kernel (width 64, 64-channel gradient) — against CPU
+    autograd of Linear∘LayerNorm."""
+    torch.manual_seed(23 + C + Mz)
+    x = torch.randn(B, C, *S) * 1.5 + 0.3
+    gz, gadd = torch.randn(B, Mz, *S), torch.randn(B, C, *S)
+    w = torch.randn(Mz, C) * 0.2
+    ln_w, ln_b = torch.rand(C) + 0.5, torch.randn(C) * 0.1
+    xc = x.clone().requires_grad_(True)
+    lw, lb = ln_w.clone().requires_grad_(True), ln_b.clone().requires_grad_(True)
+    yc = _lin_cpu(F.layer_norm(xc.movedim(1, -1), (C,), lw, lb, 1e-5).movedim(-1, 1), w.unsqueeze(-1), None)
+    gxc, ggc, gbc = torch.autograd.grad(yc, [xc, lw, lb], gz)
+    d = lambda t: t.to(DEV).contiguous()  # noqa: E731
+    xd = d(x)
+    V = x[0, 0].numel()
+    st = torch.cat([xd.mean(1, keepdim=True), (xd.var(1, unbiased=False, keepdim=True) + 1e-5).rsqrt()], 1).reshape(B, 2, V).contiguous()
+    n0 = _native.launch_count()
+    gx, gg, gb = PW._dgrad_lnbwd(d(gz), d(w), xd, st, d(ln_w), d(gadd))
+    assert _native.launch_count() > n0
+    _cmp(gx, gxc + gadd, "gx")
+    _cmp(gg, ggc, "dgamma")
+    _cmp(gb, gbc, "dbeta")
+
+
 def test_flat_adamw_kernel_matches_torch():
     """fz_adamw_step (csrc/optim.hip) against torch.optim.AdamW on the CPU: 5 steps over a 1 000 003-element
     buffer (odd length: vector body + scalar tail), lr 1e-4 / wd 1e-5 of train.yaml:72-76."""
