@@ -116,7 +116,7 @@ class MlpDesc(_c.Structure):
     _fields_ = [("mode", _i), ("inp", _vp), ("w1", _vp), ("w2", _vp), ("b1", _vp), ("b2", _vp), ("ln_g", _vp),
                 ("ln_b", _vp), ("ln_eps", _f), ("stats", _vp), ("z1", _vp), ("gz1", _vp), ("x1", _vp), ("out", _vp),
                 ("part", _vp), ("B", _i), ("C", _i), ("H", _i), ("V", _i64), ("act_dtype", _i), ("wpart", _vp),
-                ("gw1", _vp), ("gb1", _vp), ("gw2", _vp), ("gb2", _vp), ("gln", _vp)]
+                ("gw1", _vp), ("gb1", _vp), ("gw2", _vp), ("gb2", _vp), ("gln", _vp), ("glp", _vp)]
 
 
 class GemmDwDesc(_c.Structure):

@@ -1090,9 +1090,16 @@ __device__ __forceinline__ void gelu_both(float x, float& g, float& dg) {
   dg = cdf + x * (0.3989422804014327f * E);
 }
 
-template <typename AT>
-__global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT> p, ChainArgsT<AT> c, int ntiles, float* wpart) {
-  constexpr int NACC = 2, HB = 2, HID = 64, N1 = 16 * HB * 64;
+// HALVES = 2 (hidden 128, mlp_ratio 4 of the BraTS bundle, train.yaml:62): the 128 accumulator registers of the weight
+// gradients do not fit next to the chain, so the kernel runs once per 64-row half of the hidden tensor — launch `half`
+// = 0 leaves its part of W1ᵀ·gz1 in `glp` (fp32, accumulator layout in HBM), launch 1 starts GEMM 2 from it and ends
+// with the LayerNorm backward.  12 plane-sets for both launches against 21 of the unfused chain + weight gradients.
+template <typename AT, int HALVES = 1>
+__global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT> p, ChainArgsT<AT> c, int ntiles, float* wpart,
+                                                                   int half, float* glp) {
+  constexpr int NACC = 2, HB = 2, HID = 64 * HALVES, N1 = 16 * HB * 64;
+  const int hoff = 64 * half;                 // first hidden row of this launch
+  const bool last = half == HALVES - 1;       // this launch ends with the LayerNorm backward
   constexpr int kWave = 48 * kTS;             // floats of one wave's (Bf | T) region
   extern __shared__ __attribute__((aligned(16))) float fz_lds_cw[];
   float* As1 = fz_lds_cw;
@@ -1115,12 +1122,12 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
       float wv;
       if (idx < N1) {
         const int l = idx & 63, rb = (idx >> 6) % HB, a = idx / (64 * HB);
-        wv = weight_at(p, rb * 32 + (l & 31), 2 * a + (l >> 5));
+        wv = weight_at(p, hoff + rb * 32 + (l & 31), 2 * a + (l >> 5));
       } else {
         const int i2 = idx - N1;
         const int l = i2 & 63, s2 = i2 >> 6;
         const int r = s2 & 15, rb = s2 >> 4;
-        const int k = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), m = l & 31;
+        const int k = hoff + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), m = l & 31;
         wv = c.wB_t ? c.wB[(int64_t)k * c.ldwB + m] : c.wB[(int64_t)m * c.ldwB + k];
       }
       tmp[uu] = wv;
@@ -1179,7 +1186,7 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int rr = g8 * 8 + i, rb = rr >> 4, r = rr & 15;
-        const int rbase = rb * 32 + (r & 3) + 8 * (r >> 2);
+        const int rbase = hoff + rb * 32 + (r & 3) + 8 * (r >> 2);
         vload<NACC>(p.emul + ((int64_t)b * HID + rbase) * p.Ncol + lane_row, dst[i]);
       }
     };
@@ -1255,7 +1262,7 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
           dW2[0][g8] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u], bq[u], dW2[0][g8], 0, 0, 0);
           dW2[1][g8] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u], bq[u], dW2[1][g8], 0, 0, 0);
         }
-        if (g8 == 0) {   // db2 = Σ_v g2 from the operands of the first group (pinned: the optimiser otherwise postpones
+        if (g8 == 0 && (HALVES == 1 || half == 0)) {   // db2 = Σ_v g2 from the operands of the first group (pinned: the optimiser otherwise postpones
                          // the sums — and keeps the operands alive — to the end of the tile)
           db2[0] += ((a0[0] + a0[1]) + (a0[2] + a0[3])) + ((a0[4] + a0[5]) + (a0[6] + a0[7]));
           db2[1] += ((a1[0] + a1[1]) + (a1[2] + a1[3])) + ((a1[4] + a1[5]) + (a1[6] + a1[7]));
@@ -1308,16 +1315,27 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
 
     // residual rows (g2 again: L2 / MALL), requested before GEMM 2
     float ga[2][8][NACC];
+    if (last) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-      vload<NACC>(p.lnb_gadd + sample + (int64_t)((r & 3) + 8 * (r >> 2)) * p.Ncol + lane_row, ga[r >> 3][r & 7]);
+      for (int r = 0; r < 16; ++r)
+        vload<NACC>(p.lnb_gadd + sample + (int64_t)((r & 3) + 8 * (r >> 2)) * p.Ncol + lane_row, ga[r >> 3][r & 7]);
+    }
 
-    // ---- GEMM 2: gl = W1ᵀ gz1 straight from the accumulators ----
+    // ---- GEMM 2: gl = W1ᵀ gz1 straight from the accumulators (second half: on top of the first half's part) ----
     f32x16 acc2[NACC];
+    if (HALVES == 2 && half == 1) {
 #pragma unroll
-    for (int q = 0; q < NACC; ++q)
+      for (int r = 0; r < 16; ++r) {
+        float v[NACC];
+        vload<NACC>(glp + sample + (int64_t)((r & 3) + 8 * (r >> 2)) * p.Ncol + lane_row, v);
+        acc2[0][r] = v[0]; acc2[1][r] = v[1];
+      }
+    } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc2[q][r] = 0.f;
+      for (int q = 0; q < NACC; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[q][r] = 0.f;
+    }
 #pragma unroll
     for (int rb = 0; rb < HB; ++rb)
 #pragma unroll
@@ -1329,6 +1347,16 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
       }
     fetch_tile(tile + gridDim.x < ntiles ? tile + gridDim.x : tile);
 
+    if (HALVES == 2 && !last) {   // first half: park the partial W1ᵀ·gz1 (fp32), no epilogue
+      if (col_ok) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v[NACC] = {acc2[0][r], acc2[1][r]};
+          vstore<NACC>(glp + sample + (int64_t)((r & 3) + 8 * (r >> 2)) * p.Ncol + lane_row, v);
+        }
+      }
+      continue;
+    }
     // ---- LayerNorm backward + residual gradient (x̂ from Bf in the accumulator layout, g2 re-read: L2 / MALL) ----
     float m1[NACC] = {0.f, 0.f}, m2[NACC] = {0.f, 0.f};
 #pragma unroll
@@ -1425,8 +1453,10 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
 
 // gw2 = Σ rows dW2;  gb2, gb1 likewise;  gw1[c][k] = γ[k]·Σ S1[c][k] + β[k]·gb1[c]   (z1 = W1·(γ x̂ + β) + b1).
 // 256 threads = 16 elements x 16 row slices; slices walk the rows with stride 16 and are added in slice order.
+// (hidden 128: called once per half with gw2 advanced by 64·half columns and ldw2 = 128, gw1 / gb1 by 64·half rows;
+// gb2 from the first half, gln from the second — null where not wanted)
 __global__ __launch_bounds__(256) void chain_wg_finish_kernel(const float* wpart, int rows, const float* ln_g, const float* ln_b,
-                                                              float* gw1, float* gb1, float* gw2, float* gb2, float* gln) {
+                                                              float* gw1, float* gb1, float* gw2, int ldw2, float* gb2, float* gln) {
   __shared__ float s[16][17];
   __shared__ float sb1[64];
   const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
@@ -1457,11 +1487,11 @@ __global__ __launch_bounds__(256) void chain_wg_finish_kernel(const float* wpart
     __syncthreads();
   }
   if (sl != 0 || e >= kWgRow) return;
-  if (e < 2048) gw2[e] = v;
+  if (e < 2048) gw2[(e >> 6) * ldw2 + (e & 63)] = v;
   else if (e < 4096) { const int k = (e - 2048) & 31; gw1[e - 2048] = ln_g[k] * v + ln_b[k] * sb1[0]; }
-  else if (e < 4096 + 32) gb2[e - 4096] = v;
+  else if (e < 4096 + 32) { if (gb2 != nullptr) gb2[e - 4096] = v; }
   else if (e < 4096 + 96) gb1[e - 4096 - 32] = v;
-  else gln[e - 4096 - 96] = v;          // dγ (32) | dβ (32)
+  else if (gln != nullptr) gln[e - 4096 - 96] = v;          // dγ (32) | dβ (32)
 }
 
 // =================================================================================================
@@ -2326,7 +2356,7 @@ extern "C" int fz_mlp_wgrad_rows(int B, int64_t V) {
   return (int)(nt < wgs ? nt : wgs);
 }
 extern "C" int64_t fz_mlp_wgrad_workspace_bytes(int B, int64_t V) {
-  return (int64_t)fz_mlp_wgrad_rows(B, V) * kWgRow * (int64_t)sizeof(float);
+  return 2 * (int64_t)fz_mlp_wgrad_rows(B, V) * kWgRow * (int64_t)sizeof(float);   // two row blocks (hidden 128 runs in two halves)
 }
 
 extern "C" int fz_mlp_supported(int C, int H, int64_t V) {
@@ -2345,14 +2375,14 @@ static int mlp_launch(const fz_mlp_desc* d, fz_stream_t stream) {
   if (d->mode == 1 && (!d->gz1 || !d->x1 || !d->ln_g || !d->part)) return fail(FZ_E_ARG, "fz_mlp_chain: backward needs gz1, x1, gamma, part");
   if (d->mode == 2 && (!d->x1 || !d->ln_g || !d->ln_b || !d->gln || !d->wpart || !d->gw1 || !d->gb1 || !d->gw2 || !d->gb2))
     return fail(FZ_E_ARG, "fz_mlp_chain: backward with weight gradients needs x1, gamma, beta, gln, wpart, gw1, gb1, gw2, gb2");
-  if (d->mode == 2 && d->H != 64) return fail(FZ_E_UNSUPPORTED, "fz_mlp_chain: the fused weight gradients need H == 64");
+  if (d->mode == 2 && d->H == 128 && !d->glp) return fail(FZ_E_ARG, "fz_mlp_chain: the fused weight gradients at H == 128 need the glp buffer");
   if (d->mode < 0 || d->mode > 2) return fail(FZ_E_ARG, "fz_mlp_chain: bad mode");
   if (d->B == 0) {
     if (d->mode == 2) {   // no voxels: the sums are empty
       hipStream_t s0 = (hipStream_t)stream;
-      FZ_HIP_OK(hipMemsetAsync(d->gw1, 0, sizeof(float) * 64 * 32, s0));
-      FZ_HIP_OK(hipMemsetAsync(d->gw2, 0, sizeof(float) * 64 * 32, s0));
-      FZ_HIP_OK(hipMemsetAsync(d->gb1, 0, sizeof(float) * 64, s0));
+      FZ_HIP_OK(hipMemsetAsync(d->gw1, 0, sizeof(float) * d->H * 32, s0));
+      FZ_HIP_OK(hipMemsetAsync(d->gw2, 0, sizeof(float) * d->H * 32, s0));
+      FZ_HIP_OK(hipMemsetAsync(d->gb1, 0, sizeof(float) * d->H, s0));
       FZ_HIP_OK(hipMemsetAsync(d->gb2, 0, sizeof(float) * 32, s0));
       FZ_HIP_OK(hipMemsetAsync(d->gln, 0, sizeof(float) * 64, s0));
     }
@@ -2409,13 +2439,27 @@ static int mlp_launch(const fz_mlp_desc* d, fz_stream_t stream) {
     c.wB = d->w1; c.wB_t = 1; c.ldwB = 32;
     const int rows = fz_mlp_wgrad_rows(d->B, d->V);
     constexpr int lds = (2 * 2048 + 32 + 256 + 4 * 48 * kTS) * (int)sizeof(float);
-    auto kern = gemm_chain_bwd_wg_kernel<AT>;
-    FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)rows), block, lds, st, a, c, ntiles, (float*)d->wpart);
-    FZ_LAUNCH_CHECK();
-    hipLaunchKernelGGL(chain_wg_finish_kernel, dim3(kWgRow / 16), dim3(256), 0, st, (const float*)d->wpart, rows, d->ln_g, d->ln_b,
-                       d->gw1, d->gb1, d->gw2, d->gb2, d->gln);
-    FZ_LAUNCH_CHECK();
+    if (d->H == 64) {
+      auto kern = gemm_chain_bwd_wg_kernel<AT, 1>;
+      FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      hipLaunchKernelGGL(kern, dim3((unsigned)rows), block, lds, st, a, c, ntiles, (float*)d->wpart, 0, (float*)nullptr);
+      FZ_LAUNCH_CHECK();
+      hipLaunchKernelGGL(chain_wg_finish_kernel, dim3(kWgRow / 16), dim3(256), 0, st, (const float*)d->wpart, rows, d->ln_g, d->ln_b,
+                         d->gw1, d->gb1, d->gw2, 64, d->gb2, d->gln);
+      FZ_LAUNCH_CHECK();
+    } else {   // hidden 128: one launch per 64-row half (wpart holds two row blocks)
+      auto kern = gemm_chain_bwd_wg_kernel<AT, 2>;
+      FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      for (int half = 0; half < 2; ++half) {
+        float* wp = (float*)d->wpart + (int64_t)half * rows * kWgRow;
+        hipLaunchKernelGGL(kern, dim3((unsigned)rows), block, lds, st, a, c, ntiles, wp, half, d->glp);
+        FZ_LAUNCH_CHECK();
+        hipLaunchKernelGGL(chain_wg_finish_kernel, dim3(kWgRow / 16), dim3(256), 0, st, (const float*)wp, rows, d->ln_g, d->ln_b,
+                           d->gw1 + half * 64 * 32, d->gb1 + half * 64, d->gw2 + half * 64, 128,
+                           half == 0 ? d->gb2 : (float*)nullptr, half == 1 ? d->gln : (float*)nullptr);
+        FZ_LAUNCH_CHECK();
+      }
+    }
     return FZ_OK;
   } else {
     a.w = d->w2; a.w_t = 1; a.ldw = d->H;            // A1[m = hidden][k = c] = W2[c][hidden]

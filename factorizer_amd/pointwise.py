@@ -226,8 +226,9 @@ def _mlp_bwd_chain(g2, z1, w12, w22, x1, st, ln_w):
 
 
 def _mlp_wgrad_fused_ok(C, Hd, V):
-    """the chain backward that also forms dW1, db1, dW2, db2 (csrc/gemm.hip gemm_chain_bwd_wg_kernel): hidden 64"""
-    return _mlp_chain_ok(C, Hd, V) and Hd == 64 and os.environ.get("FZ_MLP_FUSED_WGRAD", "1") != "0"
+    """the chain backward that also forms dW1, db1, dW2, db2 (csrc/gemm.hip gemm_chain_bwd_wg_kernel): C = 32, hidden 64
+    (one launch) or 128 (one launch per 64-row half of the hidden tensor)"""
+    return _mlp_chain_ok(C, Hd, V) and C == 32 and Hd in (64, 128) and os.environ.get("FZ_MLP_FUSED_WGRAD", "1") != "0"
 
 
 def _mlp_bwd_chain_wgrad(g2, z1, w12, w22, x1, st, ln_w, ln_b):
@@ -248,10 +249,14 @@ def _mlp_bwd_chain_wgrad(g2, z1, w12, w22, x1, st, ln_w, ln_b):
     d.ln_g, d.ln_b, d.stats, d.z1, d.x1 = ln_w.data_ptr(), ln_b.data_ptr(), st.data_ptr(), z1.data_ptr(), x1.data_ptr()
     d.out, d.gln, d.wpart = gx1.data_ptr(), gpar.data_ptr(), wpart.data_ptr()
     d.gw1, d.gb1, d.gw2, d.gb2 = gw1.data_ptr(), gb1.data_ptr(), gw2.data_ptr(), gb2.data_ptr()
+    glp = torch.empty(x1.shape, dtype=torch.float32, device=dev) if Hd == 128 else None
+    d.glp = _p(glp)
     d.B, d.C, d.H, d.V = B, C, Hd, V
     d.act_dtype = N.act_dtype(x1)
+    # algorithmic bytes: H = 64: g2, z1, x1 in, gx1 out; H = 128: both halves read g2 and x1, + the fp32 partial out and in
+    nbytes = x1.element_size() * (3 * x1.numel() + z1.numel()) + (0 if Hd == 64 else x1.element_size() * 2 * x1.numel() + 8 * x1.numel())
     with torch.cuda.device(dev):
-        rc = Fn._timed(f"mlp_chain_bwd_wgrad_{C}", x1.element_size() * (3 * x1.numel() + z1.numel()),
+        rc = Fn._timed(f"mlp_chain_bwd_wgrad_{C}" + ("" if Hd == 64 else f"x{Hd}"), nbytes,
                        lambda: N.lib().fz_mlp_chain(ctypes.byref(d), N.stream_ptr(x1)))
         N.check(rc, "fz_mlp_chain")
     return gx1, gpar[:32], gpar[32:], gw1, gb1, gw2, gb2

@@ -226,7 +226,8 @@ int fz_gemm(const fz_gemm_desc* desc, fz_stream_t stream);
  *           out = LayerNormBackward(W1ᵀ·gz1; x1, stats, gamma) + in ; part receives
  *           fz_mlp_partials(B, V) rows of 64 floats (dgamma | dbeta partial sums, reduce with
  *           fz_reduce_rows)
- *   mode 2  (H = 64) mode 1 WITH the two weight gradients and bias gradients of the MLP, gz1 never reaching
+ *   mode 2  (C = 32; H = 64 in one launch, H = 128 in one launch per 64-row half of the hidden tensor) mode 1 WITH
+ *           the two weight gradients and bias gradients of the MLP, gz1 never reaching
  *           HBM: gw2 (C, H) = sum_v in[.,v] gelu(z1[.,v])^T, gb2 (C) = sum_v in, gb1 (H) = sum_v gz1,
  *           gw1 (H, C) = sum_v gz1 (ln_g * xhat + ln_b)^T.  wpart: fz_mlp_wgrad_workspace_bytes(B, V) bytes of
  *           caller workspace (one row of partial sums per resident workgroup, added in row order).
@@ -256,6 +257,7 @@ typedef struct fz_mlp_desc {
   float* gw2;         /* mode 2: (C, H)                                                      */
   float* gb2;         /* mode 2: (C)                                                         */
   float* gln;         /* mode 2: (2*C) dgamma | dbeta of the LayerNorm (part is not used)    */
+  float* glp;         /* mode 2, H = 128: (B, C, V) fp32 scratch (the first half's part of W1^T gz1) */
 } fz_mlp_desc;
 
 /* ---- input gradient AND weight gradient of a 32 -> 32 1x1 layer in one pass (in_proj behind LayerNorm, out_proj;

@@ -311,15 +311,16 @@ def test_mlp_chain_kernel(B, S, C, Hd):
     _cmp(gb, lb.grad, "dbeta")
 
 
+@pytest.mark.parametrize("Hd", [64, 128])
 @pytest.mark.parametrize("bf", [False, True])
 @pytest.mark.parametrize("B,S", [(2, (8, 8, 8)), (1, (6, 4, 5)), (2, (16, 16, 12)), (3, (32, 32, 40))])
-def test_mlp_chain_backward_with_weight_gradients(B, S, bf):
+def test_mlp_chain_backward_with_weight_gradients(B, S, bf, Hd):
     """fz_mlp_chain mode 2 (gemm_chain_bwd_wg_kernel): the input-gradient chain AND dW1, db1, dW2, db2 of the MLP from
     one pass over (g2, z1, x1) — transposed MFMA operands through wave-private LDS, sums carried across the tiles of
     the persistent workgroups, rows added in order.  Against CPU autograd of x + fc2(gelu(fc1(LN(x)))); V = 120
     covers a ragged tile, (3, 32·32·40) several tiles per workgroup.  Run twice: bit-identical."""
     torch.manual_seed(11)
-    C, Hd = 32, 64
+    C = 32    # Hd = 128 (mlp_ratio 4, BraTS bundle): one launch per 64-row half of the hidden tensor
     rnd = (lambda t: t.bfloat16().float()) if bf else (lambda t: t)
     x = rnd(torch.randn(B, C, *S) * 2 + 0.5)
     ln_w, ln_b = torch.rand(C) + 0.5, torch.randn(C) * 0.1
