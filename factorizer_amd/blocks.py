@@ -90,7 +90,8 @@ class FactorizerBlock(nn.Module):
 
     def _core_cfg(self):
         """(grad steps, solver id) if matricize→NMF→inverse can run as the fused channels-first
-        kernels (SWMatricize head_dim 8 / patch 8³, native MU/HALS, rank ≤ 2), else None."""
+        kernels (SWMatricize head_dim 8, patch 8³ — csrc/nmf_cf.hip — or any patch of ≤ 256 voxels — csrc/nmf_pcf.hip;
+        native MU/HALS, rank ≤ 2), else None."""
         f = self.fact
         mf = f.factorize
         if not (isinstance(f.reshape, SWMatricize) and isinstance(mf, MatrixFactorization)):
@@ -99,7 +100,8 @@ class FactorizerBlock(nn.Module):
         if sid is None or not isinstance(mf.init, RandomInit) or mf.solver.factor != (0, 1) or mf.verbose:
             return None
         G = min(max(mf.num_grad_steps, 0), mf.num_iters)
-        if tuple(mf.size) != (8, 512) or not Fn.nmf_cf_supported(f.reshape.geometry, mf.rank, mf.num_iters, G):
+        geo = f.reshape.geometry
+        if tuple(mf.size) != (8, geo.P) or not Fn.nmf_core_supported(geo, mf.rank, mf.num_iters, G):
             return None
         return G, sid
 

@@ -1,0 +1,294 @@
+// nmf_pcf.hip — FactMixer core on channels-first tensors for ANY patch size with head_dim 8 and at most 256 voxels
+// per patch: shifted-window matricize → NMF → inverse matricize in one kernel per window, like nmf_cf.hip (which keeps
+// the 8x8x8 hot shape and its line-coalesced exchange).
+//
+// Replaces SWMatricize.forward → NMF.forward → SWMatricize.inverse_forward (factorizer/factorizer.py:41-50;
+// operations.py:417-434; matrix_factorization.py:514-546) where the patch is not 8³ — BASELINE configs[4]
+// (160×192×160 is not divisible by 8: patch (5,6,5), 8×150 matrices), the p = 4 / p = 5 configurations of the
+// reference's tests.  The modular chain it replaces moved every activation five times per window (matricize write +
+// read, NMF result write + read, inverse); here a wave gathers its 8×P matrix straight from t with the window's cyclic
+// shift, runs the wave program of nmf_core.h (column n = 64·j + lane, masked beyond P) and scatters u vᵀ into the
+// averaged output — window 0 stores 0 + z_0, window w > 0 adds z_w, the last window divides by the number of windows
+// (operations.py:426-433 order).  Windows are separate launches on one stream: the accumulation is deterministic.
+// Accesses are one element per lane: runs of p2 contiguous voxels per patch row (20 B at p2 = 5) — not the 16-byte
+// lanes of the 8³ kernels, but 2 passes over t instead of 5 over t-sized tensors.
+#include <cstdlib>
+
+#include "fz_common.h"
+#include "nmf_core.h"
+
+namespace fz {
+
+struct PcfGeom {
+  int B, C, D, H, W;
+  int h;                // heads (C / 8)
+  int p0, p1, p2, P;    // patch, voxels per patch
+  int G0, G1, G2;       // patch grid
+  int s0, s1, s2;       // this window's shift, normalised to [0, S)
+  int accumulate;       // add to the existing output (windows > 0)
+  int divisor;          // > 1: divide the result by it (last window, forward)
+  float gscale_div;     // backward: gY = gather(ga) / gscale_div
+};
+
+template <int NPL>
+struct PcfWave {
+  using F = float;
+  int lane, nreal;
+  __device__ __forceinline__ int col(int j) const { return j * 64 + lane; }
+  __device__ __forceinline__ float sum(float v) const { return wave_sum(v); }
+  __device__ __forceinline__ void sum8(float (&v)[8]) const { wave_sum8(v, lane); }
+  __device__ __forceinline__ void st_priv(float* base, int idx, float v) const { base[idx * 64 + lane] = v; }
+  __device__ __forceinline__ float ld_priv(const float* base, int idx) const { return base[idx * 64 + lane]; }
+  __device__ __forceinline__ void st_uni(float* base, int idx, float v) const {
+    if (lane == 0) base[idx] = v;
+  }
+  __device__ __forceinline__ float ld_uni(const float* base, int idx) const { return base[idx]; }
+  __device__ __forceinline__ float ld_uni_global(const float* p, int idx) const { return p[idx]; }
+  __device__ __forceinline__ float ld_v0(const float* v0, int j, int r, int R) const {
+    const int n = col(j);
+    return n < nreal ? v0[n * R + r] : 0.f;
+  }
+  __device__ __forceinline__ float keep_col(int j, float v) const { return col(j) < nreal ? v : 0.f; }
+  __device__ __forceinline__ void fence() const { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+};
+
+// plane base of the wave's (sample, head) and the in-plane element offset of each of the lane's columns
+template <int NPL>
+__device__ __forceinline__ void pcf_decode(const PcfGeom& q, int64_t mat, int lane, int64_t& base, int64_t& V,
+                                           int (&voff)[NPL], bool (&ok)[NPL]) {
+  unsigned t = (unsigned)mat;  // the host rejects > 2^31 matrices
+  const int g2 = (int)(t % (unsigned)q.G2); t /= (unsigned)q.G2;
+  const int g1 = (int)(t % (unsigned)q.G1); t /= (unsigned)q.G1;
+  const int g0 = (int)(t % (unsigned)q.G0); t /= (unsigned)q.G0;
+  const int hh = (int)(t % (unsigned)q.h);
+  const int b = (int)(t / (unsigned)q.h);
+  V = (int64_t)q.D * q.H * q.W;
+  base = ((int64_t)b * q.C + (int64_t)hh * 8) * V;
+#pragma unroll
+  for (int j = 0; j < NPL; ++j) {
+    const int n = j * 64 + lane;
+    ok[j] = n < q.P;
+    const int nn = ok[j] ? n : 0;
+    const int c2 = nn % q.p2, c1 = (nn / q.p2) % q.p1, c0 = nn / (q.p2 * q.p1);
+    int z0 = g0 * q.p0 + c0 - q.s0; if (z0 < 0) z0 += q.D;
+    int z1 = g1 * q.p1 + c1 - q.s1; if (z1 < 0) z1 += q.H;
+    int z2 = g2 * q.p2 + c2 - q.s2; if (z2 < 0) z2 += q.W;
+    voff[j] = (z0 * q.H + z1) * q.W + z2;   // < 2^31: checked by the host
+  }
+}
+
+template <int NPL, typename AT>
+__device__ __forceinline__ void pcf_load(const AT* __restrict__ t, int64_t base, int64_t V, const int (&voff)[NPL],
+                                         const bool (&ok)[NPL], float (&x)[8][NPL]) {
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      const float v = aget(t + base + m * V + voff[j]);   // masked lanes read voxel 0 of the patch: always valid
+      x[m][j] = ok[j] ? v : 0.f;
+    }
+}
+
+template <int NPL, int R, int SOLVER, typename AT>
+__global__ __launch_bounds__(256) void nmf_pcf_fwd_kernel(const AT* __restrict__ t, const float* __restrict__ u0,
+                                                          const float* __restrict__ v0, AT* __restrict__ out, PcfGeom q,
+                                                          int64_t nmat, int T, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t mat = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (mat >= nmat) return;
+  PcfWave<NPL> w{lane, q.P};
+  int64_t base, V;
+  int voff[NPL];
+  bool ok[NPL];
+  pcf_decode<NPL>(q, mat, lane, base, V, voff, ok);
+  float x[8][NPL], u[8][R], v[NPL][R];
+  pcf_load<NPL>(t, base, V, voff, ok, x);
+  nmf_forward_wave<8, NPL, R, SOLVER>(w, u0, v0, x, u, v, 8, T, eps);
+  const float dv = (float)q.divisor;
+  const bool pow2 = (__float_as_uint(dv) & 0x007fffffu) == 0u;   // 2 or 4 windows: exact scaling, no IEEE division
+  const float inv = 1.0f / dv;
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      if (!ok[j]) continue;
+      AT* p = out + base + m * V + voff[j];
+      float o = q.accumulate ? aget(p) + x[m][j] : 0.0f + x[m][j];
+      if (q.divisor > 1) o = pow2 ? o * inv : o / dv;
+      aput(p, o);
+    }
+}
+
+// backward: gY = gather_w(ga) / W ; gt (+)= [t > 0] ∘ scatter_w(gX)
+template <int NPL, int R, int SOLVER, typename AT>
+__global__ __launch_bounds__(256, 2) void nmf_pcf_bwd_kernel(const AT* __restrict__ t, const float* __restrict__ u0,
+                                                             const float* __restrict__ v0, const AT* __restrict__ ga,
+                                                             AT* __restrict__ gt, PcfGeom q, int64_t nmat, int T, int G,
+                                                             float eps, int relu_gate) {
+  extern __shared__ __attribute__((aligned(16))) float fz_lds_pcf[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t mat = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+  if (mat >= nmat) return;
+  PcfWave<NPL> w{lane, q.P};
+  int64_t base, V;
+  int voff[NPL];
+  bool ok[NPL];
+  pcf_decode<NPL>(q, mat, lane, base, V, voff, ok);
+  Hist<8, NPL, R> h;
+  h.carve(fz_lds_pcf + wave * Hist<8, NPL, R>::floats(G), G);
+  float x[8][NPL], g[8][NPL];
+  pcf_load<NPL>(t, base, V, voff, ok, x);
+  pcf_load<NPL>(ga, base, V, voff, ok, g);
+  if (q.gscale_div != 1.0f) {
+    const float dv = q.gscale_div;
+    const bool pow2 = (__float_as_uint(dv) & 0x007fffffu) == 0u;
+    const float inv = 1.0f / dv;
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+      for (int j = 0; j < NPL; ++j) g[m][j] = pow2 ? g[m][j] * inv : g[m][j] / dv;
+  }
+  nmf_backward_wave<8, NPL, R, SOLVER>(w, u0, v0, x, g, h, 8, T, G, eps, nullptr, nullptr);
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      if (!ok[j]) continue;
+      AT* p = gt + base + m * V + voff[j];
+      float r = (!relu_gate || x[m][j] > 0.f) ? g[m][j] : 0.f;
+      if (q.accumulate) r += aget(p);
+      aput(p, r);
+    }
+}
+
+static int pcf_geom(PcfGeom& q, int B, int C, int D, int H, int W, int pd, int ph, int pw, const int* shift, int accumulate,
+                    int divisor) {
+  if (B < 0 || C < 8 || (C % 8) || pd < 1 || ph < 1 || pw < 1 || D < pd || H < ph || W < pw || (D % pd) || (H % ph) || (W % pw))
+    return fail(FZ_E_SHAPE, "fz_nmf_pcf: needs C % 8 == 0 and spatial dims multiples of the patch");
+  if ((int64_t)pd * ph * pw > 256) return fail(FZ_E_UNSUPPORTED, "fz_nmf_pcf: more than 256 voxels per patch");
+  if ((int64_t)D * H * W >= ((int64_t)1 << 31)) return fail(FZ_E_UNSUPPORTED, "fz_nmf_pcf: more than 2^31 voxels per channel plane");
+  if (!shift) return fail(FZ_E_ARG, "fz_nmf_pcf: shift is null");
+  q.B = B; q.C = C; q.D = D; q.H = H; q.W = W; q.h = C / 8;
+  q.p0 = pd; q.p1 = ph; q.p2 = pw; q.P = pd * ph * pw;
+  q.G0 = D / pd; q.G1 = H / ph; q.G2 = W / pw;
+  const int S[3] = {D, H, W};
+  int s[3];
+  for (int i = 0; i < 3; ++i) { s[i] = shift[i] % S[i]; if (s[i] < 0) s[i] += S[i]; }
+  q.s0 = s[0]; q.s1 = s[1]; q.s2 = s[2];
+  q.accumulate = accumulate; q.divisor = divisor; q.gscale_div = 1.0f;
+  return FZ_OK;
+}
+
+template <int NPL, int R>
+static int pcf_hist_bytes(int G) { return Hist<8, NPL, R>::floats(G) * (int)sizeof(float); }
+
+static int pcf_npl(int P) { return P <= 64 ? 1 : (P <= 128 ? 2 : (P <= 192 ? 3 : 4)); }
+
+static int pcf_per_wave(int P, int R, int G) {
+  const int npl = pcf_npl(P);
+  return ((G + 1) * R * npl * 64 + (G + 1) * 8 * R + G * (8 * R + R * R)) * (int)sizeof(float);
+}
+
+template <typename AT>
+static int pcf_fwd_launch(const AT* t, const float* u0, const float* v0, AT* out, const PcfGeom& q, int R, int T, int solver,
+                          float eps, hipStream_t st) {
+  const int64_t nmat = (int64_t)q.B * q.h * q.G0 * q.G1 * q.G2;
+  if (nmat >= (int64_t)1 << 31) return fail(FZ_E_UNSUPPORTED, "fz_nmf_pcf: more than 2^31 matrices");
+  dim3 grid((unsigned)((nmat + 3) / 4)), block(256);
+#define FZ_PCF_FWD(NN, RR, SS) hipLaunchKernelGGL((nmf_pcf_fwd_kernel<NN, RR, SS, AT>), grid, block, 0, st, t, u0, v0, out, q, nmat, T, eps)
+#define FZ_PCF_FWD_RS(NN)                                                                                    \
+  do {                                                                                                       \
+    if (R == 1) { if (solver == FZ_SOLVER_MU) FZ_PCF_FWD(NN, 1, SOLVER_MU); else FZ_PCF_FWD(NN, 1, SOLVER_HALS); } \
+    else { if (solver == FZ_SOLVER_MU) FZ_PCF_FWD(NN, 2, SOLVER_MU); else FZ_PCF_FWD(NN, 2, SOLVER_HALS); }  \
+  } while (0)
+  switch (pcf_npl(q.P)) {
+    case 1: FZ_PCF_FWD_RS(1); break;
+    case 2: FZ_PCF_FWD_RS(2); break;
+    case 3: FZ_PCF_FWD_RS(3); break;
+    default: FZ_PCF_FWD_RS(4); break;
+  }
+  FZ_LAUNCH_CHECK();
+  return FZ_OK;
+}
+
+template <typename AT>
+static int pcf_bwd_launch(const AT* t, const float* u0, const float* v0, const AT* ga, AT* gt, const PcfGeom& q, int R, int T,
+                          int G, int solver, float eps, int relu_gate, hipStream_t st) {
+  const int64_t nmat = (int64_t)q.B * q.h * q.G0 * q.G1 * q.G2;
+  if (nmat >= (int64_t)1 << 31) return fail(FZ_E_UNSUPPORTED, "fz_nmf_pcf: more than 2^31 matrices");
+  const int per_wave = pcf_per_wave(q.P, R, G);
+  if (per_wave > 160 * 1024) return fail(FZ_E_UNSUPPORTED, "fz_nmf_pcf_bwd: history exceeds LDS");
+  int wpb = 65536 / per_wave;
+  if (wpb > 4) wpb = 4;
+  if (wpb < 1) wpb = 1;
+  const int lds = per_wave * wpb;
+  dim3 grid((unsigned)((nmat + wpb - 1) / wpb)), block(64 * wpb);
+#define FZ_PCF_BWD(NN, RR, SS)                                                                                \
+  do {                                                                                                        \
+    auto kern = nmf_pcf_bwd_kernel<NN, RR, SS, AT>;                                                           \
+    if (lds > 65536)                                                                                          \
+      FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, t, u0, v0, ga, gt, q, nmat, T, G, eps, relu_gate);         \
+  } while (0)
+#define FZ_PCF_BWD_RS(NN)                                                                                     \
+  do {                                                                                                        \
+    if (R == 1) { if (solver == FZ_SOLVER_MU) FZ_PCF_BWD(NN, 1, SOLVER_MU); else FZ_PCF_BWD(NN, 1, SOLVER_HALS); } \
+    else { if (solver == FZ_SOLVER_MU) FZ_PCF_BWD(NN, 2, SOLVER_MU); else FZ_PCF_BWD(NN, 2, SOLVER_HALS); }   \
+  } while (0)
+  switch (pcf_npl(q.P)) {
+    case 1: FZ_PCF_BWD_RS(1); break;
+    case 2: FZ_PCF_BWD_RS(2); break;
+    case 3: FZ_PCF_BWD_RS(3); break;
+    default: FZ_PCF_BWD_RS(4); break;
+  }
+  FZ_LAUNCH_CHECK();
+  return FZ_OK;
+}
+
+}  // namespace fz
+
+using namespace fz;
+
+extern "C" int fz_nmf_pcf_supported(int C, int D, int H, int W, int d, int pd, int ph, int pw, int R, int T, int Tgrad) {
+  if (d != 8 || (C % 8) || pd < 1 || ph < 1 || pw < 1 || (D % pd) || (H % ph) || (W % pw)) return 0;
+  if ((int64_t)pd * ph * pw > 256 || (int64_t)D * H * W >= ((int64_t)1 << 31)) return 0;
+  if (R < 1 || R > 2 || T < 0) return 0;
+  const int G = Tgrad < 0 ? 0 : (Tgrad > T ? T : Tgrad);
+  return pcf_per_wave(pd * ph * pw, R, G) <= 160 * 1024 ? 1 : 0;
+}
+
+extern "C" int fz_nmf_pcf_fwd(const void* t, const float* u0, const float* v0, void* out, int B, int C, int D, int H, int W,
+                              int pd, int ph, int pw, const int* shift, int accumulate, int divisor, int R, int T, int solver,
+                              float eps, int act_dtype, fz_stream_t stream) {
+  PcfGeom q;
+  const int rc = pcf_geom(q, B, C, D, H, W, pd, ph, pw, shift, accumulate, divisor);
+  if (rc != FZ_OK) return rc;
+  if (!t || !u0 || !v0 || !out) return fail(FZ_E_ARG, "fz_nmf_pcf_fwd: null pointer");
+  if (R < 1 || R > 2) return fail(FZ_E_UNSUPPORTED, "fz_nmf_pcf_fwd: rank 1..2");
+  if (solver != FZ_SOLVER_MU && solver != FZ_SOLVER_HALS) return fail(FZ_E_ARG, "fz_nmf_pcf_fwd: bad solver");
+  if (B == 0) return FZ_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (act_dtype == FZ_STORE_F32) return pcf_fwd_launch<float>((const float*)t, u0, v0, (float*)out, q, R, T, solver, eps, st);
+  if (act_dtype == FZ_STORE_BF16) return pcf_fwd_launch<bf16>((const bf16*)t, u0, v0, (bf16*)out, q, R, T, solver, eps, st);
+  return fail(FZ_E_ARG, "fz_nmf_pcf_fwd: bad act_dtype");
+}
+
+extern "C" int fz_nmf_pcf_bwd(const void* t, const float* u0, const float* v0, const void* ga, void* gt, int B, int C, int D,
+                              int H, int W, int pd, int ph, int pw, const int* shift, int accumulate, int nshift, int relu_gate,
+                              int R, int T, int Tgrad, int solver, float eps, int act_dtype, fz_stream_t stream) {
+  PcfGeom q;
+  const int rc = pcf_geom(q, B, C, D, H, W, pd, ph, pw, shift, accumulate, 1);
+  if (rc != FZ_OK) return rc;
+  if (!t || !u0 || !v0 || !ga || !gt) return fail(FZ_E_ARG, "fz_nmf_pcf_bwd: null pointer");
+  if (R < 1 || R > 2) return fail(FZ_E_UNSUPPORTED, "fz_nmf_pcf_bwd: rank 1..2");
+  if (solver != FZ_SOLVER_MU && solver != FZ_SOLVER_HALS) return fail(FZ_E_ARG, "fz_nmf_pcf_bwd: bad solver");
+  if (B == 0) return FZ_OK;
+  q.gscale_div = (float)(nshift > 1 ? nshift : 1);
+  const int G = Tgrad < 0 ? 0 : (Tgrad > T ? T : Tgrad);
+  hipStream_t st = (hipStream_t)stream;
+  if (act_dtype == FZ_STORE_F32)
+    return pcf_bwd_launch<float>((const float*)t, u0, v0, (const float*)ga, (float*)gt, q, R, T, G, solver, eps, relu_gate, st);
+  if (act_dtype == FZ_STORE_BF16)
+    return pcf_bwd_launch<bf16>((const bf16*)t, u0, v0, (const bf16*)ga, (bf16*)gt, q, R, T, G, solver, eps, relu_gate, st);
+  return fail(FZ_E_ARG, "fz_nmf_pcf_bwd: bad act_dtype");
+}

@@ -7,6 +7,7 @@ route them to `composed.py`).  Backward passes are hand-written kernels as well
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 
@@ -353,9 +354,21 @@ def gnmf_decompose(x, u0, v0, T, G, solver, eps=1e-16):
 
 # ---- fused FactMixer core on channels-first tensors ------------------------------------------
 def nmf_cf_supported(geo: Geometry, R, T, G) -> bool:
-    if len(geo.spatial) != 3 or any(s[2] % 2 for s in geo.shifts):  # odd W-axis shifts: modular kernels
+    """the 8x8x8 hot-shape kernels (csrc/nmf_cf.hip)"""
+    if len(geo.spatial) != 3 or any(s[2] % 2 for s in geo.shifts):  # odd W-axis shifts: the generic-patch kernels
         return False
     return bool(N.lib().fz_nmf_cf_supported(geo.C, *geo.spatial, geo.d, *geo.patch, int(R), int(T), int(G)))
+
+
+def nmf_pcf_supported(geo: Geometry, R, T, G) -> bool:
+    """the generic-patch fused core (csrc/nmf_pcf.hip): head_dim 8, <= 256 voxels per patch, any shift"""
+    if len(geo.spatial) != 3 or os.environ.get("FZ_NMF_PCF", "1") == "0":
+        return False
+    return bool(N.lib().fz_nmf_pcf_supported(geo.C, *geo.spatial, geo.d, *geo.patch, int(R), int(T), int(G)))
+
+
+def nmf_core_supported(geo: Geometry, R, T, G) -> bool:
+    return nmf_cf_supported(geo, R, T, G) or nmf_pcf_supported(geo, R, T, G)
 
 
 class FactCoreFn(torch.autograd.Function):
@@ -373,14 +386,20 @@ class FactCoreFn(torch.autograd.Function):
         es = t.element_size()
         nb = 2 * es * t.numel()
         ad = N.act_dtype(t)
+        hot = nmf_cf_supported(geo, R, T, G)      # 8x8x8 patches: csrc/nmf_cf.hip; any other patch: csrc/nmf_pcf.hip
         with _dev_guard(t):
             for w, s in enumerate(geo.shifts):
                 arr = (N._i * 3)(*s)
-                rc = _timed(f"nmf_cf_fwd_{geo.C}x" + "x".join(str(v) for v in geo.spatial), nb + (es * t.numel() if w else 0), lambda: N.lib().fz_nmf_cf_fwd(
-                    t.data_ptr(), u0.data_ptr(), v0.data_ptr(), out.data_ptr(), B, geo.C, *geo.spatial, arr,
-                    int(w > 0), geo.nshift if w == geo.nshift - 1 else 1, R, T, N.SOLVER_ID[solver], eps,
-                    ad, N.stream_ptr(t)))
-                N.check(rc, "fz_nmf_cf_fwd")
+                last = geo.nshift if w == geo.nshift - 1 else 1
+                if hot:
+                    rc = _timed(f"nmf_cf_fwd_{geo.C}x" + "x".join(str(v) for v in geo.spatial), nb + (es * t.numel() if w else 0), lambda: N.lib().fz_nmf_cf_fwd(
+                        t.data_ptr(), u0.data_ptr(), v0.data_ptr(), out.data_ptr(), B, geo.C, *geo.spatial, arr,
+                        int(w > 0), last, R, T, N.SOLVER_ID[solver], eps, ad, N.stream_ptr(t)))
+                else:
+                    rc = _timed(f"nmf_pcf_fwd_{geo.C}x" + "x".join(str(v) for v in geo.spatial), nb + (es * t.numel() if w else 0), lambda: N.lib().fz_nmf_pcf_fwd(
+                        t.data_ptr(), u0.data_ptr(), v0.data_ptr(), out.data_ptr(), B, geo.C, *geo.spatial, *geo.patch, arr,
+                        int(w > 0), last, R, T, N.SOLVER_ID[solver], eps, ad, N.stream_ptr(t)))
+                N.check(rc, "fz_nmf_cf_fwd" if hot else "fz_nmf_pcf_fwd")
         ctx.save_for_backward(t, u0, v0)
         ctx.cfg = (geo, T, G, solver, eps, relu_gate)
         return out
@@ -400,14 +419,21 @@ class FactCoreFn(torch.autograd.Function):
         es = t.element_size()
         nb = 3 * es * t.numel()
         ad = N.act_dtype(t)
+        hot = nmf_cf_supported(geo, R, T, G)
         with _dev_guard(t):
             for w, s in enumerate(geo.shifts):
                 arr = (N._i * 3)(*s)
-                rc = _timed(f"nmf_cf_bwd_{geo.C}x" + "x".join(str(v) for v in geo.spatial), nb + (es * t.numel() if w else 0), lambda: N.lib().fz_nmf_cf_bwd(
-                    t.data_ptr(), u0.data_ptr(), v0.data_ptr(), ga.data_ptr(), gt.data_ptr(), B, geo.C,
-                    *geo.spatial, arr, int(w > 0), geo.nshift, int(relu_gate), R, T, G, N.SOLVER_ID[solver], eps,
-                    ad, N.stream_ptr(t)))
-                N.check(rc, "fz_nmf_cf_bwd")
+                if hot:
+                    rc = _timed(f"nmf_cf_bwd_{geo.C}x" + "x".join(str(v) for v in geo.spatial), nb + (es * t.numel() if w else 0), lambda: N.lib().fz_nmf_cf_bwd(
+                        t.data_ptr(), u0.data_ptr(), v0.data_ptr(), ga.data_ptr(), gt.data_ptr(), B, geo.C,
+                        *geo.spatial, arr, int(w > 0), geo.nshift, int(relu_gate), R, T, G, N.SOLVER_ID[solver], eps,
+                        ad, N.stream_ptr(t)))
+                else:
+                    rc = _timed(f"nmf_pcf_bwd_{geo.C}x" + "x".join(str(v) for v in geo.spatial), nb + (es * t.numel() if w else 0), lambda: N.lib().fz_nmf_pcf_bwd(
+                        t.data_ptr(), u0.data_ptr(), v0.data_ptr(), ga.data_ptr(), gt.data_ptr(), B, geo.C,
+                        *geo.spatial, *geo.patch, arr, int(w > 0), geo.nshift, int(relu_gate), R, T, G, N.SOLVER_ID[solver], eps,
+                        ad, N.stream_ptr(t)))
+                N.check(rc, "fz_nmf_cf_bwd" if hot else "fz_nmf_pcf_bwd")
         return (gt,) + (None,) * 8
 
 

@@ -144,6 +144,17 @@ int fz_nmf_cf_bwd(const void* t, const float* u0, const float* v0, const void* g
                   int relu_gate, int R, int T, int Tgrad, int solver, float eps, int act_dtype,
                   fz_stream_t stream);
 
+/* The same fused core for ANY patch (pd, ph, pw) with head_dim 8 and at most 256 voxels per patch (csrc/nmf_pcf.hip:
+ * BASELINE configs[4] uses patch (5,6,5) because 160x192x160 is not divisible by 8; the p = 4 test configurations):
+ * same call protocol and semantics as fz_nmf_cf_fwd / fz_nmf_cf_bwd, any shift parity. */
+int fz_nmf_pcf_supported(int C, int D, int H, int W, int d, int pd, int ph, int pw, int R, int T, int Tgrad);
+int fz_nmf_pcf_fwd(const void* t, const float* u0, const float* v0, void* out, int B, int C, int D, int H, int W,
+                   int pd, int ph, int pw, const int* shift, int accumulate, int divisor, int R, int T, int solver,
+                   float eps, int act_dtype, fz_stream_t stream);
+int fz_nmf_pcf_bwd(const void* t, const float* u0, const float* v0, const void* ga, void* gt, int B, int C, int D,
+                   int H, int W, int pd, int ph, int pw, const int* shift, int accumulate, int nshift, int relu_gate,
+                   int R, int T, int Tgrad, int solver, float eps, int act_dtype, fz_stream_t stream);
+
 /* ---- channels-first GEMM family (1x1 layers, k2s2 conv / transposed conv, input grads) ----
  * Out[m, n] = epilogue( sum_k A[m,k] * prologue(In)[k,n] ), n = voxel.  One descriptor drives
  * every dense layer of the block and of the U-shape:

@@ -398,6 +398,41 @@ def test_fact_core_fused_vs_modular(S, shifts, solver, R):
     assert torch.allclose(g3, g1 * (t > 0), rtol=0, atol=0)
 
 
+@pytest.mark.parametrize("S,patch", [((10, 12, 20), (5, 6, 5)), ((8, 8, 16), (4, 4, 4)), ((6, 10, 14), (3, 5, 7)),
+                                     ((4, 8, 16), (2, 4, 8)), ((8, 8, 8), (8, 8, 4))])
+@pytest.mark.parametrize("shifts", [None, [None, (1, 2, 3), (2, 0, 1)], [None]])
+@pytest.mark.parametrize("solver,R", [("hals", 1), ("mu", 2), ("hals", 2)])
+def test_fact_core_any_patch_vs_modular(S, patch, shifts, solver, R):
+    """csrc/nmf_pcf.hip — the fused gather → NMF → scatter/average core for ANY patch of <= 256 voxels (patch (5,6,5) of
+    BASELINE configs[4], p = 4, anisotropic patches, 1 - 4 columns per lane) and any shift parity (odd W-axis shifts
+    are outside the 8x8x8 kernels) — against the modular chain SWMatricize → NMF → inverse, values and gradients,
+    with and without the ReLU gate."""
+    from factorizer_amd import functional as Fn
+    torch.manual_seed(13)
+    C = 16
+    m = ft.SWMatricize((None, C, *S), head_dim=8, patch_size=patch, shifts=shifts)
+    geo = m.geometry
+    nmf = ft.NMF(size=(8, geo.P), rank=R, num_iters=4, num_grad_steps=3, init="uniform", solver=solver).to(DEV)
+    t = torch.rand(2, C, *S, device=DEV)
+    t[0, :8, :patch[0], :patch[1], :patch[2]] = 0      # an all-zero matrix in window 0
+    G = 3
+    assert Fn.nmf_pcf_supported(geo, R, 4, G) and not Fn.nmf_cf_supported(geo, R, 4, G)
+    t1 = t.clone().requires_grad_(True)
+    t2 = t.clone().requires_grad_(True)
+    with Launches():
+        a1 = Fn.FactCoreFn.apply(t1, nmf.init.u0, nmf.init.v0, geo, 4, G, solver, 1e-16, False)
+    a2 = m.inverse_forward(nmf(m(t2)))
+    P.close("a fused vs modular", a1, a2, rel=1e-5)
+    ga = torch.rand_like(a1)
+    (g1,) = torch.autograd.grad(a1, t1, ga)
+    (g2,) = torch.autograd.grad(a2, t2, ga)
+    P.close("gt fused vs modular", g1, g2)
+    t3 = t.clone().requires_grad_(True)
+    a3 = Fn.FactCoreFn.apply(t3, nmf.init.u0, nmf.init.v0, geo, 4, G, solver, 1e-16, True)
+    (g3,) = torch.autograd.grad(a3, t3, ga)
+    assert torch.allclose(g3, g1 * (t > 0), rtol=0, atol=0)
+
+
 # ---------------------------------------------------------------- other BASELINE / §8f configs ------
 def _block_vs_oracle(C, S, reshape_kw, nmf_kw, mlp_ratio=2, B=1, tol=1e-4, why=None):
     torch.manual_seed(0)
