@@ -177,6 +177,20 @@ struct Hist {
   }
 };
 
+// waves per workgroup of a backward launch whose history needs `per_wave` bytes of LDS per wave: the count (1..4) that
+// puts the most waves on a CU (160 KB of LDS), larger workgroups on ties.  (A fixed 64 KB budget per workgroup left
+// the R = 2, T = 10 history of BASELINE configs[4] — 18.4 KB per wave — at 3 waves x 2 workgroups = 6 waves per CU; 4 x 2 = 8.)
+static inline int fz_hist_waves_per_block(int per_wave) {
+  int best = 1, best_waves = 0;
+  for (int wv = 1; wv <= 4; ++wv) {
+    const int lds = per_wave * wv;
+    if (lds > 160 * 1024) break;
+    const int waves = (160 * 1024 / lds) * wv;
+    if (waves >= best_waves) { best_waves = waves; best = wv; }
+  }
+  return best;
+}
+
 template <int M, int NPL, int R, class W>
 FZ_HD void save_state(W& w, const Hist<M, NPL, R>& h, int s, const typename W::F (&u)[M][R],
                       const typename W::F (&v)[NPL][R]) {

@@ -218,9 +218,7 @@ static int pcf_bwd_launch(const AT* t, const float* u0, const float* v0, const A
   if (nmat >= (int64_t)1 << 31) return fail(FZ_E_UNSUPPORTED, "fz_nmf_pcf: more than 2^31 matrices");
   const int per_wave = pcf_per_wave(q.P, R, G);
   if (per_wave > 160 * 1024) return fail(FZ_E_UNSUPPORTED, "fz_nmf_pcf_bwd: history exceeds LDS");
-  int wpb = 65536 / per_wave;
-  if (wpb > 4) wpb = 4;
-  if (wpb < 1) wpb = 1;
+  const int wpb = fz_hist_waves_per_block(per_wave);
   const int lds = per_wave * wpb;
   dim3 grid((unsigned)((nmat + wpb - 1) / wpb)), block(64 * wpb);
 #define FZ_PCF_BWD(NN, RR, SS)                                                                                \
