@@ -1462,7 +1462,16 @@ __global__ __launch_bounds__(256) void chain_wg_finish_kernel(const float* wpart
   const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
   auto total = [&](int e) {
     float t = 0.f;
-    for (int r = sl; r < rows; r += 16) t += wpart[(int64_t)r * kWgRow + e];
+    // 8 row loads in flight per thread (the adds stay in row order: same result, a fraction of the round trips)
+    int r = sl;
+    for (; r + 7 * 16 < rows; r += 8 * 16) {
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = wpart[(int64_t)(r + 16 * i) * kWgRow + e];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t += v[i];
+    }
+    for (; r < rows; r += 16) t += wpart[(int64_t)r * kWgRow + e];
     return t;
   };
   // every block also needs db1 of the rows it scales: blocks over S1 recompute the 16-row slice sums of their db1 entry
@@ -1739,7 +1748,16 @@ __global__ __launch_bounds__(256) void dw_finish_kernel(const float* wpart, int 
   const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
   auto total = [&](int e) {
     float t = 0.f;
-    for (int r = sl; r < rows; r += 16) t += wpart[(int64_t)r * kDwRow + e];
+    // 8 row loads in flight per thread (the adds stay in row order: same result, a fraction of the round trips)
+    int r = sl;
+    for (; r + 7 * 16 < rows; r += 8 * 16) {
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = wpart[(int64_t)(r + 16 * i) * kDwRow + e];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t += v[i];
+    }
+    for (; r < rows; r += 16) t += wpart[(int64_t)r * kDwRow + e];
     return t;
   };
   const int e = blockIdx.x * 16 + el;      // kDwRow = 70 x 16
