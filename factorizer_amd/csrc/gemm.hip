@@ -1094,12 +1094,15 @@ __device__ __forceinline__ void gelu_both(float x, float& g, float& dg) {
 // gradients do not fit next to the chain, so the kernel runs once per 64-row half of the hidden tensor — launch `half`
 // = 0 leaves its part of W1ᵀ·gz1 in `glp` (fp32, accumulator layout in HBM), launch 1 starts GEMM 2 from it and ends
 // with the LayerNorm backward.  12 plane-sets for both launches against 21 of the unfused chain + weight gradients.
-template <typename AT, int HALVES = 1>
+// (HALVES / HALF are compile-time: with a run-time half the one-launch form lost its spill-free register allocation —
+// 32 spilled VGPRs, 0.94 -> 1.03 ms per launch, 215 MB of scratch writes in the WRITE_SIZE counter.)
+template <typename AT, int HALVES = 1, int HALF = 0>
 __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT> p, ChainArgsT<AT> c, int ntiles, float* wpart,
-                                                                   int half, float* glp) {
+                                                                   float* glp) {
   constexpr int NACC = 2, HB = 2, HID = 64 * HALVES, N1 = 16 * HB * 64;
-  const int hoff = 64 * half;                 // first hidden row of this launch
-  const bool last = half == HALVES - 1;       // this launch ends with the LayerNorm backward
+  constexpr int half = HALF;
+  constexpr int hoff = 64 * HALF;             // first hidden row of this launch
+  constexpr bool last = HALF == HALVES - 1;   // this launch ends with the LayerNorm backward
   constexpr int kWave = 48 * kTS;             // floats of one wave's (Bf | T) region
   extern __shared__ __attribute__((aligned(16))) float fz_lds_cw[];
   float* As1 = fz_lds_cw;
@@ -2458,19 +2461,22 @@ static int mlp_launch(const fz_mlp_desc* d, fz_stream_t stream) {
     const int rows = fz_mlp_wgrad_rows(d->B, d->V);
     constexpr int lds = (2 * 2048 + 32 + 256 + 4 * 48 * kTS) * (int)sizeof(float);
     if (d->H == 64) {
-      auto kern = gemm_chain_bwd_wg_kernel<AT, 1>;
+      auto kern = gemm_chain_bwd_wg_kernel<AT, 1, 0>;
       FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-      hipLaunchKernelGGL(kern, dim3((unsigned)rows), block, lds, st, a, c, ntiles, (float*)d->wpart, 0, (float*)nullptr);
+      hipLaunchKernelGGL(kern, dim3((unsigned)rows), block, lds, st, a, c, ntiles, (float*)d->wpart, (float*)nullptr);
       FZ_LAUNCH_CHECK();
       hipLaunchKernelGGL(chain_wg_finish_kernel, dim3(kWgRow / 16), dim3(256), 0, st, (const float*)d->wpart, rows, d->ln_g, d->ln_b,
                          d->gw1, d->gb1, d->gw2, 64, d->gb2, d->gln);
       FZ_LAUNCH_CHECK();
     } else {   // hidden 128: one launch per 64-row half (wpart holds two row blocks)
-      auto kern = gemm_chain_bwd_wg_kernel<AT, 2>;
-      FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      auto kern0 = gemm_chain_bwd_wg_kernel<AT, 2, 0>;
+      auto kern1 = gemm_chain_bwd_wg_kernel<AT, 2, 1>;
+      FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern0), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern1), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
       for (int half = 0; half < 2; ++half) {
         float* wp = (float*)d->wpart + (int64_t)half * rows * kWgRow;
-        hipLaunchKernelGGL(kern, dim3((unsigned)rows), block, lds, st, a, c, ntiles, wp, half, d->glp);
+        if (half == 0) hipLaunchKernelGGL(kern0, dim3((unsigned)rows), block, lds, st, a, c, ntiles, wp, d->glp);
+        else hipLaunchKernelGGL(kern1, dim3((unsigned)rows), block, lds, st, a, c, ntiles, wp, d->glp);
         FZ_LAUNCH_CHECK();
         hipLaunchKernelGGL(chain_wg_finish_kernel, dim3(kWgRow / 16), dim3(256), 0, st, (const float*)wp, rows, d->ln_g, d->ln_b,
                            d->gw1 + half * 64 * 32, d->gb1 + half * 64, d->gw2 + half * 64, 128,

@@ -262,7 +262,9 @@ __device__ __forceinline__ void cf_to_owner(float* S, const int (&lidx)[2], int 
 }
 
 template <int R, int SOLVER, int WPB, bool HALF, typename AT>
-__global__ __launch_bounds__(WPB * 64, WPB == 8 ? 2 : (WPB == 4 ? 4 : (WPB == 1 ? 8 : 1))) void nmf_cf_fwd_tile_kernel(const AT* __restrict__ t,
+// (second launch-bounds argument = minimum WAVES PER SIMD in HIP, not workgroups per CU: 8 capped the one-patch variant
+// at 64 VGPRs — 170 spilled registers)
+__global__ __launch_bounds__(WPB * 64, WPB == 8 ? 2 : 4) void nmf_cf_fwd_tile_kernel(const AT* __restrict__ t,
                                                                    const float* __restrict__ u0,
                                                                    const float* __restrict__ v0,
                                                                    AT* __restrict__ out, CfGeom q, int T, float eps,
@@ -373,7 +375,7 @@ __global__ __launch_bounds__(512, 2) void nmf_cf_bwd_kernel(const AT* __restrict
 // line-coalesced backward: same exchange for t and for the incoming gradient, ReLU gate applied on
 // the owner side before the exchange back, read-modify-write of gt with the coalesced map
 template <int R, int SOLVER, int WPB, bool HALF, typename AT>
-__global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : (WPB == 1 ? 8 : 1)) void nmf_cf_bwd_tile_kernel(
+__global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : (WPB == 1 ? 2 : 1)) void nmf_cf_bwd_tile_kernel(
     const AT* __restrict__ t, const float* __restrict__ u0, const float* __restrict__ v0,
     const AT* __restrict__ ga, AT* __restrict__ gt, CfGeom q, int T, int G, float eps, int relu_gate,
     int xcd_remap) {
