@@ -179,9 +179,6 @@ static int pcf_geom(PcfGeom& q, int B, int C, int D, int H, int W, int pd, int p
   return FZ_OK;
 }
 
-template <int NPL, int R>
-static int pcf_hist_bytes(int G) { return Hist<8, NPL, R>::floats(G) * (int)sizeof(float); }
-
 static int pcf_npl(int P) { return P <= 64 ? 1 : (P <= 128 ? 2 : (P <= 192 ? 3 : 4)); }
 
 static int pcf_per_wave(int P, int R, int G) {
