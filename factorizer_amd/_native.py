@@ -150,6 +150,7 @@ _SIGS.update({
     "fz_nmf_pcf_fwd": ([_vp] * 4 + [_i] * 8 + [_c.POINTER(_i)] + [_i] * 5 + [_f, _i, _vp], _i),
     "fz_nmf_pcf_bwd": ([_vp] * 5 + [_i] * 8 + [_c.POINTER(_i)] + [_i] * 7 + [_f, _i, _vp], _i),
     "fz_gemm": ([_c.POINTER(GemmDesc), _vp], _i),
+    "fz_gemm_bx_enable": ([_i], _i),
     "fz_gemm_lnbwd_partials": ([_c.POINTER(GemmDesc)], _i64),
     "fz_reduce_rows": ([_vp, _i64, _i, _vp, _vp, _vp], _i),
     "fz_adamw_step": ([_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _vp], _i),

@@ -227,6 +227,11 @@ int64_t fz_gemm_lnbwd_partials(const fz_gemm_desc* desc);
 int fz_reduce_rows(const float* part, int64_t rows, int n, float* out, float* tmp, fz_stream_t stream);
 
 int fz_gemm(const fz_gemm_desc* desc, fz_stream_t stream);
+/* fz_gemm runs layers with a reduction length >= 64 on the bf16 matrix cores with every fp32 operand split into three
+ * bf16 values and six exact products per fp32 product (csrc/gemm_bx.hip: fp32 accuracy at 6/16 of the fp32-MFMA time).
+ * on = 0 keeps them on v_mfma_f32_32x32x2_f32, on = 1 enables, on < 0 only queries; returns the previous setting.
+ * Default: environment FZ_GEMM_BX (read once), else enabled. */
+int fz_gemm_bx_enable(int on);
 
 /* ---- MLP chain ((C, H) = (32, 64), (32, 128) or (64, 128)): two GEMMs, hidden tensor stays in the accumulators
  * (modes 0 and 1; part rows are 2*C floats: dgamma | dbeta)
