@@ -23,60 +23,16 @@
 // converts, and the NACC voxel components feed NACC column groups (voxel NACC·j + q) exactly as in gemm.hip — the
 // accumulator layout (row in (register, h), column in j) and with it every epilogue of gemm_common.h is unchanged.
 // Weights are split once per workgroup into LDS in operand order: As[K16-step][row block][term][lane] x 16 B.
-#include "gemm_common.h"
+#include "gemm_bx.h"
 
 namespace fz {
-
-typedef __bf16 bx8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bx2 __attribute__((ext_vector_type(2)));
-typedef float fx2 __attribute__((ext_vector_type(2)));
-
-enum { BXPRO_NONE = 0, BXPRO_LN = 1, BXPRO_GELU = 2, BXPRO_BMUL = 3 };
-
-// x[0..7] -> up to three bf16 levels, round-to-nearest at each (v_cvt_pk_bf16_f32 converts two floats)
-template <int NT>
-__device__ __forceinline__ void bx_split(const float (&x)[8], bx8 (&t)[NT]) {
-#pragma unroll
-  for (int i = 0; i < 8; i += 2) {
-    fx2 v = {x[i], x[i + 1]};
-    const bx2 a = __builtin_convertvector(v, bx2);
-    t[0][i] = a[0]; t[0][i + 1] = a[1];
-    if constexpr (NT >= 2) {
-      v = v - __builtin_convertvector(a, fx2);
-      const bx2 b = __builtin_convertvector(v, bx2);
-      t[1][i] = b[0]; t[1][i + 1] = b[1];
-      if constexpr (NT >= 3) {
-        v = v - __builtin_convertvector(b, fx2);
-        const bx2 c = __builtin_convertvector(v, bx2);
-        t[2][i] = c[0]; t[2][i + 1] = c[1];
-      }
-    }
-  }
-}
-
-// acc += Σ_{i + j <= max(NTA, NTB) - 1} a_i · b_j, smallest terms first
-template <int NTA, int NTB>
-__device__ __forceinline__ void bx_mfma(f32x16& acc, const bx8 (&a)[NTA], const bx8 (&b)[NTB]) {
-  constexpr int L = (NTA > NTB ? NTA : NTB) - 1;
-#pragma unroll
-  for (int s = L; s >= 0; --s)
-#pragma unroll
-    for (int i = 0; i < NTA; ++i) {
-      const int jj = s - i;
-      if (jj >= 0 && jj < NTB) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[jj], acc, 0, 0, 0);
-    }
-}
-
-// Storage-type traits: terms of the column operand / of the weights
-template <typename AT> struct BxTerms { static constexpr int B = 3, A = 3; };
-template <> struct BxTerms<bf16> { static constexpr int B = 1, A = 2; };
 
 // =================================================================================================
 // MB row blocks of 32 x (4 waves x 32·NACC columns) per workgroup; RD K16-groups of operand loads in flight per lane.
 // =================================================================================================
 template <int MB, int NACC, int LOADER, int EPI, int PRO, int RD, typename AT>
 __global__ __launch_bounds__(256, 2) void gemm_bx_kernel(GemmArgsT<AT> p) {
-  constexpr int NTA = BxTerms<AT>::A, NTB = BxTerms<AT>::B;
+  constexpr int NTA = BxTerms<AT>::A, NTB = bx_terms_b<AT>(PRO);
   constexpr int TN = 32 * NACC;
   constexpr bool S2D = LOADER == LOAD_S2D;
   static_assert(!S2D || NACC == 2, "space-to-depth loader: two coarse voxels per lane");
@@ -348,6 +304,20 @@ int gemm_bx_launch(const GemmArgsT<AT>& a0, int loader, int epilogue, int pro, f
   hipStream_t st = (hipStream_t)stream;
   const int mblocks = (a.M + 31) / 32;
   int nacc, mb;
+  {
+    // narrow problems (stages 2-4): K-split form — tile chosen for >= 512 workgroups where the problem has them
+    int ks = (a.Ncol * a.B <= 65536) ? 1 : 0;
+    int kn = 2, km = mblocks >= 2 ? 2 : 1;
+    auto wgs = [&](int na, int mbb) { return ((a.Ncol + 32 * na - 1) / (32 * na)) * a.B * ((mblocks + mbb - 1) / mbb); };
+    if (wgs(kn, km) < 512 && km == 2) km = 1;
+    if (wgs(kn, km) < 512 && loader != LOAD_S2D) kn = 1;
+    const char* e = getenv("FZ_BX_KS");  // diagnostics: "0" | "1" | "1<nacc><mb>"
+    if (e && e[0]) { ks = e[0] - '0'; if (e[1] && e[2]) { kn = e[1] - '0'; km = e[2] - '0'; if (km > mblocks) km = 1; if (loader == LOAD_S2D) kn = 2; } }
+    if (ks) {
+      const int rc = gemm_bxk_launch<AT>(a, loader, epilogue, pro, kn, km, stream);
+      if (rc != FZ_E_UNSUPPORTED) return rc;   // shapes outside the K-split form: the streaming kernel below
+    }
+  }
   if (loader == LOAD_S2D) {
     nacc = 2;
     mb = mblocks >= 2 ? 2 : 1;
@@ -360,9 +330,9 @@ int gemm_bx_launch(const GemmArgsT<AT>& a0, int loader, int epilogue, int pro, f
     if (wgs(nacc, mb) < 512) nacc = 2;
     if (wgs(nacc, mb) < 512 && mb == 2) mb = 1;
     if (wgs(nacc, mb) < 256) nacc = 1;
-    if (epilogue == EPI_D2S && nacc == 1) nacc = 2;
     const char* e = getenv("FZ_BX_CFG");  // diagnostics: "<nacc><mb>"
     if (e && e[0] && e[1]) { nacc = e[0] - '0'; mb = e[1] - '0'; if (mb > mblocks) mb = 1; }
+    if (epilogue == EPI_D2S && nacc == 1) nacc = 2;
   }
   const int TN = 32 * nacc;
   const int64_t tiles = (a.Ncol + TN * 4 - 1) / (TN * 4);

@@ -25,17 +25,22 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// fp32 -> (hi, mid) bf16 pair with round-to-nearest at both levels: x = hi + mid + O(2^-18 |x|).
-// v_cvt_pk_bf16_f32 converts two floats per instruction: 2.5 VALU instructions per element.
-__device__ __forceinline__ void split_bf16x8(const float (&x)[8], bf16x8& hi, bf16x8& mid) {
+// fp32 -> three bf16 levels (hi, mid, lo), round-to-nearest at each: x = hi + mid + lo exactly (8 + 8 + 8 significand
+// bits).  The products keep the six terms hi·hi + (hi·mid + mid·hi) + (hi·lo + mid·mid + lo·hi): what is dropped is
+// <= 2^-23 |pq| — an fp32 product in 6/16 of the fp32-MFMA time (gemm_bx.hip; tools/probes/bx6_accuracy.hip).
+// v_cvt_pk_bf16_f32 converts two floats per instruction: 5.5 VALU instructions per element.
+__device__ __forceinline__ void split_bf16x8(const float (&x)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
 #pragma unroll
   for (int e = 0; e < 8; e += 2) {
     const f32x2 v = {x[e], x[e + 1]};
     const bf16x2 h2 = __builtin_convertvector(v, bf16x2);
     const f32x2 r = v - __builtin_convertvector(h2, f32x2);
     const bf16x2 m2 = __builtin_convertvector(r, bf16x2);
+    const f32x2 r2 = r - __builtin_convertvector(m2, f32x2);
+    const bf16x2 l2 = __builtin_convertvector(r2, bf16x2);
     hi[e] = h2[0]; hi[e + 1] = h2[1];
     mid[e] = m2[0]; mid[e + 1] = m2[1];
+    lo[e] = l2[0]; lo[e + 1] = l2[1];
   }
 }
 
@@ -74,7 +79,7 @@ __device__ __forceinline__ float gelu_grad_w(float x) {
 }
 
 // MBP x MBQ blocks of 32x32 outputs per workgroup; 4 waves split the voxel tiles.
-// BF: 0 = fp32 MFMAs; 3 = split-bf16 products (see wgrad_fast_kernel), opt-in; 1 = plain bf16 MFMAs
+// BF: 0 = fp32 MFMAs; 6 = six-term split-bf16 products (fp32 accuracy, the default: see wgrad_fast_kernel); 1 = plain bf16 MFMAs
 // (operands rounded to bf16, fp32 accumulation) — the mixed-precision mode, where P and Q are bf16 in HBM
 // anyway and only a prologue (LayerNorm / GELU) result takes one extra rounding.
 template <int MBP, int MBQ, int QL, int BF = 0, typename AT = float>
@@ -240,26 +245,29 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgsT<AT> a) {
       // ---- 2 K-steps of 16 voxels: lane half h, element e <-> voxel 16·t + 8·h + e ----
 #pragma unroll
       for (int t16 = 0; t16 < 2; ++t16) {
-        bf16x8 ph[MBP], pm[MBP], qh[MBQ], qm[MBQ];
+        bf16x8 ph[MBP], pm[MBP], pl[MBP], qh[MBQ], qm[MBQ], ql[MBQ];
 #pragma unroll
         for (int i = 0; i < MBP; ++i) {
           float x8[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) { x8[e] = Pt[(i * 32 + c) * kStride + 16 * t16 + 8 * h + e]; psum[i] += x8[e]; }
-          split_bf16x8(x8, ph[i], pm[i]);
+          split_bf16x8(x8, ph[i], pm[i], pl[i]);
         }
 #pragma unroll
         for (int jq = 0; jq < MBQ; ++jq) {
           float x8[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) x8[e] = Qt[(jq * 32 + c) * kStride + 16 * t16 + 8 * h + e];
-          split_bf16x8(x8, qh[jq], qm[jq]);
+          split_bf16x8(x8, qh[jq], qm[jq], ql[jq]);
         }
 #pragma unroll
         for (int i = 0; i < MBP; ++i)
 #pragma unroll
           for (int jq = 0; jq < MBQ; ++jq) {
-            if (BF == 3) {
+            if (BF == 6) {   // smallest terms first
+              acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pl[i], qh[jq], acc[i][jq], 0, 0, 0);
+              acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pm[i], qm[jq], acc[i][jq], 0, 0, 0);
+              acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph[i], ql[jq], acc[i][jq], 0, 0, 0);
               acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pm[i], qh[jq], acc[i][jq], 0, 0, 0);
               acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph[i], qm[jq], acc[i][jq], 0, 0, 0);
             }
@@ -340,11 +348,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgsT<AT> a) {
 enum { QP_NONE = 0, QP_STATS = 1, QP_GELU = 2, QP_RELU = 3 };
 constexpr int kStrideF = 36;
 
-// BF3: the products run on the bf16 matrix pipe as three terms (hi·hi + hi·mid + mid·hi) of a two-level
-// bf16 split of both operands — 16 voxels per MFMA at twice the issue rate of the fp32 MFMA's 2, i.e. 3
-// instead of 16 MFMA slots per 16 voxels, for a relative error of <= 3·2^-18 per product.  A weight
-// gradient is a sum over 10^4..10^6 voxels whose rounding errors average out and feed nothing but the
-// optimizer; the input-gradient / forward GEMMs stay on fp32 MFMAs (errors there chain through ~40 layers).
+// BF = 6: the products run on the bf16 matrix pipe as the six leading terms of a three-level bf16 split of both operands
+// (split_bf16x8) — 16 voxels per MFMA at twice the issue rate of the fp32 MFMA's 2, i.e. 6 instead of 16 MFMA slots per
+// 16 voxels, with every kept term exact in the fp32 accumulator and <= 2^-23 |pq| dropped: fp32 accuracy.  Round 2
+// carried a three-term variant (relative error 3·2^-18 per product) as an opt-in; the six-term form has no such caveat and
+// is the default (fz_gemm_bx_enable(0) returns to v_mfma_f32_32x32x2_f32).
 // The k index of an MFMA operand element is (lane half, element): ANY assignment of voxels to it is
 // valid as long as both operands use the same one — half h, element e <-> voxel 16·t + 8·h + e of K-step t.
 template <int MBP, int MBQ, int QPRO, int BF = 0, typename AT = float>
@@ -451,31 +459,35 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(WgradArgsT<AT> a) {
     if (BF != 0) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        bf16x8 ph[MBP], pm[MBP], qh[MBQ], qm[MBQ];
+        // (the splits of one operand block at a time: all twelve operand tiles live at once spill beside the accumulators)
+        bf16x8 ph[MBP], pm[MBP], pl[MBP];
 #pragma unroll
         for (int i = 0; i < MBP; ++i) {
           float x8[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) x8[e] = pa[i][8 * t + e];
-          split_bf16x8(x8, ph[i], pm[i]);
+          split_bf16x8(x8, ph[i], pm[i], pl[i]);
         }
 #pragma unroll
         for (int jq = 0; jq < MBQ; ++jq) {
+          bf16x8 qh, qm, ql;
           float x8[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) x8[e] = qb[jq][8 * t + e];
-          split_bf16x8(x8, qh[jq], qm[jq]);
-        }
+          split_bf16x8(x8, qh, qm, ql);
 #pragma unroll
-        for (int i = 0; i < MBP; ++i)
-#pragma unroll
-          for (int jq = 0; jq < MBQ; ++jq) {
-            if (BF == 3) {
-              acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pm[i], qh[jq], acc[i][jq], 0, 0, 0);
-              acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph[i], qm[jq], acc[i][jq], 0, 0, 0);
+          for (int i = 0; i < MBP; ++i) {
+            if (BF == 6) {   // smallest terms first
+              acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pl[i], qh, acc[i][jq], 0, 0, 0);
+              acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pm[i], qm, acc[i][jq], 0, 0, 0);
+              acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph[i], ql, acc[i][jq], 0, 0, 0);
+              acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pm[i], qh, acc[i][jq], 0, 0, 0);
+              acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph[i], qm, acc[i][jq], 0, 0, 0);
             }
-            acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph[i], qh[jq], acc[i][jq], 0, 0, 0);
+            acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph[i], qh, acc[i][jq], 0, 0, 0);
           }
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     } else {
 #pragma unroll
@@ -740,12 +752,12 @@ static int wgrad_launch(const fz_wgrad_desc* d, void* workspace, fz_stream_t str
   const size_t lds = (size_t)4 * (PR + QR) * kStride * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   constexpr bool kBf16 = !std::is_same<AT, float>::value;  // bf16 activations: plain bf16 MFMAs
-  int bf3g = 0;
-  { const char* e = getenv("FZ_WGRAD_BF3"); if (e) bf3g = atoi(e); }
+  // fp32 activations: six-term split-bf16 products unless the split-bf16 family is switched off (fz_gemm_bx_enable)
+  const int bf3g = fz_gemm_bx_enable(-1);
 #define FZ_WG(MBP, MBQ, QL)                                                                        \
   do {                                                                                             \
     if (kBf16) hipLaunchKernelGGL((wgrad_kernel<MBP, MBQ, QL, 1>), grid, block, lds, st, a);       \
-    else if (bf3g) hipLaunchKernelGGL((wgrad_kernel<MBP, MBQ, QL, 3>), grid, block, lds, st, a);   \
+    else if (bf3g) hipLaunchKernelGGL((wgrad_kernel<MBP, MBQ, QL, 6>), grid, block, lds, st, a);   \
     else hipLaunchKernelGGL((wgrad_kernel<MBP, MBQ, QL, 0>), grid, block, lds, st, a);             \
   } while (0)
 #define FZ_WG_SHAPES(QL)                                 \
@@ -760,12 +772,11 @@ static int wgrad_launch(const fz_wgrad_desc* d, void* workspace, fz_stream_t str
     const size_t ldsf = (size_t)4 * (PR + QR) * kStrideF * sizeof(float);
     const size_t ldsr = (size_t)4 * 1024 * sizeof(float);
     const size_t ldsz = ldsf > ldsr ? ldsf : ldsr;
-    int bf3 = 0;
-    { const char* e = getenv("FZ_WGRAD_BF3"); if (e) bf3 = atoi(e); }
+    const int bf3 = bf3g;
 #define FZ_WGF(MBP, MBQ, QP)                                                                              \
   do {                                                                                                    \
     if (kBf16) hipLaunchKernelGGL((wgrad_fast_kernel<MBP, MBQ, QP, 1>), grid, block, ldsz, st, a);        \
-    else if (bf3) hipLaunchKernelGGL((wgrad_fast_kernel<MBP, MBQ, QP, 3>), grid, block, ldsz, st, a);     \
+    else if (bf3) hipLaunchKernelGGL((wgrad_fast_kernel<MBP, MBQ, QP, 6>), grid, block, ldsz, st, a);     \
     else hipLaunchKernelGGL((wgrad_fast_kernel<MBP, MBQ, QP, 0>), grid, block, ldsz, st, a);              \
   } while (0)
 #define FZ_WGF_SHAPES(QP)                                \

@@ -22,13 +22,15 @@ class KernelTimer:
     """Optional per-launch timing of the native kernels with HIP events recorded on the
     stream the kernels are launched on (torch's current stream).  bench.py installs one over
     its timed region to get the dominant kernel's average launch duration and algorithmic
-    bytes for the roofline line."""
+    bytes for the roofline line.  Every record also carries the launch's voxel-column count
+    (`cols`: batch x voxels of the finest tensor it touches — which stage of the U-shape it belongs to) and its
+    matrix-core flops (`flops`: 2·M·K per output column of the GEMM-shaped layers; 0 for the byte-moving kernels)."""
 
     def __init__(self, only=None):
-        self.records = []  # (name, algorithmic_bytes, start_event, end_event)
+        self.records = []  # (name, algorithmic_bytes, start_event, end_event, cols, flops)
         self.only = None if only is None else set(only)  # time these keys only (events cost ~1 us of stream each)
 
-    def launch(self, name, nbytes, fn):
+    def launch(self, name, nbytes, fn, cols=0, flops=0):
         if self.only is not None and name not in self.only:
             return fn()
         s = torch.cuda.Event(enable_timing=True)
@@ -36,17 +38,19 @@ class KernelTimer:
         s.record()
         out = fn()
         e.record()
-        self.records.append((name, nbytes, s, e))
+        self.records.append((name, nbytes, s, e, cols, flops))
         return out
 
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for name, nbytes, s, e in self.records:
-            a = agg.setdefault(name, {"calls": 0, "ms": 0.0, "bytes": 0})
+        for name, nbytes, s, e, cols, flops in self.records:
+            a = agg.setdefault(name, {"calls": 0, "ms": 0.0, "bytes": 0, "flops": 0, "cols": cols})
             a["calls"] += 1
             a["ms"] += s.elapsed_time(e)
             a["bytes"] += nbytes
+            a["flops"] += flops
+            a["cols"] = max(a["cols"], cols)
         return agg
 
 
@@ -58,10 +62,10 @@ def set_timer(t):
     _timer = t
 
 
-def _timed(name, nbytes, fn):
+def _timed(name, nbytes, fn, cols=0, flops=0):
     if _timer is None:
         return fn()
-    return _timer.launch(name, nbytes, fn)
+    return _timer.launch(name, nbytes, fn, cols, flops)
 
 
 class Geometry:
@@ -392,11 +396,11 @@ class FactCoreFn(torch.autograd.Function):
                 arr = (N._i * 3)(*s)
                 last = geo.nshift if w == geo.nshift - 1 else 1
                 if hot:
-                    rc = _timed(f"nmf_cf_fwd_{geo.C}x" + "x".join(str(v) for v in geo.spatial), nb + (es * t.numel() if w else 0), lambda: N.lib().fz_nmf_cf_fwd(
+                    rc = _timed(f"nmf_cf_fwd_{geo.C}x" + "x".join(str(v) for v in geo.spatial), nb + (es * t.numel() if w else 0), cols=t.numel() // geo.C, fn=lambda: N.lib().fz_nmf_cf_fwd(
                         t.data_ptr(), u0.data_ptr(), v0.data_ptr(), out.data_ptr(), B, geo.C, *geo.spatial, arr,
                         int(w > 0), last, R, T, N.SOLVER_ID[solver], eps, ad, N.stream_ptr(t)))
                 else:
-                    rc = _timed(f"nmf_pcf_fwd_{geo.C}x" + "x".join(str(v) for v in geo.spatial), nb + (es * t.numel() if w else 0), lambda: N.lib().fz_nmf_pcf_fwd(
+                    rc = _timed(f"nmf_pcf_fwd_{geo.C}x" + "x".join(str(v) for v in geo.spatial), nb + (es * t.numel() if w else 0), cols=t.numel() // geo.C, fn=lambda: N.lib().fz_nmf_pcf_fwd(
                         t.data_ptr(), u0.data_ptr(), v0.data_ptr(), out.data_ptr(), B, geo.C, *geo.spatial, *geo.patch, arr,
                         int(w > 0), last, R, T, N.SOLVER_ID[solver], eps, ad, N.stream_ptr(t)))
                 N.check(rc, "fz_nmf_cf_fwd" if hot else "fz_nmf_pcf_fwd")
@@ -424,12 +428,12 @@ class FactCoreFn(torch.autograd.Function):
             for w, s in enumerate(geo.shifts):
                 arr = (N._i * 3)(*s)
                 if hot:
-                    rc = _timed(f"nmf_cf_bwd_{geo.C}x" + "x".join(str(v) for v in geo.spatial), nb + (es * t.numel() if w else 0), lambda: N.lib().fz_nmf_cf_bwd(
+                    rc = _timed(f"nmf_cf_bwd_{geo.C}x" + "x".join(str(v) for v in geo.spatial), nb + (es * t.numel() if w else 0), cols=t.numel() // geo.C, fn=lambda: N.lib().fz_nmf_cf_bwd(
                         t.data_ptr(), u0.data_ptr(), v0.data_ptr(), ga.data_ptr(), gt.data_ptr(), B, geo.C,
                         *geo.spatial, arr, int(w > 0), geo.nshift, int(relu_gate), R, T, G, N.SOLVER_ID[solver], eps,
                         ad, N.stream_ptr(t)))
                 else:
-                    rc = _timed(f"nmf_pcf_bwd_{geo.C}x" + "x".join(str(v) for v in geo.spatial), nb + (es * t.numel() if w else 0), lambda: N.lib().fz_nmf_pcf_bwd(
+                    rc = _timed(f"nmf_pcf_bwd_{geo.C}x" + "x".join(str(v) for v in geo.spatial), nb + (es * t.numel() if w else 0), cols=t.numel() // geo.C, fn=lambda: N.lib().fz_nmf_pcf_bwd(
                         t.data_ptr(), u0.data_ptr(), v0.data_ptr(), ga.data_ptr(), gt.data_ptr(), B, geo.C,
                         *geo.spatial, *geo.patch, arr, int(w > 0), geo.nshift, int(relu_gate), R, T, G, N.SOLVER_ID[solver], eps,
                         ad, N.stream_ptr(t)))

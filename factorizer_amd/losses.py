@@ -45,7 +45,7 @@ class DiceBCEFn(torch.autograd.Function):
         part = torch.empty((planes, nchunk, 4), dtype=z.dtype, device=z.device)
         with torch.cuda.device(z.device):
             rc = Fn._timed("dice_bce_sums", 8 * z.numel(), lambda: lib.fz_dice_bce_sums(
-                z.data_ptr(), t.data_ptr(), part.data_ptr(), planes, V, N.stream_ptr(z)))
+                z.data_ptr(), t.data_ptr(), part.data_ptr(), planes, V, N.stream_ptr(z)), cols=z.shape[0] * V)
         N.check(rc, "fz_dice_bce_sums")
         s = part.sum(dim=1)  # (planes, 4) — tiny
         num = 2.0 * s[:, 0] + smooth
@@ -64,7 +64,7 @@ class DiceBCEFn(torch.autograd.Function):
         with torch.cuda.device(z.device):
             rc = Fn._timed("dice_bce_grad", 12 * z.numel(), lambda: N.lib().fz_dice_bce_grad(
                 z.data_ptr(), t.data_ptr(), coef.data_ptr(), gz.data_ptr(), planes, V, 1.0 / planes,
-                1.0 / (planes * V), gs.data_ptr(), N.stream_ptr(z)))
+                1.0 / (planes * V), gs.data_ptr(), N.stream_ptr(z)), cols=z.shape[0] * V)
         N.check(rc, "fz_dice_bce_grad")
         return gz, None, None
 
@@ -116,7 +116,7 @@ class DiceCEFn(torch.autograd.Function):
         part = torch.empty((B, nchunk, 3 * C + 1), dtype=z.dtype, device=z.device)
         with torch.cuda.device(z.device):
             rc = Fn._timed("dice_ce_sums", 8 * z.numel(), lambda: lib.fz_dice_ce_sums(
-                z.data_ptr(), t.data_ptr(), part.data_ptr(), B, C, V, N.stream_ptr(z)))
+                z.data_ptr(), t.data_ptr(), part.data_ptr(), B, C, V, N.stream_ptr(z)), cols=B * V)
         N.check(rc, "fz_dice_ce_sums")
         s = part.sum(dim=1)  # (B, 3C+1) — tiny
         d = s[:, :3 * C].reshape(B, C, 3)
@@ -136,7 +136,7 @@ class DiceCEFn(torch.autograd.Function):
         with torch.cuda.device(z.device):
             rc = Fn._timed("dice_ce_grad", 12 * z.numel(), lambda: N.lib().fz_dice_ce_grad(
                 z.data_ptr(), t.data_ptr(), coef.data_ptr(), gz.data_ptr(), B, C, V, 1.0 / (B * C),
-                1.0 / (B * V), gs.data_ptr(), N.stream_ptr(z)))
+                1.0 / (B * V), gs.data_ptr(), N.stream_ptr(z)), cols=B * V)
         N.check(rc, "fz_dice_ce_grad")
         return gz, None, None
 

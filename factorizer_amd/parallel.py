@@ -35,7 +35,8 @@ class FlatGradSync:
         if not self.params:
             raise ValueError("no trainable parameters")
         dev, dt = self.params[0].device, self.params[0].dtype
-        total = sum(p.numel() for p in self.params)
+        from .training import flat_align   # same 16-byte-aligned layout as FlatAdamW's buffers (it aliases this one)
+        total = sum(flat_align(p.numel()) for p in self.params)
         self.flat = torch.zeros(total, device=dev, dtype=dt)
         # autograd produces gradients roughly in reverse registration order: bucket 0 = the
         # parameters registered LAST (decoder / head), reduced first.
@@ -48,8 +49,8 @@ class FlatGradSync:
             n = p.numel()
             self.views[p] = self.flat[off:off + n].view_as(p)
             cur.append(p)
-            off += n
-            cur_n += n
+            off += flat_align(n)
+            cur_n += flat_align(n)
             if cur_n >= per:
                 self.buckets.append({"params": cur, "lo": start, "hi": off})
                 cur, cur_n, start = [], 0, off

@@ -60,7 +60,8 @@ def _gemm(xs, w, y, *, B, Cin, Vin, M, K, Ncol, w_t=False, ldw=None, bias=None, 
     nbytes = x0.element_size() * (sum(t.numel() for t in xs) + y.numel() + (res.numel() if res is not None else 0))
     with torch.cuda.device(x0.device):
         rc = Fn._timed(f"{name}_{Cin}->{M}", nbytes,
-                       lambda: N.lib().fz_gemm(ctypes.byref(d), N.stream_ptr(x0)))
+                       lambda: N.lib().fz_gemm(ctypes.byref(d), N.stream_ptr(x0)),
+                       cols=B * max(Vin, Ncol * (8 if epilogue == EPI_D2S else 1)), flops=2 * B * Ncol * M * K)
     N.check(rc, "fz_gemm")
     return y
 
@@ -85,7 +86,8 @@ def _wgrad(p, qs, gw, *, B, M, Cin, K, Vq, Ncols, gbias=None, pmul=None, pmul_ki
     nbytes = p.element_size() * (p.numel() + sum(t.numel() for t in qs))
     with torch.cuda.device(p.device):
         rc = Fn._timed(f"{name}_{M}x{K}", nbytes,
-                       lambda: N.lib().fz_wgrad(ctypes.byref(d), ws.data_ptr(), N.stream_ptr(p)))
+                       lambda: N.lib().fz_wgrad(ctypes.byref(d), ws.data_ptr(), N.stream_ptr(p)),
+                       cols=B * max(Vq, Ncols), flops=2 * B * Ncols * M * K)
     N.check(rc, "fz_wgrad")
     return gw
 
@@ -101,7 +103,7 @@ def _ln_backward(gl, x, stats, ln_w, gadd=None):
     with torch.cuda.device(x.device):
         rc = Fn._timed(f"ln_bwd_{C}", 3 * x.element_size() * x.numel(), lambda: N.lib().fz_ln_bwd(
             gl.data_ptr(), x.data_ptr(), stats.data_ptr(), ln_w.data_ptr(), _p(gadd), gx.data_ptr(), _p(gpar), _p(ws),
-            B, C, V, N.act_dtype(x), N.stream_ptr(x)))
+            B, C, V, N.act_dtype(x), N.stream_ptr(x)), cols=B * V)
     N.check(rc, "fz_ln_bwd")
     return gx, gpar[:C], gpar[C:]
 
@@ -133,7 +135,8 @@ def _dgrad_lnbwd(gz, w2, x, stats, ln_w, gadd):
     tmp = torch.empty((64, 2 * C), dtype=torch.float32, device=x.device)
     nbytes = x.element_size() * (gz.numel() + 2 * x.numel() + (gadd.numel() if gadd is not None else 0))
     with torch.cuda.device(x.device):
-        rc = Fn._timed(f"dgrad_lnbwd_{Mz}->{C}", nbytes, lambda: N.lib().fz_gemm(ctypes.byref(d), N.stream_ptr(x)))
+        rc = Fn._timed(f"dgrad_lnbwd_{Mz}->{C}", nbytes, lambda: N.lib().fz_gemm(ctypes.byref(d), N.stream_ptr(x)),
+                       cols=B * V, flops=2 * B * V * C * Mz)
         N.check(rc, "fz_gemm")
         rc = N.lib().fz_reduce_rows(part.data_ptr(), rows, 2 * C, gpar.data_ptr(), tmp.data_ptr(), N.stream_ptr(x))
         N.check(rc, "fz_reduce_rows")
@@ -165,7 +168,8 @@ def _gemm_dw(g, w2, q, ln=None, stats=None, gadd=None, want_bias=False, name="dg
         d.ln, d.stats, d.ln_g, d.ln_b, d.gadd, d.gln = 1, stats.data_ptr(), ln[0].data_ptr(), ln[1].data_ptr(), _p(gadd), gpar.data_ptr()
     nbytes = q.element_size() * (3 * q.numel() + (gadd.numel() if gadd is not None else 0))
     with torch.cuda.device(dev):
-        rc = Fn._timed(f"{name}_{C}", nbytes, lambda: N.lib().fz_gemm_dw(ctypes.byref(d), N.stream_ptr(q)))
+        rc = Fn._timed(f"{name}_{C}", nbytes, lambda: N.lib().fz_gemm_dw(ctypes.byref(d), N.stream_ptr(q)),
+                       cols=B * V, flops=4 * B * V * C * C)
         N.check(rc, "fz_gemm_dw")
     if ln is not None:
         return y, gw, gb, gpar[:32], gpar[32:]
@@ -194,7 +198,7 @@ def _mlp_fwd_chain(x1, ln_w, ln_b, eps, w12, b1, w22, b2):
     d.act_dtype = N.act_dtype(x1)
     with torch.cuda.device(x1.device):
         rc = Fn._timed(f"mlp_chain_fwd_{C}", x1.element_size() * (2 * x1.numel() + z1.numel()),
-                       lambda: N.lib().fz_mlp_chain(ctypes.byref(d), N.stream_ptr(x1)))
+                       lambda: N.lib().fz_mlp_chain(ctypes.byref(d), N.stream_ptr(x1)), cols=B * V, flops=4 * B * V * C * Hd)
     N.check(rc, "fz_mlp_chain")
     return x2, z1, st
 
@@ -218,7 +222,7 @@ def _mlp_bwd_chain(g2, z1, w12, w22, x1, st, ln_w):
     d.act_dtype = N.act_dtype(x1)
     with torch.cuda.device(x1.device):
         rc = Fn._timed(f"mlp_chain_bwd_{C}", x1.element_size() * (3 * x1.numel() + 2 * z1.numel()),
-                       lambda: N.lib().fz_mlp_chain(ctypes.byref(d), N.stream_ptr(x1)))
+                       lambda: N.lib().fz_mlp_chain(ctypes.byref(d), N.stream_ptr(x1)), cols=B * V, flops=4 * B * V * C * Hd)
         N.check(rc, "fz_mlp_chain")
         rc = N.lib().fz_reduce_rows(part.data_ptr(), rows, 2 * C, gpar.data_ptr(), tmp.data_ptr(), N.stream_ptr(x1))
         N.check(rc, "fz_reduce_rows")
@@ -257,7 +261,7 @@ def _mlp_bwd_chain_wgrad(g2, z1, w12, w22, x1, st, ln_w, ln_b):
     nbytes = x1.element_size() * (3 * x1.numel() + z1.numel()) + (0 if Hd == 64 else x1.element_size() * 2 * x1.numel() + 8 * x1.numel())
     with torch.cuda.device(dev):
         rc = Fn._timed(f"mlp_chain_bwd_wgrad_{C}" + ("" if Hd == 64 else f"x{Hd}"), nbytes,
-                       lambda: N.lib().fz_mlp_chain(ctypes.byref(d), N.stream_ptr(x1)))
+                       lambda: N.lib().fz_mlp_chain(ctypes.byref(d), N.stream_ptr(x1)), cols=B * V, flops=8 * B * V * C * Hd)
         N.check(rc, "fz_mlp_chain")
     return gx1, gpar[:32], gpar[32:], gw1, gb1, gw2, gb2
 
@@ -484,7 +488,7 @@ class LayerNormFn(torch.autograd.Function):
         with torch.cuda.device(x.device):
             rc = Fn._timed(f"ln_fwd_{C}", 2 * x.element_size() * x.numel(), lambda: N.lib().fz_ln_fwd(
                 x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), B, C, V, eps,
-                N.act_dtype(x), N.stream_ptr(x)))
+                N.act_dtype(x), N.stream_ptr(x)), cols=B * V)
         N.check(rc, "fz_ln_fwd")
         ctx.save_for_backward(x, stats, w)
         return y
@@ -616,7 +620,8 @@ class ConvK3Fn(torch.autograd.Function):
         if C * 27 * 64 * 4 <= 65536:
             with torch.cuda.device(x.device):
                 rc = Fn._timed(f"conv_k3_{C}->{O}", x.element_size() * (x.numel() + y.numel()), lambda: N.lib().fz_conv3_fwd(
-                    x.data_ptr(), w.data_ptr(), _p(b), y.data_ptr(), B, C, O, D, H, W, N.act_dtype(x), N.stream_ptr(x)))
+                    x.data_ptr(), w.data_ptr(), _p(b), y.data_ptr(), B, C, O, D, H, W, N.act_dtype(x), N.stream_ptr(x)),
+                    cols=B * V, flops=2 * B * V * 27 * C * O)
             N.check(rc, "fz_conv3_fwd")
         else:
             _gemm([x], w, y, B=B, Cin=C, Vin=V, M=O, K=27 * C, Ncol=V, bias=b, loader=LOAD_K3, Di=D, Hi=H, Wi=W,
@@ -663,7 +668,8 @@ class ConvK3Fn(torch.autograd.Function):
                     if rc == 0:
                         rc = lib.fz_chunk_reduce(pbias.data_ptr(), nchunk, O, gb.data_ptr(), 0, st)
                     return rc
-                rc = Fn._timed(f"wgrad_conv_k3_{O}x{K}", x.element_size() * (x.numel() + gy.numel()), run)
+                rc = Fn._timed(f"wgrad_conv_k3_{O}x{K}", x.element_size() * (x.numel() + gy.numel()), run,
+                               cols=B * V, flops=2 * B * V * K * O)
             N.check(rc, "fz_conv3_wgrad")
         else:
             _wgrad(gy, [x], gw, B=B, M=O, Cin=C, K=27 * C, Vq=V, Ncols=V, gbias=gb, loader=LOAD_K3, D=D, H=H, W=W,

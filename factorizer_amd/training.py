@@ -20,6 +20,12 @@ import torch
 
 from . import _native as N
 
+FLAT_ALIGN = 4  # floats: every parameter starts on a 16-byte boundary of the flat buffers (float4 kernels, 32-byte weight reads)
+
+
+def flat_align(n: int) -> int:
+    return (n + FLAT_ALIGN - 1) // FLAT_ALIGN * FLAT_ALIGN
+
 
 class FlatAdamW:
     """AdamW (decoupled weight decay, no amsgrad) over the trainable parameters of `module`, moved
@@ -46,8 +52,10 @@ class FlatAdamW:
         order = self.params if grad_views is None else list(grad_views.keys())
         if grad_views is not None and set(order) != set(self.params):
             raise ValueError("FlatAdamW: grad_views must cover exactly the trainable parameters")
-        total = sum(p.numel() for p in order)
-        self.flat_param = torch.empty(total, device=dev, dtype=dt)
+        # every parameter starts 16-byte aligned (padding elements stay zero in all four buffers: a zero parameter with a
+        # zero gradient is a fixed point of the update), so any sub-range launch of the float4 kernel is aligned too
+        total = sum(flat_align(p.numel()) for p in order)
+        self.flat_param = torch.zeros(total, device=dev, dtype=dt)
         self.flat_grad = flat_grad if flat_grad is not None else torch.zeros(total, device=dev, dtype=dt)
         if self.flat_grad.numel() != total:
             raise ValueError("FlatAdamW: flat_grad size mismatch")
@@ -62,7 +70,7 @@ class FlatAdamW:
                 p.data = view
                 self.grad_views[p] = grad_views[p] if grad_views is not None else self.flat_grad[off:off + n].view_as(p)
                 self.offsets[p] = off
-                off += n
+                off += flat_align(n)
         self.order = order
         self.lr, self.betas, self.eps, self.weight_decay = float(lr), tuple(betas), float(eps), float(weight_decay)
         self.base_lr = float(lr)
@@ -132,12 +140,13 @@ class FlatAdamW:
                 continue
             self.steps[p] += 1
             lo = self.offsets[p]
+            hi = lo + flat_align(p.numel())   # (the padding rides along: zeros stay zeros)
             if run and run[1] == lo and run[2] == self.steps[p]:
-                run[1] = lo + p.numel()
+                run[1] = hi
             else:
                 if run:
                     self._update(*run, grad_scale)
-                run = [lo, lo + p.numel(), self.steps[p]]
+                run = [lo, hi, self.steps[p]]
         if run:
             self._update(*run, grad_scale)
 
@@ -161,8 +170,13 @@ class FlatAdamW:
             for p in self.params:
                 self.steps[p] = int(sd["t"])
             self.lr = float(sd["lr"])
-            self.exp_avg.copy_(sd["exp_avg"])
-            self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+            src = 0  # that layout packed the parameters without alignment padding
+            with torch.no_grad():
+                for p in self.order:
+                    lo, n = self.offsets[p], p.numel()
+                    self.exp_avg[lo:lo + n].copy_(sd["exp_avg"][src:src + n])
+                    self.exp_avg_sq[lo:lo + n].copy_(sd["exp_avg_sq"][src:src + n])
+                    src += n
             return
         groups = sd["param_groups"]
         ids = [i for g in groups for i in g["params"]]
