@@ -91,8 +91,8 @@ MODEL_KW = dict(in_channels=4, out_channels=3, spatial_size=(128, 128, 128),
 def cpu_baseline_sample():
     """CPU oracle (a port of the reference's CPU path, pinned to goldens generated by the imported reference) on a
     bounded sample of THIS workload: one whole training step of the README Swin Factorizer — forward, DiceCE loss,
-    backward, AdamW — on ONE 128^3 volume (the benchmark's per-GPU batch is 2), measured, not extrapolated
-    (≈ 15-20 s on 32 threads).  The long form (cfg 1-4 at full batch, warm-up + repetitions) is
+    backward, AdamW — on ONE 128^3 volume (the benchmark's per-GPU batch is 2), measured, not extrapolated:
+    one warm-up step + 2 timed steps (≈ 3 x 15 s on 32 threads).  The long form (cfg 1-4 at full batch, warm-up + repetitions) is
     tools/cpu_baseline_full.py → profiles/rNN_cpu_baseline.json."""
     from oracle import cpu_ref as O
     # ATen's CPU kernels stop scaling (and regress) beyond a few dozen threads on these sizes
@@ -115,55 +115,32 @@ def cpu_baseline_sample():
     for _ in range(20):
         O.nmf_forward(x1, u0, v0, 5, "mu")
     t_cfg1 = (time.perf_counter() - t1) / 20
-    t0 = time.perf_counter()
-    opt.zero_grad(set_to_none=True)
-    loss = O.dice_ce_loss(O.factorizer_forward(x, full, cfg), tgt)
-    loss.backward()
-    opt.step()
-    t = time.perf_counter() - t0
-    assert torch.isfinite(loss).item()
+    def one_step():
+        t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        loss = O.dice_ce_loss(O.factorizer_forward(x, full, cfg), tgt)
+        loss.backward()
+        opt.step()
+        assert torch.isfinite(loss).item()
+        return time.perf_counter() - t0
+
+    warm = one_step()                       # first touch of every buffer, thread-pool start-up
+    samples = sorted(one_step() for _ in range(2))
+    t = sum(samples) / len(samples)
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next(line.split(":", 1)[1].strip() for line in f if line.startswith("model name"))
+    except Exception:
+        pass
     return {"value": 1.0 / t, "unit": "volumes/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "oracle: ONE whole training step (forward + DiceCE + backward + AdamW) of the README Swin Factorizer "
-                      f"on one 128^3 volume (batch 1; the benchmark's per-GPU batch is 2), {t:.1f} s, measured once, no "
-                      "warm-up; full-batch runs with warm-up and repetitions: profiles/r02_cpu_baseline.json",
-            "seconds_sample": t, "cfg1_nmf_8x512_mu_r2_t5_fwd_us": round(t_cfg1 * 1e6, 1), "host_cpus": os.cpu_count()}
-
-
-def by_stage(table, nsteps, B, stage0_cols):
-    """Where the step's kernel time is: per stage of the U-shape (a launch belongs to the stage of the finest tensor it
-    touches: `cols` = batch x voxels, stage s has stage0_cols / 8^s) the summed launch time of the instrumented warm-up
-    steps, the algorithmic bytes and matrix-core flops of those launches, and both as fractions of the chip's roofs
-    (8 TB/s HBM; 157.3 TFLOP/s fp32 matrix peak — the layers with K >= 64 run their fp32 products as six bf16 products
-    on the bf16 pipe, so their share of the fp32 roof can legitimately pass 1/2.67 of it and is only descriptive).
-    `bound` = the roof whose minimum time for that work is larger.  Side-stream launches overlap the main stream, so the
-    stage times add up to more than the step."""
-    out = {}
-    fam = {}
-    for name, a in table.items():
-        cols = a.get("cols", 0)
-        s = 0
-        while cols and cols * 8 ** s < stage0_cols and s < 8:
-            s += 1
-        key = "unattributed" if not cols else ("stage0" if s == 0 else "stage1" if s == 1 else "stage2-4")
-        for k2, dst in ((key, out), ("gemm_family" if a.get("flops", 0) and not name.startswith(("wgrad", "mlp_chain", "dgrad_", "conv_k3")) else None, fam)):
-            if k2 is None:
-                continue
-            d = dst.setdefault(k2, {"kernel_ms": 0.0, "GB": 0.0, "GFLOP": 0.0, "launches": 0})
-            d["kernel_ms"] += a["ms"] / nsteps
-            d["GB"] += a["bytes"] / nsteps / 1e9
-            d["GFLOP"] += a.get("flops", 0) / nsteps / 1e9
-            d["launches"] += a["calls"] // max(nsteps, 1)
-    for dst in (out, fam):
-        for d in dst.values():
-            ms = max(d["kernel_ms"], 1e-9)
-            d["hbm_frac"] = round(d["GB"] / ms / HBM_PEAK_GBS * 1e3, 4)
-            d["mfma_frac_of_fp32_peak"] = round(d["GFLOP"] / ms / FP32_MFMA_PEAK_TFLOPS, 4)
-            d["bound"] = "mfma" if d["GFLOP"] / FP32_MFMA_PEAK_TFLOPS > d["GB"] / HBM_PEAK_GBS * 1e3 else "hbm"
-            d["frac_of_binding_roof"] = max(d["hbm_frac"], d["mfma_frac_of_fp32_peak"]) if d["bound"] == "mfma" else d["hbm_frac"]
-            for k in ("kernel_ms", "GB", "GFLOP"):
-                d[k] = round(d[k], 3)
-    out.update({"fz_gemm (1x1 layers, k2s2 convolutions: gemm_stream / gemm_bx / gemm_bxk / gemm_resident)": v for v in fam.values()})
-    return out
+            "sample": "oracle (port of the reference's CPU path): whole training steps (forward + DiceCE + backward + AdamW) of "
+                      "the README Swin Factorizer on one 128^3 volume (batch 1; the benchmark's per-GPU batch is 2): one "
+                      f"warm-up step ({warm:.1f} s) + 2 timed steps ({samples[0]:.1f}, {samples[1]:.1f} s), mean {t:.1f} s, on "
+                      f"{torch.get_num_threads()} threads of {os.cpu_count()} host CPUs ({cpu_model}); ATen's CPU kernels stop "
+                      "scaling beyond a few dozen threads at these sizes; full-batch runs: profiles/r02_cpu_baseline.json",
+            "seconds_sample": t, "seconds_warmup": warm, "seconds_timed": samples, "cpu_model": cpu_model,
+            "cfg1_nmf_8x512_mu_r2_t5_fwd_us": round(t_cfg1 * 1e6, 1), "host_cpus": os.cpu_count()}
 
 
 NMF_FLOP_FWD = 95312  # SURVEY.md §8(d): HALS R=1 T=5 on one 8x512 matrix, forward (T·F_iter + F_recon)

@@ -1600,7 +1600,7 @@ enum { PRO_NONE = 0, PRO_LN = 1, PRO_GELU = 2, PRO_BMUL = 3 };
 // MFMA chains: 512->512 at 8^3 is 128 workgroups x 256 serial steps without it.
 // (2 workgroups per CU: 3 or 4 — narrower tiles under tighter launch bounds — measured no faster,
 // an occupancy sweep: the operand traffic of these launches runs at 4.1-5.1 TB/s even with the
-// MFMAs compiled out (tools/debug/gemm_probe7.py), the fp32 MFMA time comes largely on top of it.)
+// MFMAs compiled out (round-1/2 probe `gemm_probe7`), the fp32 MFMA time comes largely on top of it.)
 template <int MB, int NACC, int LOADER, int EPI, int PRO, int KS = 1, typename AT = float>
 __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgsT<AT> p) {
   constexpr int TN = 32 * NACC;
@@ -2049,7 +2049,7 @@ static int gemm_launch(const fz_gemm_desc* d, fz_stream_t stream) {
   }
 
   // ---- Kernel A: whole operand in registers (K <= 64, plain loader) ----
-  // measured (tools/debug/gemm_probe5.py): the register-resident kernel wins for K <= 32, the
+  // measured (round-1/2 probe `gemm_probe5`): the register-resident kernel wins for K <= 32, the
   // streaming ring for K = 64 (4.4 vs 3.3 TB/s at 64->32, 128^3)
   int res_maxk = 32;
   { const char* e = getenv("FZ_GEMM_RESMAXK"); if (e) res_maxk = atoi(e); }
@@ -2058,7 +2058,7 @@ static int gemm_launch(const fz_gemm_desc* d, fz_stream_t stream) {
   // kernel overlaps its MFMAs with the loads still in flight, which the LayerNorm prologue of the
   // resident kernel cannot (it needs the whole column first): 32->32 at 128^3, LayerNorm + ReLU 345 -> 274 us,
   // plain 278 -> 248 us; with a residual (357 vs 362 us) or two row blocks (391 vs 439 us) the resident
-  // kernel stays ahead (tools/debug/gemm_probe9.py)
+  // kernel stays ahead (round-1/2 probe `gemm_probe9`)
   const bool stream_small = mblocks == 1 && d->K >= 16 && d->K <= 32 && !d->res && !d->bmul && !d->emul &&
                             d->epilogue == EPI_PLAIN && d->bact == 0 && !getenv("FZ_GEMM_RESMAXK");
   if (d->loader == LOAD_PLAIN && d->K <= res_maxk && !stream_small) {
@@ -2091,7 +2091,7 @@ static int gemm_launch(const fz_gemm_desc* d, fz_stream_t stream) {
   // those GEMMs sit at 56-71 TFLOP/s of fp32 MFMA with the operand loads as the stall reason, not the
   // per-tile prologue / epilogue.)
   // ---- Kernel B: streaming; pick the column-tile width so the grid fills the chip ----
-  // tile choice from a sweep on MI355X (tools/debug/gemm_probe3.py, FZ_GEMM_CFG): take the widest
+  // tile choice from a sweep on MI355X (round-1/2 probe `gemm_probe3`, FZ_GEMM_CFG): take the widest
   // column tile that still gives >= 256 workgroups (one per CU); two row blocks per workgroup only
   // when that still leaves >= 512 workgroups
   int nacc = 4, MBsel = mblocks >= 2 ? 2 : 1;
@@ -2106,7 +2106,7 @@ static int gemm_launch(const fz_gemm_desc* d, fz_stream_t stream) {
     if (narrow_ok) {
       if (wgs(nacc, MBsel) < 256) nacc = 2;
       // (when even 32-voxel tiles cannot give one workgroup per CU — the 8^3 bottleneck — stay with 64-voxel tiles and
-      // let the K-split below fill the chip: 8-byte lane loads; 512->1024 at 2 x 8^3: 33 against 43 us, tools/debug/gemm_deep.py)
+      // let the K-split below fill the chip: 8-byte lane loads; 512->1024 at 2 x 8^3: 33 against 43 us, round-1/2 probe `gemm_deep`)
       if (wgs(nacc, MBsel) < 256 && !(wgs(1, MBsel) < 256 && d->K >= 256)) nacc = 1;
       const char* e = getenv("FZ_GEMM_CFG");  // diagnostics: "<nacc><mb>", e.g. 42
       if (e && e[0] && e[1]) { nacc = e[0] - '0'; MBsel = e[1] - '0'; if (MBsel == 2 && (nacc != 4 || mblocks < 2)) MBsel = 1; }
@@ -2180,7 +2180,7 @@ extern "C" int64_t fz_gemm_lnbwd_partials(const fz_gemm_desc* d) {
 // Linear∘LayerNorm + Linear∘GELU + residual (layers/mlp.py:54-63, factorizer.py:76) in the
 // forward and the two input-gradient GEMMs + LayerNorm backward in the backward.
 // columns per lane = 2: 64-column wave tiles, <= 168 VGPRs → 3 waves/SIMD with the next-tile prefetch
-// (4 columns per lane: 0.71 / 1.38 ms against 0.63 / 1.00 ms, tools/debug/mlp_probe.py)
+// (4 columns per lane: 0.71 / 1.38 ms against 0.63 / 1.00 ms, round-1/2 probe `mlp_probe`)
 static int mlp_nacc() { return 2; }
 
 extern "C" int64_t fz_mlp_partials(int B, int64_t V) {

@@ -489,7 +489,7 @@ static int cf_fwd_launch(const AT* t, const float* u0, const float* v0, AT* out,
   if (B == 0) return FZ_OK;
   const int64_t nmat = (int64_t)B * q.h * q.G0 * q.G1 * q.G2;
   if (nmat >= (int64_t)1 << 31) return fail(FZ_E_UNSUPPORTED, "fz_nmf_cf: more than 2^31 matrices");
-  // measured on MI355X (tools/debug/cf_probe.py): a workgroup = one full row of patches along W
+  // measured on MI355X (round-1/2 probe `cf_probe`): a workgroup = one full row of patches along W
   // (up to 16 waves) consumes whole 128-B lines inside one CU: 0.856 -> 0.725 ms at stage 0
   int wpb = 16;
   { const char* e = getenv("FZ_CF_WPB"); if (e) wpb = atoi(e); }

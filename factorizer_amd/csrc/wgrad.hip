@@ -683,7 +683,7 @@ __global__ __launch_bounds__(256) void ln_fold_kernel(float* __restrict__ gw, co
 using namespace fz;
 
 // Register-operand kernel (wgrad_fast_kernel): whole 64x64 blocks, whole tiles, at most two concatenated
-// sources split on a multiple of 8 (measured, tools/debug/wgrad_probe.py: 8-13 % faster for 64x64
+// sources split on a multiple of 8 (measured, round-1/2 probe `wgrad_probe`: 8-13 % faster for 64x64
 // blocks, slower for the HBM-bound 32-row blocks of stage 0, which keep the generic kernel)
 static bool use_fast(const fz_wgrad_desc* d) {
   const int PR = d->M > 32 ? 64 : 32, QR = d->K > 32 ? 64 : 32;
@@ -698,7 +698,7 @@ static bool use_fast(const fz_wgrad_desc* d) {
 
 static int pick_chunks(int64_t total_tiles, int out_blocks, bool fast, int* tiles_per_chunk) {
   // (workgroup, wave) units over the whole grid, at least 1 tile each.  Measured sweep on MI355X
-  // (tools/debug/wgrad_probe2.py, FZ_WGRAD_UNITS): every workgroup pays a fixed prologue (first tile's
+  // (round-1/2 probe `wgrad_probe2`, FZ_WGRAD_UNITS): every workgroup pays a fixed prologue (first tile's
   // round trip) and epilogue (4-wave reduction, partial block) of a few microseconds, and a grid that is
   // not a whole number of workgroups per CU leaves a tail — ONE workgroup per CU (1024 units) is the
   // optimum for the register-operand kernel (64x64 at 64^3: 83 us against 107 with 4 per CU), two per CU

@@ -113,21 +113,31 @@ def test_reference_test_config_global_matricize():
     gm = torch.rand_like(td)
 
     def timeit(fn, n=20):
+        """median and maximum of n per-call timings (events around every call).  Round 2 recorded a MEAN of 4.84 ms for
+        forward + backward where 0.25-0.30 ms is the rule: inside the full suite ONE of the 20 calls absorbs a ~90 ms
+        pause (the per-call list shows it; the five calls profiled right after take 0.4 ms each, tools/probes/wide_nmf_*.py
+        reproduce 0.25 ms in every isolated setting) — the median is what the kernels take, the maximum is recorded too."""
         for _ in range(3):
             fn()
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
+        ts = []
         for _ in range(n):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
             fn()
-        e.record()
+            e.record()
+            ts.append((s, e))
         torch.cuda.synchronize()
-        return s.elapsed_time(e) / n
+        calls = [round(s.elapsed_time(e), 3) for s, e in ts]
+        ms = sorted(calls)
+        return ms[len(ms) // 2], calls
     with torch.no_grad():
-        f_ms = timeit(lambda: nmf(td))
-    fb_ms = timeit(lambda: torch.autograd.grad(nmf(td), td, gm))
+        f_ms, f_max = timeit(lambda: nmf(td))
+    fb_ms, fb_max = timeit(lambda: torch.autograd.grad(nmf(td), td, gm))
     nbytes = td.numel() * 4
     # the kernels read X twice per iteration + once for the first partials, and write Y: (2T + 2) passes
-    P.note("wide_nmf_16x262144_mu_r1_t5", fwd_ms=f_ms, fwd_bwd_ms=fb_ms, launches_fwd=11,
+    # 11 launches forward (60-70 us), 0.25-0.30 ms forward + backward on MI355X (profiles/r03_wide_nmf_timing.json)
+    assert f_ms <= 0.15 and fb_ms <= 0.6, (f_ms, fb_ms)
+    P.note("wide_nmf_16x262144_mu_r1_t5", fwd_ms=f_ms, fwd_bwd_ms=fb_ms, fwd_max_ms=max(f_max), fwd_bwd_max_ms=max(fb_max), fwd_bwd_calls_ms=fb_max, launches_fwd=11,
            fwd_traffic_GBps=(2 * 5 + 2) * nbytes / (f_ms * 1e-3) / 1e9,
            algorithmic_GBps=2 * nbytes / (f_ms * 1e-3) / 1e9)
 

@@ -1,5 +1,5 @@
 """One training step out of a rocprofv3 kernel trace: per-kernel start / duration / stream, and busy time per stream.
-usage: python tools/debug/step_timeline.py <kernel_trace.csv> [--full]"""
+usage: python tools/step_timeline.py <kernel_trace.csv> [--full]"""
 import csv, re, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 idx = [i for i, r in enumerate(rows) if 'adamw' in r['Kernel_Name']]
