@@ -36,12 +36,27 @@ def test_deconver_model_on_device(golden, tag):
     assert _native.launch_count() > n0
     P.close("y", y, g[f"{tag}:y"])
     P.close("y (no_grad: fused update epilogue)", y_inf, g[f"{tag}:y"])
-    why = "tiny-model goldens: the reference's own CPU evaluation orders agree to 2e-4 only (tests/test_deconver_cpu.py)"
-    P.close("gx", grads[0], g[f"{tag}:gx"], rel=2e-4, why=why)
-    for k, gr in zip(names, grads[1:]):
-        key = f"{tag}:grad:{k}"
-        if key in g.z:
-            P.close("grad:" + k, gr, g[key], rel=2e-4, why=why)
+    # Round 2 held the model gradients to 2e-4 "because the reference's CPU evaluation orders agree to 2e-4 only".  An fp64
+    # evaluation of the same model (the composed CPU path in float64) says otherwise: the reference's fp32 gradients (the
+    # goldens) are within 3e-6 of it, and so is the device.  Every gradient is held to the 1e-4 bound against the goldens,
+    # and the distances to the fp64 evaluation are recorded next to each other.
+    m64 = ft.Deconver(in_channels=4, out_channels=3, **MODELS[tag]).eval().double()
+    m64.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in g.case(f"{tag}:sd").items()})
+    x64 = g[f"{tag}:x"].double().requires_grad_(True)
+    g64 = torch.autograd.grad(m64(x64), [x64] + list(m64.parameters()), g[f"{tag}:gy"].double(), allow_unused=True)
+    P.close("gx", grads[0], g[f"{tag}:gx"])
+    worst_gold = worst_dev = 0.0
+    for k, gr, r64 in zip(["x"] + names, grads, g64):
+        key = f"{tag}:gx" if k == "x" else f"{tag}:grad:{k}"
+        if key not in g.z:
+            continue
+        if k != "x":
+            P.close("grad:" + k, gr, g[key])
+        scale = r64.abs().max().item() + 1e-30
+        worst_gold = max(worst_gold, (g[key].double() - r64).abs().max().item() / scale)
+        worst_dev = max(worst_dev, (gr.double().cpu() - r64).abs().max().item() / scale)
+    P.note(f"deconver {tag}: gradient distance to the fp64 evaluation", reference_fp32_goldens=worst_gold, device=worst_dev)
+    assert worst_dev <= max(1e-5, 4 * worst_gold), (worst_dev, worst_gold)
 
 
 @pytest.mark.parametrize("nd,k,G,Ci,Co,S,batched", [
