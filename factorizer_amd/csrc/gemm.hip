@@ -141,8 +141,12 @@ __device__ __forceinline__ void lnbwd_block(const GemmArgsT<AT>& p, const f32x16
 // workgroup sequentially with one accumulator set: the input is read from HBM exactly once for
 // all output rows and 10+ KiB per wave are in flight.
 // =================================================================================================
-template <int NSTEP, int EPI, bool BMUL, bool GADD = false, typename AT = float>
-__global__ __launch_bounds__(256, ((NSTEP <= 16 && EPI != EPI_LNBWD) ? 3 : 2)) void gemm_resident_kernel(GemmArgsT<AT> p, int RB) {
+template <int NSTEP, int EPI, bool BMUL, bool GADD = false, typename AT = float, int PF = 3>
+// (waves per SIMD chosen so that NO variant needs scratch: see the note on scratch and concurrent streams in nmf_pcf.hip)
+__global__ __launch_bounds__(256, ((NSTEP <= 16 && EPI == EPI_PLAIN && !BMUL && !(PF & 2)) ? 3 : (NSTEP <= 16 ? 2 : 1))) void gemm_resident_kernel(GemmArgsT<AT> p, int RB) {
+  // PF: prologue code compiled in — bit 0 input activation, bit 1 LayerNorm.  A runtime branch alone keeps a second copy
+  // of the operand registers alive (normalised / activated next to raw): the K <= 32 form spilled because of it.
+  constexpr bool ACTIN = (PF & 1) != 0, LNP = (PF & 2) != 0;
   extern __shared__ __attribute__((aligned(16))) float lds_a[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, h = lane >> 5;
@@ -163,10 +167,11 @@ __global__ __launch_bounds__(256, ((NSTEP <= 16 && EPI != EPI_LNBWD) ? 3 : 2)) v
   const int m0 = blockIdx.y * 32 * RB;
 
   // batched fill (8 independent loads per thread before the LDS stores)
-  for (int base = threadIdx.x; base < (p.dbg == 3 ? 0 : nA * RB * 64); base += blockDim.x * 8) {
-    float tmp[8];
+  constexpr int kFill = (NSTEP <= 16 && EPI == EPI_PLAIN && !BMUL) ? 4 : 8;   // independent loads per thread and round
+  for (int base = threadIdx.x; base < (p.dbg == 3 ? 0 : nA * RB * 64); base += blockDim.x * kFill) {
+    float tmp[kFill];
 #pragma unroll
-    for (int uu = 0; uu < 8; ++uu) {
+    for (int uu = 0; uu < kFill; ++uu) {
       const int idx = base + uu * blockDim.x;
       const bool in = idx < nA * RB * 64;
       const int ii = in ? idx : 0;
@@ -178,16 +183,16 @@ __global__ __launch_bounds__(256, ((NSTEP <= 16 && EPI != EPI_LNBWD) ? 3 : 2)) v
       const bool ok = in && m < p.M && k < p.K;
       const int mc = m < p.M ? m : p.M - 1, kc = k < p.K ? k : p.K - 1;
       float wv = weight_at(p, mc, kc);
-      if (p.ln) wv *= p.ln_g[kc];
+      if (LNP && p.ln) wv *= p.ln_g[kc];
       tmp[uu] = ok ? wv : 0.f;
     }
 #pragma unroll
-    for (int uu = 0; uu < 8; ++uu) {
+    for (int uu = 0; uu < kFill; ++uu) {
       const int idx = base + uu * blockDim.x;
       if (idx < nA * RB * 64) As[idx] = tmp[uu];
     }
   }
-  if (p.ln) {
+  if (LNP && p.ln) {
     for (int r = threadIdx.x; r < 32 * RB; r += blockDim.x) {
       const int m = m0 + r;
       float t = 0.f;
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(256, ((NSTEP <= 16 && EPI != EPI_LNBWD) ? 3 : 2)) v
 #pragma unroll
   for (int s = 0; s < NSTEP; ++s) fetch_plain<4, BMUL>(p, b, 2 * s + h, col_off, col_ok, bv[s]);
 
-  if (p.ln) {
+  if (LNP && p.ln) {
     // exact two-pass statistics over the Cin channels (this lane holds the parity-h half)
     float mu[4], rs[4];
 #pragma unroll
@@ -239,12 +244,14 @@ __global__ __launch_bounds__(256, ((NSTEP <= 16 && EPI != EPI_LNBWD) ? 3 : 2)) v
       *reinterpret_cast<float4*>(so + p.Vin + col_off) = make_float4(rs[0], rs[1], rs[2], rs[3]);
     }
   }
-  if (p.bact == ACT_GELU) {
+  // (ACTIN = false: no input-activation code at all — the runtime branch alone kept a second copy of the 64 operand
+  // registers alive and spilled the K <= 32 form)
+  if (ACTIN && p.bact == ACT_GELU) {
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s)
 #pragma unroll
       for (int e = 0; e < 4; ++e) bv[s][e] = gelu_f(bv[s][e]);
-  } else if (p.bact == ACT_RELU) {
+  } else if (ACTIN && p.bact == ACT_RELU) {
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s)
 #pragma unroll
@@ -272,11 +279,14 @@ __global__ __launch_bounds__(256, ((NSTEP <= 16 && EPI != EPI_LNBWD) ? 3 : 2)) v
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[s][q], acc[q], 0, 0, 0);
       }
+      // (at most 4 weight operands requested ahead: all NSTEP of them in flight cost the registers that put the K <= 32
+      // form one over the 168 of three waves per SIMD — it spilled 3 of them to scratch)
+      if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
     if (EPI == EPI_LNBWD) {
       lnbwd_block<4, GADD>(p, acc, b, col_off, col_ok, lane, wave, tW + 32 * RB, blockIdx.x, tW);
     } else {
-      if (col_ok) store_block<4, (EPI == EPI_LNBWD ? EPI_PLAIN : EPI), false>(p, acc, b, m0 + rb * 32, col_off, h, p.ln ? tW + rb * 32 : nullptr);
+      if (col_ok) store_block<4, (EPI == EPI_LNBWD ? EPI_PLAIN : EPI), false>(p, acc, b, m0 + rb * 32, col_off, h, (LNP && p.ln) ? tW + rb * 32 : nullptr);
     }
   }
 }
@@ -309,7 +319,7 @@ struct ChainArgsT {
 // HB = 32-row blocks of the hidden tensor: 2 (mlp_ratio 2, the README model) or 4 (mlp_ratio 4, the
 // BraTS bundle, train.yaml:62)
 template <bool BWD, int NACC, int HB, typename AT = float>
-__global__ __launch_bounds__(256, (NACC == 2 && HB == 2) ? 3 : 2) void gemm_chain_kernel(GemmArgsT<AT> p, ChainArgsT<AT> c, int ntiles) {
+__global__ __launch_bounds__(256, (NACC == 2 && HB == 2 && !BWD) ? 3 : 2) void gemm_chain_kernel(GemmArgsT<AT> p, ChainArgsT<AT> c, int ntiles) {
   constexpr int HID = 32 * HB, N1 = 16 * HB * 64;  // hidden rows; floats of each staged weight block
   __shared__ float As1[N1];
   __shared__ float As2[N1];
@@ -1602,7 +1612,7 @@ enum { PRO_NONE = 0, PRO_LN = 1, PRO_GELU = 2, PRO_BMUL = 3 };
 // an occupancy sweep: the operand traffic of these launches runs at 4.1-5.1 TB/s even with the
 // MFMAs compiled out (round-1/2 probe `gemm_probe7`), the fp32 MFMA time comes largely on top of it.)
 template <int MB, int NACC, int LOADER, int EPI, int PRO, int KS = 1, typename AT = float>
-__global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgsT<AT> p) {
+__global__ __launch_bounds__(256, ((MB == 2 && NACC == 4 && PRO == 3 /* gate operand in the ring */) ? 1 : 2)) void gemm_stream_kernel(GemmArgsT<AT> p) {
   constexpr int TN = 32 * NACC;
   constexpr int NL = (LOADER == LOAD_S2D) ? 4 : NACC;  // floats fetched per load step
   // operand prefetch depth (load steps): narrow tiles are latency-bound (L2 round trip ≈ 500-900
@@ -2045,7 +2055,10 @@ static int gemm_launch(const fz_gemm_desc* d, fz_stream_t stream) {
     const bool one_pro = (d->ln != 0) + (d->bact != 0) + (d->bmul != nullptr) <= 1;
     if (bx_on && one_pro && d->bact != ACT_RELU && d->K >= 64 && d->M >= 32 && (d->loader == LOAD_PLAIN || d->loader == LOAD_S2D) &&
         (d->epilogue == EPI_PLAIN || d->epilogue == EPI_D2S) && !(d->loader == LOAD_S2D && pro_bx) && !(d->epilogue == EPI_D2S && pro_bx))
-      return gemm_bx_launch<AT>(a, d->loader, d->epilogue, pro_bx, stream);
+    {
+      const int rc = gemm_bx_launch<AT>(a, d->loader, d->epilogue, pro_bx, stream);
+      if (rc != FZ_E_UNSUPPORTED) return rc;   // shapes outside the family (K % 64, M % 32, alignment): the kernels below
+    }
   }
 
   // ---- Kernel A: whole operand in registers (K <= 64, plain loader) ----
@@ -2068,7 +2081,15 @@ static int gemm_launch(const fz_gemm_desc* d, fz_stream_t stream) {
     const size_t lds = (size_t)(nA * RB * 64 + 32 * RB + (d->epilogue == EPI_LNBWD ? 256 : 0)) * sizeof(float);
     const int64_t tiles = (d->Ncol + 511) / 512;
     dim3 grid((unsigned)(tiles * d->B), (unsigned)((mblocks + RB - 1) / RB)), block(256);
-#define FZ_RES(NS, E, BM) hipLaunchKernelGGL((gemm_resident_kernel<NS, E, BM>), grid, block, lds, st, a, RB)
+#define FZ_RES_PF(NS, E, BM, PFv) hipLaunchKernelGGL((gemm_resident_kernel<NS, E, BM, false, AT, PFv>), grid, block, lds, st, a, RB)
+#define FZ_RES(NS, E, BM)                                                  \
+  do {                                                                    \
+    const int pf = (d->bact ? 1 : 0) | (d->ln ? 2 : 0);                   \
+    if (pf == 0) FZ_RES_PF(NS, E, BM, 0);                                 \
+    else if (pf == 1) FZ_RES_PF(NS, E, BM, 1);                            \
+    else if (pf == 2) FZ_RES_PF(NS, E, BM, 2);                            \
+    else FZ_RES_PF(NS, E, BM, 3);                                         \
+  } while (0)
     if (d->epilogue == EPI_LNBWD) {
       if (d->bmul) return fail(FZ_E_UNSUPPORTED, "fz_gemm: bmul with LayerNorm-backward epilogue");
 #define FZ_RES_LNB(NS, GA) hipLaunchKernelGGL((gemm_resident_kernel<NS, EPI_LNBWD, false, GA>), grid, block, lds, st, a, RB)

@@ -55,6 +55,110 @@ __host__ __device__ constexpr int bx_terms_b(int pro) {
   return sizeof(AT) == 4 ? 3 : ((pro == BXPRO_LN || pro == BXPRO_GELU) ? 2 : 1);
 }
 
+// uniform base (SGPR pair) + per-lane byte offset (one VGPR): global_load ... v_off, s[base]
+template <int N, typename AT>
+__device__ __forceinline__ void uload(const AT* ubase, unsigned lane_bytes, float (&v)[N]) {
+  vload<N>(reinterpret_cast<const AT*>(reinterpret_cast<const char*>(ubase) + lane_bytes), v);
+}
+
+// Epilogue of both kernel forms.  Bias rows come from LDS (staged at kernel start), residual / gate operands are
+// requested for a batch of rows before the first is used, every address is `scalar base + 32-bit lane offset`, and there
+// is no branch per row (M % 32 == 0 is a host-side condition of the family).
+template <int MB, int NACC, int EPI, bool S2D, bool LN, typename AT>
+__device__ __forceinline__ void bx_epilogue(const GemmArgsT<AT>& p, f32x16 (&acc)[MB][NACC], int b, int m0, int64_t n0, int j, int h,
+                                            int64_t col_off, const float* sBias, const float* sW, const float* tW,
+                                            const float (&rstd)[NACC], const float (&mu_d)[NACC]) {
+  constexpr int ES = (int)sizeof(AT);
+  if constexpr (EPI == EPI_PLAIN) {
+    // y[b][m][ncol..]: lane part (4h·Ncol + ncol), uniform part (b·M + m0 + 32mb + rbase(r))·Ncol
+    const int64_t ncol = S2D ? n0 + 2 * j : col_off;   // (s2d: col_off addresses the FINE input grid)
+    const unsigned yoff = (unsigned)(((int64_t)4 * h * p.Ncol + ncol) * ES);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const int64_t urow = (int64_t)b * p.M + m0 + mb * 32;
+      // residual / gate operands of RBT rows at a time are requested before the first of them is used
+      constexpr int RBT = NACC == 4 ? 4 : (NACC == 2 ? 8 : 16);
+#pragma unroll
+      for (int r0 = 0; r0 < 16; r0 += RBT) {
+      float ev[RBT][NACC], rv[RBT][NACC];
+      if (p.emul != nullptr) {
+#pragma unroll
+        for (int rr = 0; rr < RBT; ++rr) uload<NACC>(p.emul + (urow + ((r0 + rr) & 3) + 8 * ((r0 + rr) >> 2)) * p.Ncol, yoff, ev[rr]);
+      }
+      if (p.res != nullptr) {
+#pragma unroll
+        for (int rr = 0; rr < RBT; ++rr) uload<NACC>(p.res + (urow + ((r0 + rr) & 3) + 8 * ((r0 + rr) >> 2)) * p.Ncol, yoff, rv[rr]);
+      }
+#pragma unroll
+      for (int rr = 0; rr < RBT; ++rr) {
+        const int r = r0 + rr;
+        const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
+        float add = sBias[mb * 32 + rl];
+        float v[NACC];
+        if (LN) {
+          const float sw = sW[mb * 32 + rl];
+          add += tW[mb * 32 + rl];
+#pragma unroll
+          for (int q = 0; q < NACC; ++q) v[q] = rstd[q] * (acc[mb][q][r] - mu_d[q] * sw) + add;
+        } else {
+#pragma unroll
+          for (int q = 0; q < NACC; ++q) v[q] = acc[mb][q][r] + add;
+        }
+        if (p.eact) {
+#pragma unroll
+          for (int q = 0; q < NACC; ++q) v[q] = act_f(p.eact, v[q]);
+        }
+        if (p.emul != nullptr) {
+#pragma unroll
+          for (int q = 0; q < NACC; ++q) v[q] *= act_grad_f(p.emul_kind, ev[rr][q]);
+        }
+        if (p.res != nullptr) {
+#pragma unroll
+          for (int q = 0; q < NACC; ++q) v[q] += rv[rr][q];
+        }
+        AT* yp = reinterpret_cast<AT*>(reinterpret_cast<char*>(p.y + (urow + (r & 3) + 8 * (r >> 2)) * p.Ncol) + yoff);
+        vstore<NACC>(yp, v);
+      }
+      }
+    }
+  } else {
+    // depth-to-space: rows (o, td, th, tw), td = h, th = (r >> 1) & 1, tw = r & 1, o_local = r >> 2; the NACC coarse
+    // voxels of a lane are neighbours along W (even Wo), so a lane owns 2·NACC consecutive fine voxels per (o, td, th)
+    const int Wf = 2 * p.Wo, Hf = 2 * p.Ho;
+    const int64_t Vf = 8 * p.Ncol;
+    const int Mo = p.M >> 3;
+    const int wo = (int)(col_off % p.Wo);
+    const int64_t t2 = col_off / p.Wo;
+    const int ho = (int)(t2 % p.Ho);
+    const int dz = (int)(t2 / p.Ho);
+    const unsigned foff = (unsigned)((((int64_t)(2 * dz + h) * Hf + 2 * ho) * Wf + 2 * wo) * ES);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const int64_t uo = (int64_t)b * Mo + ((m0 + mb * 32) >> 3);
+      float rv[8][2 * NACC];
+      if (p.res != nullptr) {
+#pragma unroll
+        for (int rp = 0; rp < 8; ++rp)
+          uload<2 * NACC>(p.res + (uo + (rp >> 1)) * Vf + (int64_t)(rp & 1) * Wf, foff, rv[rp]);
+      }
+#pragma unroll
+      for (int rp = 0; rp < 8; ++rp) {
+        const int r0 = 2 * rp;
+        const float bs = sBias[mb * 32 + 8 * (rp >> 1)];   // bias of o_local = rp >> 1 (first row of that o)
+        float v[2 * NACC];
+#pragma unroll
+        for (int q = 0; q < NACC; ++q) { v[2 * q] = acc[mb][q][r0] + bs; v[2 * q + 1] = acc[mb][q][r0 + 1] + bs; }
+        if (p.res != nullptr) {
+#pragma unroll
+          for (int i = 0; i < 2 * NACC; ++i) v[i] += rv[rp][i];
+        }
+        AT* yp = reinterpret_cast<AT*>(reinterpret_cast<char*>(p.y + (uo + (rp >> 1)) * Vf + (int64_t)(rp & 1) * Wf) + foff);
+        vstore<2 * NACC>(yp, v);
+      }
+    }
+  }
+}
+
 // K-split form (gemm_bxk.hip); nacc, mb: tile; returns FZ_OK or an error
 template <typename AT>
 int gemm_bxk_launch(const GemmArgsT<AT>& a, int loader, int epilogue, int pro, int nacc, int mb, fz_stream_t stream);

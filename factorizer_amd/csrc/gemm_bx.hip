@@ -28,26 +28,37 @@
 namespace fz {
 
 // =================================================================================================
-// MB row blocks of 32 x (4 waves x 32·NACC columns) per workgroup; RD K16-groups of operand loads in flight per lane.
+// Streaming form (stage 1 and the wide k2s2 convolutions: > 64 K voxels): MB row blocks of 32 x (4 waves x 32·NACC
+// columns) per workgroup; each wave owns a column tile and streams its column operand through a register ring of RD
+// K16-groups; the weights of the workgroup's rows are split once per 64-index chunk into LDS (double-buffered: the next
+// chunk travels global -> registers under the products of the current one).  Same rules as the K-split form
+// (gemm_bxk.hip): no branch between a load and its use (shapes restricted on the host), scalar base + 32-bit lane
+// offset addressing, bias rows in LDS, batched epilogue operands.  LayerNorm prologue: the row sums s[m] = Σ_k W[m][k]γ[k],
+// t[m] = Σ_k W[m][k]β[k] fall out of the weight staging (every thread stages the SAME row in every chunk).
 // =================================================================================================
-template <int MB, int NACC, int LOADER, int EPI, int PRO, int RD, typename AT>
+template <int MB, int NACC, int LOADER, int EPI, int PRO, int RD, bool WT, typename AT>
 __global__ __launch_bounds__(256, 2) void gemm_bx_kernel(GemmArgsT<AT> p) {
   constexpr int NTA = BxTerms<AT>::A, NTB = bx_terms_b<AT>(PRO);
   constexpr int TN = 32 * NACC;
   constexpr bool S2D = LOADER == LOAD_S2D;
   static_assert(!S2D || NACC == 2, "space-to-depth loader: two coarse voxels per lane");
-  constexpr int NL = S2D ? 4 : NACC;          // elements per load
-  constexpr int SPG = S2D ? 4 : 8;            // loads (ring slots) per K16-group
-  constexpr int NR = (PRO == BXPRO_BMUL) ? 2 * NL : NL;
-  constexpr int CH = 4;                       // K16-steps per weight chunk (64 reduction indices)
-  constexpr int kItemHalfs = 8;               // one operand item = 8 bf16 = 16 B per lane
+  constexpr int NL = S2D ? 4 : NACC;
+  constexpr int SPG = S2D ? 4 : 8;
+  constexpr int ES = (int)sizeof(AT);
+  constexpr bool LN = PRO == BXPRO_LN, GATE = PRO == BXPRO_BMUL;
+  constexpr int CH = 4;                        // K16-groups per weight chunk
+  static_assert(CH % RD == 0, "ring slots must be static inside a chunk");
+  constexpr int kItemHalfs = 8;                // one operand item = 8 bf16 = 16 B per lane
   constexpr int kBufItems = CH * MB * NTA * 64;
-  constexpr int IPT = CH * MB * 64 / 256;     // weight items (8 consecutive k of one row) per thread and chunk
+  constexpr int IPT = CH * MB * 64 / 256;      // weight items (8 consecutive k of one row) per thread and chunk
   __shared__ __attribute__((aligned(16))) __bf16 As[2 * kBufItems * kItemHalfs];
   __shared__ float sW[32 * MB];
   __shared__ float tW[32 * MB];
+  __shared__ float sBias[32 * MB];
+  __shared__ float sRed[LN ? 2 * 256 : 1];
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 31, h = lane >> 5;
   const int tiles_per_sample = (int)((p.Ncol + TN * 4 - 1) / (TN * 4));
   int bx = blockIdx.x, by = blockIdx.y;
@@ -60,9 +71,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bx_kernel(GemmArgsT<AT> p) {
   const int b = bx / tiles_per_sample;
   const int64_t n0 = ((int64_t)(bx % tiles_per_sample) * 4 + wave) * TN;
   const int m0 = by * 32 * MB;
-  const int nG = (p.K + 15) / 16;  // K16-groups
+  const int nG = p.K >> 4;   // K % 64 == 0
 
-  // ---- per-lane input addressing ----
+  if (threadIdx.x < 32 * MB) {
+    const int m = m0 + threadIdx.x;
+    float bv = 0.f;
+    if (p.bias != nullptr) bv = (EPI == EPI_D2S) ? p.bias[m >> 3] : p.bias[m];
+    sBias[threadIdx.x] = bv;
+  }
+
+  // ---- per-lane byte offsets ----
   int64_t col_off;
   bool col_ok;
   if (S2D) {
@@ -79,94 +97,110 @@ __global__ __launch_bounds__(256, 2) void gemm_bx_kernel(GemmArgsT<AT> p) {
     col_ok = col_off < p.Ncol;
   }
   const int64_t coff = col_ok ? col_off : 0;
+  const unsigned boff = (unsigned)(((int64_t)(S2D ? h : 8 * h) * p.Vin + coff) * ES);
 
-  // slot s (global load index): plain: group s/8, channel 16g + 8h + s%8 ; s2d: group s/4, channel 2g + h, rows (td, th) = s%4
-  auto fetch = [&](int s, float (&v)[NR]) {
+  // weight staging: thread -> items idx = tid + 256u: lane l = tid & 63 and row block mb = (tid >> 6) % MB are the same
+  // for every u and every chunk; the K16-group inside the chunk is gl = (tid >> 6) / MB + (4 / MB)·u
+  const int wl = threadIdx.x & 63;
+  const int wmb = (threadIdx.x >> 6) % MB;
+  const int wgl0 = (threadIdx.x >> 6) / MB;
+  const int wrow = m0 + wmb * 32 + (wl & 31);
+  const unsigned woff = WT ? (unsigned)(((int64_t)8 * (wl >> 5) * p.ldw + wrow) * 4)
+                           : (unsigned)(((int64_t)wrow * p.ldw + 8 * (wl >> 5)) * 4);
+  const unsigned goff = (unsigned)(32 * (wl >> 5));
+
+  struct Slot { float bv[SPG][GATE ? 2 * NL : NL]; };
+  auto fetch = [&](int g, Slot& sl) {
+    g = g < nG ? g : nG - 1;   // past the end: harmless re-read of the last group (never consumed)
     if constexpr (!S2D) {
-      const int c = 16 * (s >> 3) + 8 * h + (s & 7);
-      const int cc = c < p.Cin ? c : p.Cin - 1;
-      const bool first = cc < p.c0;
-      const AT* base = first ? p.x[0] : p.x[1];
+      const int c16 = 16 * g;
+      const bool first = c16 < p.c0;
+      const AT* src = first ? p.x[0] : p.x[1];
       const int cs = first ? p.c0 : p.Cin - p.c0;
-      const int ci = first ? cc : cc - p.c0;
-      float a[NL];
-      vload<NL>(base + ((int64_t)b * cs + ci) * p.Vin + coff, a);
+      const int ci = first ? c16 : c16 - p.c0;
+      const AT* ub = src + ((int64_t)b * cs + ci) * p.Vin;
+      const AT* ug = GATE ? p.bmul + ((int64_t)b * p.Cin + c16) * p.Vin : nullptr;
 #pragma unroll
-      for (int i = 0; i < NL; ++i) v[i] = a[i];
-      if constexpr (PRO == BXPRO_BMUL) {
-        float e[NL];
-        vload<NL>(p.bmul + ((int64_t)b * p.Cin + cc) * p.Vin + coff, e);
+      for (int e = 0; e < 8; ++e) {
+        float a[NL];
+        uload<NL>(ub + (int64_t)e * p.Vin, boff, a);
 #pragma unroll
-        for (int i = 0; i < NL; ++i) v[NL + i] = e[i];
+        for (int i = 0; i < NL; ++i) sl.bv[e][i] = a[i];
+        if constexpr (GATE) {
+          float t[NL];
+          uload<NL>(ug + (int64_t)e * p.Vin, boff, t);
+#pragma unroll
+          for (int i = 0; i < NL; ++i) sl.bv[e][NL + i] = t[i];
+        }
       }
     } else {
-      const int c = 2 * (s >> 2) + h;
-      const int cc = c < p.Cin ? c : p.Cin - 1;
-      const int64_t off = coff + (int64_t)((s >> 1) & 1) * p.Hi * p.Wi + (int64_t)(s & 1) * p.Wi;
-      float a[NL];
-      vload<NL>(p.x[0] + ((int64_t)b * p.Cin + cc) * p.Vin + off, a);
+      const AT* ub = p.x[0] + ((int64_t)b * p.Cin + 2 * g) * p.Vin;
 #pragma unroll
-      for (int i = 0; i < NL; ++i) v[i] = a[i];
+      for (int e = 0; e < 4; ++e) {
+        float a[NL];
+        uload<NL>(ub + (int64_t)(e >> 1) * p.Hi * p.Wi + (int64_t)(e & 1) * p.Wi, boff, a);
+#pragma unroll
+        for (int i = 0; i < NL; ++i) sl.bv[e][i] = a[i];
+      }
     }
   };
 
-  const int nslots = nG * SPG;
-  float ring[RD * SPG][NR];
+  Slot ring[RD];
 #pragma unroll
-  for (int i = 0; i < RD * SPG; ++i) fetch(i < nslots ? i : nslots - 1, ring[i]);
+  for (int i = 0; i < RD; ++i) fetch(i, ring[i]);
 
-  if (PRO == BXPRO_LN) {
-    // s[m] = Σ_k W[m][k]·γ[k], t[m] = Σ_k W[m][k]·β[k]  (8 threads per row)
-    for (int r0 = 0; r0 < 32 * MB; r0 += 32) {
-      const int r = r0 + (threadIdx.x >> 3), part = threadIdx.x & 7;
-      const int m = m0 + r;
-      float s = 0.f, t = 0.f;
-      if (m < p.M)
-        for (int k = part; k < p.K; k += 8) {
-          const float wv = weight_at(p, m, k);
-          s += wv * p.ln_g[k];
-          t += wv * p.ln_b[k];
-        }
-      s += __shfl_xor(s, 1, 64); t += __shfl_xor(t, 1, 64);
-      s += __shfl_xor(s, 2, 64); t += __shfl_xor(t, 2, 64);
-      s += __shfl_xor(s, 4, 64); t += __shfl_xor(t, 4, 64);
-      if (part == 0) { sW[r] = s; tW[r] = t; }
-    }
+  float shift[NACC];
+#pragma unroll
+  for (int e = 0; e < NACC; ++e) shift[e] = 0.f;
+  if (LN) {
+    // pivot = channel-0 value of the lane's voxels (both lane halves need it): well-conditioned single-pass variance
+    float pv[NL];
+    vload<NL>(p.x[0] + ((int64_t)b * p.c0) * p.Vin + coff, pv);
+#pragma unroll
+    for (int e = 0; e < NACC; ++e) shift[e] = pv[e % NL];
   }
 
-  // ---- weights: chunk [g0, g0 + CH) of K16-groups -> registers (raw fp32) -> split -> LDS in operand order ----
+  // ---- weights: chunk of CH groups -> registers (raw fp32, times gamma under LayerNorm) -> split -> LDS ----
   float wraw[IPT][8];
+  float sWp = 0.f, tWp = 0.f;
   auto load_chunk = [&](int g0) {
 #pragma unroll
     for (int u = 0; u < IPT; ++u) {
-      const int idx = threadIdx.x + u * 256;           // (gl, mb, lane)
-      const int l = idx & 63;
-      const int mb = (idx >> 6) % MB;
-      const int g = g0 + idx / (64 * MB);
-      const int m = m0 + mb * 32 + (l & 31);
-      const int k0 = 16 * g + 8 * (l >> 5);
-      const int mc = m < p.M ? m : p.M - 1;
+      int g = g0 + wgl0 + (4 / MB) * u;
+      g = g < nG ? g : nG - 1;
+      if constexpr (!WT) {
+        uload<8>(p.w + 16 * g, woff, wraw[u]);
+      } else {
+        const float* uw = p.w + (int64_t)16 * g * p.ldw;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int k = k0 + e;
-        const int kc = k < p.K ? k : p.K - 1;
-        float wv = weight_at(p, mc, kc);
-        if (PRO == BXPRO_LN) wv *= p.ln_g[kc];
-        wraw[u][e] = (m < p.M && k < p.K) ? wv : 0.f;
+        for (int e = 0; e < 8; ++e) {
+          float t[1];
+          uload<1>(uw + (int64_t)e * p.ldw, woff, t);
+          wraw[u][e] = t[0];
+        }
+      }
+      if constexpr (LN) {
+        float gm[8], bt[8];
+        uload<8>(p.ln_g + 16 * g, goff, gm);
+        uload<8>(p.ln_b + 16 * g, goff, bt);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          tWp += wraw[u][e] * bt[e];
+          wraw[u][e] *= gm[e];
+          sWp += wraw[u][e];
+        }
       }
     }
   };
   auto store_chunk = [&](int buf) {
 #pragma unroll
     for (int u = 0; u < IPT; ++u) {
-      const int idx = threadIdx.x + u * 256;
-      const int l = idx & 63;
-      const int gm = idx >> 6;                          // gl * MB + mb
+      const int gm = (threadIdx.x >> 6) + 4 * u;   // gl * MB + mb
       bx8 t[NTA];
       bx_split<NTA>(wraw[u], t);
 #pragma unroll
       for (int i = 0; i < NTA; ++i)
-        *reinterpret_cast<bx8*>(&As[((buf * CH * MB + gm) * NTA + i) * 64 * kItemHalfs + l * kItemHalfs]) = t[i];
+        *reinterpret_cast<bx8*>(&As[((buf * CH * MB + gm) * NTA + i) * 64 * kItemHalfs + wl * kItemHalfs]) = t[i];
     }
   };
 
@@ -177,77 +211,55 @@ __global__ __launch_bounds__(256, 2) void gemm_bx_kernel(GemmArgsT<AT> p) {
     for (int q = 0; q < NACC; ++q)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mb][q][r] = 0.f;
-
-  float s1[NACC], s2[NACC], shift[NACC];
+  float s1[NACC], s2[NACC];
 #pragma unroll
-  for (int e = 0; e < NACC; ++e) s1[e] = s2[e] = shift[e] = 0.f;
-  if (PRO == BXPRO_LN) {
-    // pivot = channel-0 value (lane half 0, slot 0): well-conditioned single-pass variance
-#pragma unroll
-    for (int e = 0; e < NACC; ++e) shift[e] = __shfl(ring[0][e % NL], j, 64);
-  }
+  for (int e = 0; e < NACC; ++e) s1[e] = s2[e] = 0.f;
 
   load_chunk(0);
   store_chunk(0);
-  __syncthreads();  // sW / tW and chunk 0
+  __syncthreads();
   int cbuf = 0;
   for (int g0 = 0; g0 < nG; g0 += CH) {
     const bool more = g0 + CH < nG;
-    if (more) load_chunk(g0 + CH);  // in flight during the MFMAs below
+    if (more) load_chunk(g0 + CH);   // in flight during the products below
     const __bf16* Ab = As + cbuf * kBufItems * kItemHalfs;
-    // RD groups per unrolled body so that ring indices are static
-    for (int gl = 0; gl < CH; gl += RD) {
 #pragma unroll
-      for (int rd = 0; rd < RD; ++rd) {
-        const int g = g0 + gl + rd;
-        if (RD > 1 && CH % RD != 0 && gl + rd >= CH) break;
-        // ---- column operands of this group: prologue + split, column group by column group ----
-        bx8 bop[NACC][NTB];
+    for (int gl = 0; gl < CH; ++gl) {
+      Slot& sl = ring[gl % RD];
+      // ---- column operands: prologue + split ----
+      bx8 bop[NACC][NTB];
 #pragma unroll
-        for (int q = 0; q < NACC; ++q) {
-          float x[8];
+      for (int q = 0; q < NACC; ++q) {
+        float x[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float t;
-            if constexpr (S2D) {
-              // k = c*8 + td*4 + th*2 + tw: slot (td, th) = e >> 1, component 2q + tw
-              t = ring[rd * SPG + (e >> 1)][2 * q + (e & 1)];
-              const bool cok = col_ok && (2 * g + h) < p.Cin;
-              t = cok ? t : 0.f;
-            } else {
-              t = ring[rd * SPG + e][q % NL];
-              const bool cok = col_ok && (16 * g + 8 * h + e) < p.Cin;
-              if (PRO == BXPRO_BMUL) t = ring[rd * SPG + e][(NL + q) % NR] > 0.f ? t : 0.f;
-              if (PRO == BXPRO_LN) {
-                t = cok ? t - shift[q] : 0.f;
-                s1[q] += t;
-                s2[q] += t * t;
-              } else {
-                t = cok ? t : 0.f;
-              }
-              if (PRO == BXPRO_GELU) t = gelu_f(t);
+        for (int e = 0; e < 8; ++e) {
+          float t;
+          if constexpr (S2D) {
+            t = sl.bv[e >> 1][2 * q + (e & 1)];     // k = c·8 + td·4 + th·2 + tw
+          } else {
+            t = sl.bv[e][q];
+            if (GATE) t = sl.bv[e][NL + q] > 0.f ? t : 0.f;
+            if (LN) {
+              t -= shift[q];
+              s1[q] += t;
+              s2[q] += t * t;
             }
-            x[e] = t;
+            if (PRO == BXPRO_GELU) t = gelu_f(t);
           }
-          bx_split<NTB>(x, bop[q]);
+          x[e] = t;
         }
-        // ---- refill the slots just consumed (group g + RD) ----
+        bx_split<NTB>(x, bop[q]);
+      }
+      fetch(g0 + gl + RD, sl);   // refill the slot just consumed
+      // ---- products ----
 #pragma unroll
-        for (int e = 0; e < SPG; ++e) {
-          const int sn = (g + RD) * SPG + e;
-          fetch(sn < nslots ? sn : nslots - 1, ring[rd * SPG + e]);
-        }
-        // ---- MFMAs ----
-        const int al = gl + rd;
+      for (int mb = 0; mb < MB; ++mb) {
+        bx8 aop[NTA];
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-          bx8 aop[NTA];
+        for (int i = 0; i < NTA; ++i)
+          aop[i] = *reinterpret_cast<const bx8*>(&Ab[((gl * MB + mb) * NTA + i) * 64 * kItemHalfs + lane * kItemHalfs]);
 #pragma unroll
-          for (int i = 0; i < NTA; ++i)
-            aop[i] = *reinterpret_cast<const bx8*>(&Ab[((al * MB + mb) * NTA + i) * 64 * kItemHalfs + lane * kItemHalfs]);
-#pragma unroll
-          for (int q = 0; q < NACC; ++q) bx_mfma<NTA, NTB>(acc[mb][q], aop, bop[q]);
-        }
+        for (int q = 0; q < NACC; ++q) bx_mfma<NTA, NTB>(acc[mb][q], aop, bop[q]);
       }
     }
     if (more) {
@@ -258,7 +270,21 @@ __global__ __launch_bounds__(256, 2) void gemm_bx_kernel(GemmArgsT<AT> p) {
   }
 
   float mu_d[NACC], rstd[NACC];
-  if (PRO == BXPRO_LN) {
+#pragma unroll
+  for (int e = 0; e < NACC; ++e) { mu_d[e] = 0.f; rstd[e] = 1.f; }
+  if (LN) {
+    // row sums: the threads that staged row (mb, i) are tid = 64·w + 32·hh + i with w % MB == mb
+    sRed[threadIdx.x] = sWp;
+    sRed[256 + threadIdx.x] = tWp;
+    __syncthreads();
+    if (threadIdx.x < 32 * MB) {
+      const int mb = threadIdx.x >> 5, i = threadIdx.x & 31;
+      float a = 0.f, c = 0.f;
+      for (int w = mb; w < 4; w += MB)
+        for (int hh = 0; hh < 2; ++hh) { a += sRed[64 * w + 32 * hh + i]; c += sRed[256 + 64 * w + 32 * hh + i]; }
+      sW[threadIdx.x] = a;
+      tW[threadIdx.x] = c;
+    }
 #pragma unroll
     for (int e = 0; e < NACC; ++e) {
       const float t1 = s1[e] + __shfl_xor(s1[e], 32, 64);
@@ -278,22 +304,27 @@ __global__ __launch_bounds__(256, 2) void gemm_bx_kernel(GemmArgsT<AT> p) {
       vstore<NACC>(so + col_off, mean);
       vstore<NACC>(so + p.Vin + col_off, rstd);
     }
+    __syncthreads();
   }
   if (!col_ok) return;
-  const int64_t ncol = S2D ? n0 + 2 * j : col_off;
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb) {
-    if (PRO == BXPRO_LN) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const float sw = sW[mb * 32 + rl];
-#pragma unroll
-        for (int q = 0; q < NACC; ++q) acc[mb][q][r] = rstd[q] * (acc[mb][q][r] - mu_d[q] * sw);
-      }
-    }
-    store_block<NACC, EPI, S2D>(p, acc[mb], b, m0 + mb * 32, ncol, h, PRO == BXPRO_LN ? tW + mb * 32 : nullptr);
-  }
+  bx_epilogue<MB, NACC, EPI, S2D, LN, AT>(p, acc, b, m0, n0, j, h, col_off, sBias, sW, tW, rstd, mu_d);
+}
+
+// shapes the family takes (everything else stays with the fp32-MFMA kernels of gemm.hip)
+template <typename AT>
+bool gemm_bx_ok(const GemmArgsT<AT>& a, int loader, int epilogue, int pro, int nacc) {
+  if (a.K % 64 != 0 || a.M % 32 != 0) return false;
+  if (loader == LOAD_PLAIN && (a.c0 % 16 != 0 || a.Cin != a.K)) return false;
+  if (loader == LOAD_S2D && (8 * a.Cin != a.K || pro != BXPRO_NONE || epilogue != EPI_PLAIN || (a.Wo & 1))) return false;
+  if (epilogue == EPI_D2S && (pro != BXPRO_NONE || (nacc >= 2 && (a.Wo % nacc) != 0))) return false;
+  if (a.Ncol % nacc != 0 || a.Vin % nacc != 0) return false;
+  if (!a.w_t && ((a.ldw & 3) != 0 || (reinterpret_cast<uintptr_t>(a.w) & 15) != 0)) return false;   // 32-byte weight reads
+  if (pro == BXPRO_LN && ((reinterpret_cast<uintptr_t>(a.ln_g) & 15) != 0 || (reinterpret_cast<uintptr_t>(a.ln_b) & 15) != 0)) return false;
+  const int64_t es = (int64_t)sizeof(AT);
+  if ((8 * a.Vin + a.Vin) * es >= ((int64_t)1 << 31)) return false;                 // 32-bit lane offsets
+  if (((int64_t)a.M * a.ldw + 8 * a.ldw) * 4 >= ((int64_t)1 << 31)) return false;
+  if ((4 * a.Ncol + a.Ncol) * es * 8 >= ((int64_t)1 << 31)) return false;
+  return true;
 }
 
 // Host side: tile selection and launch.  Returns FZ_E_UNSUPPORTED (without setting an error) when the descriptor is
@@ -321,41 +352,50 @@ int gemm_bx_launch(const GemmArgsT<AT>& a0, int loader, int epilogue, int pro, f
   if (loader == LOAD_S2D) {
     nacc = 2;
     mb = mblocks >= 2 ? 2 : 1;
-    auto wgs = [&](int mbb) { return ((a.Ncol + 255) / 256) * a.B * ((mblocks + mbb - 1) / mbb); };
-    if (mb == 2 && wgs(2) < 256) mb = 1;
   } else {
     // widest tile that still gives every CU about two workgroups
     nacc = 4; mb = mblocks >= 2 ? 2 : 1;
     auto wgs = [&](int na, int mbb) { return ((a.Ncol + 128 * na - 1) / (128 * na)) * a.B * ((mblocks + mbb - 1) / mbb); };
     if (wgs(nacc, mb) < 512) nacc = 2;
     if (wgs(nacc, mb) < 512 && mb == 2) mb = 1;
-    if (wgs(nacc, mb) < 256) nacc = 1;
     const char* e = getenv("FZ_BX_CFG");  // diagnostics: "<nacc><mb>"
     if (e && e[0] && e[1]) { nacc = e[0] - '0'; mb = e[1] - '0'; if (mb > mblocks) mb = 1; }
-    if (epilogue == EPI_D2S && nacc == 1) nacc = 2;
+    if (nacc != 2 && nacc != 4) nacc = 2;
+    // the LayerNorm prologue (row sums, statistics) and the gated operand (second ring) do not fit beside 128-voxel wave
+    // tiles without spilling: 64-voxel tiles
+    if (pro == BXPRO_LN || pro == BXPRO_BMUL) nacc = 2;
   }
+  if (mblocks % mb != 0) mb = 1;
+  if (!gemm_bx_ok(a, loader, epilogue, pro, nacc)) return FZ_E_UNSUPPORTED;
   const int TN = 32 * nacc;
   const int64_t tiles = (a.Ncol + TN * 4 - 1) / (TN * 4);
-  const int ygr = (mblocks + mb - 1) / mb;
+  const int ygr = mblocks / mb;
   a.ygroups = (ygr > 1 && ygr <= 8 && tiles * a.B >= 64) ? ygr : 0;
   a.xtiles = (int)(tiles * a.B);
   dim3 grid((unsigned)(tiles * a.B), (unsigned)ygr), block(256);
   if (a.ygroups > 1) grid = dim3((unsigned)(((tiles * a.B + 7) / 8) * 8 * ygr), 1);
-#define FZ_BX(MBv, NAv, L, E, PR, RDv) hipLaunchKernelGGL((gemm_bx_kernel<MBv, NAv, L, E, PR, RDv, AT>), grid, block, 0, st, a)
-#define FZ_BX_TILES(L, E, PR)                                                   \
-  do {                                                                          \
-    if (nacc == 4) { if (mb == 2) FZ_BX(2, 4, L, E, PR, 1); else FZ_BX(1, 4, L, E, PR, 1); } \
-    else if (nacc == 2) { if (mb == 2) FZ_BX(2, 2, L, E, PR, 2); else FZ_BX(1, 2, L, E, PR, 2); } \
-    else { if (mb == 2) FZ_BX(2, 1, L, E, PR, 2); else FZ_BX(1, 1, L, E, PR, 2); } \
+  const bool wt = a.w_t != 0;
+#define FZ_BX(MBv, NAv, L, E, PR, RDv)                                                                           \
+  do {                                                                                                           \
+    if (wt) hipLaunchKernelGGL((gemm_bx_kernel<MBv, NAv, L, E, PR, RDv, true, AT>), grid, block, 0, st, a);      \
+    else hipLaunchKernelGGL((gemm_bx_kernel<MBv, NAv, L, E, PR, RDv, false, AT>), grid, block, 0, st, a);        \
+  } while (0)
+// ring depth by tile: RD slots of 8·NACC registers (x2 with the gate operand) beside MB·NACC·16 accumulators
+#define FZ_BX_TILES(L, E, PR)                                                                                    \
+  do {                                                                                                           \
+    if (nacc == 4) { if (mb == 2) FZ_BX(2, 4, L, E, PR, 1); else FZ_BX(1, 4, L, E, PR, 2); }                      \
+    else { if (mb == 2) FZ_BX(2, 2, L, E, PR, 4); else FZ_BX(1, 2, L, E, PR, 4); }                                \
+  } while (0)
+#define FZ_BX_TILES2(L, E, PR, RD2)                                                                              \
+  do {                                                                                                           \
+    if (mb == 2) FZ_BX(2, 2, L, E, PR, RD2); else FZ_BX(1, 2, L, E, PR, 4);                                       \
   } while (0)
   if (loader == LOAD_S2D) {
     if (mb == 2) FZ_BX(2, 2, LOAD_S2D, EPI_PLAIN, BXPRO_NONE, 4); else FZ_BX(1, 2, LOAD_S2D, EPI_PLAIN, BXPRO_NONE, 4);
-  } else if (epilogue == EPI_D2S) {
-    if (nacc == 4) { if (mb == 2) FZ_BX(2, 4, LOAD_PLAIN, EPI_D2S, BXPRO_NONE, 1); else FZ_BX(1, 4, LOAD_PLAIN, EPI_D2S, BXPRO_NONE, 1); }
-    else { if (mb == 2) FZ_BX(2, 2, LOAD_PLAIN, EPI_D2S, BXPRO_NONE, 2); else FZ_BX(1, 2, LOAD_PLAIN, EPI_D2S, BXPRO_NONE, 2); }
-  } else if (pro == BXPRO_LN) FZ_BX_TILES(LOAD_PLAIN, EPI_PLAIN, BXPRO_LN);
+  } else if (epilogue == EPI_D2S) FZ_BX_TILES(LOAD_PLAIN, EPI_D2S, BXPRO_NONE);
+  else if (pro == BXPRO_LN) FZ_BX_TILES2(LOAD_PLAIN, EPI_PLAIN, BXPRO_LN, 4);
   else if (pro == BXPRO_GELU) FZ_BX_TILES(LOAD_PLAIN, EPI_PLAIN, BXPRO_GELU);
-  else if (pro == BXPRO_BMUL) FZ_BX_TILES(LOAD_PLAIN, EPI_PLAIN, BXPRO_BMUL);
+  else if (pro == BXPRO_BMUL) FZ_BX_TILES2(LOAD_PLAIN, EPI_PLAIN, BXPRO_BMUL, 2);
   else FZ_BX_TILES(LOAD_PLAIN, EPI_PLAIN, BXPRO_NONE);
   FZ_LAUNCH_CHECK();
   return FZ_OK;

@@ -18,12 +18,6 @@
 
 namespace fz {
 
-template <int N, typename AT>
-__device__ __forceinline__ void uload(const AT* ubase, unsigned lane_bytes, float (&v)[N]) {
-  // uniform base (SGPR pair) + per-lane byte offset (one VGPR): global_load ... v_off, s[base]
-  vload<N>(reinterpret_cast<const AT*>(reinterpret_cast<const char*>(ubase) + lane_bytes), v);
-}
-
 template <int MB, int NACC, int LOADER, int EPI, int PRO, int RD, bool WT, typename AT>
 __global__ __launch_bounds__(256, 2) void gemm_bxk_kernel(GemmArgsT<AT> p) {
   constexpr int NTA = BxTerms<AT>::A, NTB = bx_terms_b<AT>(PRO);
@@ -326,88 +320,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bxk_kernel(GemmArgsT<AT> p) {
   }
   if (!col_ok) return;
 
-  if constexpr (EPI == EPI_PLAIN) {
-    // y[b][m][ncol..]: lane part (4h·Ncol + ncol), uniform part (b·M + m0 + 32mb + rbase(r))·Ncol
-    const int64_t ncol = S2D ? n0 + 2 * j : col_off;   // (s2d: col_off addresses the FINE input grid)
-    const unsigned yoff = (unsigned)(((int64_t)4 * h * p.Ncol + ncol) * ES);
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-      const int64_t urow = (int64_t)b * p.M + m0 + mb * 32;
-      float ev[16][NACC], rv[16][NACC];
-      if (p.emul != nullptr) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) uload<NACC>(p.emul + (urow + (r & 3) + 8 * (r >> 2)) * p.Ncol, yoff, ev[r]);
-      }
-      if (p.res != nullptr) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) uload<NACC>(p.res + (urow + (r & 3) + 8 * (r >> 2)) * p.Ncol, yoff, rv[r]);
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
-        float add = sBias[mb * 32 + rl];
-        float v[NACC];
-        if (LN) {
-          const float sw = sW[mb * 32 + rl];
-          add += tW[mb * 32 + rl];
-#pragma unroll
-          for (int q = 0; q < NACC; ++q) v[q] = rstd[q] * (acc[mb][q][r] - mu_d[q] * sw) + add;
-        } else {
-#pragma unroll
-          for (int q = 0; q < NACC; ++q) v[q] = acc[mb][q][r] + add;
-        }
-        if (p.eact) {
-#pragma unroll
-          for (int q = 0; q < NACC; ++q) v[q] = act_f(p.eact, v[q]);
-        }
-        if (p.emul != nullptr) {
-#pragma unroll
-          for (int q = 0; q < NACC; ++q) v[q] *= act_grad_f(p.emul_kind, ev[r][q]);
-        }
-        if (p.res != nullptr) {
-#pragma unroll
-          for (int q = 0; q < NACC; ++q) v[q] += rv[r][q];
-        }
-        AT* yp = reinterpret_cast<AT*>(reinterpret_cast<char*>(p.y + (urow + (r & 3) + 8 * (r >> 2)) * p.Ncol) + yoff);
-        vstore<NACC>(yp, v);
-      }
-    }
-  } else {
-    // depth-to-space: rows (o, td, th, tw), td = h, th = (r >> 1) & 1, tw = r & 1, o_local = r >> 2; the NACC coarse
-    // voxels of a lane are neighbours along W (even Wo), so a lane owns 2·NACC consecutive fine voxels per (o, td, th)
-    const int Wf = 2 * p.Wo, Hf = 2 * p.Ho;
-    const int64_t Vf = 8 * p.Ncol;
-    const int Mo = p.M >> 3;
-    const int wo = (int)(col_off % p.Wo);
-    const int64_t t2 = col_off / p.Wo;
-    const int ho = (int)(t2 % p.Ho);
-    const int dz = (int)(t2 / p.Ho);
-    const unsigned foff = (unsigned)((((int64_t)(2 * dz + h) * Hf + 2 * ho) * Wf + 2 * wo) * ES);
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-      const int64_t uo = (int64_t)b * Mo + ((m0 + mb * 32) >> 3);
-      float rv[8][2 * NACC];
-      if (p.res != nullptr) {
-#pragma unroll
-        for (int rp = 0; rp < 8; ++rp)
-          uload<2 * NACC>(p.res + (uo + (rp >> 1)) * Vf + (int64_t)(rp & 1) * Wf, foff, rv[rp]);
-      }
-#pragma unroll
-      for (int rp = 0; rp < 8; ++rp) {
-        const int r0 = 2 * rp;
-        const float bs = sBias[mb * 32 + 8 * (rp >> 1)];   // bias of o_local = rp >> 1 (first row of that o)
-        float v[2 * NACC];
-#pragma unroll
-        for (int q = 0; q < NACC; ++q) { v[2 * q] = acc[mb][q][r0] + bs; v[2 * q + 1] = acc[mb][q][r0 + 1] + bs; }
-        if (p.res != nullptr) {
-#pragma unroll
-          for (int i = 0; i < 2 * NACC; ++i) v[i] += rv[rp][i];
-        }
-        AT* yp = reinterpret_cast<AT*>(reinterpret_cast<char*>(p.y + (uo + (rp >> 1)) * Vf + (int64_t)(rp & 1) * Wf) + foff);
-        vstore<2 * NACC>(yp, v);
-      }
-    }
-  }
+  bx_epilogue<MB, NACC, EPI, S2D, LN, AT>(p, acc, b, m0, n0, j, h, col_off, sBias, sW, tW, rstd, mu_d);
 }
 
 // shapes this form takes (everything else stays with the streaming kernels)

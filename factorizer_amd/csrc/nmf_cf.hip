@@ -264,7 +264,8 @@ __device__ __forceinline__ void cf_to_owner(float* S, const int (&lidx)[2], int 
 template <int R, int SOLVER, int WPB, bool HALF, typename AT>
 // (second launch-bounds argument = minimum WAVES PER SIMD in HIP, not workgroups per CU: 8 capped the one-patch variant
 // at 64 VGPRs — 170 spilled registers)
-__global__ __launch_bounds__(WPB * 64, WPB == 8 ? 2 : 4) void nmf_cf_fwd_tile_kernel(const AT* __restrict__ t,
+// (rank 2 needs more than the 128 registers of four waves per SIMD: two — NO variant may spill to scratch, see nmf_pcf.hip)
+__global__ __launch_bounds__(WPB * 64, (WPB == 8 || R >= 2) ? 2 : 4) void nmf_cf_fwd_tile_kernel(const AT* __restrict__ t,
                                                                    const float* __restrict__ u0,
                                                                    const float* __restrict__ v0,
                                                                    AT* __restrict__ out, CfGeom q, int T, float eps,
@@ -334,7 +335,8 @@ __global__ __launch_bounds__(WPB * 64, WPB == 8 ? 2 : 4) void nmf_cf_fwd_tile_ke
 
 // backward: gY = gather_w(ga) / W ; gt (+)= [t > 0] ∘ scatter_w(gX)
 template <int R, int SOLVER, typename AT>
-__global__ __launch_bounds__(512, 2) void nmf_cf_bwd_kernel(const AT* __restrict__ t, const float* __restrict__ u0,
+// (launched with 64 .. 256 threads; everything but the hot HALS rank-1 form runs one wave per SIMD rather than spill)
+__global__ __launch_bounds__(256, (R == 1 && SOLVER == 1) ? 2 : 1) void nmf_cf_bwd_kernel(const AT* __restrict__ t, const float* __restrict__ u0,
                                                             const float* __restrict__ v0,
                                                             const AT* __restrict__ ga, AT* __restrict__ gt,
                                                             CfGeom q, int64_t nmat, int T, int G, float eps,
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(512, 2) void nmf_cf_bwd_kernel(const AT* __restrict
 // line-coalesced backward: same exchange for t and for the incoming gradient, ReLU gate applied on
 // the owner side before the exchange back, read-modify-write of gt with the coalesced map
 template <int R, int SOLVER, int WPB, bool HALF, typename AT>
-__global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : (WPB == 1 ? 2 : 1)) void nmf_cf_bwd_tile_kernel(
+__global__ __launch_bounds__(WPB * 64, (R == 1 && SOLVER == 1 && (WPB == 4 || WPB == 1)) ? 2 : 1) void nmf_cf_bwd_tile_kernel(
     const AT* __restrict__ t, const float* __restrict__ u0, const float* __restrict__ v0,
     const AT* __restrict__ ga, AT* __restrict__ gt, CfGeom q, int T, int G, float eps, int relu_gate,
     int xcd_remap) {

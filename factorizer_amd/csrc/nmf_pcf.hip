@@ -120,8 +120,13 @@ __global__ __launch_bounds__(256) void nmf_pcf_fwd_kernel(const AT* __restrict__
 }
 
 // backward: gY = gather_w(ga) / W ; gt (+)= [t > 0] ∘ scatter_w(gX)
+// (the R = 2 multiplicative-update kernels of 3-4 columns per lane and the HALS one of 4 need more than the 256 registers
+// of two waves per SIMD: they run one wave per SIMD rather than spill — no scratch, see the kernel body)
+template <int NPL, int R, int SOLVER>
+constexpr int pcf_bwd_waves_per_simd() { return (R >= 2 && NPL >= 3 && !(NPL == 3 && SOLVER == 1)) ? 1 : 2; }
+
 template <int NPL, int R, int SOLVER, typename AT>
-__global__ __launch_bounds__(256, 2) void nmf_pcf_bwd_kernel(const AT* __restrict__ t, const float* __restrict__ u0,
+__global__ __launch_bounds__(256, (pcf_bwd_waves_per_simd<NPL, R, SOLVER>())) void nmf_pcf_bwd_kernel(const AT* __restrict__ t, const float* __restrict__ u0,
                                                              const float* __restrict__ v0, const AT* __restrict__ ga,
                                                              AT* __restrict__ gt, PcfGeom q, int64_t nmat, int T, int G,
                                                              float eps, int relu_gate) {
@@ -130,15 +135,23 @@ __global__ __launch_bounds__(256, 2) void nmf_pcf_bwd_kernel(const AT* __restric
   const int64_t mat = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
   if (mat >= nmat) return;
   PcfWave<NPL> w{lane, q.P};
-  int64_t base, V;
-  int voff[NPL];
-  bool ok[NPL];
-  pcf_decode<NPL>(q, mat, lane, base, V, voff, ok);
   Hist<8, NPL, R> h;
   h.carve(fz_lds_pcf + wave * Hist<8, NPL, R>::floats(G), G);
   float x[8][NPL], g[8][NPL];
-  pcf_load<NPL>(t, base, V, voff, ok, x);
-  pcf_load<NPL>(ga, base, V, voff, ok, g);
+  {
+    // The voxel offsets are decoded twice — here for the loads and again for the stores — instead of living in 2·NPL + 4
+    // registers across the whole wave program: the R = 2 kernels sat 3-23 registers over the 256 of two waves per SIMD
+    // and spilled.  NO kernel of this library may use scratch: a kernel with a private segment that ran while the
+    // weight-gradient kernels of the second stream were in flight returned (rarely, one matrix at a time) slightly
+    // different values from run to run on ROCm 7.2 / gfx950 (tools/probes/bf16_replay_trace.py: bitwise reproducible with the
+    // spill removed, or with the streams serialised); tests/test_no_spills.py keeps every kernel at zero scratch.
+    int64_t base, V;
+    int voff[NPL];
+    bool ok[NPL];
+    pcf_decode<NPL>(q, mat, lane, base, V, voff, ok);
+    pcf_load<NPL>(t, base, V, voff, ok, x);
+    pcf_load<NPL>(ga, base, V, voff, ok, g);
+  }
   if (q.gscale_div != 1.0f) {
     const float dv = q.gscale_div;
     const bool pow2 = (__float_as_uint(dv) & 0x007fffffu) == 0u;
@@ -149,6 +162,14 @@ __global__ __launch_bounds__(256, 2) void nmf_pcf_bwd_kernel(const AT* __restric
       for (int j = 0; j < NPL; ++j) g[m][j] = pow2 ? g[m][j] * inv : g[m][j] / dv;
   }
   nmf_backward_wave<8, NPL, R, SOLVER>(w, u0, v0, x, g, h, 8, T, G, eps, nullptr, nullptr);
+  int64_t base, V;
+  int voff[NPL];
+  bool ok[NPL];
+  {
+    int64_t mat2 = mat;
+    asm volatile("" : "+v"(mat2));   // opaque: keeps the compiler from carrying the first decode across the wave program
+    pcf_decode<NPL>(q, mat2, lane, base, V, voff, ok);
+  }
 #pragma unroll
   for (int m = 0; m < 8; ++m)
 #pragma unroll

@@ -174,6 +174,15 @@ def nmf_supported(M, N_, R, T, G) -> bool:
     return bool(N.lib().fz_nmf_supported(int(M), int(N_), int(R), int(T), int(G)))
 
 
+def _join_side_streams(t):
+    """The standalone NMF kernels (csrc/nmf_r*.hip) are the only ones of the library that use scratch; a kernel with a
+    private segment must not run beside the weight-gradient kernels of the second stream (results varied from run to run,
+    tests/test_no_spills.py): the current stream waits for the side streams first."""
+    from . import pointwise as _PW
+    if _PW._SIDE:
+        _PW.wait_wgrad_streams_all(t.device)
+
+
 def _nmf_fwd_raw(x, u0, v0, T, solver, eps, want_uv=False):
     M, Nn = x.shape[-2:]
     R = u0.shape[1]
@@ -186,6 +195,7 @@ def _nmf_fwd_raw(x, u0, v0, T, solver, eps, want_uv=False):
         v = torch.empty((*x.shape[:-2], Nn, R), dtype=torch.float32, device=x.device)
     ad = N.act_dtype(x)
     with _dev_guard(x):
+        _join_side_streams(x)
         rc = _timed(f"nmf_fwd_{M}x{Nn}", 2 * x.numel() * x.element_size(), lambda: N.lib().fz_nmf_fwd(
             x.data_ptr(), u0.data_ptr(), v0.data_ptr(), y.data_ptr(), N.ptr(u), N.ptr(v), nmat, M, Nn, R, T,
             N.SOLVER_ID[solver], eps, ad, N.stream_ptr(x)))
@@ -204,6 +214,7 @@ def _nmf_bwd_raw(x, u0, v0, gy, gu, gv, T, G, solver, eps):
     if gu is not None:
         gu, gv = gu.float().contiguous(), gv.float().contiguous()
     with _dev_guard(x):
+        _join_side_streams(x)
         rc = _timed(f"nmf_bwd_{M}x{Nn}", 3 * x.numel() * x.element_size(), lambda: N.lib().fz_nmf_bwd(
             x.data_ptr(), u0.data_ptr(), v0.data_ptr(), N.ptr(gy), N.ptr(gu), N.ptr(gv), gx.data_ptr(), nmat,
             M, Nn, R, T, G, N.SOLVER_ID[solver], eps, ad, N.stream_ptr(x)))

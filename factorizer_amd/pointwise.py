@@ -321,6 +321,15 @@ def wait_wgrad_streams():
     d.keep.clear()
 
 
+def wait_wgrad_streams_all(dev):
+    """Current stream of `dev` waits for that device's side stream whether or not a deferred join is pending (used in
+    front of the few kernels that must not run beside any other kernel of the library, functional._join_side_streams)."""
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    st = _SIDE.get(key)
+    if st is not None:
+        torch.cuda.current_stream(dev).wait_stream(st)
+
+
 def join_wgrad_streams():
     """After backward: `wait_wgrad_streams()` + check that every parameter still holds the very tensor
     its gradient was written into."""
