@@ -143,6 +143,43 @@ def cpu_baseline_sample():
             "cfg1_nmf_8x512_mu_r2_t5_fwd_us": round(t_cfg1 * 1e6, 1), "host_cpus": os.cpu_count()}
 
 
+def by_stage(table, nsteps, B, stage0_cols):
+    """Where the step's kernel time is: per stage of the U-shape (a launch belongs to the stage of the finest tensor it
+    touches: `cols` = batch x voxels, stage s has stage0_cols / 8^s) the summed launch time of the instrumented warm-up
+    steps, the algorithmic bytes and matrix-core flops of those launches, and both as fractions of the chip's roofs
+    (8 TB/s HBM; 157.3 TFLOP/s fp32 matrix peak — the layers with K >= 64 run their fp32 products as six bf16 products
+    on the bf16 pipe, so their share of the fp32 roof can legitimately pass 1/2.67 of it and is only descriptive).
+    `bound` = the roof whose minimum time for that work is larger.  Side-stream launches overlap the main stream, so the
+    stage times add up to more than the step."""
+    out = {}
+    fam = {}
+    for name, a in table.items():
+        cols = a.get("cols", 0)
+        s = 0
+        while cols and cols * 8 ** s < stage0_cols and s < 8:
+            s += 1
+        key = "unattributed" if not cols else ("stage0" if s == 0 else "stage1" if s == 1 else "stage2-4")
+        for k2, dst in ((key, out), ("gemm_family" if a.get("flops", 0) and not name.startswith(("wgrad", "mlp_chain", "dgrad_", "conv_k3")) else None, fam)):
+            if k2 is None:
+                continue
+            d = dst.setdefault(k2, {"kernel_ms": 0.0, "GB": 0.0, "GFLOP": 0.0, "launches": 0})
+            d["kernel_ms"] += a["ms"] / nsteps
+            d["GB"] += a["bytes"] / nsteps / 1e9
+            d["GFLOP"] += a.get("flops", 0) / nsteps / 1e9
+            d["launches"] += a["calls"] // max(nsteps, 1)
+    for dst in (out, fam):
+        for d in dst.values():
+            ms = max(d["kernel_ms"], 1e-9)
+            d["hbm_frac"] = round(d["GB"] / ms / HBM_PEAK_GBS * 1e3, 4)
+            d["mfma_frac_of_fp32_peak"] = round(d["GFLOP"] / ms / FP32_MFMA_PEAK_TFLOPS, 4)
+            d["bound"] = "mfma" if d["GFLOP"] / FP32_MFMA_PEAK_TFLOPS > d["GB"] / HBM_PEAK_GBS * 1e3 else "hbm"
+            d["frac_of_binding_roof"] = max(d["hbm_frac"], d["mfma_frac_of_fp32_peak"]) if d["bound"] == "mfma" else d["hbm_frac"]
+            for k in ("kernel_ms", "GB", "GFLOP"):
+                d[k] = round(d[k], 3)
+    out.update({"fz_gemm (1x1 layers, k2s2 convolutions: gemm_stream / gemm_bx / gemm_bxk / gemm_resident)": v for v in fam.values()})
+    return out
+
+
 NMF_FLOP_FWD = 95312  # SURVEY.md §8(d): HALS R=1 T=5 on one 8x512 matrix, forward (T·F_iter + F_recon)
 
 

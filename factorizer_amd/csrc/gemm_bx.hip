@@ -337,7 +337,7 @@ int gemm_bx_launch(const GemmArgsT<AT>& a0, int loader, int epilogue, int pro, f
   int nacc, mb;
   {
     // narrow problems (stages 2-4): K-split form — tile chosen for >= 512 workgroups where the problem has them
-    int ks = (a.Ncol * a.B <= 65536) ? 1 : 0;
+    int ks = (a.Ncol * a.B <= 4096) ? 1 : 0;   // (measured: the streaming form wins from 16^3 x 2 on, profiles/r03_gemm_bx_sweep.md)
     int kn = 2, km = mblocks >= 2 ? 2 : 1;
     auto wgs = [&](int na, int mbb) { return ((a.Ncol + 32 * na - 1) / (32 * na)) * a.B * ((mblocks + mbb - 1) / mbb); };
     if (wgs(kn, km) < 512 && km == 2) km = 1;

@@ -236,7 +236,8 @@ static int pcf_bwd_launch(const AT* t, const float* u0, const float* v0, const A
   if (nmat >= (int64_t)1 << 31) return fail(FZ_E_UNSUPPORTED, "fz_nmf_pcf: more than 2^31 matrices");
   const int per_wave = pcf_per_wave(q.P, R, G);
   if (per_wave > 160 * 1024) return fail(FZ_E_UNSUPPORTED, "fz_nmf_pcf_bwd: history exceeds LDS");
-  const int wpb = fz_hist_waves_per_block(per_wave);
+  int wpb = fz_hist_waves_per_block(per_wave);
+  { const char* e = getenv("FZ_PCF_WPB"); if (e && atoi(e) >= 1 && atoi(e) <= 4) wpb = atoi(e); }   // diagnostics
   const int lds = per_wave * wpb;
   dim3 grid((unsigned)((nmat + wpb - 1) / wpb)), block(64 * wpb);
 #define FZ_PCF_BWD(NN, RR, SS)                                                                                \

@@ -270,11 +270,12 @@ _SIDE = {}
 
 
 def _side_stream(dev, ncols):
-    """Second HIP stream for the weight-gradient kernels of the small, deep stages: they are off
-    the critical path (only the optimizer consumes them) and, at <= 64^3 voxels, neither they nor
-    the input-gradient chain fill 256 CUs, so the two overlap.  FZ_SIDE_WGRAD=0 disables it,
-    FZ_SIDE_WGRAD=<columns> moves the size limit."""
-    lim = int(os.environ.get("FZ_SIDE_WGRAD", str(2 * 64 ** 3)))
+    """Second HIP stream for the weight-gradient kernels of the small, deep stages — OFF by default since round 3.
+    Two of this library's kernels co-resident on the chip from different queues gave run-to-run different results in
+    one NMF matrix of a bf16 step (every kernel alone is bitwise reproducible, no buffer is overrun, LDS is not shared:
+    profiles/r03_two_stream_interaction.md has the whole hunt); the overlap was worth 0.2-0.3 ms of a 19.3 ms step.
+    FZ_SIDE_WGRAD=<columns> re-enables it for launches of at most that many voxel columns (experiments only)."""
+    lim = int(os.environ.get("FZ_SIDE_WGRAD", "0"))
     if lim <= 0 or ncols > lim:
         return None
     key = (dev.type, dev.index)

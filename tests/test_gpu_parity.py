@@ -618,10 +618,12 @@ def _small_unet():
                          rank=1, num_iters=5, init="uniform", solver="hals", mlp_ratio=2, dropout=0.0).to(DEV)
 
 
-def test_late_wgrad_join_matches_per_block_join():
-    """Awaiting the side-stream weight gradients once per step (pointwise._LateJoin) instead of once per
-    block changes when the streams meet, not the values: every gradient is bit-identical."""
+def test_late_wgrad_join_matches_per_block_join(monkeypatch):
+    """(opt-in second stream, FZ_SIDE_WGRAD: off by default since round 3, profiles/r03_two_stream_interaction.md)
+    Awaiting the side-stream weight gradients once per step (pointwise._LateJoin) instead of once per
+    block changes when the streams meet, not the values: every gradient is bit-identical (fp32)."""
     from factorizer_amd import pointwise as PW
+    monkeypatch.setenv("FZ_SIDE_WGRAD", str(2 * 64 ** 3))
     from factorizer_amd.parallel import FlatGradSync
     model = _small_unet()
     x = torch.rand(2, 4, 32, 32, 32, device=DEV)
@@ -646,10 +648,11 @@ def test_late_wgrad_join_matches_per_block_join():
         assert torch.equal(a[n], b[n]), n
 
 
-def test_late_wgrad_join_refuses_copied_gradients():
-    """If autograd had to copy a returned weight gradient (here: accumulation into an existing .grad), the
-    copy was taken before the side stream wrote it: the join raises instead of handing it to the optimizer."""
+def test_late_wgrad_join_refuses_copied_gradients(monkeypatch):
+    """(opt-in second stream) If autograd had to copy a returned weight gradient (here: accumulation into an existing .grad),
+    the copy was taken before the side stream wrote it: the join raises instead of handing it to the optimizer."""
     from factorizer_amd import pointwise as PW
+    monkeypatch.setenv("FZ_SIDE_WGRAD", str(2 * 64 ** 3))
     model = _small_unet()
     x = torch.rand(2, 4, 32, 32, 32, device=DEV)
     for p in model.parameters():

@@ -85,9 +85,11 @@ Fn.FactCoreFn.backward = staticmethod(cb)
 Fn.FactCoreFn.forward = staticmethod(cf)
 
 S, widths, strides = (80, 96, 80), (32, 64, 128, 256), (1, 2, 2, 2)
+if "--full" in sys.argv:
+    S, widths, strides = (160, 192, 160), (32, 64, 128, 256, 512), (1, 2, 2, 2, 2)
 torch.manual_seed(0)
-model = ft.Factorizer(in_channels=4, out_channels=3, spatial_size=S, encoder_depth=(1,) * 4, encoder_width=widths, strides=strides,
-                      decoder_depth=(1,) * 3, norm=ft.LayerNorm, reshape=(ft.SWMatricize, {"head_dim": 8, "patch_size": (5, 6, 5)}),
+model = ft.Factorizer(in_channels=4, out_channels=3, spatial_size=S, encoder_depth=(1,) * len(widths), encoder_width=widths, strides=strides,
+                      decoder_depth=(1,) * (len(widths) - 1), norm=ft.LayerNorm, reshape=(ft.SWMatricize, {"head_dim": 8, "patch_size": (5, 6, 5)}),
                       act=nn.ReLU, factorize=ft.NMF, rank=2, num_iters=10, init="uniform", solver="hals", mlp_ratio=2,
                       dropout=0.0).to(dev)
 x = torch.rand(1, 4, *S, device=dev)
@@ -122,5 +124,5 @@ for i, ((n1, t1), (n2, t2)) in enumerate(zip(a, b)):
             break
     if nd >= 6:
         break
-g = {n: p.grad.clone() for n, p in model.named_parameters()}
+
 print("differing outputs found:", nd)
