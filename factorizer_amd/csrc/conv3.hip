@@ -14,11 +14,9 @@
 // halo rows of every input channel (34 floats each) in LDS; the 27·C_in shifted operands are then
 // LDS reads at lane-dependent offsets, so the input is fetched 9x (L1/L2 hits) instead of 27x and
 // gY exactly once.  Partial sums per workgroup, deterministic reduction (wgrad.hip's reducer).
-#include "fz_common.h"
+#include "gemm_bx.h"   // split-bf16 operand helpers (bx_split, bx_mfma); brings fz_common.h and f32x16
 
 namespace fz {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // AT = storage type of the activation tensors x / y / gy (float or bf16)
 template <typename AT>
@@ -127,6 +125,133 @@ __global__ __launch_bounds__(256, 2) void conv3_fwd_kernel(Conv3ArgsT<AT> p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same forward on the bf16 matrix pipe with split fp32 operands (gemm_bx.hip: six exact bf16 products per fp32
+// product, fp32 accuracy at 6/16 of the fp32-MFMA time).  The fp32 kernel above walks K = 27·C_in as K-steps of two
+// (channel 2cp + h, tap): eight consecutive steps are ONE v_mfma_f32_32x32x16_bf16 K-step whose element e of lane half h
+// is step 8g + e — any assignment of reduction indices to (half, element) slots is valid as long as both operands use
+// the same one, so the operand registers of the fp32 form are simply packed eight at a time.  CP = C_in / 2 is a
+// compile-time constant (the whole tap loop is unrolled: groups straddle channel pairs).  Weights are split once per
+// workgroup into LDS: As[group][row block][term][lane] x 16 B; the tail group is zero-padded.
+template <int MB, int CP, typename AT>
+__global__ __launch_bounds__(256, 2) void conv3_fwd_bx_kernel(Conv3ArgsT<AT> p) {
+  constexpr int NTA = BxTerms<AT>::A, NTB = bx_terms_b<AT>(BXPRO_NONE);
+  constexpr int NS = CP * 27;                 // K-steps of two
+  constexpr int NG = (NS + 7) / 8;            // groups of eight steps
+  __shared__ __attribute__((aligned(16))) __bf16 As[NG * MB * NTA * 64 * 8];
+  __shared__ float sBias[32 * MB];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int64_t V = (int64_t)p.D * p.H * p.W;
+  const int tiles_per_sample = (int)((V + 511) / 512);
+  const int b = blockIdx.x / tiles_per_sample;
+  const int64_t n0 = ((int64_t)(blockIdx.x % tiles_per_sample) * 4 + wave) * 128;
+  const int m0 = blockIdx.y * 32 * MB;
+  const int Cin = 2 * CP;
+
+  for (int idx = threadIdx.x; idx < NG * MB * 64; idx += 256) {
+    const int l = idx & 63, mb = (idx >> 6) % MB, g = idx / (64 * MB);
+    const int m = m0 + mb * 32 + (l & 31);
+    const int mc = m < p.M ? m : p.M - 1;
+    float wv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int a = 8 * g + e;
+      const int ac = a < NS ? a : NS - 1;
+      const int c = 2 * (ac / 27) + (l >> 5), tap = ac % 27;
+      const float t = p.w[((int64_t)mc * Cin + c) * 27 + tap];
+      wv[e] = (a < NS && m < p.M) ? t : 0.f;
+    }
+    bx8 t3[NTA];
+    bx_split<NTA>(wv, t3);
+#pragma unroll
+    for (int i = 0; i < NTA; ++i) *reinterpret_cast<bx8*>(&As[(((g * MB + mb) * NTA + i) * 64 + l) * 8]) = t3[i];
+  }
+  if (threadIdx.x < 32 * MB) {
+    const int m = m0 + threadIdx.x;
+    sBias[threadIdx.x] = (p.bias != nullptr && m < p.M) ? p.bias[m] : 0.f;
+  }
+  __syncthreads();
+
+  const int64_t col = n0 + 4 * j;
+  const bool col_ok = col < V;
+  const int64_t cc = col_ok ? col : 0;
+  const int w0 = (int)(cc % p.W);
+  const int h0 = (int)((cc / p.W) % p.H);
+  const int d0 = (int)(cc / ((int64_t)p.W * p.H));
+  const bool lok = w0 > 0, rok = w0 + 4 < p.W;
+
+  f32x16 acc[MB][4];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][q][r] = 0.f;
+
+  float xg[4][8];   // the group being collected: [voxel q][step in group]
+#pragma unroll
+  for (int cp = 0; cp < CP; ++cp) {
+    const AT* plane = p.x + ((int64_t)b * Cin + 2 * cp + h) * V;
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) {
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int zd = d0 + kd - 1, zh = h0 + kh - 1;
+        const bool ok = col_ok && zd >= 0 && zd < p.D && zh >= 0 && zh < p.H;
+        const int zdc = zd < 0 ? 0 : (zd >= p.D ? p.D - 1 : zd);
+        const int zhc = zh < 0 ? 0 : (zh >= p.H ? p.H - 1 : zh);
+        const AT* row = plane + ((int64_t)zdc * p.H + zhc) * p.W;
+        const float4 t = ld4(row + w0);
+        const float lf = aget(row + (lok ? w0 - 1 : w0));
+        const float rt = aget(row + (rok ? w0 + 4 : w0));
+        const float c0 = ok ? t.x : 0.f, c1 = ok ? t.y : 0.f, c2 = ok ? t.z : 0.f, c3 = ok ? t.w : 0.f;
+        const float l0 = (ok && lok) ? lf : 0.f, r0 = (ok && rok) ? rt : 0.f;
+        const float bv[3][4] = {{l0, c0, c1, c2}, {c0, c1, c2, c3}, {c1, c2, c3, r0}};
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int a = cp * 27 + (kd * 3 + kh) * 3 + kw;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) xg[q][a & 7] = bv[kw][q];
+          if ((a & 7) == 7 || a == NS - 1) {
+            const int g = a >> 3;
+            if (a == NS - 1) {
+#pragma unroll
+              for (int e = (NS - 1) % 8 + 1; e < 8; ++e)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xg[q][e] = 0.f;   // zero-padded tail (its weights are zero too)
+            }
+            bx8 bop[4][NTB];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bx_split<NTB>(xg[q], bop[q]);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+              bx8 aop[NTA];
+#pragma unroll
+              for (int i = 0; i < NTA; ++i)
+                aop[i] = *reinterpret_cast<const bx8*>(&As[(((g * MB + mb) * NTA + i) * 64 + lane) * 8]);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) bx_mfma<NTA, NTB>(acc[mb][q], aop, bop[q]);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (!col_ok) return;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int m = m0 + mb * 32 + rl;
+      const float bs = sBias[mb * 32 + rl];
+      if (m < p.M)
+        st4(p.y + ((int64_t)b * p.M + m) * V + col,
+            make_float4(acc[mb][0][r] + bs, acc[mb][1][r] + bs, acc[mb][2][r] + bs, acc[mb][3][r] + bs));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // weight gradient: GW[m][(ci, kd, kh, kw)] = Σ_{b,v} gY[b,m,v] · x[b,ci,v + off(kd,kh,kw)]
 template <typename AT>
 struct Conv3WgradArgsT {
@@ -138,9 +263,16 @@ struct Conv3WgradArgsT {
   int tiles_per_unit;
 };
 
-constexpr int kXs = 40;  // halo row stride: [3] = w0-1, [4..35] = the 32 interior voxels (16-byte aligned), [36] = w0+32
+// halo row stride: [3] = w0-1, [4..35] = the 32 interior voxels (16-byte aligned), [36] = w0+32.  The operand reads are
+// one float per lane, lane = column (ci, kd, kh, kw): bank = (row·kXs + kw + const) mod 32 with row = (ci, kd, kh).  At
+// stride 40 the rows fall into 4 bank classes (8·row mod 32) — 32 lanes on 12 banks, SQ_LDS_BANK_CONFLICT 0.57 of the LDS
+// cycles in round 2; at 44 (12·row mod 32: eight classes 4 apart, 3 taps each) the first 24 lanes are conflict-free and
+// the last 8 of a 32-column block share a bank with one other lane.
+constexpr int kXs = 44;
 
-template <int KB, typename AT>  // KB = number of 32-column blocks covering 27*Cin (4 for Cin = 4)
+// BX: products on the bf16 matrix pipe from split fp32 operands (see conv3_fwd_bx_kernel): the 32 voxels of a tile are two
+// K-steps of 16, element e of lane half h = voxel 16g + 8h + e — for gY eight contiguous floats of the lane's row.
+template <int KB, typename AT, bool BX = false>  // KB = number of 32-column blocks covering 27*Cin (4 for Cin = 4)
 __global__ __launch_bounds__(256) void conv3_wgrad_kernel(Conv3WgradArgsT<AT> a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -236,6 +368,30 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(Conv3WgradArgsT<AT> a)
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (t + 1 < t_end) issue(t + 1);  // in flight during the MFMA loop
+    if constexpr (BX) {
+      constexpr int NTA = BxTerms<AT>::A;   // both operands are activations; gY may carry rounding of a bf16 tensor only
+      constexpr int NT = sizeof(AT) == 4 ? 3 : 1;
+      (void)NTA;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        float a8[8];
+        const float4 a0 = *reinterpret_cast<const float4*>(Pt + c * 36 + 16 * g + 8 * h);
+        const float4 a1 = *reinterpret_cast<const float4*>(Pt + c * 36 + 16 * g + 8 * h + 4);
+        a8[0] = a0.x; a8[1] = a0.y; a8[2] = a0.z; a8[3] = a0.w; a8[4] = a1.x; a8[5] = a1.y; a8[6] = a1.z; a8[7] = a1.w;
+        psum += ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+        bx8 aop[NT];
+        bx_split<NT>(a8, aop);
+#pragma unroll
+        for (int jb = 0; jb < KB; ++jb) {
+          float b8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) b8[e] = Xs[xoff[jb] + 16 * g + 8 * h + e];
+          bx8 bop[NT];
+          bx_split<NT>(b8, bop);
+          bx_mfma<NT, NT>(acc[jb], aop, bop);
+        }
+      }
+    } else {
 #pragma unroll 4
     for (int s = 0; s < 16; ++s) {
       const float av = Pt[c * 36 + 2 * s + h];
@@ -245,6 +401,7 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(Conv3WgradArgsT<AT> a)
         const float bv = Xs[xoff[jb] + 2 * s + h];
         acc[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[jb], 0, 0, 0);
       }
+    }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
@@ -295,6 +452,12 @@ static int conv3_fwd_launch(const void* x, const float* w, const float* bias, vo
   if (lds > 65536) return fail(FZ_E_UNSUPPORTED, "fz_conv3_fwd: C_in too large for the stem kernel");
   dim3 grid((unsigned)(((V + 511) / 512) * B), (unsigned)((mblocks + MB - 1) / MB)), block(256);
   hipStream_t st = (hipStream_t)stream;
+  if (Cin == 4 && fz_gemm_bx_enable(-1)) {   // the stem of the README model: split-bf16 form (fz_gemm_bx_enable(0): fp32 MFMAs)
+    if (MB == 2) hipLaunchKernelGGL((conv3_fwd_bx_kernel<2, 2, AT>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((conv3_fwd_bx_kernel<1, 2, AT>), grid, block, 0, st, p);
+    FZ_LAUNCH_CHECK();
+    return FZ_OK;
+  }
   if (MB == 2) hipLaunchKernelGGL((conv3_fwd_kernel<2, AT>), grid, block, lds, st, p);
   else hipLaunchKernelGGL((conv3_fwd_kernel<1, AT>), grid, block, lds, st, p);
   FZ_LAUNCH_CHECK();
@@ -335,7 +498,10 @@ static int conv3_wgrad_launch(const void* gy, const void* x, float* part, float*
   const size_t lds = (size_t)4 * (32 * 36 + 36 * kXs) * sizeof(float);
   const size_t lds_red = 4096 * sizeof(float);
   dim3 grid(nchunk, (M + 31) / 32), block(256);
-  hipLaunchKernelGGL((conv3_wgrad_kernel<4, AT>), grid, block, lds > lds_red ? lds : lds_red, (hipStream_t)stream, a);
+  if (fz_gemm_bx_enable(-1))
+    hipLaunchKernelGGL((conv3_wgrad_kernel<4, AT, true>), grid, block, lds > lds_red ? lds : lds_red, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL((conv3_wgrad_kernel<4, AT, false>), grid, block, lds > lds_red ? lds : lds_red, (hipStream_t)stream, a);
   FZ_LAUNCH_CHECK();
   return FZ_OK;
 }

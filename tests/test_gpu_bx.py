@@ -183,3 +183,27 @@ def test_bx_is_the_default_path_and_bitwise_deterministic():
     a = PW.linear_cf(x, w, None)
     b = PW.linear_cf(x, w, None)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,S", [(2, (16, 16, 32)), (1, (8, 12, 64))])
+def test_stem_conv_k3_fp64(B, S):
+    """The stem Conv3d(4 -> 32, k3, p1) forward and its weight gradient (csrc/conv3.hip, split-bf16 forms) against float64,
+    next to the fp32-MFMA kernels."""
+    torch.manual_seed(8)
+    x = torch.randn(B, 4, *S)
+    w = torch.randn(32, 4, 3, 3, 3) / 108 ** 0.5
+    ref = F.conv3d(x.double(), w.double(), padding=1)
+    mag = F.conv3d(x.double().abs(), w.double().abs(), padding=1)
+    xd, wd = x.to(DEV), w.to(DEV).requires_grad_(True)
+    y_bx, y_f32 = _both(lambda: PW.ConvK3Fn.apply(xd, wd, None))
+    _check("conv_k3 4->32", y_bx, y_f32, ref, mag)
+    gy = torch.randn(B, 32, *S)
+    gref = torch.nn.grad.conv3d_weight(x.double(), w.shape, gy.double(), padding=1)
+    gmag = torch.nn.grad.conv3d_weight(x.double().abs(), w.shape, gy.double().abs(), padding=1)
+    gd = gy.to(DEV)
+
+    def run():
+        (g,) = torch.autograd.grad(PW.ConvK3Fn.apply(xd, wd, None), wd, gd)
+        return g
+    g_bx, g_f32 = _both(run)
+    _check("conv_k3 wgrad 32x108", g_bx, g_f32, gref, gmag, slack=4.0)   # sum over B·V = 8-16 K voxels in tile / chunk order
