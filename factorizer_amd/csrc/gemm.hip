@@ -19,7 +19,7 @@
 // Weights (the A operand) are staged once per workgroup in LDS in operand order.
 // The accumulator tile has its row in (register, h) and its column in j, so the epilogue
 // stores 16-byte vectors (4 voxels) per register: 512 B contiguous per output row.
-#include "gemm_common.h"
+#include "gemm_bx.h"   // split-bf16 operand helpers for the fused kernels (brings gemm_common.h)
 
 namespace fz {
 
@@ -897,10 +897,15 @@ __device__ __forceinline__ void gelu_both2(const float (&x)[2], float (&g)[2], f
 
 // (HALVES / HALF are compile-time: with a run-time half the one-launch form lost its spill-free register allocation —
 // 32 spilled VGPRs, 0.94 -> 1.03 ms per launch, 215 MB of scratch writes in the WRITE_SIZE counter.)
-template <typename AT, int HALVES = 1, int HALF = 0>
+// BX: the two input-gradient GEMMs (half of the kernel's matrix work) run as split-bf16 products (gemm_bx.hip): the K-steps
+// of two of the fp32 form are packed eight at a time — element e of lane half h of a 32x32x16 bf16 MFMA = step 8g + e —
+// with the weights pre-split in LDS (As1 / As2 hold bf16x8 triples instead of floats: 12 KB each instead of 8).  The two
+// weight-gradient passes keep their transposed fp32 operands (v_mfma_f32_16x16x4_f32).
+template <typename AT, int HALVES = 1, int HALF = 0, bool BX = false>
 __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT> p, ChainArgsT<AT> c, int ntiles, float* wpart,
                                                                    float* glp) {
-  constexpr int NACC = 2, HB = 2, HID = 64 * HALVES, N1 = 16 * HB * 64;
+  constexpr int NACC = 2, HB = 2, HID = 64 * HALVES, N1 = BX ? 3072 : 16 * HB * 64;   // floats of each staged weight block
+  constexpr int NTA = BxTerms<AT>::A, NTB = bx_terms_b<AT>(BXPRO_GELU);   // (operands are computed values: full split)
   constexpr int half = HALF;
   constexpr int hoff = 64 * HALF;             // first hidden row of this launch
   constexpr bool last = HALF == HALVES - 1;   // this launch ends with the LayerNorm backward
@@ -918,6 +923,33 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
   float* T = Bf + 32 * kTS;
   const int tiles_per_sample = (int)((p.Ncol + 128 * NACC - 1) / (128 * NACC));
 
+  if constexpr (BX) {
+    // 512 operand items of 8 steps each: As1x[g (2)][rb (2)][term][lane], As2x[g (4)][term][lane]
+    for (int it = threadIdx.x; it < 512; it += 256) {
+      float wv[8];
+      const int l = it & 63;
+      __bf16* dst;
+      if (it < 256) {
+        const int rb = (it >> 6) & 1, g = it >> 7;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wv[e] = weight_at(p, hoff + rb * 32 + (l & 31), 2 * (8 * g + e) + (l >> 5));
+        dst = reinterpret_cast<__bf16*>(As1) + ((g * HB + rb) * NTA * 64 + l) * 8;
+      } else {
+        const int g = (it - 256) >> 6;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int s2 = 8 * g + e, r = s2 & 15, rb = s2 >> 4;
+          const int k = hoff + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), m = l & 31;
+          wv[e] = c.wB_t ? c.wB[(int64_t)k * c.ldwB + m] : c.wB[(int64_t)m * c.ldwB + k];
+        }
+        dst = reinterpret_cast<__bf16*>(As2) + (g * NTA * 64 + l) * 8;
+      }
+      bx8 t3[NTA];
+      bx_split<NTA>(wv, t3);
+#pragma unroll
+      for (int i = 0; i < NTA; ++i) *reinterpret_cast<bx8*>(dst + i * 64 * 8) = t3[i];
+    }
+  } else {
   for (int base = threadIdx.x; base < 2 * N1; base += 256 * 8) {
     float tmp[8];
 #pragma unroll
@@ -941,6 +973,7 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
       const int idx = base + uu * 256;
       if (idx < N1) As1[idx] = tmp[uu]; else As2[idx - N1] = tmp[uu];
     }
+  }
   }
   if (threadIdx.x < 32) tB[threadIdx.x] = p.lnb_g[threadIdx.x];
 
@@ -1013,6 +1046,29 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
       for (int q = 0; q < NACC; ++q)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc1[rb][q][r] = 0.f;
+    if constexpr (BX) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        bx8 bop[NACC][NTB];
+#pragma unroll
+        for (int q = 0; q < NACC; ++q) {
+          float x8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x8[e] = bv[8 * g + e][q];
+          bx_split<NTB>(x8, bop[q]);
+        }
+#pragma unroll
+        for (int rb = 0; rb < HB; ++rb) {
+          bx8 aop[NTA];
+#pragma unroll
+          for (int i = 0; i < NTA; ++i)
+            aop[i] = *reinterpret_cast<const bx8*>(reinterpret_cast<const __bf16*>(As1) + (((g * HB + rb) * NTA + i) * 64 + lane) * 8);
+#pragma unroll
+          for (int q = 0; q < NACC; ++q) bx_mfma<NTA, NTB>(acc1[rb][q], aop, bop[q]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
 #pragma unroll
     for (int s = 0; s < 16; ++s)
 #pragma unroll
@@ -1022,6 +1078,7 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
         for (int q = 0; q < NACC; ++q) acc1[rb][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[s][q], acc1[rb][q], 0, 0, 0);
         if (rb == HB - 1 && (s & 1) == 1) __builtin_amdgcn_sched_barrier(0);
       }
+    }
     // (the next tile's operand is requested after GEMM 2: its 32 registers would otherwise be live next to the 64
     // gz1 accumulators and the 64 weight-gradient accumulators; the epilogue and the other resident waves cover
     // the round trip)
@@ -1139,6 +1196,25 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[q][r] = 0.f;
     }
+    if constexpr (BX) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {   // steps (rb, r) = (g >> 1, 8 (g & 1) + e): accumulator registers as the column operand
+        bx8 aop[NTA];
+#pragma unroll
+        for (int i = 0; i < NTA; ++i)
+          aop[i] = *reinterpret_cast<const bx8*>(reinterpret_cast<const __bf16*>(As2) + ((g * NTA + i) * 64 + lane) * 8);
+#pragma unroll
+        for (int q = 0; q < NACC; ++q) {
+          float x8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x8[e] = acc1[g >> 1][q][8 * (g & 1) + e];
+          bx8 bop[NTB];
+          bx_split<NTB>(x8, bop);
+          bx_mfma<NTA, NTB>(acc2[q], aop, bop);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
 #pragma unroll
     for (int rb = 0; rb < HB; ++rb)
 #pragma unroll
@@ -1148,6 +1224,7 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
         for (int q = 0; q < NACC; ++q) acc2[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, acc1[rb][q][r], acc2[q], 0, 0, 0);
         if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
+    }
     fetch_tile(tile + gridDim.x < ntiles ? tile + gridDim.x : tile);
 
     if (HALVES == 2 && !last) {   // first half: park the partial W1ᵀ·gz1 (fp32), no epilogue
@@ -2299,9 +2376,10 @@ static int mlp_launch(const fz_mlp_desc* d, fz_stream_t stream) {
     a.lnb_x = (const AT*)d->x1; a.lnb_stats = d->stats; a.lnb_g = d->ln_g; a.lnb_gadd = (const AT*)d->in; a.lnb_part = d->part;
     c.wB = d->w1; c.wB_t = 1; c.ldwB = 32;
     const int rows = fz_mlp_wgrad_rows(d->B, d->V);
-    constexpr int lds = (2 * 2048 + 32 + 256 + 4 * 48 * kTS) * (int)sizeof(float);
+    const bool bxon = gemm_bx_enabled() != 0;
+    const int lds = (2 * (bxon ? 3072 : 2048) + 32 + 256 + 4 * 48 * kTS) * (int)sizeof(float);
     if (d->H == 64) {
-      auto kern = gemm_chain_bwd_wg_kernel<AT, 1, 0>;
+      auto kern = bxon ? gemm_chain_bwd_wg_kernel<AT, 1, 0, true> : gemm_chain_bwd_wg_kernel<AT, 1, 0, false>;
       FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
       hipLaunchKernelGGL(kern, dim3((unsigned)rows), block, lds, st, a, c, ntiles, (float*)d->wpart, (float*)nullptr);
       FZ_LAUNCH_CHECK();
@@ -2309,8 +2387,8 @@ static int mlp_launch(const fz_mlp_desc* d, fz_stream_t stream) {
                          d->gw1, d->gb1, d->gw2, 64, d->gb2, d->gln);
       FZ_LAUNCH_CHECK();
     } else {   // hidden 128: one launch per 64-row half (wpart holds two row blocks)
-      auto kern0 = gemm_chain_bwd_wg_kernel<AT, 2, 0>;
-      auto kern1 = gemm_chain_bwd_wg_kernel<AT, 2, 1>;
+      auto kern0 = bxon ? gemm_chain_bwd_wg_kernel<AT, 2, 0, true> : gemm_chain_bwd_wg_kernel<AT, 2, 0, false>;
+      auto kern1 = bxon ? gemm_chain_bwd_wg_kernel<AT, 2, 1, true> : gemm_chain_bwd_wg_kernel<AT, 2, 1, false>;
       FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern0), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
       FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern1), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
       for (int half = 0; half < 2; ++half) {

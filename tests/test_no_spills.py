@@ -2,10 +2,6 @@
 scratch traffic inside the tile loop: 32 of them cost the fused MLP backward 10 % (935 -> 1025 us, +215 MB of writes in
 the WRITE_SIZE counter) after a template change that looked harmless.  The kernels named here must stay spill-free."""
 import os
-import re
-import subprocess
-import tempfile
-from concurrent.futures import ThreadPoolExecutor
 
 import pytest
 
@@ -22,23 +18,19 @@ HOT = {
 }
 
 
-def _asm(src):
-    with tempfile.NamedTemporaryFile(suffix=".s") as tmp:
-        cmd = [B._hipcc(), *B.FLAGS, *B.PER_FILE_FLAGS.get(src, []), "-I", os.path.join(ROOT, "include"), "--cuda-device-only",
-               "-S", os.path.join(CSRC, src), "-o", tmp.name]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        assert r.returncode == 0, r.stderr[-2000:]
-        return open(tmp.name).read()
-
-
 @pytest.fixture(scope="module")
 def metadata():
-    with ThreadPoolExecutor(len(HOT)) as ex:
-        texts = dict(zip(HOT, ex.map(_asm, HOT)))
+    """{mangled kernel name: (vgpr_count, vgpr_spill_count)} of the hot translation units, read from the notes of the BUILT
+    objects (factorizer_amd/csrc/build; tools/scratch_audit.py) — what ships, and no recompilation."""
+    import importlib.util
+    B.build(verbose=False)
+    spec = importlib.util.spec_from_file_location("scratch_audit", os.path.join(ROOT, "tools", "scratch_audit.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
     out = {}
-    for src, txt in texts.items():
-        for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)", txt):
-            out[m.group(1)] = (int(m.group(2)), int(m.group(3)))
+    for src in HOT:
+        for name, _scratch, spills, vgprs in mod.kernels_of(os.path.join(CSRC, "build", src[:-4] + ".o")):
+            out[name] = (vgprs, spills)
     return out
 
 
