@@ -176,6 +176,7 @@ _SIGS.update({
     "fz_dice_bce_grad": ([_vp, _vp, _vp, _vp, _i, _i64, _f, _f, _vp, _vp], _i),
     "fz_dice_ce_sums": ([_vp, _vp, _vp, _i, _i, _i64, _vp], _i),
     "fz_dice_ce_grad": ([_vp, _vp, _vp, _vp, _i, _i, _i64, _f, _f, _vp, _vp], _i),
+    "fz_dice_ce_finish": ([_vp, _i, _i, _i64, _f, _vp, _vp, _vp], _i),
     "fz_rowsum_chunks": ([_i64], _i),
     "fz_rowsum": ([_vp, _vp, _vp, _i, _i, _i64, _i, _vp], _i),
     "fz_ln_fwd": ([_vp] * 5 + [_i, _i, _i64, _f, _i, _vp], _i),

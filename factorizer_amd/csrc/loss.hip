@@ -247,6 +247,48 @@ extern "C" int fz_dice_ce_sums(const float* z, const float* t, float* part, int 
   return FZ_OK;
 }
 
+// One workgroup turns the partial sums into the loss and the Dice coefficients of the gradient pass: replaces a dozen
+// launch-bound framework kernels (sum over chunks, 2·inter + smooth, den + smooth, 1 - num/den, means) between the two
+// passes.  Chunks are added in a fixed order: lane-strided partial sums, then the wave butterfly of fz_common.h.
+__global__ __launch_bounds__(256) void dice_ce_finish_kernel(const float* __restrict__ part, int nchunk, int B, int C, float inv_bv,
+                                                             float smooth, float* __restrict__ loss, float* __restrict__ coef) {
+  __shared__ float cols[8 * 25 + 8];   // (B <= 8) x (3C + 1 <= 25) column totals
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ncol = 3 * C + 1;
+  for (int col = wave; col < B * ncol; col += 4) {
+    const int b = col / ncol, k = col % ncol;
+    float t = 0.f;
+    for (int ch = lane; ch < nchunk; ch += 64) t += part[((int64_t)b * nchunk + ch) * ncol + k];
+    t = wave_sum(t);
+    if (lane == 0) cols[col] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float dice = 0.f, ce = 0.f;
+    for (int b = 0; b < B; ++b) {
+      for (int c = 0; c < C; ++c) {
+        const float num = 2.0f * cols[b * ncol + 3 * c] + smooth;
+        const float den = cols[b * ncol + 3 * c + 1] + cols[b * ncol + 3 * c + 2] + smooth;
+        coef[(b * C + c) * 2] = num;
+        coef[(b * C + c) * 2 + 1] = den;
+        dice += 1.0f - num / den;
+      }
+      ce += cols[b * ncol + 3 * C];
+    }
+    loss[0] = dice / (float)(B * C) + ce * inv_bv;
+  }
+}
+
+extern "C" int fz_dice_ce_finish(const float* part, int B, int C, int64_t V, float smooth, float* loss, float* coef,
+                                 fz_stream_t stream) {
+  if (!part || !loss || !coef) return fail(FZ_E_ARG, "fz_dice_ce_finish: null pointer");
+  if (B < 1 || B > 8 || C < 2 || C > 8) return fail(FZ_E_UNSUPPORTED, "fz_dice_ce_finish: 1 <= B <= 8, 2 <= C <= 8");
+  hipLaunchKernelGGL(dice_ce_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part, fz_dice_bce_chunks(V), B, C,
+                     1.0f / ((float)B * (float)V), smooth, loss, coef);
+  FZ_LAUNCH_CHECK();
+  return FZ_OK;
+}
+
 // coef: (B·C, 2) = {2·inter + smooth, den + smooth};  cd = 1/(B·C), cb = 1/(B·V)
 extern "C" int fz_dice_ce_grad(const float* z, const float* t, const float* coef, float* gz, int B, int C, int64_t V,
                                float cd, float cb, const float* gscale, fz_stream_t stream) {

@@ -417,6 +417,9 @@ int fz_dice_bce_grad(const float* z, const float* t, const float* coef, float* g
  * sums: part (B, fz_dice_bce_chunks(V), 3C+1) = per channel {sum p*t, sum p^2, sum t^2}, then sum CE.
  * grad: gz = gscale * (cd * dDice/dz + cb * (softmax_c * sum_c' t_c' - t_c)), coef (B*C, 2) = {2*inter+s, den+s}. */
 int fz_dice_ce_sums(const float* z, const float* t, float* part, int B, int C, int64_t V, fz_stream_t stream);
+/* loss (1 float) = mean_{b,c}(1 - num/den) + sum(CE)/(B V) and coef (B*C, 2) = {num, den} from the partial sums of
+ * fz_dice_ce_sums, chunks added in a fixed order; B <= 8 (larger batches: reduce `part` with framework ops) */
+int fz_dice_ce_finish(const float* part, int B, int C, int64_t V, float smooth, float* loss, float* coef, fz_stream_t stream);
 int fz_dice_ce_grad(const float* z, const float* t, const float* coef, float* gz, int B, int C, int64_t V,
                     float cd, float cb, const float* gscale, fz_stream_t stream);
 
