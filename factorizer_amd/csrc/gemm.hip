@@ -532,6 +532,53 @@ __global__ __launch_bounds__(256, (NACC == 2 && HB == 2 && !BWD) ? 3 : 2) void g
   }
 }
 
+// Eight K-steps of two of an fp32-MFMA loop as ONE split-bf16 K-step (gemm_bx.hip) for NRB row blocks x NQ column blocks:
+// load_a(rb, a8) = the lane's weights of the eight steps (fp32, from the LDS operand image of the fp32 form, split here),
+// get_x(q, x8) = the column operands of the same steps.  Element e of lane half h of v_mfma_f32_32x32x16_bf16 = step e of the
+// group: any assignment of reduction indices to (half, element) slots is valid as long as both operands use the same one.
+// HOIST splits the column operands once for all row blocks (NQ x NTB x 4 more live registers); without it they are split
+// per row block (the fp32 chain kernels sit at the 256-register limit).
+template <bool HOIST, int NRB, int NQ, int NTA, int NTB, typename FA, typename FX>
+__device__ __forceinline__ void bx_group(f32x16 (&acc)[NRB][NQ], FA load_a, FX get_x) {
+  if constexpr (HOIST) {
+    bx8 bop[NQ][NTB];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      float x8[8];
+      get_x(q, x8);
+      bx_split<NTB>(x8, bop[q]);
+    }
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) {
+      float a8[8];
+      load_a(rb, a8);
+      bx8 aop[NTA];
+      bx_split<NTA>(a8, aop);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) bx_mfma<NTA, NTB>(acc[rb][q], aop, bop[q]);
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      bx8 bop[NTB];
+      {
+        float x8[8];
+        get_x(q, x8);
+        bx_split<NTB>(x8, bop);
+      }
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb) {
+        float a8[8];
+        load_a(rb, a8);
+        bx8 aop[NTA];
+        bx_split<NTA>(a8, aop);
+        bx_mfma<NTA, NTB>(acc[rb][q], aop, bop);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
 // =================================================================================================
 // MLP chain for C = 64, hidden 128 (stage 1 of the README model): the same two chained GEMMs as gemm_chain_kernel,
 // with the hidden tensor produced and consumed in TWO passes of 64 rows — 64 accumulator registers for the pass,
@@ -544,9 +591,13 @@ __global__ __launch_bounds__(256, (NACC == 2 && HB == 2 && !BWD) ? 3 : 2) void g
 // =================================================================================================
 // SINGLE (BWD only): ONE 64 -> 64 input-gradient GEMM (in_proj of a C = 64 block) in front of the same LayerNorm-backward
 // epilogue — fz_gemm with EPI_LNBWD and M = K = 64: the pre-LayerNorm gradient never reaches HBM.
-template <bool BWD, typename AT, bool SINGLE = false>
+// BX: every GEMM of the chain on split-bf16 products — the weights stay fp32 in LDS (64 KB: a pre-split image would be 96 KB
+// and halve the occupancy) and are split per use, the column operands once per group of eight steps.
+template <bool BWD, typename AT, bool SINGLE = false, bool BX = false>
 __global__ __launch_bounds__(256, 2) void gemm_chain64_kernel(GemmArgsT<AT> p, ChainArgsT<AT> c, int ntiles) {
   constexpr int NACC = 2, C = 64, HID = 128;
+  constexpr int NTA = BxTerms<AT>::A, NTB = bx_terms_b<AT>(BXPRO_GELU);
+  constexpr bool HOIST = SINGLE || sizeof(AT) == 2;
   extern __shared__ __attribute__((aligned(16))) float fz_lds_c64[];
   float* As1 = fz_lds_c64;            // [32 steps][4 row blocks][64]
   float* As2 = As1 + 8192;            // [4 x 16 (rb, r) steps][2 row blocks][64]
@@ -656,6 +707,21 @@ __global__ __launch_bounds__(256, 2) void gemm_chain64_kernel(GemmArgsT<AT> p, C
         for (int r = 0; r < 16; ++r) acc2[mb][q][r] = 0.f;
 
     if (SINGLE) {
+      if constexpr (BX) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          bx_group<HOIST, 2, NACC, NTA, NTB>(acc2,
+              [&](int mb, float (&a8)[8]) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a8[e] = As1[((8 * g + e) * 2 + mb) * 64 + lane];
+              },
+              [&](int q, float (&x8)[8]) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x8[e] = bv[8 * g + e][q];
+              });
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
 #pragma unroll
       for (int s = 0; s < 32; ++s) {
 #pragma unroll
@@ -665,6 +731,7 @@ __global__ __launch_bounds__(256, 2) void gemm_chain64_kernel(GemmArgsT<AT> p, C
           for (int q = 0; q < NACC; ++q) acc2[mb][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[s][q], acc2[mb][q], 0, 0, 0);
         }
         if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
       }
       fetch_tile(tile + gridDim.x < ntiles ? tile + gridDim.x : tile);
     }
@@ -678,6 +745,21 @@ __global__ __launch_bounds__(256, 2) void gemm_chain64_kernel(GemmArgsT<AT> p, C
         for (int q = 0; q < NACC; ++q)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc1[rbl][q][r] = 0.f;
+      if constexpr (BX) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          bx_group<HOIST, 2, NACC, NTA, NTB>(acc1,
+              [&](int rbl, float (&a8)[8]) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a8[e] = As1[((8 * g + e) * 4 + 2 * p2 + rbl) * 64 + lane];
+              },
+              [&](int q, float (&x8)[8]) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x8[e] = bv[8 * g + e][q];
+              });
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
 #pragma unroll
       for (int s = 0; s < 32; ++s) {
 #pragma unroll
@@ -687,6 +769,7 @@ __global__ __launch_bounds__(256, 2) void gemm_chain64_kernel(GemmArgsT<AT> p, C
           for (int q = 0; q < NACC; ++q) acc1[rbl][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[s][q], acc1[rbl][q], 0, 0, 0);
         }
         if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
       }
       if (p2 == 1) fetch_tile(tile + gridDim.x < ntiles ? tile + gridDim.x : tile);   // the operand tile is consumed
 
@@ -731,6 +814,21 @@ __global__ __launch_bounds__(256, 2) void gemm_chain64_kernel(GemmArgsT<AT> p, C
       }
 
       // ---- GEMM 2 += (64 result rows) x (these 64 hidden rows), straight from the accumulators ----
+      if constexpr (BX) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {   // steps (rbl, r) = (g >> 1, 8 (g & 1) + e): accumulator registers as the column operand
+          bx_group<HOIST, 2, NACC, NTA, NTB>(acc2,
+              [&](int mb, float (&a8)[8]) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a8[e] = As2[(((2 * p2 + (g >> 1)) * 16 + 8 * (g & 1) + e) * 2 + mb) * 64 + lane];
+              },
+              [&](int q, float (&x8)[8]) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x8[e] = acc1[g >> 1][q][8 * (g & 1) + e];
+              });
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
 #pragma unroll
       for (int rbl = 0; rbl < 2; ++rbl)
 #pragma unroll
@@ -743,6 +841,7 @@ __global__ __launch_bounds__(256, 2) void gemm_chain64_kernel(GemmArgsT<AT> p, C
           }
           if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
+      }
     }
 
     const int64_t sample = (int64_t)b * C * p.Ncol;
@@ -905,7 +1004,7 @@ template <typename AT, int HALVES = 1, int HALF = 0, bool BX = false>
 __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT> p, ChainArgsT<AT> c, int ntiles, float* wpart,
                                                                    float* glp) {
   constexpr int NACC = 2, HB = 2, HID = 64 * HALVES, N1 = BX ? 3072 : 16 * HB * 64;   // floats of each staged weight block
-  constexpr int NTA = BxTerms<AT>::A, NTB = bx_terms_b<AT>(BXPRO_GELU);   // (operands are computed values: full split)
+  constexpr int NTA = BxTerms<AT>::A, NTB = bx_terms_b<AT>(BXPRO_GELU);
   constexpr int half = HALF;
   constexpr int hoff = 64 * HALF;             // first hidden row of this launch
   constexpr bool last = HALF == HALVES - 1;   // this launch ends with the LayerNorm backward
@@ -2116,7 +2215,7 @@ static int gemm_launch(const fz_gemm_desc* d, fz_stream_t stream) {
     ChainArgsT<AT> c = {};
     const int ntiles = (int)fz_mlp_partials(d->B, d->Ncol);
     constexpr int lds64 = (8192 + 8192 + 128 + 64 + 512) * (int)sizeof(float);
-    auto kern = gemm_chain64_kernel<true, AT, true>;
+    auto kern = gemm_bx_enabled() ? gemm_chain64_kernel<true, AT, true, true> : gemm_chain64_kernel<true, AT, true, false>;
     FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds64));
     hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles < 512 ? ntiles : 512)), dim3(256), lds64, st, a, c, ntiles);
     FZ_LAUNCH_CHECK();
@@ -2343,7 +2442,8 @@ static int mlp_launch(const fz_mlp_desc* d, fz_stream_t stream) {
       a.bias = d->b1; a.ln = 1; a.ln_g = d->ln_g; a.ln_b = d->ln_b; a.ln_eps = d->ln_eps; a.stats_out = d->stats;
       a.res = (const AT*)d->in; a.y = (AT*)d->out;
       c.wB = d->w2; c.wB_t = 0; c.ldwB = 128; c.biasB = d->b2; c.side = (AT*)d->z1;
-      auto kern = gemm_chain64_kernel<false, AT>;
+      // split-bf16 products only where the kernel stays inside 256 registers without scratch (fp32 storage: 6 / 23 spilled)
+      auto kern = gemm_bx_enabled() && sizeof(AT) == 2 ? gemm_chain64_kernel<false, AT, false, sizeof(AT) == 2> : gemm_chain64_kernel<false, AT, false, false>;
       FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds64));
       hipLaunchKernelGGL(kern, grid64, dim3(256), lds64, st, a, c, ntiles);
     } else {
@@ -2352,7 +2452,7 @@ static int mlp_launch(const fz_mlp_desc* d, fz_stream_t stream) {
       a.lnb_x = (const AT*)d->x1; a.lnb_stats = d->stats; a.lnb_g = d->ln_g; a.lnb_gadd = (const AT*)d->in; a.lnb_part = d->part;
       c.wB = d->w1; c.wB_t = 1; c.ldwB = 64;           // A2[m = c][k = hidden] = W1[hidden][c]
       c.side = (AT*)d->gz1;
-      auto kern = gemm_chain64_kernel<true, AT>;
+      auto kern = gemm_bx_enabled() && sizeof(AT) == 2 ? gemm_chain64_kernel<true, AT, false, sizeof(AT) == 2> : gemm_chain64_kernel<true, AT, false, false>;
       FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds64));
       hipLaunchKernelGGL(kern, grid64, dim3(256), lds64, st, a, c, ntiles);
     }
