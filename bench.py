@@ -19,6 +19,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -36,6 +37,34 @@ from factorizer_amd.parallel import FlatGradSync  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP32_MFMA_PEAK_TFLOPS = 157.3   # dense fp32 matrix peak, /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32, 256 CUs)
+BF16_MFMA_PEAK_TFLOPS = 16 * FP32_MFMA_PEAK_TFLOPS   # same guide: the fp32 MFMA runs at 1/16 of the dense bf16 rate (~2.5 PFLOP/s)
+
+
+def split_products(name, dtype):
+    """bf16 MFMA products one fp32 product of this launch family is formed from (0 = it runs on v_mfma_f32_32x32x2_f32).
+    fp32 storage: both operands split in three bf16 levels, the six products of weight >= 2^-24 kept (csrc/gemm_bx.h; error
+    <= the fp32 MFMA's own, profiles/r03_bx6_accuracy.json).  bf16 storage: weights two levels, the column operand one (two
+    behind a LayerNorm / GELU prologue): two or three products — three is used."""
+    if os.environ.get("FZ_GEMM_BX", "1") == "0":
+        return 0
+    m = re.search(r"_(\d+)(?:->|x)", name)
+    k = int(m.group(1)) if m else 0
+    if name.startswith(("wgrad_", "conv_k3", "mlp_chain_bwd_wgrad_", "dgrad_lnbwd_64", "conv_k2s2", "tconv_k2s2")):
+        bx = True
+    elif name.startswith(("ln_linear_", "act_linear_res_", "cat_linear_", "linear_dgrad_", "linear_")):
+        bx = k >= 64
+    else:
+        bx = dtype == "bf16" and name.startswith(("mlp_chain_fwd_64", "mlp_chain_bwd_64"))
+    return 0 if not bx else (6 if dtype == "f32" else 3)
+
+
+def mfma_roof_tflops(name, dtype):
+    """matrix-pipe roof of one launch family in fp32-equivalent TFLOP/s: 157.3 on the fp32 MFMA, dense bf16 peak / products
+    per fp32 product on the split-bf16 path (419 TFLOP/s at six products)"""
+    n = split_products(name, dtype)
+    return FP32_MFMA_PEAK_TFLOPS if n == 0 else BF16_MFMA_PEAK_TFLOPS / n
+
+
 # fp32 MFMA flop per ALGORITHMIC byte of the fused kernels whose arithmetic intensity is above the fp32 ridge
 # (157.3 TFLOP/s / 8 TB/s = 19.7 flop/B).  mlp_chain_bwd_wgrad (C = 32, hidden 64): per voxel 2 input-gradient GEMMs
 # + 2 weight-gradient GEMMs of 2*32*64 flop each = 16 384 flop over 5 planes of 32 channels * 4 B = 640 B.
@@ -47,7 +76,7 @@ MFMA_FLOP_PER_BYTE = {"mlp_chain_bwd_wgrad_": 16384 / 640}
 # read from inside the benchmark: the committed summary of the profiled run is quoted, and
 # `traffic_source` says which file (with its content hash and the commit it was measured at), so a stale
 # number is visible as such.
-PMC_TRAFFIC = os.path.join(ROOT, "profiles", os.environ.get("FZ_PMC_TRAFFIC", "r02_pmc_traffic.json"))
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", os.environ.get("FZ_PMC_TRAFFIC", "r03_pmc_traffic.json"))
 # timer key of a BASELINE-size (stage-0) launch -> kernel-name prefix in the PMC summary; the summary averages
 # the launches with the largest grid of each kernel, i.e. the same stage-0 launches the key times
 PMC_KERNEL = {"nmf_cf_bwd_32x128x128x128": "fz::nmf_cf_bwd_tile_kernel<",
@@ -138,19 +167,20 @@ def cpu_baseline_sample():
                       "the README Swin Factorizer on one 128^3 volume (batch 1; the benchmark's per-GPU batch is 2): one "
                       f"warm-up step ({warm:.1f} s) + 2 timed steps ({samples[0]:.1f}, {samples[1]:.1f} s), mean {t:.1f} s, on "
                       f"{torch.get_num_threads()} threads of {os.cpu_count()} host CPUs ({cpu_model}); ATen's CPU kernels stop "
-                      "scaling beyond a few dozen threads at these sizes; full-batch runs: profiles/r02_cpu_baseline.json",
+                      "scaling beyond a few dozen threads at these sizes; full-batch runs: profiles/r02_cpu_baseline.json (round 2, unchanged oracle)",
             "seconds_sample": t, "seconds_warmup": warm, "seconds_timed": samples, "cpu_model": cpu_model,
             "cfg1_nmf_8x512_mu_r2_t5_fwd_us": round(t_cfg1 * 1e6, 1), "host_cpus": os.cpu_count()}
 
 
-def by_stage(table, nsteps, B, stage0_cols):
+def by_stage(table, nsteps, B, stage0_cols, dtype="f32"):
     """Where the step's kernel time is: per stage of the U-shape (a launch belongs to the stage of the finest tensor it
     touches: `cols` = batch x voxels, stage s has stage0_cols / 8^s) the summed launch time of the instrumented warm-up
-    steps, the algorithmic bytes and matrix-core flops of those launches, and both as fractions of the chip's roofs
-    (8 TB/s HBM; 157.3 TFLOP/s fp32 matrix peak — the layers with K >= 64 run their fp32 products as six bf16 products
-    on the bf16 pipe, so their share of the fp32 roof can legitimately pass 1/2.67 of it and is only descriptive).
-    `bound` = the roof whose minimum time for that work is larger.  Side-stream launches overlap the main stream, so the
-    stage times add up to more than the step."""
+    steps, the algorithmic bytes and matrix-core flops of those launches, and the minimum time either roof allows for that
+    work: `hbm_min_ms` at 8 TB/s; `mfma_min_ms` with every launch family priced on the pipe it runs on — 157.3 TFLOP/s for
+    the fp32 MFMA, dense bf16 peak / 6 = 419 TFLOP/s fp32-equivalent for the layers whose fp32 products are six bf16
+    products (`split_products`).  `bound` = the larger of the two, `frac_of_binding_roof` = that minimum / the measured
+    time.  `mfma_frac_of_fp32_peak` (flops / time / 157.3) is kept for comparison with round 2 and can pass 1 for the
+    split-bf16 layers."""
     out = {}
     fam = {}
     for name, a in table.items():
@@ -162,19 +192,24 @@ def by_stage(table, nsteps, B, stage0_cols):
         for k2, dst in ((key, out), ("gemm_family" if a.get("flops", 0) and not name.startswith(("wgrad", "mlp_chain", "dgrad_", "conv_k3")) else None, fam)):
             if k2 is None:
                 continue
-            d = dst.setdefault(k2, {"kernel_ms": 0.0, "GB": 0.0, "GFLOP": 0.0, "launches": 0})
+            d = dst.setdefault(k2, {"kernel_ms": 0.0, "GB": 0.0, "GFLOP": 0.0, "GFLOP_split_bf16": 0.0, "mfma_min_ms": 0.0, "launches": 0})
             d["kernel_ms"] += a["ms"] / nsteps
             d["GB"] += a["bytes"] / nsteps / 1e9
             d["GFLOP"] += a.get("flops", 0) / nsteps / 1e9
+            if split_products(name, dtype):
+                d["GFLOP_split_bf16"] += a.get("flops", 0) / nsteps / 1e9
+            d["mfma_min_ms"] += a.get("flops", 0) / nsteps / 1e9 / mfma_roof_tflops(name, dtype)
             d["launches"] += a["calls"] // max(nsteps, 1)
     for dst in (out, fam):
         for d in dst.values():
             ms = max(d["kernel_ms"], 1e-9)
+            d["hbm_min_ms"] = round(d["GB"] / HBM_PEAK_GBS * 1e3, 3)
             d["hbm_frac"] = round(d["GB"] / ms / HBM_PEAK_GBS * 1e3, 4)
             d["mfma_frac_of_fp32_peak"] = round(d["GFLOP"] / ms / FP32_MFMA_PEAK_TFLOPS, 4)
-            d["bound"] = "mfma" if d["GFLOP"] / FP32_MFMA_PEAK_TFLOPS > d["GB"] / HBM_PEAK_GBS * 1e3 else "hbm"
-            d["frac_of_binding_roof"] = max(d["hbm_frac"], d["mfma_frac_of_fp32_peak"]) if d["bound"] == "mfma" else d["hbm_frac"]
-            for k in ("kernel_ms", "GB", "GFLOP"):
+            d["mfma_frac"] = round(d["mfma_min_ms"] / ms, 4)
+            d["bound"] = "mfma" if d["mfma_min_ms"] > d["hbm_min_ms"] else "hbm"
+            d["frac_of_binding_roof"] = max(d["hbm_frac"], d["mfma_frac"])
+            for k in ("kernel_ms", "GB", "GFLOP", "GFLOP_split_bf16", "mfma_min_ms"):
                 d[k] = round(d[k], 3)
     out.update({"fz_gemm (1x1 layers, k2s2 convolutions: gemm_stream / gemm_bx / gemm_bxk / gemm_resident)": v for v in fam.values()})
     return out
@@ -265,7 +300,7 @@ def main():
 
     torch.manual_seed(0)
     model = ft.Factorizer(**MODEL_KW).to(dev).train()
-    sync = FlatGradSync(model, num_buckets=2, overlap=True, late_wgrad_join=not args.no_late_join,
+    sync = FlatGradSync(model, num_buckets=4, overlap=True, late_wgrad_join=not args.no_late_join,
                         force_collectives=args.force_dist)
     sync.broadcast_state(0)
     # AdamW of the recipe (train.yaml:72-76: lr 1e-4, wd 1e-5) as ONE kernel over the flat parameter /
@@ -354,9 +389,10 @@ def main():
             # which roof binds: the one with the larger minimum time for this launch's algorithmic work
             fpb = next((v for k, v in MFMA_FLOP_PER_BYTE.items() if name.startswith(k)), 0.0)
             tflops = fpb * gbs / 1e3
-            if fpb * HBM_PEAK_GBS / 1e3 > FP32_MFMA_PEAK_TFLOPS:     # arithmetic intensity above the fp32 ridge
-                head = {"bound": "mfma", "kernel": name, "achieved": round(tflops, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(tflops / FP32_MFMA_PEAK_TFLOPS, 4),
+            mpeak = round(mfma_roof_tflops(name, args.dtype), 1)   # the pipe this kernel's products run on
+            if fpb * HBM_PEAK_GBS / 1e3 > mpeak:     # arithmetic intensity above that pipe's ridge
+                head = {"bound": "mfma", "kernel": name, "achieved": round(tflops, 2), "peak": mpeak,
+                        "unit": "TFLOP/s", "frac": round(tflops / mpeak, 4),
                         "flop_per_algorithmic_byte": fpb, "hbm_GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)}
             else:
                 head = {"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
@@ -372,7 +408,7 @@ def main():
                     "native_kernels_ms_per_step": {k: round(v["ms"] / (wsteps if wagg else max(args.steps, 1)), 3) for k, v in (wagg or agg).items()},
                     "native_kernels_GBps": {k: round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 0) for k, v in (wagg or agg).items()},
                     "native_kernels_table_from": "warm-up steps" if wagg else "timed steps",
-                    "by_stage": by_stage(wagg or agg, wsteps if wagg else max(args.steps, 1), B, B * 128 ** 3)}
+                    "by_stage": by_stage(wagg or agg, wsteps if wagg else max(args.steps, 1), B, B * 128 ** 3, args.dtype)}
         out = {
             "metric": "volumes/sec fwd+bwd, Swin Factorizer 128^3",
             "value": round(world * B * args.steps / elapsed, 4),
@@ -385,7 +421,11 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32" if args.dtype == "f32" else "bf16",
-            "dtype_note": ("fp32 throughout (the reference runs amp: false, train.yaml:34)" if args.dtype == "f32" else
+            "dtype_note": ("fp32 storage, fp32 accumulation, fp32-accurate products throughout (the reference runs amp: false, "
+                           "train.yaml:34): layers with a reduction length >= 64 and all weight gradients form each fp32 product "
+                           "from six exact bf16 MFMA products of three-level operand splits — error <= the fp32 MFMA's own, "
+                           "profiles/r03_bx6_accuracy.json, tests/test_gpu_bx.py; FZ_GEMM_BX=0 puts every product back on "
+                           "v_mfma_f32_32x32x2_f32" if args.dtype == "f32" else
                            "torch.autocast(bfloat16): bf16 activation storage; parameters, LayerNorm statistics, MFMA "
                            "accumulation, weight gradients and the NMF iteration (U, V, Gram, eps) fp32"),
             "data": "synthetic",

@@ -122,7 +122,7 @@ class MlpDesc(_c.Structure):
 class GemmDwDesc(_c.Structure):
     _fields_ = [("g", _vp), ("q", _vp), ("w", _vp), ("ln", _i), ("stats", _vp), ("ln_g", _vp), ("ln_b", _vp), ("gadd", _vp),
                 ("y", _vp), ("gln", _vp), ("wpart", _vp), ("gw", _vp), ("gb", _vp), ("B", _i), ("C", _i), ("V", _i64),
-                ("act_dtype", _i)]
+                ("act_dtype", _i), ("ldgw", _i)]
 
 
 class WgradDesc(_c.Structure):

@@ -1721,7 +1721,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_kernel(DwArgsT<AT> p, int ntil
 
 // gw[m][k] = (ln ? γ[k]·S[m][k] + β[k]·sg[m] : S[m][k]),  gb[m] = sg[m] (when wanted); rows added in slice order
 __global__ __launch_bounds__(256) void dw_finish_kernel(const float* wpart, int rows, const float* ln_g, const float* ln_b,
-                                                        float* gw, float* gb, float* gln) {
+                                                        float* gw, float* gb, float* gln, int ldgw) {
   __shared__ float s[16][17];
   __shared__ float sm;
   const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
@@ -1761,7 +1761,7 @@ __global__ __launch_bounds__(256) void dw_finish_kernel(const float* wpart, int 
   if (sl != 0) return;
   if (is_w) {
     const int k = e & 31;
-    gw[e] = ln_g != nullptr ? ln_g[k] * v + ln_b[k] * sm : v;
+    gw[(e >> 5) * ldgw + k] = ln_g != nullptr ? ln_g[k] * v + ln_b[k] * sm : v;
   } else if (e < 1024 + 32) {
     if (gb != nullptr) gb[e - 1024] = v;
   } else if (gln != nullptr) {
@@ -2537,7 +2537,8 @@ static int gemm_dw_launch(const fz_gemm_dw_desc* d, fz_stream_t stream) {
   }
   FZ_LAUNCH_CHECK();
   hipLaunchKernelGGL(dw_finish_kernel, dim3(kDwRow / 16), dim3(256), 0, st, (const float*)d->wpart, rows,
-                     d->ln ? d->ln_g : (const float*)nullptr, d->ln_b, d->gw, d->gb, d->ln ? d->gln : (float*)nullptr);
+                     d->ln ? d->ln_g : (const float*)nullptr, d->ln_b, d->gw, d->gb, d->ln ? d->gln : (float*)nullptr,
+                     d->ldgw > 0 ? d->ldgw : 32);
   FZ_LAUNCH_CHECK();
   return FZ_OK;
 }
@@ -2558,6 +2559,7 @@ extern "C" int fz_gemm_dw(const fz_gemm_dw_desc* d, fz_stream_t stream) {
   if (d->ln && (!d->stats || !d->ln_g || !d->ln_b || !d->gln)) return fail(FZ_E_ARG, "fz_gemm_dw: the LayerNorm form needs stats, gamma, beta, gln");
   if (!d->ln && d->gadd) return fail(FZ_E_UNSUPPORTED, "fz_gemm_dw: gadd only with the LayerNorm backward");
   if (d->C != 32) return fail(FZ_E_UNSUPPORTED, "fz_gemm_dw: needs C == 32");
+  if (d->ldgw != 0 && d->ldgw < 32) return fail(FZ_E_ARG, "fz_gemm_dw: ldgw must be 0 (= 32) or >= 32");
   if (d->B < 1 || d->V < 1 || d->V % 4 != 0 || d->V > ((int64_t)1 << 27)) return fail(FZ_E_UNSUPPORTED, "fz_gemm_dw: needs B >= 1, V % 4 == 0, V <= 2^27");
   if (d->act_dtype == FZ_STORE_F32) return gemm_dw_launch<float>(d, stream);
   if (d->act_dtype == FZ_STORE_BF16) return gemm_dw_launch<bf16>(d, stream);

@@ -8,7 +8,8 @@ train_multigpu.yaml:3-6,27).  The Factorizer has 5.86 M parameters (23.4 MB fp32
 payload is latency-bound, so gradients live in a single flat buffer (p.grad are views into
 it — no gather/scatter copies) and each bucket is reduced by one collective, launched from
 autograd hooks as soon as the bucket's last gradient is produced so that it overlaps the rest
-of the backward pass.
+of the backward pass.  The weight-gradient kernels write straight into the bucket memory (gradbuf.py): only the
+small vectors (biases, LayerNorm parameters) are packed by a multi-tensor copy before a bucket's collective.
 """
 from __future__ import annotations
 
@@ -17,7 +18,7 @@ import torch.distributed as dist
 
 
 class FlatGradSync:
-    def __init__(self, module: torch.nn.Module, process_group=None, num_buckets: int = 2,
+    def __init__(self, module: torch.nn.Module, process_group=None, num_buckets: int = 4,
                  overlap: bool = True, late_wgrad_join: bool = False, force_collectives: bool = False):
         # force_collectives: run the hook-launched all-reduces and finish() even in a one-rank group
         # (bench.py --force-dist: the N = 1 line then executes the same RCCL path as N > 1)
@@ -56,6 +57,10 @@ class FlatGradSync:
                 cur, cur_n, start = [], 0, off
         if cur:
             self.buckets.append({"params": cur, "lo": start, "hi": off})
+        # the weight-gradient launches write straight into the bucket memory (gradbuf.py; a FlatAdamW built on these
+        # views re-registers them once it has moved the parameters into its own flat buffer)
+        from . import gradbuf as _GB
+        _GB.register(self.flat, self.views)
         self._pending = []
         self._ready = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
@@ -88,8 +93,8 @@ class FlatGradSync:
             _PW.wait_wgrad_streams()  # (ownership is checked in finish(), once every gradient is assigned)
         # pack the bucket's gradients into the flat buffer with one multi-tensor copy (autograd
         # produced them as separate tensors: assigning, not accumulating, costs no kernel)
-        ps = [p for p in b["params"] if p.grad is not None]
-        if ps:
+        ps = [p for p in b["params"] if p.grad is not None and p.grad.data_ptr() != self.views[p].data_ptr()]
+        if ps:   # (weight gradients are already in place — gradbuf.py; biases and LayerNorm parameters are packed here)
             torch._foreach_copy_([self.views[p] for p in ps], [p.grad for p in ps])
         missing = [p for p in b["params"] if p.grad is None]
         for p in missing:
@@ -103,6 +108,8 @@ class FlatGradSync:
         launching one accumulate kernel per parameter."""
         for p in self.params:
             p.grad = None
+        from . import gradbuf as _GB
+        _GB.release(self.flat)
         self._ready = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
 

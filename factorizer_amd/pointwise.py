@@ -19,6 +19,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _native as N
+from . import gradbuf as _GB
 from . import functional as Fn
 
 ACT = {"none": 0, "relu": 1, "gelu": 2}
@@ -148,20 +149,22 @@ def _dw_fused_ok(C, V):
     return C == 32 and V % 4 == 0 and V <= (1 << 27) and os.environ.get("FZ_DW_FUSED", "1") != "0"
 
 
-def _gemm_dw(g, w2, q, ln=None, stats=None, gadd=None, want_bias=False, name="dgrad_wgrad"):
+def _gemm_dw(g, w2, q, ln=None, stats=None, gadd=None, want_bias=False, name="dgrad_wgrad", gw_out=None):
     """y = Wᵀ g [→ LayerNorm backward + gadd], gw = Σ_v g ⊗ in, gb = Σ_v g — fz_gemm_dw.  ln = (γ, β) or None.
     Returns (y, gw, gb or None, gγ, gβ) (gγ, gβ None without ln)."""
     B, C = q.shape[:2]
     V = _vox(q)
     dev = q.device
     y = torch.empty_like(q)
-    gw = torch.empty((C, C), dtype=torch.float32, device=dev)
+    # gw_out: a (C, C) column block of a wider weight gradient (row stride = its width), written in place
+    gw = _GB.out_like(w2, (C, C), torch.float32) if gw_out is None else gw_out
     gb = torch.empty(C, dtype=torch.float32, device=dev) if want_bias else None
     wpart = torch.empty(N.lib().fz_gemm_dw_workspace_bytes(B, V) // 4, dtype=torch.float32, device=dev)
     d = N.GemmDwDesc()
     d.g, d.q, d.w, d.y = g.data_ptr(), q.data_ptr(), w2.data_ptr(), y.data_ptr()
     d.wpart, d.gw, d.gb = wpart.data_ptr(), gw.data_ptr(), _p(gb)
     d.B, d.C, d.V, d.act_dtype = B, C, V, N.act_dtype(q)
+    d.ldgw = gw.stride(0)
     gpar = None
     if ln is not None:
         gpar = torch.empty(64, dtype=torch.float32, device=dev)
@@ -244,8 +247,8 @@ def _mlp_bwd_chain_wgrad(g2, z1, w12, w22, x1, st, ln_w, ln_b):
     gx1 = torch.empty_like(x1)
     gpar = torch.empty(64, dtype=torch.float32, device=dev)
     wpart = torch.empty(N.lib().fz_mlp_wgrad_workspace_bytes(B, V) // 4, dtype=torch.float32, device=dev)
-    gw1 = torch.empty((Hd, C), dtype=torch.float32, device=dev)
-    gw2 = torch.empty((C, Hd), dtype=torch.float32, device=dev)
+    gw1 = _GB.out_like(w12, (Hd, C), torch.float32)
+    gw2 = _GB.out_like(w22, (C, Hd), torch.float32)
     gb1 = torch.empty(Hd, dtype=torch.float32, device=dev)
     gb2 = torch.empty(C, dtype=torch.float32, device=dev)
     d = N.MlpDesc()
@@ -394,7 +397,7 @@ class LNLinearFn(torch.autograd.Function):
               bmul_kind=ACT["relu"], name="linear_dgrad")
         gx, ggamma, gbeta = _ln_backward(gl, x, stats, ln_w)
         # weight / bias grads: GW = (gy∘gate) · LN(x)ᵀ with the affine folded in the reduce step
-        gw = torch.empty_like(w2)
+        gw = _GB.out_like(w2)
         gb = torch.empty(M, dtype=torch.float32, device=x.device)
         _wgrad(gy, [x], gw, B=B, M=M, Cin=C, K=C, Vq=V, Ncols=V, gbias=gb, pmul=gate, pmul_kind=ACT["relu"],
                stats=stats, ln=(ln_w, ln_b), name="wgrad_ln_linear")
@@ -429,7 +432,7 @@ class ActLinearResFn(torch.autograd.Function):
         gz = torch.empty_like(z)
         _gemm([gy], w2, gz, B=B, Cin=M, Vin=V, M=C, K=M, Ncol=V, w_t=True, ldw=C,
               emul=(z if ctx.bact != "none" else None), emul_kind=ACT[ctx.bact], name="linear_dgrad")
-        gw = torch.empty_like(w2)
+        gw = _GB.out_like(w2)
         gb = torch.empty(M, dtype=torch.float32, device=z.device)
         _wgrad(gy, [z], gw, B=B, M=M, Cin=C, K=C, Vq=V, Ncols=V, gbias=gb, qact=ACT[ctx.bact], name="wgrad_linear")
         return gz, gw.reshape(ctx.wshape), (gb if ctx.has_bias else None), (gy if ctx.has_res else None), None
@@ -463,14 +466,15 @@ class CatLinearFn(torch.autograd.Function):
         if M == 32 and C1 == 32 and C2 == 32 and _dw_fused_ok(M, V):
             # full-resolution adapter (64 -> 32): each half is a 32 -> 32 layer — input gradient and weight gradient of a
             # half in one pass (gy is read twice instead of three times, x1 / x2 once instead of twice)
-            g1, gwa, gb, _, _ = _gemm_dw(gy, w2[:, :C1].contiguous(), x1, want_bias=ctx.has_bias, name="dgrad_wgrad")
-            g2, gwb, _, _, _ = _gemm_dw(gy, w2[:, C1:].contiguous(), x2, name="dgrad_wgrad")
-            return g1, g2, torch.cat([gwa, gwb], 1).reshape(ctx.wshape), gb
+            gw = _GB.out_like(w2)
+            g1, _, gb, _, _ = _gemm_dw(gy, w2[:, :C1].contiguous(), x1, want_bias=ctx.has_bias, name="dgrad_wgrad", gw_out=gw[:, :C1])
+            g2, _, _, _, _ = _gemm_dw(gy, w2[:, C1:].contiguous(), x2, name="dgrad_wgrad", gw_out=gw[:, C1:])
+            return g1, g2, gw.reshape(ctx.wshape), gb
         g1 = torch.empty_like(x1)
         g2 = torch.empty_like(x2)
         _gemm([gy], w2, g1, B=B, Cin=M, Vin=V, M=C1, K=M, Ncol=V, w_t=True, ldw=C, name="linear_dgrad")
         _gemm([gy], w2[:, C1:], g2, B=B, Cin=M, Vin=V, M=C2, K=M, Ncol=V, w_t=True, ldw=C, name="linear_dgrad")
-        gw = torch.empty_like(w2)
+        gw = _GB.out_like(w2)
         gb = torch.empty(M, dtype=torch.float32, device=gy.device)
         _wgrad(gy, [x1, x2], gw, B=B, M=M, Cin=C, K=C, Vq=V, Ncols=V, gbias=gb, c0=C1, name="wgrad_cat_linear")
         return g1, g2, gw.reshape(ctx.wshape), (gb if ctx.has_bias else None)
@@ -546,7 +550,7 @@ class ConvK2S2Fn(torch.autograd.Function):
             # rows (ci, tap), reduction over o:  A[m][k] = w[k*(8C) + m]
             _gemm([gy], w, gx, B=B, Cin=O, Vin=Vc, M=8 * C, K=O, Ncol=Vc, w_t=True, ldw=8 * C,
                   epilogue=EPI_D2S, Ho=Ho, Wo=Wo, res=g_skip, name="conv_k2s2_dgrad")
-        gw = torch.empty_like(w)
+        gw = _GB.out_like(w)
         gb = torch.empty(O, dtype=torch.float32, device=x.device)
         _wgrad(gy, [x], gw, B=B, M=O, Cin=C, K=8 * C, Vq=D * H * W, Ncols=Vc, gbias=gb, loader=LOAD_S2D,
                D=D, H=H, W=W, Ho=Ho, Wo=Wo, name="wgrad_conv_k2s2")
@@ -600,7 +604,7 @@ class TConvK2S2Fn(torch.autograd.Function):
             # GX[ci, coarse] = Σ_{o,tap} w[ci, o, tap] · GY[o, fine]: a k2s2 "conv" of gy with w as [C][8O]
             _gemm([gy], w, gx, B=B, Cin=O, Vin=8 * V, M=C, K=8 * O, Ncol=V, loader=LOAD_S2D,
                   Di=2 * D, Hi=2 * H, Wi=2 * W, Ho=H, Wo=W, name="tconv_k2s2_dgrad")
-        gw = torch.empty_like(w)
+        gw = _GB.out_like(w)
         # GW[ci][(o,tap)] = Σ X[ci][n] · GY[o][fine(n,tap)]
         _wgrad(x, [gy], gw, B=B, M=C, Cin=O, K=8 * O, Vq=8 * V, Ncols=V, loader=LOAD_S2D, D=2 * D, H=2 * H,
                W=2 * W, Ho=H, Wo=W, name="wgrad_tconv_k2s2")
@@ -659,7 +663,7 @@ class ConvK3Fn(torch.autograd.Function):
             else:
                 _warn_composed("Conv3d(k=3) input gradient", x)
                 gx = torch.nn.grad.conv3d_input(x.shape, w, gy, padding=1)
-        gw = torch.empty_like(w)
+        gw = _GB.out_like(w)
         gb = torch.empty(O, dtype=torch.float32, device=x.device)
         if W % 32 == 0 and 27 * C <= 128:
             lib = N.lib()
@@ -842,12 +846,12 @@ class FactorizerBlockFn(torch.autograd.Function):
                 gz1 = torch.empty_like(z1)
                 _gemm([g2], w22, gz1, B=B, Cin=C, Vin=V, M=Hd, K=C, Ncol=V, w_t=True, ldw=Hd, emul=z1,
                       emul_kind=ACT["gelu"], name="linear_dgrad")
-            gw2 = torch.empty_like(w22)
+            gw2 = _GB.out_like(w22)
             gb2 = torch.empty(C, dtype=torch.float32, device=dev)
             wgrad(g2, [z1], gw2, B=B, M=C, Cin=Hd, K=Hd, Vq=V, Ncols=V, gbias=gb2, qact=ACT["gelu"], name="wgrad_linear")
             if not chain:
                 gx1, gg2, gbt2 = _dgrad_lnbwd(gz1, w12, x1, st2, n2w, g2)      # + residual path of the MLP
-            gw1 = torch.empty_like(w12)
+            gw1 = _GB.out_like(w12)
             gb1 = torch.empty(Hd, dtype=torch.float32, device=dev)
             wgrad(gz1, [x1], gw1, B=B, M=Hd, Cin=C, K=C, Vq=V, Ncols=V, gbias=gb1, stats=st2, ln=(n2w, n2b),
                    name="wgrad_ln_linear")
@@ -859,7 +863,7 @@ class FactorizerBlockFn(torch.autograd.Function):
         else:
             ga = torch.empty_like(a)
             _gemm([gx1], wout2, ga, B=B, Cin=C, Vin=V, M=C, K=C, Ncol=V, w_t=True, ldw=C, name="linear_dgrad")
-            gwo = torch.empty_like(wout2)
+            gwo = _GB.out_like(wout2)
             gbo = torch.empty(C, dtype=torch.float32, device=dev)
             wgrad(gx1, [a], gwo, B=B, M=C, Cin=C, K=C, Vq=V, Ncols=V, gbias=gbo, name="wgrad_linear")
         # --- core (gradient arrives gated by [t > 0]) ---
@@ -882,7 +886,7 @@ class FactorizerBlockFn(torch.autograd.Function):
             gx, gwi, _, gg1, gbt1 = _gemm_dw(gt, win2, x, ln=(n1w, n1b), stats=st1, gadd=gx1, name="dgrad_lnbwd_wgrad")
         else:
             gx, gg1, gbt1 = _dgrad_lnbwd(gt, win2, x, st1, n1w, gx1)        # + residual path of the mixer
-            gwi = torch.empty_like(win2)
+            gwi = _GB.out_like(win2)
             wgrad(gt, [x], gwi, B=B, M=C, Cin=C, K=C, Vq=V, Ncols=V, stats=st1, ln=(n1w, n1b), name="wgrad_ln_linear")
         if side is not None:
             if _LateJoin.enabled:

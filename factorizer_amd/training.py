@@ -19,6 +19,7 @@ from typing import Any, Dict, Iterable
 import torch
 
 from . import _native as N
+from . import gradbuf as _GB
 
 FLAT_ALIGN = 4  # floats: every parameter starts on a 16-byte boundary of the flat buffers (float4 kernels, 32-byte weight reads)
 
@@ -72,6 +73,8 @@ class FlatAdamW:
                 self.offsets[p] = off
                 off += flat_align(n)
         self.order = order
+        # the weight-gradient launches write straight into flat_grad (gradbuf.py): no packing copy in step()
+        _GB.register(self.flat_grad, self.grad_views)
         self.lr, self.betas, self.eps, self.weight_decay = float(lr), tuple(betas), float(eps), float(weight_decay)
         self.base_lr = float(lr)
         self.steps = {p: 0 for p in self.params}     # per-parameter step counts, as torch keeps them
@@ -103,6 +106,7 @@ class FlatAdamW:
     def zero_grad(self, set_to_none: bool = True):
         for p in self.params:
             p.grad = None
+        _GB.release(self.flat_grad)
 
     def _update(self, lo, hi, t, grad_scale):
         b1, b2 = self.betas

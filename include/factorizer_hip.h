@@ -295,11 +295,12 @@ typedef struct fz_gemm_dw_desc {
   void* y;             /* activation (B, 32, V)                                               */
   float* gln;          /* ln: (64) dgamma | dbeta                                             */
   void* wpart;
-  float* gw;           /* (32, 32)                                                            */
+  float* gw;           /* (32, 32), row stride ldgw                                           */
   float* gb;           /* (32) or NULL                                                        */
   int B, C;
   int64_t V;
   int act_dtype;
+  int ldgw;            /* floats between rows of gw; 0 = 32 (a column block of a wider weight gradient: its width) */
 } fz_gemm_dw_desc;
 int fz_gemm_dw_rows(int B, int64_t V);
 int64_t fz_gemm_dw_workspace_bytes(int B, int64_t V);

@@ -492,6 +492,60 @@ def test_flat_adamw_skipped_parameter_subranges_are_aligned():
             assert torch.allclose(d.detach().cpu(), r.detach(), rtol=1e-6, atol=1e-7), (use_sync, i)
 
 
+def test_weight_gradients_land_in_the_flat_buffer():
+    """With a FlatAdamW / FlatGradSync attached, every weight-gradient launch writes into its parameter's slice of the flat
+    gradient buffer (factorizer_amd/gradbuf.py): after backward p.grad of every matrix / convolution weight IS that slice (no
+    packing copy), the values equal the unattached run's bit for bit, a second backward without zero_grad accumulates
+    (torch semantics), and the optimizer step equals the one taken from separately allocated gradients."""
+    from factorizer_amd import gradbuf
+    from factorizer_amd.parallel import FlatGradSync
+    kw = dict(in_channels=4, out_channels=3, spatial_size=(32, 32, 32), encoder_depth=(1, 1, 1), encoder_width=(32, 64, 128),
+              strides=(1, 2, 2), decoder_depth=(1, 1), norm=ft.LayerNorm, reshape=(ft.SWMatricize, {"head_dim": 8, "patch_size": 8}),
+              act=torch.nn.ReLU, factorize=ft.NMF, rank=1, num_iters=5, init="uniform", solver="hals", mlp_ratio=2, dropout=0.0)
+    torch.manual_seed(0)
+    ref = ft.Factorizer(**kw).to(DEV)
+    x = torch.rand(2, 4, 32, 32, 32, device=DEV)
+    t = (torch.rand(2, 3, 32, 32, 32, device=DEV) > 0.5).float()
+    ft.dice_ce_loss(ref(x), t).backward()
+    g_ref = {n: p.grad.clone() for n, p in ref.named_parameters()}
+    for with_sync in (False, True):
+        torch.manual_seed(0)
+        model = ft.Factorizer(**kw).to(DEV)
+        if with_sync:
+            sync = FlatGradSync(model, overlap=False)
+            assert len(sync.buckets) >= 4
+            opt = ft.FlatAdamW(model, lr=1e-3, flat_grad=sync.flat, grad_views=sync.views)
+        else:
+            opt = ft.FlatAdamW(model, lr=1e-3)
+        opt.zero_grad()
+        ft.dice_ce_loss(model(x), t).backward()
+        in_place = 0
+        for n, p in model.named_parameters():
+            assert torch.equal(p.grad, g_ref[n]), n
+            if p.grad.data_ptr() == opt.grad_views[p].data_ptr():
+                in_place += p.numel()
+            else:
+                # (biases, LayerNorm parameters and the position embeddings — a batch sum formed by the framework — are packed)
+                assert p.ndim == 1 or n.endswith("pos_embed.pos"), f"{n}: a weight gradient was produced outside the flat buffer"
+        weights = sum(p.numel() for n, p in model.named_parameters() if p.ndim > 1 and not n.endswith("pos_embed.pos"))
+        assert in_place >= weights > 0.5 * sum(p.numel() for p in model.parameters()), (in_place, weights)
+        ft.dice_ce_loss(model(x), t).backward()          # no zero_grad: accumulate
+        for n, p in model.named_parameters():
+            assert torch.allclose(p.grad, 2 * g_ref[n], rtol=1e-6, atol=1e-9), n
+            assert p.ndim == 1 or n.endswith("pos_embed.pos") or p.grad.data_ptr() == opt.grad_views[p].data_ptr(), n
+        opt.zero_grad()
+        ft.dice_ce_loss(model(x), t).backward()
+        opt.step()
+        o_ref = torch.optim.AdamW(ref.parameters(), lr=1e-3)
+        o_ref.step()
+        for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+            assert torch.allclose(p, q, rtol=1e-6, atol=1e-7), n
+        torch.manual_seed(0)                             # a fresh reference for the second variant
+        ref = ft.Factorizer(**kw).to(DEV)
+        ft.dice_ce_loss(ref(x), t).backward()
+        gradbuf.unregister(opt.flat_grad)
+
+
 @pytest.mark.parametrize("M,K,S", [(64, 64, (16, 16, 16)), (128, 64, (8, 8, 16)), (64, 128, (8, 16, 16)), (32, 64, (16, 16, 16)),
                                    (3, 32, (8, 8, 12))])
 def test_wgrad_split_bf16_mode(M, K, S):
