@@ -212,29 +212,35 @@ __global__ __launch_bounds__(64 * NW) void ln_bwd_split_kernel(const AT* __restr
 }
 
 // Channel-sliced backward with compile-time slices (C = 8·CS: the 64..512-channel stages).
-// 8 waves per workgroup, wave w owns channels [w·CS, (w+1)·CS), lanes = 64 consecutive voxel quads.
+// 8 waves per workgroup, wave w owns channels [w·CS, (w+1)·CS).  SUB = 1: lanes = 64 consecutive voxel quads.
+// SUB = 4 (the deep stages: a few thousand voxels): lanes = 16 voxel quads x 4 channel sub-slices of CS / 4 channels, so
+// the grid is 4x larger (stage 4 of the README model at B = 2: 16 workgroups instead of 4, 16 channels per lane instead
+// of 64 — one batch of loads instead of sixteen dependent ones) and the slice fits the registers up to C = 512.
 // All loads of a pass are issued before the first use (no per-channel dependent round trips), the
 // optional added gradient and the affine partials are template flags (no branches in the loops),
-// and for CS <= 16 the slice stays in registers between the two passes (each tensor is read once).
-template <int CS, bool GADD, bool PART, typename AT>
+// and for <= 16 channels per lane the slice stays in registers between the two passes (each tensor is read once).
+template <int CS, bool GADD, bool PART, typename AT, int SUB = 1>
 __global__ __launch_bounds__(512) void ln_bwd_slice_kernel(const AT* __restrict__ gl, const AT* __restrict__ x,
                                                            const float* __restrict__ stats,
                                                            const float* __restrict__ g,
                                                            const AT* __restrict__ gadd, AT* __restrict__ gx,
                                                            float* __restrict__ part, int B, int64_t V) {
   constexpr int NW = 8, C = NW * CS;
-  constexpr bool KEEP = CS <= 16;
-  constexpr int U = KEEP ? CS : 8;  // channels per batch of loads
+  constexpr int QW = 64 / SUB;        // voxel quads per workgroup
+  constexpr int CL = CS / SUB;        // channels per lane
+  constexpr bool KEEP = CL <= 16;
+  constexpr int U = KEEP ? CL : 8;    // channels per batch of loads
   __shared__ float red[NW][8][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ql = lane & (QW - 1), sub = lane / QW;
   const int64_t nvec = V / 4;
   const int64_t total = nvec * B;
-  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+  const int64_t i = (int64_t)blockIdx.x * QW + ql;
   const bool ok = i < total;
   const int64_t ii = ok ? i : 0;
   const int b = (int)(ii / nvec);
   const int64_t v = (ii % nvec) * 4;
-  const int c0 = wave * CS;
+  const int c0 = wave * CS + sub * CL;
   const int64_t base = ((int64_t)b * C + c0) * V + v;
   const float* sp = stats + (int64_t)b * 2 * V + v;
   const float4 mu = *reinterpret_cast<const float4*>(sp);
@@ -242,7 +248,7 @@ __global__ __launch_bounds__(512) void ln_bwd_slice_kernel(const AT* __restrict_
   float m[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float4 t[U], d[U];
 #pragma unroll 1
-  for (int cb = 0; cb < CS; cb += U) {
+  for (int cb = 0; cb < CL; cb += U) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       t[u] = ld4(x + base + (int64_t)(cb + u) * V);
@@ -258,14 +264,30 @@ __global__ __launch_bounds__(512) void ln_bwd_slice_kernel(const AT* __restrict_
       m[0] += ax; m[1] += ay; m[2] += az; m[3] += aw;
       m[4] += ax * t[u].x; m[5] += ay * t[u].y; m[6] += az * t[u].z; m[7] += aw * t[u].w;
       if (PART) {
-        const float sg = wave_sum(ok ? (d[u].x * t[u].x + d[u].y * t[u].y) + (d[u].z * t[u].z + d[u].w * t[u].w) : 0.f);
-        const float sb = wave_sum(ok ? (d[u].x + d[u].y) + (d[u].z + d[u].w) : 0.f);
-        if (lane == 0) {
+        float sg = ok ? (d[u].x * t[u].x + d[u].y * t[u].y) + (d[u].z * t[u].z + d[u].w * t[u].w) : 0.f;
+        float sb = ok ? (d[u].x + d[u].y) + (d[u].z + d[u].w) : 0.f;
+        if (SUB == 1) {
+          sg = wave_sum(sg);
+          sb = wave_sum(sb);
+        } else {   // the QW lanes of this channel sub-slice
+#pragma unroll
+          for (int o = 1; o < QW; o <<= 1) {
+            sg += __shfl_xor(sg, o, 64);
+            sb += __shfl_xor(sb, o, 64);
+          }
+        }
+        if (ql == 0) {
           part[(int64_t)blockIdx.x * 2 * C + c0 + cb + u] = sg;
           part[(int64_t)blockIdx.x * 2 * C + C + c0 + cb + u] = sb;
         }
       }
     }
+  }
+  if (SUB > 1) {   // the sub-slices of one voxel quad sit QW lanes apart
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+      for (int o = QW; o < 64; o <<= 1) m[e] += __shfl_xor(m[e], o, 64);
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) red[wave][e][lane] = m[e];
@@ -279,14 +301,39 @@ __global__ __launch_bounds__(512) void ln_bwd_slice_kernel(const AT* __restrict_
     for (int w = 0; w < NW; ++w) acc += red[w][e][lane];
     mm[e] = acc * inv;
   }
-#pragma unroll 1
-  for (int cb = 0; cb < CS; cb += U) {
-    float4 r[GADD ? U : 1];
-    if (GADD) {
+  auto finish = [&](int cb, int u, const float4& rr) {
+    const float gc = g[c0 + cb + u];
+    float4 o;
+    o.x = rs.x * (d[u].x * gc - mm[0] - t[u].x * mm[4]);
+    o.y = rs.y * (d[u].y * gc - mm[1] - t[u].y * mm[5]);
+    o.z = rs.z * (d[u].z * gc - mm[2] - t[u].z * mm[6]);
+    o.w = rs.w * (d[u].w * gc - mm[3] - t[u].w * mm[7]);
+    if (GADD) { o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w; }
+    if (ok) st4(gx + base + (int64_t)(cb + u) * V, o);
+  };
+  if constexpr (KEEP) {
+    // the slice is in registers (one batch: cb = 0); the added gradient arrives in batches of <= 8 channels (16 more
+    // float4 next to the 32 of a 16-channel slice would not fit 256 registers)
+    constexpr int U2 = (GADD && CL > 8) ? 8 : CL;
 #pragma unroll
-      for (int u = 0; u < U; ++u) r[GADD ? u : 0] = ld4(gadd + base + (int64_t)(cb + u) * V);
+    for (int hb = 0; hb < CL; hb += U2) {
+      float4 r[GADD ? U2 : 1];
+      if (GADD) {
+#pragma unroll
+        for (int u = 0; u < U2; ++u) r[GADD ? u : 0] = ld4(gadd + base + (int64_t)(hb + u) * V);
+      }
+#pragma unroll
+      for (int u = 0; u < U2; ++u) finish(0, hb + u, r[GADD ? u : 0]);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (!KEEP) {
+  } else {
+#pragma unroll 1
+    for (int cb = 0; cb < CL; cb += U) {
+      float4 r[GADD ? U : 1];
+      if (GADD) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) r[GADD ? u : 0] = ld4(gadd + base + (int64_t)(cb + u) * V);
+      }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         t[u] = ld4(x + base + (int64_t)(cb + u) * V);
@@ -297,20 +344,8 @@ __global__ __launch_bounds__(512) void ln_bwd_slice_kernel(const AT* __restrict_
         t[u].x = (t[u].x - mu.x) * rs.x; t[u].y = (t[u].y - mu.y) * rs.y;
         t[u].z = (t[u].z - mu.z) * rs.z; t[u].w = (t[u].w - mu.w) * rs.w;
       }
-    }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const float gc = g[c0 + cb + u];
-      float4 o;
-      o.x = rs.x * (d[u].x * gc - mm[0] - t[u].x * mm[4]);
-      o.y = rs.y * (d[u].y * gc - mm[1] - t[u].y * mm[5]);
-      o.z = rs.z * (d[u].z * gc - mm[2] - t[u].z * mm[6]);
-      o.w = rs.w * (d[u].w * gc - mm[3] - t[u].w * mm[7]);
-      if (GADD) {
-        const float4 rr = r[GADD ? u : 0];
-        o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
-      }
-      if (ok) st4(gx + base + (int64_t)(cb + u) * V, o);
+      for (int u = 0; u < U; ++u) finish(cb, u, r[GADD ? u : 0]);
     }
   }
 }
@@ -392,8 +427,10 @@ extern "C" int fz_ln_fwd(const void* x, const float* gamma, const float* beta, v
 //   gparams[0..C) = gγ, gparams[C..2C) = gβ ; workspace must hold fz_ln_bwd_workspace_bytes().
 // workspace: per-workgroup partial rows (C <= 64: <= 1024 rows; wider: one row per 64 quads) + 64
 // rows of scratch for the two-stage reduce
+static bool ln_slice_sub4(int64_t quads) { return (quads + 63) / 64 < 512; }
 extern "C" int64_t fz_ln_bwd_workspace_bytes2(int B, int C, int64_t V) {
-  const int64_t wide = ((V / 4) * B + 63) / 64;
+  const int64_t quads = (V / 4) * B;
+  const int64_t wide = ln_slice_sub4(quads) ? (quads + 15) / 16 : (quads + 63) / 64;
   const int64_t rows = C < 64 ? 1024 : (wide > 1024 ? wide : 1024);  // C >= 64: one row per 64 quads
   return (rows + 64) * 2 * C * 4;
 }
@@ -415,9 +452,14 @@ static int ln_bwd_launch(const void* gl_, const void* x_, const float* stats, co
     if (e) slice = atoi(e);
     if (slice && (C == 64 || C == 128 || C == 256 || C == 512)) {
       const int64_t quads = (V / 4) * B;
-      const unsigned gq = (unsigned)((quads + 63) / 64);
+      const bool sub4 = ln_slice_sub4(quads);   // fewer than 512 workgroups of 64 quads: 16 quads x 4 channel sub-slices each
+      const unsigned gq = (unsigned)(sub4 ? (quads + 15) / 16 : (quads + 63) / 64);
       float* part = gparams ? (float*)workspace : nullptr;
-#define FZ_LNS(CS, GA, PA) hipLaunchKernelGGL((ln_bwd_slice_kernel<CS, GA, PA, AT>), dim3(gq), dim3(512), 0, st, gl, x, stats, gamma, gadd, gx, part, B, V)
+#define FZ_LNS(CS, GA, PA)                                                                                                       \
+  do {                                                                                                                           \
+    if (sub4) hipLaunchKernelGGL((ln_bwd_slice_kernel<CS, GA, PA, AT, 4>), dim3(gq), dim3(512), 0, st, gl, x, stats, gamma, gadd, gx, part, B, V); \
+    else hipLaunchKernelGGL((ln_bwd_slice_kernel<CS, GA, PA, AT, 1>), dim3(gq), dim3(512), 0, st, gl, x, stats, gamma, gadd, gx, part, B, V);      \
+  } while (0)
 #define FZ_LNS_F(CS)                                                                       \
   do {                                                                                     \
     if (gadd) { if (part) FZ_LNS(CS, true, true); else FZ_LNS(CS, true, false); }          \
