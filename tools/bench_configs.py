@@ -160,7 +160,38 @@ def cfg5(batches=(1, 2, 4), dtypes=("bf16", "f32")):
         del x, t
 
 
+def wide():
+    """The reference test config's global matricize (tests/test_factorizer.py: Matricize(num_heads=1, grid_size=1)) at
+    16 channels x 64^3 voxels: ONE 16 x 262144 matrix, MU rank 1, 5 iterations — the split-N kernels (csrc/gnmf.hip).
+    Per-call medians (one event pair per call) of forward and forward + backward."""
+    torch.manual_seed(0)
+    nmf = ft.NMF(size=(16, 64 ** 3), rank=1, num_iters=5, init="uniform", solver="mu").to(DEV)
+    td = torch.rand(1, 1, 16, 64 ** 3, device=DEV, requires_grad=True)
+    gm = torch.rand_like(td)
+
+    def med(fn, n=30):
+        for _ in range(5):
+            fn()
+        ev = []
+        for _ in range(n):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            fn()
+            e.record()
+            ev.append((s, e))
+        torch.cuda.synchronize()
+        ts = sorted(s.elapsed_time(e) for s, e in ev)
+        return ts[len(ts) // 2], ts[-1]
+    with torch.no_grad():
+        f, fmax = med(lambda: nmf(td))
+    fb, fbmax = med(lambda: torch.autograd.grad(nmf(td), td, gm))
+    nbytes = td.numel() * 4
+    print(json.dumps({"config": "wide NMF 16 x 262144 (global matricize, MU R1 T5), one matrix", "fwd_ms": round(f, 3),
+                      "fwd_bwd_ms": round(fb, 3), "fwd_max_ms": round(fmax, 3), "fwd_bwd_max_ms": round(fbmax, 3),
+                      "fwd_kernel_traffic_GBps": round((2 * 5 + 2) * nbytes / (f * 1e-3) / 1e9, 1)}))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["cfg1", "cfg2", "cfg3", "prod"]
+    which = sys.argv[1:] or ["cfg1", "cfg2", "cfg3", "prod", "wide"]
     for name in which:
-        {"cfg1": cfg1, "cfg2": cfg2, "cfg3": cfg3, "prod": prod, "cfg5": cfg5}[name]()
+        {"cfg1": cfg1, "cfg2": cfg2, "cfg3": cfg3, "prod": prod, "cfg5": cfg5, "wide": wide}[name]()

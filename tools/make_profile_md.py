@@ -1,5 +1,5 @@
 """Assemble profiles/<name>.md from a rocprofv3 kernel-trace/stats run, the PMC summary and a bench line.
-usage: python tools/make_profile_md.py <prof_dir/prefix> <pmc.json> <bench.json> <title> <notes> [<tag>] > profiles/xxx.md
+usage: python tools/make_profile_md.py <prof_dir/prefix> <pmc_traffic.json> <bench.json> <title> <notes> [<tag>] > profiles/xxx.md
 (<tag> = prefix of the sibling files named in the footer, default r02_p2)"""
 import collections
 import csv
@@ -39,19 +39,20 @@ def main():
                f"box): {b['value']} {b['unit']}, {b['ms_per_step']} ms/step; dominant kernel `{r['kernel']}`: avg launch "
                f"{r['avg_launch_ms'] * 1e3:.1f} us, {r['algorithmic_bytes_per_launch'] / 1e9:.3f} GB algorithmic per launch, {head}.\n")
     out.append("## HBM traffic per launch from PMC counters (separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes, "
-               "FETCH_SIZE x2 per the gfx950 correction; `tools/pmc_traffic.py` -> `profiles/r02_pmc_traffic.json`; stage-0 launches)\n")
+               "FETCH_SIZE x2 per the gfx950 correction; `tools/pmc_traffic.py` -> `profiles/" + tag.split("_")[0] + "_pmc_traffic.json`; stage-0 launches)\n")
     out.append("| kernel | fetch (corrected) MB | write MB | traffic MB | algorithmic MB |\n|---|---|---|---|---|")
     alg = {"fz::nmf_cf_bwd_tile_kernel<1, 1, 4, false, float>": (3.5 * 536.87, " (avg over the 2 windows)"),
            "fz::nmf_cf_fwd_tile_kernel<1, 1, 8, false, float>": (2.5 * 536.87, " (avg over the 2 windows)"),
            "fz::gemm_chain_kernel<true, 2, 2, float>": (7 * 536.87, ""), "fz::gemm_chain_kernel<false, 2, 2, float>": (4 * 536.87, ""),
            "fz::gemm_chain_bwd_wg_kernel<float>": (5 * 536.87, " (+ 537: g2 is read a second time for the residual)"),
+           "fz::gemm_chain_bwd_wg_kernel<float, 1, 0, true>": (5 * 536.87, " (+ 537: g2 is read a second time for the residual)"),
            "fz::gemm_dw_kernel<true, float>": (4 * 536.87, ""), "fz::gemm_dw_kernel<false, float>": (3 * 536.87, "")}
     for k, (a, note) in alg.items():
         if k in pmc:
             v = pmc[k]
             out.append(f"| `{k}` | {v['fetch_bytes_corrected'] / 1e6:.0f} | {v['write_bytes'] / 1e6:.0f} | "
                        f"{v['traffic_bytes'] / 1e6:.0f} | {a:.0f}{note} |")
-    out.append(f"\nFull bench line of that run: `profiles/r02_bench_n1.json`; SQ counters (VALU / MFMA / LDS / wait shares) of the same "
+    out.append(f"\nFull bench line of that run: `profiles/" + tag.split("_")[0] + "_bench_n1.json`; SQ counters (VALU / MFMA / LDS / wait shares) of the same "
                f"command: `profiles/{tag}_pmc_sq.md`.\n")
     print("\n".join(out))
 
