@@ -2153,6 +2153,18 @@ using namespace fz;
 
 // process-wide switch of the split-bf16 MFMA family: FZ_GEMM_BX (read once) unless fz_gemm_bx_enable() set it
 static std::atomic<int> g_bx_on{-1};
+// Diagnostic environment knobs are read ONCE per process and validated (> 0): the row count that sizes a caller's
+// workspace and the grid of the launch that fills it can then never disagree, and an empty / zero value cannot produce
+// a zero-sized grid.
+static int env_pos_once(const char* name, int dflt) {
+  const char* e = getenv(name);
+  const int v = e ? atoi(e) : 0;
+  return v > 0 ? v : dflt;
+}
+static int knob_mlp_wg_wgs() { static const int v = env_pos_once("FZ_MLP_WG_WGS", 512); return v; }
+static int knob_gemm_dw_wgs() { static const int v = env_pos_once("FZ_GEMM_DW_WGS", 512); return v; }
+static int knob_mlp_wgs(int dflt) { static const int v = env_pos_once("FZ_MLP_WGS", 0); return v > 0 ? v : dflt; }
+
 static int gemm_bx_enabled() {
   int v = g_bx_on.load(std::memory_order_relaxed);
   if (v < 0) {
@@ -2388,8 +2400,7 @@ extern "C" int64_t fz_mlp_partials(int B, int64_t V) {
 // rows of `wpart` (fz_mlp_desc mode 2): one per resident workgroup (two per CU), kWgRow floats each
 extern "C" int fz_mlp_wgrad_rows(int B, int64_t V) {
   const int64_t nt = fz_mlp_partials(B, V);
-  int wgs = 512;
-  { const char* e = getenv("FZ_MLP_WG_WGS"); if (e && atoi(e) > 0) wgs = atoi(e); }
+  const int wgs = knob_mlp_wg_wgs();
   return (int)(nt < wgs ? nt : wgs);
 }
 extern "C" int64_t fz_mlp_wgrad_workspace_bytes(int B, int64_t V) {
@@ -2433,8 +2444,7 @@ static int mlp_launch(const fz_mlp_desc* d, fz_stream_t stream) {
   if (d->C == 64) {
     if (d->mode == 1 && !d->in) return fail(FZ_E_ARG, "fz_mlp_chain: null pointer");
     a.x[0] = (const AT*)d->in; a.nsrc = 1; a.c0 = 64; a.Cin = 64; a.Vin = d->V; a.M = 128; a.K = 64; a.Ncol = d->V; a.B = d->B;
-    int wgs64 = 512;
-    { const char* e = getenv("FZ_MLP_WGS"); if (e) wgs64 = atoi(e); }
+    const int wgs64 = knob_mlp_wgs(512);
     dim3 grid64((unsigned)(ntiles < wgs64 ? ntiles : wgs64));
     constexpr int lds64 = (8192 + 8192 + 128 + 64 + 512) * (int)sizeof(float);
     if (d->mode == 0) {
@@ -2459,8 +2469,7 @@ static int mlp_launch(const fz_mlp_desc* d, fz_stream_t stream) {
     FZ_LAUNCH_CHECK();
     return FZ_OK;
   }
-  int wgs = d->H == 128 ? 512 : 768;  // resident workgroups (2 or 3 per CU), each walking tiles with a stride of the grid
-  { const char* e = getenv("FZ_MLP_WGS"); if (e) wgs = atoi(e); }
+  const int wgs = knob_mlp_wgs(d->H == 128 ? 512 : 768);  // resident workgroups (2 or 3 per CU), each walking tiles with a stride of the grid
   dim3 grid((unsigned)(ntiles < wgs ? ntiles : wgs)), block(256);
   if (d->mode == 0) {
     a.w = d->w1; a.w_t = 0; a.ldw = 32;              // A1[m][k] = W1[m][k]
@@ -2545,8 +2554,7 @@ static int gemm_dw_launch(const fz_gemm_dw_desc* d, fz_stream_t stream) {
 
 extern "C" int fz_gemm_dw_rows(int B, int64_t V) {
   const int64_t nt = fz_mlp_partials(B, V);
-  int wgs = 512;
-  { const char* e = getenv("FZ_GEMM_DW_WGS"); if (e && atoi(e) > 0) wgs = atoi(e); }
+  const int wgs = knob_gemm_dw_wgs();
   return (int)(nt < wgs ? nt : wgs);
 }
 extern "C" int64_t fz_gemm_dw_workspace_bytes(int B, int64_t V) {

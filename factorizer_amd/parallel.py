@@ -106,6 +106,8 @@ class FlatGradSync:
     def zero_grad(self):
         """Gradients are dropped (set to None), so the backward pass ASSIGNS fresh tensors instead of
         launching one accumulate kernel per parameter."""
+        from . import pointwise as _PW
+        _PW.reset_late_join()
         for p in self.params:
             p.grad = None
         from . import gradbuf as _GB
@@ -117,7 +119,12 @@ class FlatGradSync:
         """Call after backward(): launches the buckets whose hooks did not all fire (a parameter that took
         no part in the loss never fires its hook: its slice of the flat buffer is zero-filled and reduced
         like the rest, as DistributedDataParallel(find_unused_parameters=True) does), waits for the
-        collectives and averages.  `average=False` leaves the SUM in the buffer and returns the factor
+        collectives and averages.  The set of unused parameters must be the SAME on every rank (as for a static graph
+        under DDP): a bucket is launched from a hook on the ranks where all its parameters were used and from here on the
+        others, and collectives must be issued in one order everywhere.  A parameter unused on EVERY rank still receives
+        a zero gradient here (weight decay and a step count under FlatAdamW at N > 1, where a single rank would skip
+        it): freeze such parameters (`requires_grad_(False)`) instead of leaving them unused.
+        `average=False` leaves the SUM in the buffer and returns the factor
         1/world for the optimizer to apply (`FlatAdamW.step(grad_scale=...)`: no extra pass)."""
         if self.late_join:
             from . import pointwise as _PW

@@ -308,6 +308,19 @@ def _end_of_backward():
     join_wgrad_streams()
 
 
+def reset_late_join():
+    """Start of a new step (the owners' zero_grad): meet the side streams and drop whatever a FAILED backward left
+    behind — an engine callback that was queued but never ran (the engine drops it when backward() raises) would leave
+    `queued` set and no later backward would re-queue the end-of-backward join; stale `owed` entries would raise a
+    spurious ownership error at the next join."""
+    d = _LateJoin
+    if d.devices:
+        wait_wgrad_streams()
+    d.owed.clear()
+    d.keep.clear()
+    d.queued = False
+
+
 def late_wgrad_join(flag: bool = True):
     if not flag:
         join_wgrad_streams()

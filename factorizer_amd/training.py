@@ -75,8 +75,10 @@ class FlatAdamW:
         self.order = order
         # the weight-gradient launches write straight into flat_grad (gradbuf.py): no packing copy in step()
         _GB.register(self.flat_grad, self.grad_views)
-        self.lr, self.betas, self.eps, self.weight_decay = float(lr), tuple(betas), float(eps), float(weight_decay)
-        self.base_lr = float(lr)
+        # ONE persistent torch-style group: schedulers and utilities written against torch optimizers read AND write
+        # it (g["lr"] = ...); lr / betas / eps / weight_decay / base_lr of this object are views of it
+        self._group = {"lr": float(lr), "initial_lr": float(lr), "betas": tuple(betas), "eps": float(eps),
+                       "weight_decay": float(weight_decay), "amsgrad": False, "params": self.all_params}
         self.steps = {p: 0 for p in self.params}     # per-parameter step counts, as torch keeps them
 
     @property
@@ -99,11 +101,19 @@ class FlatAdamW:
 
     @property
     def param_groups(self):
-        """Read-only torch-style view (lr schedulers written against torch optimizers read it)."""
-        return [{"lr": self.lr, "initial_lr": self.base_lr, "betas": self.betas, "eps": self.eps,
-                 "weight_decay": self.weight_decay, "amsgrad": False, "params": self.all_params}]
+        """torch-style groups: one persistent dict (writes to it — a scheduler's g["lr"] = ... — take effect)."""
+        return [self._group]
+
+    lr = property(lambda self: float(self._group["lr"]), lambda self, v: self._group.__setitem__("lr", float(v)))
+    base_lr = property(lambda self: float(self._group["initial_lr"]), lambda self, v: self._group.__setitem__("initial_lr", float(v)))
+    betas = property(lambda self: tuple(self._group["betas"]), lambda self, v: self._group.__setitem__("betas", tuple(v)))
+    eps = property(lambda self: float(self._group["eps"]), lambda self, v: self._group.__setitem__("eps", float(v)))
+    weight_decay = property(lambda self: float(self._group["weight_decay"]),
+                            lambda self, v: self._group.__setitem__("weight_decay", float(v)))
 
     def zero_grad(self, set_to_none: bool = True):
+        from . import pointwise as _PW
+        _PW.reset_late_join()
         for p in self.params:
             p.grad = None
         _GB.release(self.flat_grad)
@@ -188,6 +198,11 @@ class FlatAdamW:
             raise ValueError(f"FlatAdamW.load_state_dict: checkpoint has {len(ids)} parameters, optimizer has "
                              f"{len(self.all_params)}")
         g0 = groups[0]
+        for g in groups[1:]:   # one fused launch = one set of hyperparameters
+            for k in ("lr", "betas", "eps", "weight_decay"):
+                if k in g and k in g0 and (tuple(g[k]) if k == "betas" else float(g[k])) != (tuple(g0[k]) if k == "betas" else float(g0[k])):
+                    raise ValueError(f"FlatAdamW.load_state_dict: param_groups differ in {k!r}: per-group hyperparameters "
+                                     "are not supported")
         self.lr = float(g0["lr"])
         self.base_lr = float(g0.get("initial_lr", self.base_lr))
         self.betas, self.eps = tuple(g0.get("betas", self.betas)), float(g0.get("eps", self.eps))

@@ -381,6 +381,39 @@ def test_optimizer_and_scheduler_checkpoint_interchange_with_torch():
     assert abs(o_2.param_groups[0]["lr"] - o_t.param_groups[0]["lr"]) < 1e-15
 
 
+def test_flat_adamw_param_groups_are_persistent_and_single():
+    """Utilities written against torch optimizers WRITE param_groups (g["lr"] = ...): the group is one persistent dict
+    whose hyperparameters are the optimizer's own; a checkpoint with per-group hyperparameters is refused instead of
+    being loaded with the first group's."""
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7))]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt = ft.FlatAdamW(ps, lr=1e-2, weight_decay=1e-2)
+    o_ref = torch.optim.AdamW(ref, lr=1e-2, weight_decay=1e-2)
+    assert opt.param_groups[0] is opt.param_groups[0]
+    for o in (opt, o_ref):
+        for g in o.param_groups:
+            g["lr"] = 3e-3
+            g["weight_decay"] = 0.5
+    assert opt.lr == 3e-3 and opt.weight_decay == 0.5
+    opt.lr = 2e-3
+    assert opt.param_groups[0]["lr"] == 2e-3
+    o_ref.param_groups[0]["lr"] = 2e-3
+    for p, r in zip(ps, ref):
+        g = torch.randn_like(p)
+        p.grad, r.grad = g.clone(), g.clone()
+    opt.step()
+    o_ref.step()
+    for p, r in zip(ps, ref):
+        assert torch.allclose(p, r, rtol=1e-6, atol=1e-7)
+    two = torch.optim.AdamW([{"params": [ref[0]], "lr": 1e-3}, {"params": [ref[1]], "lr": 5e-4}])
+    with pytest.raises(ValueError, match="param_groups differ"):
+        opt.load_state_dict(two.state_dict())
+    same = torch.optim.AdamW([{"params": [ref[0]]}, {"params": [ref[1]]}], lr=1e-3)
+    opt.load_state_dict(same.state_dict())
+    assert opt.lr == 1e-3
+
+
 def test_flat_adamw_skips_parameters_without_gradient():
     """torch.optim.AdamW leaves a parameter whose .grad is None untouched (no decay, no step count)."""
     import copy
