@@ -579,6 +579,33 @@ __device__ __forceinline__ void bx_group(f32x16 (&acc)[NRB][NQ], FA load_a, FX g
   }
 }
 
+// The same group with the row operands PRE-SPLIT in LDS (load_term(rb, t) = level t of the row operand, one ds_read_b128):
+// no weight split on the VALU; the levels are fetched one at a time — a_0 (b_0 + b_1 + b_2), a_1 (b_0 + b_1), a_2 b_0, small
+// products first within a level — so only four operand registers are live next to the split column operand.
+template <int NRB, int NQ, int NTB, typename FA, typename FX>
+__device__ __forceinline__ void bx_group_ps(f32x16 (&acc)[NRB][NQ], FA load_term, FX get_x) {
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    bx8 bop[NTB];
+    {
+      float x8[8];
+      get_x(q, x8);
+      bx_split<NTB>(x8, bop);
+    }
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) {
+#pragma unroll
+      for (int t = 2; t >= 0; --t) {
+        const bx8 a = load_term(rb, t);
+#pragma unroll
+        for (int jj = NTB - 1; jj >= 0; --jj)
+          if (t + jj <= 2) acc[rb][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bop[jj], acc[rb][q], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);   // (keeps the operand reads of the next row block from being hoisted: registers)
+    }
+  }
+}
+
 // =================================================================================================
 // MLP chain for C = 64, hidden 128 (stage 1 of the README model): the same two chained GEMMs as gemm_chain_kernel,
 // with the hidden tensor produced and consumed in TWO passes of 64 rows — 64 accumulator registers for the pass,
@@ -593,22 +620,69 @@ __device__ __forceinline__ void bx_group(f32x16 (&acc)[NRB][NQ], FA load_a, FX g
 // epilogue — fz_gemm with EPI_LNBWD and M = K = 64: the pre-LayerNorm gradient never reaches HBM.
 // BX: every GEMM of the chain on split-bf16 products — the weights stay fp32 in LDS (64 KB: a pre-split image would be 96 KB
 // and halve the occupancy) and are split per use, the column operands once per group of eight steps.
-template <bool BWD, typename AT, bool SINGLE = false, bool BX = false>
-__global__ __launch_bounds__(256, 2) void gemm_chain64_kernel(GemmArgsT<AT> p, ChainArgsT<AT> c, int ntiles) {
+// P512 (fp32 storage, BX, not SINGLE): the fp32-weight form above does not fit 256 registers once the operand splits are
+// added (6 / 23 spilled), so the split-bf16 chain runs as ONE workgroup of 512 threads per CU — two independent 4-wave
+// halves, each walking its own tiles — sharing a PRE-SPLIT weight image (bf16x8 triples in operand order: 2 x 48 KB):
+// same two waves per SIMD, no weight splits on the VALU, 3 ds_read_b128 per row operand instead of 8 ds_read_b32.
+template <bool BWD, typename AT, bool SINGLE = false, bool BX = false, bool P512 = false>
+__global__ __launch_bounds__(P512 ? 512 : 256, 2) void gemm_chain64_kernel(GemmArgsT<AT> p, ChainArgsT<AT> c, int ntiles) {
   constexpr int NACC = 2, C = 64, HID = 128;
   constexpr int NTA = BxTerms<AT>::A, NTB = bx_terms_b<AT>(BXPRO_GELU);
   constexpr bool HOIST = SINGLE || sizeof(AT) == 2;
+  static_assert(!P512 || (BX && !SINGLE && sizeof(AT) == 4), "P512: the fp32-storage split-bf16 chain");
+  constexpr int NA = P512 ? 12288 : 8192;   // floats of one weight image (P512: [16 (group, row block)][3 terms][64 lanes] x 16 B)
   extern __shared__ __attribute__((aligned(16))) float fz_lds_c64[];
   float* As1 = fz_lds_c64;            // [32 steps][4 row blocks][64]
-  float* As2 = As1 + 8192;            // [4 x 16 (rb, r) steps][2 row blocks][64]
-  float* tW = As2 + 8192;             // [128]
+  float* As2 = As1 + NA;              // [4 x 16 (rb, r) steps][2 row blocks][64]
+  float* tW = As2 + NA;               // [128]
   float* tB = tW + 128;               // [64]
-  float* red = tB + 64;               // [4][128]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = P512 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;   // P512: which 4-wave half of the workgroup (wave-uniform)
+  float* red = tB + 64 + half * 512;  // [4][128] per half
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6) & 3);
   const int j = lane & 31, h = lane >> 5;
   const int tiles_per_sample = (int)((p.Ncol + 128 * NACC - 1) / (128 * NACC));
+  // P512 operand reads: ONE opaque per-lane base per image + compile-time element offsets (ds_read_b128 immediates; left
+  // to itself the optimiser materialises a loop-invariant VGPR address per (slot, level) — 40 of them — and spills)
+  // P512 operand reads: one OPAQUE per-lane float index per image + compile-time slot offsets (ds_read_b128 immediates are
+  // 16 bits: the second image starts at 48 KB, and left to itself the optimiser keeps one loop-invariant VGPR address for
+  // every slot beyond 64 KB — 32 of them — and spills)
+  int lane4 = lane * 4, lane4b = lane * 4 + NA;
+  if constexpr (P512) {
+    asm volatile("" : "+v"(lane4));
+    asm volatile("" : "+v"(lane4b));
+  }
+  auto ld_a1 = [&](int slot3) { return *reinterpret_cast<const bx8*>(As1 + slot3 * 256 + lane4); };
+  auto ld_a2 = [&](int slot3) { return *reinterpret_cast<const bx8*>(As1 + slot3 * 256 + lane4b); };
 
-  for (int base = threadIdx.x; base < (SINGLE ? 4096 : 16384); base += 256 * 8) {
+  if constexpr (P512) {
+    // item = (image, slot [16], lane): eight weights -> three bf16 levels -> three 16-byte stores
+    for (int item = threadIdx.x; item < 2048; item += 512) {
+      const int l = item & 63, slot = (item >> 6) & 15, img = item >> 10;
+      float a8[8];
+      if (img == 0) {        // slot = g*4 + rb: A1[m = rb*32 + (l & 31)][k = 2 (8g + e) + (l >> 5)]
+        const int g = slot >> 2, rb = slot & 3;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int k = 2 * (8 * g + e) + (l >> 5);
+          a8[e] = weight_at(p, rb * 32 + (l & 31), k);
+          if (!BWD) a8[e] *= p.ln_g[k];
+        }
+      } else {               // slot = (rb4*2 + g8)*2 + mb: A2[m = mb*32 + (l & 31)][k = rb4*32 + row(r = 8 g8 + e) + 4 (l >> 5)]
+        const int mb = slot & 1, g8 = (slot >> 1) & 1, rb4 = slot >> 2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int r = 8 * g8 + e;
+          const int k = rb4 * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), m = mb * 32 + (l & 31);
+          a8[e] = c.wB_t ? c.wB[(int64_t)k * c.ldwB + m] : c.wB[(int64_t)m * c.ldwB + k];
+        }
+      }
+      bx8 t3[3];
+      bx_split<3>(a8, t3);
+      bx8* dst = reinterpret_cast<bx8*>(img == 0 ? As1 : As2) + (slot * 3) * 64 + l;
+      dst[0] = t3[0]; dst[64] = t3[1]; dst[128] = t3[2];
+    }
+  }
+  for (int base = threadIdx.x; !P512 && base < (SINGLE ? 4096 : 16384); base += 256 * 8) {
     float tmp[8];
 #pragma unroll
     for (int uu = 0; uu < 8; ++uu) {
@@ -645,7 +719,10 @@ __global__ __launch_bounds__(256, 2) void gemm_chain64_kernel(GemmArgsT<AT> p, C
     }
   }
 
-  int tile = blockIdx.x;
+  // P512: the halves take tiles 2 i and 2 i + 1 (ntiles is even — host-checked — so both run the same number of rounds
+  // and meet at the same barriers)
+  const int tstep = P512 ? 2 * (int)gridDim.x : (int)gridDim.x;
+  int tile = P512 ? 2 * (int)blockIdx.x + half : (int)blockIdx.x;
   float bv[32][NACC];
   auto fetch_tile = [&](int t) {
     const int bt = t / tiles_per_sample;
@@ -658,7 +735,7 @@ __global__ __launch_bounds__(256, 2) void gemm_chain64_kernel(GemmArgsT<AT> p, C
   fetch_tile(tile);
   __syncthreads();
 
-  for (; tile < ntiles; tile += gridDim.x) {
+  for (; tile < ntiles; tile += tstep) {
     asm volatile("" ::: "memory");
     const int b = tile / tiles_per_sample;
     const int64_t col_off = ((int64_t)(tile % tiles_per_sample) * 4 + wave) * (32 * NACC) + NACC * j;
@@ -733,7 +810,7 @@ __global__ __launch_bounds__(256, 2) void gemm_chain64_kernel(GemmArgsT<AT> p, C
         if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
       }
-      fetch_tile(tile + gridDim.x < ntiles ? tile + gridDim.x : tile);
+      fetch_tile(tile + tstep < ntiles ? tile + tstep : tile);
     }
 #pragma unroll
     for (int p2 = 0; p2 < (SINGLE ? 0 : 2); ++p2) {
@@ -748,6 +825,14 @@ __global__ __launch_bounds__(256, 2) void gemm_chain64_kernel(GemmArgsT<AT> p, C
       if constexpr (BX) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+          if constexpr (P512)
+            bx_group_ps<2, NACC, NTB>(acc1,
+                [&](int rbl, int t) { return ld_a1((g * 4 + 2 * p2 + rbl) * 3 + t); },
+                [&](int q, float (&x8)[8]) {
+#pragma unroll
+                  for (int e = 0; e < 8; ++e) x8[e] = bv[8 * g + e][q];
+                });
+          else
           bx_group<HOIST, 2, NACC, NTA, NTB>(acc1,
               [&](int rbl, float (&a8)[8]) {
 #pragma unroll
@@ -771,7 +856,7 @@ __global__ __launch_bounds__(256, 2) void gemm_chain64_kernel(GemmArgsT<AT> p, C
         if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
       }
-      if (p2 == 1) fetch_tile(tile + gridDim.x < ntiles ? tile + gridDim.x : tile);   // the operand tile is consumed
+      if (p2 == 1) fetch_tile(tile + tstep < ntiles ? tile + tstep : tile);   // the operand tile is consumed
 
       // ---- hidden rows: transform in registers, copy to HBM for the other pass ----
       if (!BWD) {
@@ -817,6 +902,14 @@ __global__ __launch_bounds__(256, 2) void gemm_chain64_kernel(GemmArgsT<AT> p, C
       if constexpr (BX) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {   // steps (rbl, r) = (g >> 1, 8 (g & 1) + e): accumulator registers as the column operand
+          if constexpr (P512)
+            bx_group_ps<2, NACC, NTB>(acc2,
+                [&](int mb, int t) { return ld_a2((((2 * p2 + (g >> 1)) * 2 + (g & 1)) * 2 + mb) * 3 + t); },
+                [&](int q, float (&x8)[8]) {
+#pragma unroll
+                  for (int e = 0; e < 8; ++e) x8[e] = acc1[g >> 1][q][8 * (g & 1) + e];
+                });
+          else
           bx_group<HOIST, 2, NACC, NTA, NTB>(acc2,
               [&](int mb, float (&a8)[8]) {
 #pragma unroll
@@ -931,8 +1024,8 @@ __global__ __launch_bounds__(256, 2) void gemm_chain64_kernel(GemmArgsT<AT> p, C
         __builtin_amdgcn_sched_barrier(0);
       }
       __syncthreads();
-      if (threadIdx.x < 128) {
-        const int e = threadIdx.x;
+      if ((threadIdx.x & 255) < 128) {
+        const int e = threadIdx.x & 255;
         p.lnb_part[(int64_t)tile * 128 + e] = (red[e] + red[128 + e]) + (red[256 + e] + red[384 + e]);
       }
       __syncthreads();
@@ -2163,6 +2256,7 @@ static int env_pos_once(const char* name, int dflt) {
 }
 static int knob_mlp_wg_wgs() { static const int v = env_pos_once("FZ_MLP_WG_WGS", 512); return v; }
 static int knob_gemm_dw_wgs() { static const int v = env_pos_once("FZ_GEMM_DW_WGS", 512); return v; }
+static int knob_chain64_p512() { static const int v = env_pos_once("FZ_CHAIN64_P512", 1); return v == 1; }   // 2 = off (diagnostics)
 static int knob_mlp_wgs(int dflt) { static const int v = env_pos_once("FZ_MLP_WGS", 0); return v > 0 ? v : dflt; }
 
 static int gemm_bx_enabled() {
@@ -2447,12 +2541,23 @@ static int mlp_launch(const fz_mlp_desc* d, fz_stream_t stream) {
     const int wgs64 = knob_mlp_wgs(512);
     dim3 grid64((unsigned)(ntiles < wgs64 ? ntiles : wgs64));
     constexpr int lds64 = (8192 + 8192 + 128 + 64 + 512) * (int)sizeof(float);
+    // fp32 storage with split-bf16 products: one 512-thread workgroup per CU around a pre-split weight image
+    constexpr int lds512 = (12288 + 12288 + 128 + 64 + 1024) * (int)sizeof(float);
+    const bool p512 = sizeof(AT) == 4 && gemm_bx_enabled() && ntiles % 2 == 0 && knob_chain64_p512();
+    dim3 grid512((unsigned)(ntiles / 2 < 256 ? ntiles / 2 : 256));
     if (d->mode == 0) {
       a.w = d->w1; a.w_t = 0; a.ldw = 64;
       a.bias = d->b1; a.ln = 1; a.ln_g = d->ln_g; a.ln_b = d->ln_b; a.ln_eps = d->ln_eps; a.stats_out = d->stats;
       a.res = (const AT*)d->in; a.y = (AT*)d->out;
       c.wB = d->w2; c.wB_t = 0; c.ldwB = 128; c.biasB = d->b2; c.side = (AT*)d->z1;
       // split-bf16 products only where the kernel stays inside 256 registers without scratch (fp32 storage: 6 / 23 spilled)
+      if (p512) {
+        auto kern = gemm_chain64_kernel<false, AT, false, true, sizeof(AT) == 4>;
+        FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds512));
+        hipLaunchKernelGGL(kern, grid512, dim3(512), lds512, st, a, c, ntiles);
+        FZ_LAUNCH_CHECK();
+        return FZ_OK;
+      }
       auto kern = gemm_bx_enabled() && sizeof(AT) == 2 ? gemm_chain64_kernel<false, AT, false, sizeof(AT) == 2> : gemm_chain64_kernel<false, AT, false, false>;
       FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds64));
       hipLaunchKernelGGL(kern, grid64, dim3(256), lds64, st, a, c, ntiles);
@@ -2462,6 +2567,13 @@ static int mlp_launch(const fz_mlp_desc* d, fz_stream_t stream) {
       a.lnb_x = (const AT*)d->x1; a.lnb_stats = d->stats; a.lnb_g = d->ln_g; a.lnb_gadd = (const AT*)d->in; a.lnb_part = d->part;
       c.wB = d->w1; c.wB_t = 1; c.ldwB = 64;           // A2[m = c][k = hidden] = W1[hidden][c]
       c.side = (AT*)d->gz1;
+      if (p512) {
+        auto kern = gemm_chain64_kernel<true, AT, false, true, sizeof(AT) == 4>;
+        FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds512));
+        hipLaunchKernelGGL(kern, grid512, dim3(512), lds512, st, a, c, ntiles);
+        FZ_LAUNCH_CHECK();
+        return FZ_OK;
+      }
       auto kern = gemm_bx_enabled() && sizeof(AT) == 2 ? gemm_chain64_kernel<true, AT, false, sizeof(AT) == 2> : gemm_chain64_kernel<true, AT, false, false>;
       FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds64));
       hipLaunchKernelGGL(kern, grid64, dim3(256), lds64, st, a, c, ntiles);
