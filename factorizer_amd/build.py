@@ -21,7 +21,11 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
 # gemm.hip: the SLP vectorizer pairs accumulator elements of DIFFERENT MFMA tiles for v_pk_* math,
 # which needs register-to-register copies of whole accumulator tiles (adjacent VGPRs hold the same
 # column group, not the same row) — +64..128 VGPRs and scratch spills in the fused epilogues.
-PER_FILE_FLAGS = {"gemm.hip": ["-fno-slp-vectorize"]}
+# -fno-slp-vectorize: the SLP vectorizer pairs elements of different MFMA tiles (gemm.hip) and, in the NMF wave programs, forms
+# v_pk_fma_f32 / v_pk_mul_f32 pairs whose 64-bit register alignment costs more v_mov than the packing saves: the rank-2 HALS
+# backward of the generic-patch core went from 234 to 154 VGPRs and 43.9 -> 38.3 ms per cfg-5 step without it (round 3)
+_NO_SLP = ["-fno-slp-vectorize"]
+PER_FILE_FLAGS = {"gemm.hip": _NO_SLP, "nmf_pcf.hip": _NO_SLP, "nmf_cf.hip": _NO_SLP}
 
 
 def _hipcc() -> str:
