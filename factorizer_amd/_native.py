@@ -12,7 +12,8 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfactorizer_hip.so")
+# FZ_LIB_PATH: diagnostics only (A/B of two builds of this library on one box, tools/probes/build_alt.py)
+LIB_PATH = os.environ.get("FZ_LIB_PATH") or os.path.join(_HERE, "libfactorizer_hip.so")
 
 FZ_OK = 0
 FZ_E_UNSUPPORTED = -2
