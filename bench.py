@@ -386,6 +386,8 @@ def main():
             avg_ms = a["ms"] / a["calls"]
             gbs = a["bytes"] / a["calls"] / (avg_ms * 1e-3) / 1e9
             traffic, traffic_source = pmc_traffic(name)
+            if args.dtype != "f32":   # the committed counter passes are of the fp32 (headline) command
+                traffic, traffic_source = None, traffic_source + " (fp32 command: not applicable to this bf16 line)"
             # which roof binds: the one with the larger minimum time for this launch's algorithmic work
             fpb = next((v for k, v in MFMA_FLOP_PER_BYTE.items() if name.startswith(k)), 0.0)
             tflops = fpb * gbs / 1e3
