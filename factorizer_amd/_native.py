@@ -167,6 +167,7 @@ _SIGS.update({
     "fz_mlp_wgrad_workspace_bytes": ([_i, _i64], _i64),
     "fz_mlp_chain": ([_c.POINTER(MlpDesc), _vp], _i),
     "fz_wgrad": ([_c.POINTER(WgradDesc), _vp, _vp], _i),
+    "fz_wgrad_group": ([_c.POINTER(_c.POINTER(WgradDesc)), _c.POINTER(_vp), _i, _vp], _i),
     "fz_wgrad_workspace_bytes": ([_c.POINTER(WgradDesc)], _i64),
     "fz_conv3_fwd": ([_vp] * 4 + [_i] * 7 + [_vp], _i),
     "fz_conv3_wgrad_chunks": ([_i] * 4, _i),

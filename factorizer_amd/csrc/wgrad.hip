@@ -355,185 +355,63 @@ constexpr int kStrideF = 36;
 // is the default (fz_gemm_bx_enable(0) returns to v_mfma_f32_32x32x2_f32).
 // The k index of an MFMA operand element is (lane half, element): ANY assignment of voxels to it is
 // valid as long as both operands use the same one — half h, element e <-> voxel 16·t + 8·h + e of K-step t.
+// (the body lives in wgrad_fast_body.inc so that wgrad_fast_group_kernel can run several problems in one grid)
+template <int MBP, int MBQ, int QPRO, int BF, typename AT>
+__device__ __forceinline__ void wgrad_fast_body(const WgradArgsT<AT>& a, float* lds, const int bx, const int by, const int bz) {
+#define WG_BX bx
+#define WG_BY by
+#define WG_BZ bz
+#include "wgrad_fast_body.inc"
+#undef WG_BX
+#undef WG_BY
+#undef WG_BZ
+}
+
 template <int MBP, int MBQ, int QPRO, int BF = 0, typename AT = float>
 __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(WgradArgsT<AT> a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int PR = 32 * MBP, QR = 32 * MBQ;
-  constexpr int NP = PR / 8, NQ = QR / 8;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* Pt = lds + wave * (PR + QR) * kStrideF;
-  float* Qt = Pt + PR * kStrideF;
-  const int m0 = blockIdx.y * PR;
-  const int k0 = blockIdx.z * QR;
-  const int64_t tiles_per_sample = a.N / kTile;
-  const int64_t total_tiles = tiles_per_sample * a.B;
-  const int64_t unit = (int64_t)blockIdx.x * 4 + wave;
-  const int64_t t_begin = unit * a.tiles_per_chunk;
-  const int64_t t_end = min(t_begin + a.tiles_per_chunk, total_tiles);
+#define WG_BX blockIdx.x
+#define WG_BY blockIdx.y
+#define WG_BZ blockIdx.z
+#include "wgrad_fast_body.inc"
+#undef WG_BX
+#undef WG_BY
+#undef WG_BZ
+}
 
-  f32x16 acc[MBP][MBQ];
-#pragma unroll
-  for (int i = 0; i < MBP; ++i)
-#pragma unroll
-    for (int jq = 0; jq < MBQ; ++jq)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][jq][r] = 0.f;
-  float psum[MBP];
-#pragma unroll
-  for (int i = 0; i < MBP; ++i) psum[i] = 0.f;
+// Several weight-gradient problems of ONE layer block in one grid: the four dense layers of a FactorizerBlock at
+// C >= 64 (fc2, fc1 behind LayerNorm, out_proj, in_proj behind LayerNorm) each fill one workgroup per CU for 20-80 us;
+// launched back to back they leave the second resident workgroup slot of every CU empty and pay four launch
+// boundaries.  A workgroup finds its problem from a prefix table (wave-uniform) and runs the unchanged body on that
+// problem's descriptor; partial blocks, the order of every sum and the finish launches are those of the single
+// launches — bitwise the same gradients.
+constexpr int kWgGroupMax = 4;
+template <typename AT>
+struct WgradGroupT {
+  WgradArgsT<AT> a[kWgGroupMax];
+  int start[kWgGroupMax + 1];   // first workgroup of each problem
+  int gx[kWgGroupMax], gy[kWgGroupMax];
+  int qpro[kWgGroupMax];
+  int n;
+};
 
-  const int c = lane & 31, h = lane >> 5;
-  const int cq = lane & 7, r0 = lane >> 3;
-  const unsigned lane_p = (unsigned)r0 * (unsigned)a.N + (unsigned)(cq * 4);
-  const unsigned lane_q = (unsigned)r0 * (unsigned)a.Vq + (unsigned)(cq * 4);
-  float4 pv[NP], qv[NQ], mu4, rs4;
-
-  auto issue_loads = [&](int64_t t) {
-    const int b = (int)(t / tiles_per_sample);
-    const int64_t n0 = (t % tiles_per_sample) * kTile;
-    const AT* pb = a.p + ((int64_t)b * a.M + m0) * a.N + n0;  // uniform
+template <int MBP, int MBQ, int BF, typename AT>
+__global__ __launch_bounds__(256, 2) void wgrad_fast_group_kernel(WgradGroupT<AT> g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int i = 0;
 #pragma unroll
-    for (int i = 0; i < NP; ++i) pv[i] = ld4(pb + (int64_t)(8 * i) * a.N + lane_p);
-#pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-      const int k = k0 + 8 * i;  // first row of this chunk group: uniform (c0 is a multiple of 8)
-      const bool first = k < a.c0;
-      const AT* base = first ? a.q[0] : a.q[1];
-      const int cs = first ? a.c0 : a.Cin - a.c0;
-      const int ci = first ? k : k - a.c0;
-      qv[i] = ld4(base + ((int64_t)b * cs + ci) * a.Vq + n0 + lane_q);
-    }
-    if (QPRO == QP_STATS) {
-      const float* st = a.stats + (int64_t)b * 2 * a.Vq + n0 + cq * 4;
-      mu4 = *reinterpret_cast<const float4*>(st);
-      rs4 = *reinterpret_cast<const float4*>(st + a.Vq);
-    }
-  };
-
-  if (t_begin < t_end) issue_loads(t_begin);
-  for (int64_t t = t_begin; t < t_end; ++t) {
-    // ---- registers -> LDS (16-byte stores) ----
-#pragma unroll
-    for (int i = 0; i < NP; ++i) *reinterpret_cast<float4*>(Pt + (r0 + 8 * i) * kStrideF + cq * 4) = pv[i];
-#pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-      float4 v = qv[i];
-      if (QPRO == QP_STATS) {
-        v.x = (v.x - mu4.x) * rs4.x; v.y = (v.y - mu4.y) * rs4.y; v.z = (v.z - mu4.z) * rs4.z; v.w = (v.w - mu4.w) * rs4.w;
-      } else if (QPRO == QP_GELU) {
-        v.x = gelu_w(v.x); v.y = gelu_w(v.y); v.z = gelu_w(v.z); v.w = gelu_w(v.w);
-      } else if (QPRO == QP_RELU) {
-        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-      }
-      *reinterpret_cast<float4*>(Qt + (r0 + 8 * i) * kStrideF + cq * 4) = v;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    // ---- LDS -> operand registers: 16 contiguous voxels of channel c for this lane half ----
-    float pa[MBP][16], qb[MBQ][16];
-    // fp32 MFMAs: 16 contiguous voxels from 16h; bf16 split: voxels 8h.. (K-step 0) and 16 + 8h.. (K-step 1)
-#pragma unroll
-    for (int i = 0; i < MBP; ++i)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int off = BF != 0 ? (16 * (e >> 1) + 8 * h + 4 * (e & 1)) : (16 * h + 4 * e);
-        const float4 v = *reinterpret_cast<const float4*>(Pt + (i * 32 + c) * kStrideF + off);
-        pa[i][4 * e] = v.x; pa[i][4 * e + 1] = v.y; pa[i][4 * e + 2] = v.z; pa[i][4 * e + 3] = v.w;
-      }
-#pragma unroll
-    for (int jq = 0; jq < MBQ; ++jq)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int off = BF != 0 ? (16 * (e >> 1) + 8 * h + 4 * (e & 1)) : (16 * h + 4 * e);
-        const float4 v = *reinterpret_cast<const float4*>(Qt + (jq * 32 + c) * kStrideF + off);
-        qb[jq][4 * e] = v.x; qb[jq][4 * e + 1] = v.y; qb[jq][4 * e + 2] = v.z; qb[jq][4 * e + 3] = v.w;
-      }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (t + 1 < t_end) issue_loads(t + 1);  // in flight during the MFMA loop below
-#pragma unroll
-    for (int i = 0; i < MBP; ++i) {
-      float ps = 0.f;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) ps += pa[i][e];
-      psum[i] += ps;
-    }
-    if (BF != 0) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        // (the splits of one operand block at a time: all twelve operand tiles live at once spill beside the accumulators)
-        bf16x8 ph[MBP], pm[MBP], pl[MBP];
-#pragma unroll
-        for (int i = 0; i < MBP; ++i) {
-          float x8[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) x8[e] = pa[i][8 * t + e];
-          split_bf16x8(x8, ph[i], pm[i], pl[i]);
-        }
-#pragma unroll
-        for (int jq = 0; jq < MBQ; ++jq) {
-          bf16x8 qh, qm, ql;
-          float x8[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) x8[e] = qb[jq][8 * t + e];
-          split_bf16x8(x8, qh, qm, ql);
-#pragma unroll
-          for (int i = 0; i < MBP; ++i) {
-            if (BF == 6) {   // smallest terms first
-              acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pl[i], qh, acc[i][jq], 0, 0, 0);
-              acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pm[i], qm, acc[i][jq], 0, 0, 0);
-              acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph[i], ql, acc[i][jq], 0, 0, 0);
-              acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pm[i], qh, acc[i][jq], 0, 0, 0);
-              acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph[i], qm, acc[i][jq], 0, 0, 0);
-            }
-            acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph[i], qh, acc[i][jq], 0, 0, 0);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int sidx = 0; sidx < 16; ++sidx)
-#pragma unroll
-        for (int i = 0; i < MBP; ++i)
-#pragma unroll
-          for (int jq = 0; jq < MBQ; ++jq)
-            acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[i][sidx], qb[jq][sidx], acc[i][jq], 0, 0, 0);
-    }
-  }
-
-  // ---- reduce the 4 waves through LDS, then write this workgroup's partial block ----
-  __syncthreads();
-  float* red = lds;
-#pragma unroll
-  for (int i = 0; i < MBP; ++i) {
-#pragma unroll
-    for (int jq = 0; jq < MBQ; ++jq) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        red[wave * 1024 + row * 32 + c] = acc[i][jq][r];
-      }
-      __syncthreads();
-      for (int e = threadIdx.x; e < 1024; e += 256) {
-        const float sum = (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]);
-        const int row = e >> 5, col = e & 31;
-        const int m = m0 + i * 32 + row, k = k0 + jq * 32 + col;
-        a.part[((int64_t)blockIdx.x * a.M + m) * a.K + k] = sum;
-      }
-      __syncthreads();
-    }
-  }
-  if (a.part_bias != nullptr && blockIdx.z == 0) {
-#pragma unroll
-    for (int i = 0; i < MBP; ++i) {
-      const float sum = psum[i] + __shfl_xor(psum[i], 32, 64);
-      if (h == 0) red[wave * 32 + c] = sum;
-      __syncthreads();
-      if (threadIdx.x < 32) {
-        const float tot = (red[threadIdx.x] + red[32 + threadIdx.x]) + (red[64 + threadIdx.x] + red[96 + threadIdx.x]);
-        a.part_bias[(int64_t)blockIdx.x * a.M + m0 + i * 32 + threadIdx.x] = tot;
-      }
-      __syncthreads();
-    }
+  for (int t = 1; t < kWgGroupMax; ++t)
+    if (t < g.n && (int)blockIdx.x >= g.start[t]) i = t;
+  int local = (int)blockIdx.x - g.start[i];
+  const int bx = local % g.gx[i];
+  local /= g.gx[i];
+  const int by = local % g.gy[i], bz = local / g.gy[i];
+  const WgradArgsT<AT>& a = g.a[i];
+  switch (g.qpro[i]) {
+    case QP_STATS: wgrad_fast_body<MBP, MBQ, QP_STATS, BF, AT>(a, lds, bx, by, bz); break;
+    case QP_GELU: wgrad_fast_body<MBP, MBQ, QP_GELU, BF, AT>(a, lds, bx, by, bz); break;
+    case QP_RELU: wgrad_fast_body<MBP, MBQ, QP_RELU, BF, AT>(a, lds, bx, by, bz); break;
+    default: wgrad_fast_body<MBP, MBQ, QP_NONE, BF, AT>(a, lds, bx, by, bz); break;
   }
 }
 
@@ -726,31 +604,59 @@ extern "C" int64_t fz_wgrad_workspace_bytes(const fz_wgrad_desc* d) {
          (int64_t)sizeof(float);
 }
 
+static bool fz_wgrad_group_enabled() {   // FZ_WGRAD_GROUP=0: diagnostics (the single launches)
+  static const bool v = [] { const char* e = getenv("FZ_WGRAD_GROUP"); return !(e && atoi(e) == 0 && e[0] == '0'); }();
+  return v;
+}
+
 template <typename AT>
-static int wgrad_launch(const fz_wgrad_desc* d, void* workspace, fz_stream_t stream) {
+struct WgradPlan {
+  WgradArgsT<AT> a;
+  dim3 grid;
+  int PR, QR, nchunk, qp;
+  bool fast;
+};
+
+template <typename AT>
+static int wgrad_plan(const fz_wgrad_desc* d, void* workspace, WgradPlan<AT>& pl) {
   if (!d->p || !d->q[0] || !d->gw) return fail(FZ_E_ARG, "fz_wgrad: null pointer");
   if (d->loader < 0 || d->loader > 2) return fail(FZ_E_ARG, "fz_wgrad: bad loader");
   if (d->N % 4 != 0) return fail(FZ_E_UNSUPPORTED, "fz_wgrad: column count must be a multiple of 4");
   if (d->loader == QL_S2D && ((d->Wo & 1) || d->K != 8 * d->Cin)) return fail(FZ_E_SHAPE, "fz_wgrad: s2d shape");
   if (d->loader == QL_K3 && d->K != 27 * d->Cin) return fail(FZ_E_SHAPE, "fz_wgrad: k3 shape");
-  if (d->B == 0) return FZ_OK;
   const int PR = d->M > 32 ? 64 : 32, QR = d->K > 32 ? 64 : 32;
   const int gy = (d->M + PR - 1) / PR, gz = (d->K + QR - 1) / QR;
   const int64_t total_tiles = ((d->N + kTile - 1) / kTile) * d->B;
   int tpc;
-  const bool fast = use_fast(d);
-  const int nchunk = pick_chunks(total_tiles, gy * gz, fast, &tpc);
-  WgradArgsT<AT> a;
+  pl.fast = use_fast(d);
+  pl.PR = PR; pl.QR = QR;
+  pl.nchunk = pick_chunks(total_tiles, gy * gz, pl.fast, &tpc);
+  pl.qp = d->stats ? QP_STATS : (d->qact == 2 ? QP_GELU : (d->qact == 1 ? QP_RELU : QP_NONE));
+  WgradArgsT<AT>& a = pl.a;
   a.p = (const AT*)d->p; a.M = d->M; a.pmul = (const AT*)d->pmul; a.pmul_kind = d->pmul_kind;
   for (int i = 0; i < 4; ++i) a.q[i] = (const AT*)d->q[i];
   a.nsrc = d->nsrc; a.src_mode = d->src_mode; a.c0 = d->c0 > 0 ? d->c0 : d->Cin; a.Cin = d->Cin; a.K = d->K;
   a.Vq = d->Vq; a.D = d->D; a.H = d->H; a.W = d->W; a.N = d->N; a.Ho = d->Ho; a.Wo = d->Wo;
   a.stats = d->stats; a.qact = d->qact; a.B = d->B; a.tiles_per_chunk = tpc;
   a.part = (float*)workspace;
-  a.part_bias = a.part + (int64_t)nchunk * d->M * d->K;
-  dim3 grid(nchunk, gy, gz), block(256);
+  a.part_bias = a.part + (int64_t)pl.nchunk * d->M * d->K;
+  pl.grid = dim3(pl.nchunk, gy, gz);
+  return FZ_OK;
+}
+
+static size_t wgrad_fast_lds(int PR, int QR) {
+  const size_t ldsf = (size_t)4 * (PR + QR) * kStrideF * sizeof(float);
+  const size_t ldsr = (size_t)4 * 1024 * sizeof(float);
+  return ldsf > ldsr ? ldsf : ldsr;
+}
+
+// the partial-sum launch of one problem
+template <typename AT>
+static int wgrad_main_launch(const fz_wgrad_desc* d, const WgradPlan<AT>& pl, hipStream_t st) {
+  const WgradArgsT<AT>& a = pl.a;
+  const int PR = pl.PR, QR = pl.QR;
+  const dim3 grid = pl.grid, block(256);
   const size_t lds = (size_t)4 * (PR + QR) * kStride * sizeof(float);
-  hipStream_t st = (hipStream_t)stream;
   constexpr bool kBf16 = !std::is_same<AT, float>::value;  // bf16 activations: plain bf16 MFMAs
   // fp32 activations: six-term split-bf16 products unless the split-bf16 family is switched off (fz_gemm_bx_enable)
   const int bf3g = fz_gemm_bx_enable(-1);
@@ -767,11 +673,9 @@ static int wgrad_launch(const fz_wgrad_desc* d, void* workspace, fz_stream_t str
     else if (QR == 64) FZ_WG(1, 2, QL);                  \
     else FZ_WG(1, 1, QL);                                \
   } while (0)
-  if (fast) {
-    const int qp = d->stats ? QP_STATS : (d->qact == 2 ? QP_GELU : (d->qact == 1 ? QP_RELU : QP_NONE));
-    const size_t ldsf = (size_t)4 * (PR + QR) * kStrideF * sizeof(float);
-    const size_t ldsr = (size_t)4 * 1024 * sizeof(float);
-    const size_t ldsz = ldsf > ldsr ? ldsf : ldsr;
+  if (pl.fast) {
+    const int qp = pl.qp;
+    const size_t ldsz = wgrad_fast_lds(PR, QR);
     const int bf3 = bf3g;
 #define FZ_WGF(MBP, MBQ, QP)                                                                              \
   do {                                                                                                    \
@@ -794,6 +698,14 @@ static int wgrad_launch(const fz_wgrad_desc* d, void* workspace, fz_stream_t str
   else if (d->loader == QL_S2D) FZ_WG_SHAPES(QL_S2D);
   else FZ_WG_SHAPES(QL_K3);
   FZ_LAUNCH_CHECK();
+  return FZ_OK;
+}
+
+// the fixed-order reduction of one problem's partial blocks into gw / gbias
+template <typename AT>
+static int wgrad_finish_launch(const fz_wgrad_desc* d, const WgradPlan<AT>& pl, hipStream_t st) {
+  const WgradArgsT<AT>& a = pl.a;
+  const int nchunk = pl.nchunk;
   const int64_t MK = (int64_t)d->M * d->K;
   const bool fold = d->ln_g != nullptr;
   const int nbw = (int)((MK + 7) / 8);
@@ -812,11 +724,80 @@ static int wgrad_launch(const fz_wgrad_desc* d, void* workspace, fz_stream_t str
   return FZ_OK;
 }
 
+template <typename AT>
+static int wgrad_launch(const fz_wgrad_desc* d, void* workspace, fz_stream_t stream) {
+  WgradPlan<AT> pl;
+  const int rc = wgrad_plan<AT>(d, workspace, pl);
+  if (rc != FZ_OK) return rc;
+  if (d->B == 0) return FZ_OK;
+  const int rc2 = wgrad_main_launch<AT>(d, pl, (hipStream_t)stream);
+  if (rc2 != FZ_OK) return rc2;
+  return wgrad_finish_launch<AT>(d, pl, (hipStream_t)stream);
+}
+
+// n <= kWgGroupMax problems: ONE partial-sum grid when every problem takes the register-operand kernel at 64 x 64
+// blocks (the dense layers of a C >= 64 block), else the single launches in order; then the finish launches
+template <typename AT>
+static int wgrad_group_launch(const fz_wgrad_desc* const* ds, void* const* ws, int n, fz_stream_t stream) {
+  WgradPlan<AT> pl[kWgGroupMax];
+  bool groupable = n >= 2 && fz_wgrad_group_enabled();
+  for (int i = 0; i < n; ++i) {
+    const int rc = wgrad_plan<AT>(ds[i], ws[i], pl[i]);
+    if (rc != FZ_OK) return rc;
+    groupable = groupable && pl[i].fast && pl[i].PR == 64 && pl[i].QR == 64 && ds[i]->B > 0;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (!groupable) {
+    for (int i = 0; i < n; ++i) {
+      if (ds[i]->B == 0) continue;
+      int rc = wgrad_main_launch<AT>(ds[i], pl[i], st);
+      if (rc == FZ_OK) rc = wgrad_finish_launch<AT>(ds[i], pl[i], st);
+      if (rc != FZ_OK) return rc;
+    }
+    return FZ_OK;
+  }
+  WgradGroupT<AT> g;
+  int total = 0;
+  for (int i = 0; i < kWgGroupMax; ++i) {
+    const int j = i < n ? i : n - 1;
+    g.a[i] = pl[j].a;
+    g.start[i] = total;
+    g.gx[i] = (int)pl[j].grid.x; g.gy[i] = (int)pl[j].grid.y;
+    g.qpro[i] = pl[j].qp;
+    if (i < n) total += (int)(pl[i].grid.x * pl[i].grid.y * pl[i].grid.z);
+  }
+  g.start[kWgGroupMax] = total;
+  g.n = n;
+  const size_t ldsz = wgrad_fast_lds(64, 64);
+  constexpr bool kBf16 = !std::is_same<AT, float>::value;
+  const int bf3 = fz_gemm_bx_enable(-1);
+  if (kBf16) hipLaunchKernelGGL((wgrad_fast_group_kernel<2, 2, 1, AT>), dim3(total), dim3(256), ldsz, st, g);
+  else if (bf3) hipLaunchKernelGGL((wgrad_fast_group_kernel<2, 2, 6, AT>), dim3(total), dim3(256), ldsz, st, g);
+  else hipLaunchKernelGGL((wgrad_fast_group_kernel<2, 2, 0, AT>), dim3(total), dim3(256), ldsz, st, g);
+  FZ_LAUNCH_CHECK();
+  for (int i = 0; i < n; ++i) {
+    const int rc = wgrad_finish_launch<AT>(ds[i], pl[i], st);
+    if (rc != FZ_OK) return rc;
+  }
+  return FZ_OK;
+}
+
 extern "C" int fz_wgrad(const fz_wgrad_desc* d, void* workspace, fz_stream_t stream) {
   if (!d || !workspace) return fail(FZ_E_ARG, "fz_wgrad: null descriptor/workspace");
   if (d->act_dtype == FZ_STORE_F32) return wgrad_launch<float>(d, workspace, stream);
   if (d->act_dtype == FZ_STORE_BF16) return wgrad_launch<bf16>(d, workspace, stream);
   return fail(FZ_E_ARG, "fz_wgrad: act_dtype must be FZ_STORE_F32 or FZ_STORE_BF16");
+}
+
+extern "C" int fz_wgrad_group(const fz_wgrad_desc* const* descs, void* const* workspaces, int n, fz_stream_t stream) {
+  if (!descs || !workspaces || n < 1 || n > kWgGroupMax) return fail(FZ_E_ARG, "fz_wgrad_group: 1..4 descriptors");
+  for (int i = 0; i < n; ++i) {
+    if (!descs[i] || !workspaces[i]) return fail(FZ_E_ARG, "fz_wgrad_group: null descriptor/workspace");
+    if (descs[i]->act_dtype != descs[0]->act_dtype) return fail(FZ_E_ARG, "fz_wgrad_group: one activation storage type per group");
+  }
+  if (descs[0]->act_dtype == FZ_STORE_F32) return wgrad_group_launch<float>(descs, workspaces, n, stream);
+  if (descs[0]->act_dtype == FZ_STORE_BF16) return wgrad_group_launch<bf16>(descs, workspaces, n, stream);
+  return fail(FZ_E_ARG, "fz_wgrad_group: act_dtype must be FZ_STORE_F32 or FZ_STORE_BF16");
 }
 
 // out[e] (+)= Σ_chunks part[chunk][e], fixed order — exposed for kernels that produce their own

@@ -67,8 +67,9 @@ def _gemm(xs, w, y, *, B, Cin, Vin, M, K, Ncol, w_t=False, ldw=None, bias=None, 
     return y
 
 
-def _wgrad(p, qs, gw, *, B, M, Cin, K, Vq, Ncols, gbias=None, pmul=None, pmul_kind=0, src_mode=0, c0=0,
-           stats=None, qact=0, ln=None, loader=0, D=0, H=0, W=0, Ho=0, Wo=0, accumulate=False, name="wgrad"):
+def _wgrad_desc(p, qs, gw, *, B, M, Cin, K, Vq, Ncols, gbias=None, pmul=None, pmul_kind=0, src_mode=0, c0=0,
+                stats=None, qact=0, ln=None, loader=0, D=0, H=0, W=0, Ho=0, Wo=0, accumulate=False, name="wgrad"):
+    """(descriptor, workspace, timer key, algorithmic bytes, columns, flops) of one weight-gradient problem"""
     d = N.WgradDesc()
     d.p, d.M, d.pmul, d.pmul_kind = _p(p), M, _p(pmul), pmul_kind
     for i in range(4):
@@ -85,12 +86,34 @@ def _wgrad(p, qs, gw, *, B, M, Cin, K, Vq, Ncols, gbias=None, pmul=None, pmul_ki
         raise N.NativeError("fz_wgrad_workspace_bytes failed")
     ws = torch.empty(max(nb // 4, 1), dtype=torch.float32, device=p.device)
     nbytes = p.element_size() * (p.numel() + sum(t.numel() for t in qs))
+    return d, ws, f"{name}_{M}x{K}", nbytes, B * max(Vq, Ncols), 2 * B * Ncols * M * K
+
+
+def _wgrad(p, qs, gw, **kw):
+    d, ws, key, nbytes, cols, flops = _wgrad_desc(p, qs, gw, **kw)
     with torch.cuda.device(p.device):
-        rc = Fn._timed(f"{name}_{M}x{K}", nbytes,
-                       lambda: N.lib().fz_wgrad(ctypes.byref(d), ws.data_ptr(), N.stream_ptr(p)),
-                       cols=B * max(Vq, Ncols), flops=2 * B * Ncols * M * K)
+        rc = Fn._timed(key, nbytes, lambda: N.lib().fz_wgrad(ctypes.byref(d), ws.data_ptr(), N.stream_ptr(p)),
+                       cols=cols, flops=flops)
     N.check(rc, "fz_wgrad")
     return gw
+
+
+_WGRAD_GROUP = os.environ.get("FZ_WGRAD_GROUP", "1") != "0"   # diagnostics: 0 = one launch per weight gradient
+
+
+def _wgrad_group(problems, name):
+    """`problems`: up to four (p, qs, gw, kwargs) weight-gradient problems of one layer block, launched as ONE partial-sum
+    grid (fz_wgrad_group; the results are those of the single launches)."""
+    plans = [_wgrad_desc(p, qs, gw, **kw) for p, qs, gw, kw in problems]
+    n = len(plans)
+    descs = (ctypes.POINTER(N.WgradDesc) * n)(*[ctypes.pointer(pl[0]) for pl in plans])
+    wss = (ctypes.c_void_p * n)(*[pl[1].data_ptr() for pl in plans])
+    t0 = problems[0][0]
+    with torch.cuda.device(t0.device):
+        rc = Fn._timed(name, sum(pl[3] for pl in plans),
+                       lambda: N.lib().fz_wgrad_group(descs, wss, n, N.stream_ptr(t0)),
+                       cols=max(pl[4] for pl in plans), flops=sum(pl[5] for pl in plans))
+    N.check(rc, "fz_wgrad_group")
 
 
 def _ln_backward(gl, x, stats, ln_w, gadd=None):
@@ -839,8 +862,14 @@ class FactorizerBlockFn(torch.autograd.Function):
         side = _side_stream(dev, B * V)
         keep = []  # tensors read on the side stream stay referenced until the streams are joined
 
+        pending = []   # single stream: the block's weight-gradient problems go out as ONE grid at the end (fz_wgrad_group)
+
         def wgrad(*args, **kw):
             if side is None:
+                if _WGRAD_GROUP:
+                    kw.pop("name", None)
+                    pending.append((args[0], args[1], args[2], kw))   # (keeps gz1 alive until the launch)
+                    return args[2]
                 return _wgrad(*args, **kw)
             side.wait_stream(cur)
             keep.extend(t for t in (args[0], *args[1], kw.get("stats")) if t is not None)
@@ -901,6 +930,9 @@ class FactorizerBlockFn(torch.autograd.Function):
             gx, gg1, gbt1 = _dgrad_lnbwd(gt, win2, x, st1, n1w, gx1)        # + residual path of the mixer
             gwi = _GB.out_like(win2)
             wgrad(gt, [x], gwi, B=B, M=C, Cin=C, K=C, Vq=V, Ncols=V, stats=st1, ln=(n1w, n1b), name="wgrad_ln_linear")
+        if pending:
+            _wgrad_group(pending, f"wgrad_block_{C}x{Hd}")
+            pending.clear()
         if side is not None:
             if _LateJoin.enabled:
                 _LateJoin.keep.extend(keep)

@@ -349,6 +349,11 @@ typedef struct fz_wgrad_desc {
 
 int64_t fz_wgrad_workspace_bytes(const fz_wgrad_desc* desc);
 int fz_wgrad(const fz_wgrad_desc* desc, void* workspace, fz_stream_t stream);
+/* Up to 4 weight-gradient problems in ONE partial-sum grid (same results as n fz_wgrad calls, bit for bit): the four dense
+ * layers of a FactorizerBlock at C >= 64 — fc2, fc1 behind LayerNorm (mlp.py:54-63), out_proj, in_proj behind LayerNorm
+ * (factorizer.py:38,53) — whose single launches each leave half of every CU's workgroup slots empty.  Problems that do not
+ * take the 64 x 64 register-operand kernel are launched one by one, in order.  workspaces[i] >= fz_wgrad_workspace_bytes(descs[i]). */
+int fz_wgrad_group(const fz_wgrad_desc* const* descs, void* const* workspaces, int n, fz_stream_t stream);
 
 /* ---- channels-first LayerNorm (layers/norm.py:29-34), standalone ---------------------------
  * fwd: y = (x-mean)*rstd*gamma + beta over C per voxel; stats (B,2,V) = (mean, rstd) optional.

@@ -492,6 +492,42 @@ def test_flat_adamw_skipped_parameter_subranges_are_aligned():
             assert torch.allclose(d.detach().cpu(), r.detach(), rtol=1e-6, atol=1e-7), (use_sync, i)
 
 
+@pytest.mark.parametrize("C,Hd,S,dt", [(64, 128, (8, 8, 16), torch.float32), (128, 256, (4, 8, 8), torch.float32),
+                                       (64, 128, (8, 8, 16), torch.bfloat16), (48, 96, (4, 4, 8), torch.float32)])
+def test_grouped_weight_gradients_equal_single_launches(C, Hd, S, dt):
+    """fz_wgrad_group (csrc/wgrad.hip wgrad_fast_group_kernel): the four weight-gradient problems of a FactorizerBlock at
+    C >= 64 — fc2 (GELU on the input side), fc1 behind LayerNorm (statistics + affine fold), out_proj, in_proj behind
+    LayerNorm — in ONE partial-sum grid give bit for bit the gradients of the four single launches; a group that cannot
+    use the 64 x 64 register-operand kernel (C = 48) runs the single launches in order."""
+    torch.manual_seed(11)
+    B, V = 2, S[0] * S[1] * S[2]
+    r = lambda *s: torch.randn(*s, device=DEV).to(dt)  # noqa: E731
+    g2, z1, gz1, x1, gx1, a, gt, x = r(B, C, *S), r(B, Hd, *S), r(B, Hd, *S), r(B, C, *S), r(B, C, *S), r(B, C, *S), r(B, C, *S), r(B, C, *S)
+    st = torch.stack([torch.randn(B, V, device=DEV) * 0.1, torch.rand(B, V, device=DEV) + 0.5], 1).contiguous()
+    lnw, lnb = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV) * 0.1
+
+    def problems(out):
+        return [(g2, [z1], out["w2"], dict(B=B, M=C, Cin=Hd, K=Hd, Vq=V, Ncols=V, gbias=out["b2"], qact=PW.ACT["gelu"])),
+                (gz1, [x1], out["w1"], dict(B=B, M=Hd, Cin=C, K=C, Vq=V, Ncols=V, gbias=out["b1"], stats=st, ln=(lnw, lnb))),
+                (gx1, [a], out["wo"], dict(B=B, M=C, Cin=C, K=C, Vq=V, Ncols=V, gbias=out["bo"])),
+                (gt, [x], out["wi"], dict(B=B, M=C, Cin=C, K=C, Vq=V, Ncols=V, stats=st, ln=(lnw, lnb)))]
+
+    def outs():
+        e = lambda *s: torch.full(s, float("nan"), device=DEV)  # noqa: E731
+        return {"w2": e(C, Hd), "b2": e(C), "w1": e(Hd, C), "b1": e(Hd), "wo": e(C, C), "bo": e(C), "wi": e(C, C)}
+    single, grouped = outs(), outs()
+    for p, qs, gw, kw in problems(single):
+        PW._wgrad(p, qs, gw, **kw)
+    n0 = _native.launch_count()
+    PW._wgrad_group(problems(grouped), "wgrad_block_test")
+    assert _native.launch_count() > n0
+    for k in single:
+        assert torch.isfinite(grouped[k]).all(), k
+        assert torch.equal(single[k], grouped[k]), k
+    ref = torch.einsum("bmv,bkv->mk", g2.double().flatten(2), F.gelu(z1.float()).double().flatten(2))
+    assert ((grouped["w2"].double() - ref).abs().max() / ref.abs().max()).item() < (1e-4 if dt == torch.float32 else 2e-2)
+
+
 def test_weight_gradients_land_in_the_flat_buffer():
     """With a FlatAdamW / FlatGradSync attached, every weight-gradient launch writes into its parameter's slice of the flat
     gradient buffer (factorizer_amd/gradbuf.py): after backward p.grad of every matrix / convolution weight IS that slice (no
