@@ -447,16 +447,15 @@ __global__ __launch_bounds__(256) void chunk_reduce_kernel(const float* __restri
 // (8 elements each, 32 strided partial sums per element, fixed tree — bitwise reproducible),
 // optionally folding the LayerNorm affine  gw[m][k] = Σ_ch (γ_k·part[ch][m][k] + β_k·pb[ch][m]);
 // workgroups [nbw, nbw + nbb) reduce the M bias sums.  Replaces 2-4 tiny dependent launches.
-__global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restrict__ part,
-                                                           const float* __restrict__ part_bias, int nchunk, int M,
-                                                           int K, float* __restrict__ gw, float* __restrict__ gbias,
-                                                           const float* __restrict__ ln_g,
-                                                           const float* __restrict__ ln_b, int accumulate, int nbw) {
-  __shared__ float red[32][9];
+__device__ __forceinline__ void wgrad_finish_body(const float* __restrict__ part, const float* __restrict__ part_bias,
+                                                  int nchunk, int M, int K, float* __restrict__ gw,
+                                                  float* __restrict__ gbias, const float* __restrict__ ln_g,
+                                                  const float* __restrict__ ln_b, int accumulate, int nbw,
+                                                  float (*red)[9], const int bid) {
   const int el = threadIdx.x & 7, g = threadIdx.x >> 3;
-  const bool bias_blk = (int)blockIdx.x >= nbw;
+  const bool bias_blk = bid >= nbw;
   const int64_t n = bias_blk ? (int64_t)M : (int64_t)M * K;
-  const int64_t e = (int64_t)(bias_blk ? blockIdx.x - nbw : blockIdx.x) * 8 + el;
+  const int64_t e = (int64_t)(bias_blk ? bid - nbw : bid) * 8 + el;
   const float* src = bias_blk ? part_bias : part;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (e < n) {
@@ -502,21 +501,27 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restri
     out[e] = accumulate ? out[e] + t : t;
   }
 }
+__global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restrict__ part,
+                                                           const float* __restrict__ part_bias, int nchunk, int M,
+                                                           int K, float* __restrict__ gw, float* __restrict__ gbias,
+                                                           const float* __restrict__ ln_g,
+                                                           const float* __restrict__ ln_b, int accumulate, int nbw) {
+  __shared__ float red[32][9];
+  wgrad_finish_body(part, part_bias, nchunk, M, K, gw, gbias, ln_g, ln_b, accumulate, nbw, red, (int)blockIdx.x);
+}
 
 // Same result layout as wgrad_finish_kernel for FEW partial blocks of a LARGE weight (the deep stages:
 // 512x2048 weights x 4 chunks): one thread per element walks the chunks in a fixed order (bitwise
 // reproducible) with 256-byte coalesced reads, instead of 32 threads per element reading 32-byte
 // segments — 131 136 workgroups / 52 us become 4 100 / a few us.
-__global__ __launch_bounds__(256) void wgrad_finish_wide_kernel(const float* __restrict__ part,
-                                                                const float* __restrict__ part_bias, int nchunk,
-                                                                int M, int K, float* __restrict__ gw,
-                                                                float* __restrict__ gbias,
-                                                                const float* __restrict__ ln_g,
-                                                                const float* __restrict__ ln_b, int accumulate,
-                                                                int nbw) {
-  const bool bias_blk = (int)blockIdx.x >= nbw;
+__device__ __forceinline__ void wgrad_finish_wide_body(const float* __restrict__ part, const float* __restrict__ part_bias,
+                                                       int nchunk, int M, int K, float* __restrict__ gw,
+                                                       float* __restrict__ gbias, const float* __restrict__ ln_g,
+                                                       const float* __restrict__ ln_b, int accumulate, int nbw,
+                                                       const int bid) {
+  const bool bias_blk = bid >= nbw;
   const int64_t n = bias_blk ? (int64_t)M : (int64_t)M * K;
-  const int64_t e = (int64_t)(bias_blk ? blockIdx.x - nbw : blockIdx.x) * 256 + threadIdx.x;
+  const int64_t e = (int64_t)(bias_blk ? bid - nbw : bid) * 256 + threadIdx.x;
   if (e >= n) return;
   const float* src = bias_blk ? part_bias : part;
   const bool fold = !bias_blk && ln_g != nullptr;
@@ -544,6 +549,43 @@ __global__ __launch_bounds__(256) void wgrad_finish_wide_kernel(const float* __r
   float* out = bias_blk ? gbias : gw;
   out[e] = accumulate ? out[e] + t : t;
 }
+__global__ __launch_bounds__(256) void wgrad_finish_wide_kernel(const float* __restrict__ part,
+                                                                const float* __restrict__ part_bias, int nchunk,
+                                                                int M, int K, float* __restrict__ gw,
+                                                                float* __restrict__ gbias,
+                                                                const float* __restrict__ ln_g,
+                                                                const float* __restrict__ ln_b, int accumulate,
+                                                                int nbw) {
+  wgrad_finish_wide_body(part, part_bias, nchunk, M, K, gw, gbias, ln_g, ln_b, accumulate, nbw, (int)blockIdx.x);
+}
+
+// The finish launches of a grouped weight-gradient call as ONE grid (same bodies, same order of every sum).
+struct WgradFinishOne {
+  const float* part;
+  const float* part_bias;
+  float* gw;
+  float* gbias;
+  const float* ln_g;
+  const float* ln_b;
+  int nchunk, M, K, accumulate, nbw, wide;
+};
+struct WgradFinishGroup {
+  WgradFinishOne f[4];
+  int start[5];
+  int n;
+};
+__global__ __launch_bounds__(256) void wgrad_finish_group_kernel(WgradFinishGroup g) {
+  __shared__ float red[32][9];
+  int i = 0;
+#pragma unroll
+  for (int t = 1; t < 4; ++t)
+    if (t < g.n && (int)blockIdx.x >= g.start[t]) i = t;
+  const WgradFinishOne& f = g.f[i];
+  const int bid = (int)blockIdx.x - g.start[i];
+  if (f.wide) wgrad_finish_wide_body(f.part, f.part_bias, f.nchunk, f.M, f.K, f.gw, f.gbias, f.ln_g, f.ln_b, f.accumulate, f.nbw, bid);
+  else wgrad_finish_body(f.part, f.part_bias, f.nchunk, f.M, f.K, f.gw, f.gbias, f.ln_g, f.ln_b, f.accumulate, f.nbw, red, bid);
+}
+
 
 // LayerNorm affine folded into the weight gradient: gw[m][k] = γ_k · acc[m][k] + β_k · gb[m]
 __global__ __launch_bounds__(256) void ln_fold_kernel(float* __restrict__ gw, const float* __restrict__ acc,
@@ -775,10 +817,25 @@ static int wgrad_group_launch(const fz_wgrad_desc* const* ds, void* const* ws, i
   else if (bf3) hipLaunchKernelGGL((wgrad_fast_group_kernel<2, 2, 6, AT>), dim3(total), dim3(256), ldsz, st, g);
   else hipLaunchKernelGGL((wgrad_fast_group_kernel<2, 2, 0, AT>), dim3(total), dim3(256), ldsz, st, g);
   FZ_LAUNCH_CHECK();
-  for (int i = 0; i < n; ++i) {
-    const int rc = wgrad_finish_launch<AT>(ds[i], pl[i], st);
-    if (rc != FZ_OK) return rc;
+  WgradFinishGroup fg;
+  int ftotal = 0;
+  for (int i = 0; i < 4; ++i) {
+    const int j = i < n ? i : n - 1;
+    const fz_wgrad_desc* d = ds[j];
+    const int64_t MK = (int64_t)d->M * d->K;
+    const bool wide = pl[j].nchunk <= 64 && MK >= 16384;   // (the choice of wgrad_finish_launch)
+    const int per = wide ? 256 : 8;
+    const int nbw = (int)((MK + per - 1) / per);
+    const int nbb = d->gbias != nullptr ? (d->M + per - 1) / per : 0;
+    fg.f[i] = {pl[j].a.part, pl[j].a.part_bias, d->gw, d->gbias, d->ln_g != nullptr ? d->ln_g : (const float*)nullptr, d->ln_b,
+               pl[j].nchunk, d->M, d->K, d->accumulate, nbw, wide ? 1 : 0};
+    fg.start[i] = ftotal;
+    if (i < n) ftotal += nbw + nbb;
   }
+  fg.start[4] = ftotal;
+  fg.n = n;
+  hipLaunchKernelGGL(wgrad_finish_group_kernel, dim3((unsigned)ftotal), dim3(256), 0, st, fg);
+  FZ_LAUNCH_CHECK();
   return FZ_OK;
 }
 
