@@ -43,8 +43,9 @@ BF16_MFMA_PEAK_TFLOPS = 16 * FP32_MFMA_PEAK_TFLOPS   # same guide: the fp32 MFMA
 def split_products(name, dtype):
     """bf16 MFMA products one fp32 product of this launch family is formed from (0 = it runs on v_mfma_f32_32x32x2_f32).
     fp32 storage: both operands split in three bf16 levels, the six products of weight >= 2^-24 kept (csrc/gemm_bx.h; error
-    <= the fp32 MFMA's own, profiles/r03_bx6_accuracy.json).  bf16 storage: weights two levels, the column operand one (two
-    behind a LayerNorm / GELU prologue): two or three products — three is used."""
+    <= the fp32 MFMA's own, profiles/r03_bx6_accuracy.json).  bf16 storage: weights three levels, the column operand one
+    exact term (three behind a LayerNorm / GELU prologue, which produces new fp32 values): three or six products — three
+    is used for the roof (the optimistic one)."""
     if os.environ.get("FZ_GEMM_BX", "1") == "0":
         return 0
     m = re.search(r"_(\d+)(?:->|x)", name)

@@ -620,7 +620,7 @@ __device__ __forceinline__ void bx_group_ps(f32x16 (&acc)[NRB][NQ], FA load_term
 // epilogue — fz_gemm with EPI_LNBWD and M = K = 64: the pre-LayerNorm gradient never reaches HBM.
 // BX: every GEMM of the chain on split-bf16 products — the weights stay fp32 in LDS (64 KB: a pre-split image would be 96 KB
 // and halve the occupancy) and are split per use, the column operands once per group of eight steps.
-// P512 (fp32 storage, BX, not SINGLE): the fp32-weight form above does not fit 256 registers once the operand splits are
+// P512 (BX, not SINGLE; both storage types): the fp32-weight form above does not fit 256 registers once the operand splits are
 // added (6 / 23 spilled), so the split-bf16 chain runs as ONE workgroup of 512 threads per CU — two independent 4-wave
 // halves, each walking its own tiles — sharing a PRE-SPLIT weight image (bf16x8 triples in operand order: 2 x 48 KB):
 // same two waves per SIMD, no weight splits on the VALU, 3 ds_read_b128 per row operand instead of 8 ds_read_b32.
@@ -629,7 +629,7 @@ __global__ __launch_bounds__(P512 ? 512 : 256, 2) void gemm_chain64_kernel(GemmA
   constexpr int NACC = 2, C = 64, HID = 128;
   constexpr int NTA = BxTerms<AT>::A, NTB = bx_terms_b<AT>(BXPRO_GELU);
   constexpr bool HOIST = SINGLE || sizeof(AT) == 2;
-  static_assert(!P512 || (BX && !SINGLE && sizeof(AT) == 4), "P512: the fp32-storage split-bf16 chain");
+  static_assert(!P512 || (BX && !SINGLE), "P512: the split-bf16 chain around a pre-split weight image");
   constexpr int NA = P512 ? 12288 : 8192;   // floats of one weight image (P512: [16 (group, row block)][3 terms][64 lanes] x 16 B)
   extern __shared__ __attribute__((aligned(16))) float fz_lds_c64[];
   float* As1 = fz_lds_c64;            // [32 steps][4 row blocks][64]
@@ -2335,7 +2335,11 @@ static int gemm_launch(const fz_gemm_desc* d, fz_stream_t stream) {
     const int bx_on = gemm_bx_enabled();
     const int pro_bx = d->ln ? 1 : (d->bact == ACT_GELU ? 2 : (d->bmul ? 3 : 0));
     const bool one_pro = (d->ln != 0) + (d->bact != 0) + (d->bmul != nullptr) <= 1;
-    if (bx_on && one_pro && d->bact != ACT_RELU && d->K >= 64 && d->M >= 32 && (d->loader == LOAD_PLAIN || d->loader == LOAD_S2D) &&
+    // (bf16 storage, no prologue: from K = 32 — three bf16 products per fp32 product; the stage-0 layers are matrix-pipe
+    // bound there once their bytes are halved.  With a LayerNorm / GELU prologue the K = 32 half chunk would cost as
+    // much as the fp32 MFMAs it replaces; fp32 storage: those layers are HBM-bound on the fp32 MFMA)
+    const int bx_kmin = (sizeof(AT) == 2 && !d->ln && d->bact == 0) ? 32 : 64;
+    if (bx_on && one_pro && d->bact != ACT_RELU && d->K >= bx_kmin && d->M >= 32 && (d->loader == LOAD_PLAIN || d->loader == LOAD_S2D) &&
         (d->epilogue == EPI_PLAIN || d->epilogue == EPI_D2S) && !(d->loader == LOAD_S2D && pro_bx) && !(d->epilogue == EPI_D2S && pro_bx))
     {
       const int rc = gemm_bx_launch<AT>(a, d->loader, d->epilogue, pro_bx, stream);
@@ -2543,7 +2547,7 @@ static int mlp_launch(const fz_mlp_desc* d, fz_stream_t stream) {
     constexpr int lds64 = (8192 + 8192 + 128 + 64 + 512) * (int)sizeof(float);
     // fp32 storage with split-bf16 products: one 512-thread workgroup per CU around a pre-split weight image
     constexpr int lds512 = (12288 + 12288 + 128 + 64 + 1024) * (int)sizeof(float);
-    const bool p512 = sizeof(AT) == 4 && gemm_bx_enabled() && ntiles % 2 == 0 && knob_chain64_p512();
+    const bool p512 = gemm_bx_enabled() && ntiles % 2 == 0 && knob_chain64_p512();
     dim3 grid512((unsigned)(ntiles / 2 < 256 ? ntiles / 2 : 256));
     if (d->mode == 0) {
       a.w = d->w1; a.w_t = 0; a.ldw = 64;
@@ -2552,13 +2556,13 @@ static int mlp_launch(const fz_mlp_desc* d, fz_stream_t stream) {
       c.wB = d->w2; c.wB_t = 0; c.ldwB = 128; c.biasB = d->b2; c.side = (AT*)d->z1;
       // split-bf16 products only where the kernel stays inside 256 registers without scratch (fp32 storage: 6 / 23 spilled)
       if (p512) {
-        auto kern = gemm_chain64_kernel<false, AT, false, true, sizeof(AT) == 4>;
+        auto kern = gemm_chain64_kernel<false, AT, false, true, true>;
         FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds512));
         hipLaunchKernelGGL(kern, grid512, dim3(512), lds512, st, a, c, ntiles);
         FZ_LAUNCH_CHECK();
         return FZ_OK;
       }
-      auto kern = gemm_bx_enabled() && sizeof(AT) == 2 ? gemm_chain64_kernel<false, AT, false, sizeof(AT) == 2> : gemm_chain64_kernel<false, AT, false, false>;
+      auto kern = gemm_chain64_kernel<false, AT, false, false>;   // (odd tile count: the fp32-MFMA form)
       FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds64));
       hipLaunchKernelGGL(kern, grid64, dim3(256), lds64, st, a, c, ntiles);
     } else {
@@ -2568,13 +2572,13 @@ static int mlp_launch(const fz_mlp_desc* d, fz_stream_t stream) {
       c.wB = d->w1; c.wB_t = 1; c.ldwB = 64;           // A2[m = c][k = hidden] = W1[hidden][c]
       c.side = (AT*)d->gz1;
       if (p512) {
-        auto kern = gemm_chain64_kernel<true, AT, false, true, sizeof(AT) == 4>;
+        auto kern = gemm_chain64_kernel<true, AT, false, true, true>;
         FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds512));
         hipLaunchKernelGGL(kern, grid512, dim3(512), lds512, st, a, c, ntiles);
         FZ_LAUNCH_CHECK();
         return FZ_OK;
       }
-      auto kern = gemm_bx_enabled() && sizeof(AT) == 2 ? gemm_chain64_kernel<true, AT, false, sizeof(AT) == 2> : gemm_chain64_kernel<true, AT, false, false>;
+      auto kern = gemm_chain64_kernel<true, AT, false, false>;   // (odd tile count: the fp32-MFMA form)
       FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds64));
       hipLaunchKernelGGL(kern, grid64, dim3(256), lds64, st, a, c, ntiles);
     }

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bx_kernel(GemmArgsT<AT> p) {
   const int b = bx / tiles_per_sample;
   const int64_t n0 = ((int64_t)(bx % tiles_per_sample) * 4 + wave) * TN;
   const int m0 = by * 32 * MB;
-  const int nG = p.K >> 4;   // K % 64 == 0
+  const int nG = p.K >> 4;   // K % 32 == 0: a trailing half chunk runs on zero weights (bf16 storage, K = 32: stage 0)
 
   if (threadIdx.x < 32 * MB) {
     const int m = m0 + threadIdx.x;
@@ -167,6 +167,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bx_kernel(GemmArgsT<AT> p) {
 #pragma unroll
     for (int u = 0; u < IPT; ++u) {
       int g = g0 + wgl0 + (4 / MB) * u;
+      const float live = g < nG ? 1.0f : 0.0f;   // groups past the end of K (half chunk): zero weights, loads clamped
       g = g < nG ? g : nG - 1;
       if constexpr (!WT) {
         uload<8>(p.w + 16 * g, woff, wraw[u]);
@@ -179,6 +180,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bx_kernel(GemmArgsT<AT> p) {
           wraw[u][e] = t[0];
         }
       }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wraw[u][e] *= live;
       if constexpr (LN) {
         float gm[8], bt[8];
         uload<8>(p.ln_g + 16 * g, goff, gm);
@@ -241,8 +244,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bx_kernel(GemmArgsT<AT> p) {
             if (GATE) t = sl.bv[e][NL + q] > 0.f ? t : 0.f;
             if (LN) {
               t -= shift[q];
-              s1[q] += t;
-              s2[q] += t * t;
+              const float tv = (g0 + gl < nG) ? t : 0.f;   // (a clamped re-read past the end of K is not part of the row)
+              s1[q] += tv;
+              s2[q] += tv * tv;
             }
             if (PRO == BXPRO_GELU) t = gelu_f(t);
           }
@@ -313,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bx_kernel(GemmArgsT<AT> p) {
 // shapes the family takes (everything else stays with the fp32-MFMA kernels of gemm.hip)
 template <typename AT>
 bool gemm_bx_ok(const GemmArgsT<AT>& a, int loader, int epilogue, int pro, int nacc) {
-  if (a.K % 64 != 0 || a.M % 32 != 0) return false;
+  if (a.K % 32 != 0 || a.M % 32 != 0) return false;
   if (loader == LOAD_PLAIN && (a.c0 % 16 != 0 || a.Cin != a.K)) return false;
   if (loader == LOAD_S2D && (8 * a.Cin != a.K || pro != BXPRO_NONE || epilogue != EPI_PLAIN || (a.Wo & 1))) return false;
   if (epilogue == EPI_D2S && (pro != BXPRO_NONE || (nacc >= 2 && (a.Wo % nacc) != 0))) return false;

@@ -52,7 +52,8 @@ def _lin_mag(x, w, b=None, res=None):
 LIN = [(2, 64, 64, (8, 8, 8)), (1, 128, 64, (8, 8, 4)), (2, 256, 512, (4, 4, 4)), (1, 1024, 512, (4, 4, 4)),
        (1, 80, 96, (6, 4, 4)),      # K, M not multiples of 16 / 32, partial tiles
        (2, 64, 32, (16, 16, 8)),    # wide tiles (NACC 4)
-       (1, 512, 1024, (8, 8, 8))]
+       (1, 512, 1024, (8, 8, 8)),
+       (1, 96, 64, (8, 8, 8))]      # K % 64 == 32: the trailing half chunk runs on zero weights
 
 
 @pytest.mark.parametrize("B,Cin,Cout,S", LIN)
@@ -85,7 +86,8 @@ def test_linear_backward_fp64(B, Cin, Cout, S):
     _check(f"linear dgrad {Cout}->{Cin}", y_bx, y_f32, ref, mag)
 
 
-@pytest.mark.parametrize("B,C,M,S", [(2, 64, 64, (8, 8, 8)), (1, 128, 256, (8, 4, 4)), (1, 512, 512, (4, 4, 4))])
+@pytest.mark.parametrize("B,C,M,S", [(2, 64, 64, (8, 8, 8)), (1, 128, 256, (8, 4, 4)), (1, 512, 512, (4, 4, 4)),
+                                     (2, 96, 64, (8, 8, 8))])   # (K % 64 == 32: LayerNorm sums must skip the clamped re-read)
 @pytest.mark.parametrize("act", ["relu", "none"])
 def test_ln_linear_fp64(B, C, M, S, act):
     torch.manual_seed(2)
