@@ -1604,9 +1604,14 @@ template <bool LNB, typename AT>
 __global__ __launch_bounds__(256, 2) void gemm_dw_kernel(DwArgsT<AT> p, int ntiles) {
   constexpr int NACC = 2;
   constexpr int kWave = 64 * kTS;             // floats of one wave's (Gb | Qb) region
+  // BXB (bf16 storage): both GEMMs on the bf16 matrix pipe with fp32-accurate products — the activations are exact bf16
+  // terms, the weights and the LayerNorm-normalised input three levels (gemm_bx.h): 12 + 4 (LNB: 12) MFMAs of 32 cycles per
+  // tile instead of 32 + 64 fp32 MFMAs; with half the bytes this kernel is matrix-pipe bound otherwise.  fp32 storage: it
+  // is HBM-bound on the fp32 MFMAs and keeps them.
+  constexpr bool BXB = sizeof(AT) == 2;
   extern __shared__ __attribute__((aligned(16))) float fz_lds_dw[];
-  float* As = fz_lds_dw;                      // [16][64] operand order: A[m][k] = W[k][m]
-  float* tB = As + 1024;                      // gamma[32]
+  float* As = fz_lds_dw;                      // [16][64] operand order: A[m][k] = W[k][m]  (BXB: [2 groups][3 levels][64] x 16 B)
+  float* tB = As + 1536;                      // gamma[32]
   float* red = tB + 32;                       // [4][64]
   float* R = red + 256;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1616,9 +1621,22 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_kernel(DwArgsT<AT> p, int ntil
   float* Qb = Gb + 32 * kTS;
   const int tiles_per_sample = (int)((p.V + 128 * NACC - 1) / (128 * NACC));
 
+  if constexpr (BXB) {
+    if (threadIdx.x < 128) {   // item (group g, lane l): the eight steps 8g + e of the fp32 form, split in three levels
+      const int l = threadIdx.x & 63, g = threadIdx.x >> 6;
+      float a8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a8[e] = p.w[(int64_t)(2 * (8 * g + e) + (l >> 5)) * 32 + (l & 31)];
+      bx8 t3[3];
+      bx_split<3>(a8, t3);
+      bx8* dst = reinterpret_cast<bx8*>(As) + (g * 3) * 64 + l;
+      dst[0] = t3[0]; dst[64] = t3[1]; dst[128] = t3[2];
+    }
+  } else {
   for (int idx = threadIdx.x; idx < 1024; idx += 256) {
     const int l = idx & 63, a = idx >> 6;
     As[idx] = p.w[(int64_t)(2 * a + (l >> 5)) * 32 + (l & 31)];   // A[m = l&31][k = 2a + h] = W[k][m]
+  }
   }
   if (LNB && threadIdx.x < 32) tB[threadIdx.x] = p.ln_g[threadIdx.x];
 
@@ -1629,6 +1647,9 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_kernel(DwArgsT<AT> p, int ntil
     for (int b2 = 0; b2 < 2; ++b2)
 #pragma unroll
       for (int v = 0; v < 4; ++v) dW[a][b2][v] = 0.f;
+  f32x16 dWx;                                   // BXB: the 32 x 32 sum as ONE accumulator tile (row = g channel, column = q channel)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dWx[r] = 0.f;
   float db[2] = {0.f, 0.f};
   float gln = 0.f;   // threads 0..63 (LNB): running (dγ | dβ) sum of this workgroup's tiles
 
@@ -1684,15 +1705,61 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_kernel(DwArgsT<AT> p, int ntil
     for (int q = 0; q < NACC; ++q)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    if constexpr (BXB) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        bx8 bop[NACC][1];
+#pragma unroll
+        for (int q = 0; q < NACC; ++q) {
+          float x8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x8[e] = bv[8 * g + e][q];
+          bx_split<1>(x8, bop[q]);               // bf16 storage: exact
+        }
+#pragma unroll
+        for (int t = 2; t >= 0; --t) {
+          const bx8 aw = reinterpret_cast<const bx8*>(As)[(g * 3 + t) * 64 + lane];
+#pragma unroll
+          for (int q = 0; q < NACC; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw, bop[q][0], acc[q], 0, 0, 0);
+        }
+      }
+    } else {
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       const float av = As[s * 64 + lane];
 #pragma unroll
       for (int q = 0; q < NACC; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[s][q], acc[q], 0, 0, 0);
     }
+    }
     fetch_tile(tile + gridDim.x < ntiles ? tile + gridDim.x : tile);
 
     // ---- dW += g ⊗ q, db += Σ g ----
+    if constexpr (BXB) {
+      // operand element e of lane half h4 = voxel 16 gk + 8 h4 + e of the wave tile, for both operands (any assignment of
+      // reduction indices to slots is valid); rows are 8-byte aligned (stride 66 floats): four ds_read_b64 per operand
+      const int rowo = (lane & 31) * kTS + 8 * (lane >> 5);
+#pragma unroll
+      for (int gk = 0; gk < 4; ++gk) {
+        float g8[8], q8[8];
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+          const float2 gv = *reinterpret_cast<const float2*>(Gb + rowo + 16 * gk + 2 * e2);
+          const float2 qv = *reinterpret_cast<const float2*>(Qb + rowo + 16 * gk + 2 * e2);
+          g8[2 * e2] = gv.x; g8[2 * e2 + 1] = gv.y;
+          q8[2 * e2] = qv.x; q8[2 * e2 + 1] = qv.y;
+        }
+        bx8 ga[1];
+        bx_split<1>(g8, ga);                     // the stored gradient: exact
+        constexpr int NTQ = LNB ? 3 : 1;         // LNB: the normalised input is a computed fp32 value
+        bx8 qb[NTQ];
+        bx_split<NTQ>(q8, qb);
+#pragma unroll
+        for (int t = NTQ - 1; t >= 0; --t) dWx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], qb[t], dWx, 0, 0, 0);
+        db[0] += ((g8[0] + g8[1]) + (g8[2] + g8[3])) + ((g8[4] + g8[5]) + (g8[6] + g8[7]));
+        asm volatile("" : "+v"(db[0]));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else
 #pragma unroll
     for (int tc = 0; tc < 2; ++tc) {
       float a0[8], a1[8], b0[8], b1[8];
@@ -1785,18 +1852,27 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_kernel(DwArgsT<AT> p, int ntil
   // ---- workgroup row: (dW | db), waves added in index order ----
   float* row = p.wpart + (int64_t)blockIdx.x * kDwRow;
   __syncthreads();
+  if constexpr (BXB) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) R[(wave * 16 + r) * 64 + lane] = dWx[r];
+  } else {
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b2 = 0; b2 < 2; ++b2)
 #pragma unroll
       for (int v = 0; v < 4; ++v) R[(wave * 16 + (a * 2 + b2) * 4 + v) * 64 + lane] = dW[a][b2][v];
+  }
   __syncthreads();
   for (int e = threadIdx.x; e < 1024; e += 256) {
     const int idx = e >> 6, l = e & 63;
-    const int a = idx >> 3, b2 = (idx >> 2) & 1, v = idx & 3;
     const float t = (R[e] + R[1024 + e]) + (R[2048 + e] + R[3072 + e]);
-    row[(16 * a + 4 * (l >> 4) + v) * 32 + 16 * b2 + (l & 15)] = t;
+    if constexpr (BXB) {   // accumulator register idx of lane l: row (g channel) = (idx & 3) + 8 (idx >> 2) + 4 (l >> 5), column = l & 31
+      row[((idx & 3) + 8 * (idx >> 2) + 4 * (l >> 5)) * 32 + (l & 31)] = t;
+    } else {
+      const int a = idx >> 3, b2 = (idx >> 2) & 1, v = idx & 3;
+      row[(16 * a + 4 * (l >> 4) + v) * 32 + 16 * b2 + (l & 15)] = t;
+    }
   }
   __syncthreads();
   R[(wave * 2 + 0) * 64 + lane] = db[0];
@@ -1805,8 +1881,12 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_kernel(DwArgsT<AT> p, int ntil
   if (threadIdx.x < 32) {
     const int e = threadIdx.x, slot = e >> 4, i16 = e & 15;
     float t = 0.f;
-    for (int w = 0; w < 4; ++w)
-      for (int kk = 0; kk < 4; ++kk) t += R[(w * 2 + slot) * 64 + kk * 16 + i16];
+    if constexpr (BXB) {   // db[0] of lane l = partial sum of g channel l & 31 over its half of the voxels
+      for (int w = 0; w < 4; ++w) t += R[(w * 2) * 64 + e] + R[(w * 2) * 64 + 32 + e];
+    } else {
+      for (int w = 0; w < 4; ++w)
+        for (int kk = 0; kk < 4; ++kk) t += R[(w * 2 + slot) * 64 + kk * 16 + i16];
+    }
     row[1024 + e] = t;
   }
   if (threadIdx.x < 64) row[1024 + 32 + threadIdx.x] = gln;
@@ -2649,7 +2729,7 @@ static int gemm_dw_launch(const fz_gemm_dw_desc* d, fz_stream_t stream) {
   a.y = (AT*)d->y; a.wpart = (float*)d->wpart; a.V = d->V; a.B = d->B;
   const int ntiles = (int)fz_mlp_partials(d->B, d->V);
   const int rows = fz_gemm_dw_rows(d->B, d->V);
-  constexpr int lds = (1024 + 32 + 256 + 4 * 64 * kTS) * (int)sizeof(float);
+  constexpr int lds = (1536 + 32 + 256 + 4 * 64 * kTS) * (int)sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   if (d->ln) {
     auto kern = gemm_dw_kernel<true, AT>;
