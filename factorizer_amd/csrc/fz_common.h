@@ -171,6 +171,30 @@ __device__ __forceinline__ float wave_sum(float v) {
 // Order of the additions per value: x[j]+x[j+32] ; +[j+16] ; +[j+8] ; xor 1 ; xor 2 ; half-mirror
 // (tests/emul/emul.cpp mirrors it).
 typedef unsigned fz_u32x2 __attribute__((ext_vector_type(2)));
+// The same eight totals LEFT DISTRIBUTED: every lane of the 8-lane group i (lanes 8i .. 8i + 7) holds total i.  The NMF
+// wave program continues on them in that form (one factor row per lane group, nmf_core.h) instead of broadcasting each
+// total to all lanes and repeating the row arithmetic 64 times.
+__device__ __forceinline__ float wave_sum8_dist(const float (&v)[8], int lane) {
+  float y[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const fz_u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[k]), __float_as_uint(v[k + 4]), false, false);
+    y[k] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  float z[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const fz_u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(y[k]), __float_as_uint(y[k + 2]), false, false);
+    z[k] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  const bool hi8 = (lane & 8) != 0;
+  const float keep = hi8 ? z[1] : z[0], give = hi8 ? z[0] : z[1];
+  float w = keep + dpp_take<0x128, 0xf>(give);  // row_ror:8: lane l takes lane l ^ 8 of its row
+  w += dpp_take<0xB1, 0xf>(w);                  // quad_perm [1,0,3,2]
+  w += dpp_take<0x4E, 0xf>(w);                  // quad_perm [2,3,0,1]
+  w += dpp_take<0x141, 0xf>(w);                 // row_half_mirror
+  return w;
+}
 __device__ __forceinline__ void wave_sum8(float (&v)[8], int lane) {
   float y[4];
 #pragma unroll

@@ -40,6 +40,22 @@ FZ_HD float fz_relu(float v) { return v > 0.f ? v : 0.f; }
 // gate(w, g) = g where w > 0 else 0  (ReLU mask taken from the forward value)
 FZ_HD float fz_gate(float w, float g) { return w > 0.f ? g : 0.f; }
 
+// ---- optional policy capability: factor rows DISTRIBUTED over lane groups ---------------------------------
+// A policy with `static constexpr bool kDistRows = true` provides, for M = 8 rows:
+//   F    sum8_dist(const F (&v)[8])             eight wave totals, total m left in every lane of lane group m
+//   F    grp_take(F d, int m)                   the value lane group m holds, uniform
+//   bool grp_below(int n)                       this lane's group index < n
+//   void st_grp(float* base, int i0, int stride, F d)    base[i0 + group·stride] = d   (one lane per group)
+//   F    ld_grp_global(const float* p, int i0, int stride)  p[i0 + group·stride]
+// The U half-step then runs ONCE with one row per lane group instead of eight times on wave-uniform values in all 64
+// lanes (a third of the VALU instructions of a rank-2 iteration); the arithmetic of every row is unchanged, so the
+// results are bit for bit those of the uniform form.  Policies without the flag (the host emulation among them) take
+// the uniform form.
+template <class W, class = void>
+struct DistRows { static constexpr bool value = false; };
+template <class W>
+struct DistRows<W, decltype((void)W::kDistRows)> { static constexpr bool value = W::kDistRows; };
+
 // ---- wave totals of K independent per-lane partial sums, eight at a time where K allows -----------
 template <int K, class W, class F>
 FZ_HD void sum_all(W& w, F (&acc)[K]) {
@@ -204,14 +220,68 @@ FZ_HD void save_state(W& w, const Hist<M, NPL, R>& h, int s, const typename W::F
     for (int j = 0; j < NPL; ++j) w.st_priv(h.vh, (s * R + r) * NPL + j, v[j][r]);
 }
 
+template <int M, int NPL, int R, class W>
+FZ_HD void save_state_dist(W& w, const Hist<M, NPL, R>& h, int s, const typename W::F (&ud)[R],
+                           const typename W::F (&v)[NPL][R]) {
+#pragma unroll
+  for (int r = 0; r < R; ++r) w.st_grp(h.uh, s * M * R + r, R, ud[r]);
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) w.st_priv(h.vh, (s * R + r) * NPL + j, v[j][r]);
+}
+
 // ---- one full iteration: U-update then V-update ---------------------------------------
 // step >= 0: also record (a, b) of the U-update as step `step` and the new state as step+1.
+// ud (policies with kDistRows, M = 8): the CURRENT u in distributed form, ud[r] of lane group m = u[m][r]; kept in step
+// with the uniform copy `u` that the column work reads.
 template <int M, int NPL, int R, int SOLVER, class W>
 FZ_HD void nmf_step(W& w, const typename W::F (&x)[M][NPL], typename W::F (&u)[M][R],
                     typename W::F (&v)[NPL][R], int mreal, float eps,
-                    const Hist<M, NPL, R>* h, int step) {
+                    const Hist<M, NPL, R>* h, int step, typename W::F (*ud)[R] = nullptr) {
   using F = typename W::F;
-  {
+  if constexpr (DistRows<W>::value && M == 8) {
+    F ad[1][R];
+    F b[R][R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      F col[M];
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        F acc = x[m][0] * v[0][r];
+#pragma unroll
+        for (int j = 1; j < NPL; ++j) acc = acc + x[m][j] * v[j][r];
+        col[m] = acc;
+      }
+      ad[0][r] = w.sum8_dist(col);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int q = r; q < R; ++q) {
+        F acc = v[0][r] * v[0][q];
+#pragma unroll
+        for (int j = 1; j < NPL; ++j) acc = acc + v[j][r] * v[j][q];
+        F t = w.sum(acc);
+        b[r][q] = t;
+        b[q][r] = t;
+      }
+    if (h != nullptr && step >= 0) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) w.st_grp(h->ah, step * M * R + r, R, ad[0][r]);
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int q = 0; q < R; ++q) w.st_uni(h->bh, (step * R + r) * R + q, b[r][q]);
+    }
+    update_rows<1, R, SOLVER, F>(*reinterpret_cast<F (*)[1][R]>(ud), ad, b, eps);
+#pragma unroll
+    for (int r = 0; r < R; ++r) (*ud)[r] = w.grp_below(mreal) ? (*ud)[r] : F(0.f);
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+#pragma unroll
+      for (int r = 0; r < R; ++r) u[m][r] = w.grp_take((*ud)[r], m);
+  } else {
     F a[M][R];
     F b[R][R];
 #pragma unroll
@@ -283,7 +353,10 @@ FZ_HD void nmf_step(W& w, const typename W::F (&x)[M][NPL], typename W::F (&u)[M
 #pragma unroll
       for (int r = 0; r < R; ++r) v[j][r] = w.keep_col(j, v[j][r]);
   }
-  if (h != nullptr && step >= 0) save_state<M, NPL, R, W>(w, *h, step + 1, u, v);
+  if (h != nullptr && step >= 0) {
+    if constexpr (DistRows<W>::value && M == 8) save_state_dist<M, NPL, R, W>(w, *h, step + 1, *ud, v);
+    else save_state<M, NPL, R, W>(w, *h, step + 1, u, v);
+  }
 }
 
 // ---- initial factors: the broadcast RandomInit buffers (matrix_factorization.py:52-58) --
@@ -301,14 +374,32 @@ FZ_HD void nmf_init(W& w, const float* u0, const float* v0, typename W::F (&u)[M
     for (int r = 0; r < R; ++r) v[j][r] = w.ld_v0(v0, j, r, R);
 }
 
+// distributed copy of the initial u (policies with kDistRows)
+template <int M, int R, class W>
+FZ_HD void nmf_init_dist(W& w, const float* u0, typename W::F (&ud)[R], int mreal) {
+  using F = typename W::F;
+  if constexpr (DistRows<W>::value && M == 8) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const F t = w.ld_grp_global(u0, r, R);
+      ud[r] = w.grp_below(mreal) ? t : F(0.f);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < R; ++r) ud[r] = F(0.f);
+  }
+}
+
 // ---- forward: T iterations, then y = u vᵀ ---------------------------------------------
 template <int M, int NPL, int R, int SOLVER, class W>
 FZ_HD void nmf_forward_wave(W& w, const float* u0, const float* v0,
                             typename W::F (&x)[M][NPL], typename W::F (&u)[M][R],
                             typename W::F (&v)[NPL][R], int mreal, int T, float eps) {
   nmf_init<M, NPL, R, W>(w, u0, v0, u, v, mreal);
+  typename W::F ud[R];
+  nmf_init_dist<M, R, W>(w, u0, ud, mreal);
   for (int t = 0; t < T; ++t)
-    nmf_step<M, NPL, R, SOLVER, W>(w, x, u, v, mreal, eps, nullptr, -1);
+    nmf_step<M, NPL, R, SOLVER, W>(w, x, u, v, mreal, eps, nullptr, -1, &ud);
   // x becomes y
 #pragma unroll
   for (int m = 0; m < M; ++m)
@@ -337,10 +428,12 @@ FZ_HD void nmf_backward_wave(W& w, const float* u0, const float* v0,
     F u[M][R];
     F v[NPL][R];
     nmf_init<M, NPL, R, W>(w, u0, v0, u, v, mreal);
+    F ud[R];
+    nmf_init_dist<M, R, W>(w, u0, ud, mreal);
     for (int t = 0; t < T - G; ++t)
-      nmf_step<M, NPL, R, SOLVER, W>(w, x, u, v, mreal, eps, nullptr, -1);
+      nmf_step<M, NPL, R, SOLVER, W>(w, x, u, v, mreal, eps, nullptr, -1, &ud);
     save_state<M, NPL, R, W>(w, h, 0, u, v);
-    for (int s = 0; s < G; ++s) nmf_step<M, NPL, R, SOLVER, W>(w, x, u, v, mreal, eps, &h, s);
+    for (int s = 0; s < G; ++s) nmf_step<M, NPL, R, SOLVER, W>(w, x, u, v, mreal, eps, &h, s, &ud);
     // output layer  y = u_T v_Tᵀ :  gu = gY v_T ,  gv = gYᵀ u_T
 #pragma unroll
     for (int r = 0; r < R; ++r) {
