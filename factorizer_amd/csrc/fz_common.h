@@ -195,6 +195,14 @@ __device__ __forceinline__ float wave_sum8_dist(const float (&v)[8], int lane) {
   w += dpp_take<0x141, 0xf>(w);                 // row_half_mirror
   return w;
 }
+// total over the eight 8-lane groups of a value that is constant inside each group (distances 8, 16, 32), in every lane
+__device__ __forceinline__ float wave_group_sum(float v) {
+  v += dpp_take<0x128, 0xf>(v);                 // row_ror:8
+  const fz_u32x2 a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const fz_u32x2 b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
 __device__ __forceinline__ void wave_sum8(float (&v)[8], int lane) {
   float y[4];
 #pragma unroll

@@ -47,6 +47,8 @@ FZ_HD float fz_gate(float w, float g) { return w > 0.f ? g : 0.f; }
 //   bool grp_below(int n)                       this lane's group index < n
 //   void st_grp(float* base, int i0, int stride, F d)    base[i0 + group·stride] = d   (one lane per group)
 //   F    ld_grp_global(const float* p, int i0, int stride)  p[i0 + group·stride]
+//   F    ld_grp(const float* base, int i0, int stride)      the same from the wave's LDS history
+//   F    grp_sum(F d)                                        total over the eight groups of a group-constant value, uniform
 // The U half-step then runs ONCE with one row per lane group instead of eight times on wave-uniform values in all 64
 // lanes (a third of the VALU instructions of a rank-2 iteration); the arithmetic of every row is unchanged, so the
 // results are bit for bit those of the uniform form.  Policies without the flag (the host emulation among them) take
@@ -423,6 +425,7 @@ FZ_HD void nmf_backward_wave(W& w, const float* u0, const float* v0,
                              const float* gu_ext, const float* gv_ext) {
   using F = typename W::F;
   F gu[M][R];
+  F gud[R];      // (kDistRows) dL/du in distributed form: lane group m holds row m
   F gv[NPL][R];
   {
     F u[M][R];
@@ -445,11 +448,16 @@ FZ_HD void nmf_backward_wave(W& w, const float* u0, const float* v0,
         for (int j = 1; j < NPL; ++j) acc = acc + g[m][j] * v[j][r];
         col[m] = acc;
       }
+      if constexpr (DistRows<W>::value && M == 8) {
+        gud[r] = w.sum8_dist(col);
+        if (gu_ext != nullptr) gud[r] = gud[r] + (w.grp_below(mreal) ? w.ld_grp_global(gu_ext, r, R) : F(0.f));
+      } else {
       sum_all<M, W, F>(w, col);
 #pragma unroll
       for (int m = 0; m < M; ++m) {
         gu[m][r] = col[m];
         if (gu_ext != nullptr && m < mreal) gu[m][r] = gu[m][r] + w.ld_uni_global(gu_ext, m * R + r);
+      }
       }
     }
 #pragma unroll
@@ -529,6 +537,21 @@ FZ_HD void nmf_backward_wave(W& w, const float* u0, const float* v0,
     for (int r = 0; r < R; ++r)
 #pragma unroll
       for (int q = 0; q < R; ++q) gb[r][q] = w.sum(gb[r][q]);
+    F und[R];    // (kDistRows) u_{s+1} of this lane group's row
+    if constexpr (DistRows<W>::value && M == 8) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) und[r] = w.ld_grp(h.uh, (s + 1) * M * R + r, R);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        F col[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) col[m] = gup[m][r];
+        F acc = gud[r] + w.sum8_dist(col);
+#pragma unroll
+        for (int q = 0; q < R; ++q) acc = acc + und[q] * (gb[q][r] + gb[r][q]);
+        gud[r] = acc;
+      }
+    } else {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       F col[M];
@@ -543,6 +566,7 @@ FZ_HD void nmf_backward_wave(W& w, const float* u0, const float* v0,
         gu[m][r] = acc;
       }
     }
+    }
 
     // ---- undo the U-update: u_{s+1} = upd(x; u_s, v_s) ----
     F bs[R][R];
@@ -556,6 +580,29 @@ FZ_HD void nmf_backward_wave(W& w, const float* u0, const float* v0,
     for (int r = 0; r < R; ++r)
 #pragma unroll
       for (int q = 0; q < R; ++q) gbu[r][q] = F(0.f);
+    if constexpr (DistRows<W>::value && M == 8) {
+      // one row per lane group: the reverse half-step once instead of eight times on uniform values; the rows'
+      // contributions to dL/db are added over the groups in a fixed tree (the uniform form adds them row by row: the
+      // results differ by rounding only, both orders are deterministic)
+      F uold[R], as[R], gwn[R], gwo[R], gam[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        uold[r] = w.ld_grp(h.uh, s * M * R + r, R);
+        as[r] = w.ld_grp(h.ah, s * M * R + r, R);
+        gwn[r] = gud[r];
+      }
+      half_bwd_row<R, SOLVER, F>(uold, und, as, bs, gwn, gwo, gam, gbu, eps);
+#pragma unroll
+      for (int r = 0; r < R; ++r) gud[r] = gwo[r];  // gradient handed to u_s
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int q = 0; q < R; ++q) gbu[r][q] = w.grp_sum(gbu[r][q]);
+#pragma unroll
+      for (int m = 0; m < M; ++m)
+#pragma unroll
+        for (int r = 0; r < R; ++r) ga[m][r] = w.grp_take(gam[r], m);
+    } else {
 #pragma unroll
     for (int m = 0; m < M; ++m) {
       F uold[R], as[R], gwn[R], gwo[R], gam[R];
@@ -571,6 +618,7 @@ FZ_HD void nmf_backward_wave(W& w, const float* u0, const float* v0,
         ga[m][r] = gam[r];
         gu[m][r] = gwo[r];  // gradient handed to u_s
       }
+    }
     }
 #pragma unroll
     for (int j = 0; j < NPL; ++j) {

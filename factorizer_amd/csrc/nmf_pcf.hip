@@ -62,6 +62,8 @@ struct PcfWave {
     if ((lane & 7) == 0) base[i0 + (lane >> 3) * stride] = d;
   }
   __device__ __forceinline__ float ld_grp_global(const float* p, int i0, int stride) const { return p[i0 + (lane >> 3) * stride]; }
+  __device__ __forceinline__ float ld_grp(const float* base, int i0, int stride) const { return base[i0 + (lane >> 3) * stride]; }
+  __device__ __forceinline__ float grp_sum(float d) const { return wave_group_sum(d); }
 };
 
 // plane base of the wave's (sample, head) and the in-plane element offset of each of the lane's columns
