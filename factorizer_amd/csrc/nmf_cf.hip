@@ -49,6 +49,19 @@ struct CfWave {
   __device__ __forceinline__ float ld_v0(const float* v0, int j, int r, int R) const { return v0[col(j) * R + r]; }
   __device__ __forceinline__ float keep_col(int, float v) const { return v; }
   __device__ __forceinline__ void fence() const { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+  // factor rows distributed over the eight 8-lane groups (nmf_core.h DistRows)
+  static constexpr bool kDistRows = true;
+  __device__ __forceinline__ float sum8_dist(const float (&v)[8]) const { return wave_sum8_dist(v, lane); }
+  __device__ __forceinline__ float grp_take(float d, int m) const {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), 8 * m));
+  }
+  __device__ __forceinline__ bool grp_below(int n) const { return (lane >> 3) < n; }
+  __device__ __forceinline__ void st_grp(float* base, int i0, int stride, float d) const {
+    if ((lane & 7) == 0) base[i0 + (lane >> 3) * stride] = d;
+  }
+  __device__ __forceinline__ float ld_grp_global(const float* p, int i0, int stride) const { return p[i0 + (lane >> 3) * stride]; }
+  __device__ __forceinline__ float ld_grp(const float* base, int i0, int stride) const { return base[i0 + (lane >> 3) * stride]; }
+  __device__ __forceinline__ float grp_sum(float d) const { return wave_group_sum(d); }
 };
 
 // element offsets (inside one channel plane) of this lane's two vectors, and the plane base
