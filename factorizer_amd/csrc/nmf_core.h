@@ -50,9 +50,10 @@ FZ_HD float fz_gate(float w, float g) { return w > 0.f ? g : 0.f; }
 //   F    ld_grp(const float* base, int i0, int stride)      the same from the wave's LDS history
 //   F    grp_sum(F d)                                        total over the eight groups of a group-constant value, uniform
 // The U half-step then runs ONCE with one row per lane group instead of eight times on wave-uniform values in all 64
-// lanes (a third of the VALU instructions of a rank-2 iteration); the arithmetic of every row is unchanged, so the
-// results are bit for bit those of the uniform form.  Policies without the flag (the host emulation among them) take
-// the uniform form.
+// lanes (a third of the VALU instructions of a rank-2 iteration).  The arithmetic of every row is unchanged, but the
+// compiler contracts and schedules the one-row and the eight-row code separately: the two forms agree to the last bit
+// or two (4e-7 relative, tools/probes/nmf_ab.py), not bit for bit.  Policies without the flag (the host emulation among
+// them) take the uniform form.
 template <class W, class = void>
 struct DistRows { static constexpr bool value = false; };
 template <class W>
@@ -424,8 +425,12 @@ FZ_HD void nmf_backward_wave(W& w, const float* u0, const float* v0,
                              const Hist<M, NPL, R>& h, int mreal, int T, int G, float eps,
                              const float* gu_ext, const float* gv_ext) {
   using F = typename W::F;
+  // The reverse sweep on distributed rows adds the rows' contributions to dL/db in a tree over the lane groups instead of
+  // row by row.  MU keeps the row-by-row (uniform) reverse sweep (its ε⁻¹-scaled gradients are the most sensitive to
+  // rounding order in the oracle tests); its forward recomputation is distributed where the policy asks for it.
+  constexpr bool kDistBwd = DistRows<W>::value && M == 8 && SOLVER != SOLVER_MU;
   F gu[M][R];
-  F gud[R];      // (kDistRows) dL/du in distributed form: lane group m holds row m
+  F gud[R];      // (kDistBwd) dL/du in distributed form: lane group m holds row m
   F gv[NPL][R];
   {
     F u[M][R];
@@ -448,7 +453,7 @@ FZ_HD void nmf_backward_wave(W& w, const float* u0, const float* v0,
         for (int j = 1; j < NPL; ++j) acc = acc + g[m][j] * v[j][r];
         col[m] = acc;
       }
-      if constexpr (DistRows<W>::value && M == 8) {
+      if constexpr (kDistBwd) {
         gud[r] = w.sum8_dist(col);
         if (gu_ext != nullptr) gud[r] = gud[r] + (w.grp_below(mreal) ? w.ld_grp_global(gu_ext, r, R) : F(0.f));
       } else {
@@ -538,7 +543,7 @@ FZ_HD void nmf_backward_wave(W& w, const float* u0, const float* v0,
 #pragma unroll
       for (int q = 0; q < R; ++q) gb[r][q] = w.sum(gb[r][q]);
     F und[R];    // (kDistRows) u_{s+1} of this lane group's row
-    if constexpr (DistRows<W>::value && M == 8) {
+    if constexpr (kDistBwd) {
 #pragma unroll
       for (int r = 0; r < R; ++r) und[r] = w.ld_grp(h.uh, (s + 1) * M * R + r, R);
 #pragma unroll
@@ -580,7 +585,7 @@ FZ_HD void nmf_backward_wave(W& w, const float* u0, const float* v0,
     for (int r = 0; r < R; ++r)
 #pragma unroll
       for (int q = 0; q < R; ++q) gbu[r][q] = F(0.f);
-    if constexpr (DistRows<W>::value && M == 8) {
+    if constexpr (kDistBwd) {
       // one row per lane group: the reverse half-step once instead of eight times on uniform values; the rows'
       // contributions to dL/db are added over the groups in a fixed tree (the uniform form adds them row by row: the
       // results differ by rounding only, both orders are deterministic)
