@@ -3,6 +3,8 @@ factorizer.py:9-122 (same constructor arguments, sub-module names and constructi
 seeds and state_dicts line up)."""
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import nn
 
@@ -158,6 +160,23 @@ class FactorizerStage(nn.Module):
             out = PW.cat_linear(skip, up, self.adapter.linear.weight, self.adapter.linear.bias)
             return self._after_adapter(out)
         return self.forward(torch.cat([skip, up], dim=1))
+
+    def forward_up_pair(self, skip, deep, upsample):
+        """forward(torch.cat([skip, upsample(deep)], 1)) with the transposed convolution and the adapter as ONE autograd
+        node (pointwise.UpCatLinearFn: gradients from the composed weights, the up-sampled tensor is not kept), or None
+        when this stage / up-sampler / tensor is outside that node's scope."""
+        from . import convs as _convs
+        ok = (hasattr(self, "adapter") and isinstance(self.adapter, Linear) and type(upsample) is _convs.ConvTranspose3d
+              and upsample.native_ok(deep) and skip.is_cuda and skip.dtype == deep.dtype and skip.dim() == 5
+              and skip.shape[1] % 16 == 0 and upsample.out_channels % 16 == 0 and deep.shape[1] % 16 == 0
+              and self.adapter.linear.weight.dtype == torch.float32
+              and tuple(skip.shape[2:]) == tuple(2 * d for d in deep.shape[2:])
+              and self.adapter.linear.weight.shape[1] == skip.shape[1] + upsample.out_channels
+              and os.environ.get("FZ_UP_FUSED", "1") != "0")
+        if not ok:
+            return None
+        out = PW.up_cat_linear(skip, deep, upsample.weight, upsample.bias, self.adapter.linear.weight, self.adapter.linear.bias)
+        return self._after_adapter(out)
 
     def forward(self, x):
         out = self.adapter(x) if hasattr(self, "adapter") else x

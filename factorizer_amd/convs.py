@@ -59,11 +59,14 @@ class Conv3d(nn.Conv3d):
 
 
 class ConvTranspose3d(nn.ConvTranspose3d):
+    def native_ok(self, x, output_size=None):
+        return bool(x.is_cuda and x.numel() and x.dtype in (torch.float32, torch.bfloat16) and self.weight.dtype == torch.float32 and x.dim() == 5 and self.groups == 1 and output_size is None
+                    and _all(self.dilation, 1) and _all(self.kernel_size, 2) and _all(self.stride, 2)
+                    and _all(self.padding, 0) and _all(self.output_padding, 0) and self.in_channels % 2 == 0
+                    and (x.shape[2] * x.shape[3] * x.shape[4]) % 4 == 0)
+
     def forward(self, x, output_size=None):
-        ok = (x.is_cuda and x.numel() and x.dtype in (torch.float32, torch.bfloat16) and self.weight.dtype == torch.float32 and x.dim() == 5 and self.groups == 1 and output_size is None
-              and _all(self.dilation, 1) and _all(self.kernel_size, 2) and _all(self.stride, 2)
-              and _all(self.padding, 0) and _all(self.output_padding, 0) and self.in_channels % 2 == 0
-              and (x.shape[2] * x.shape[3] * x.shape[4]) % 4 == 0)
+        ok = self.native_ok(x, output_size)
         if ok:
             return PW.TConvK2S2Fn.apply(x, self.weight, self.bias)
         if x.is_cuda and x.numel():

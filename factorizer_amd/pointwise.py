@@ -172,7 +172,7 @@ def _dw_fused_ok(C, V):
     return C == 32 and V % 4 == 0 and V <= (1 << 27) and os.environ.get("FZ_DW_FUSED", "1") != "0"
 
 
-def _gemm_dw(g, w2, q, ln=None, stats=None, gadd=None, want_bias=False, name="dgrad_wgrad", gw_out=None):
+def _gemm_dw(g, w2, q, ln=None, stats=None, gadd=None, want_bias=False, name="dgrad_wgrad", gw_out=None, gb_out=None):
     """y = Wᵀ g [→ LayerNorm backward + gadd], gw = Σ_v g ⊗ in, gb = Σ_v g — fz_gemm_dw.  ln = (γ, β) or None.
     Returns (y, gw, gb or None, gγ, gβ) (gγ, gβ None without ln)."""
     B, C = q.shape[:2]
@@ -181,7 +181,7 @@ def _gemm_dw(g, w2, q, ln=None, stats=None, gadd=None, want_bias=False, name="dg
     y = torch.empty_like(q)
     # gw_out: a (C, C) column block of a wider weight gradient (row stride = its width), written in place
     gw = _GB.out_like(w2, (C, C), torch.float32) if gw_out is None else gw_out
-    gb = torch.empty(C, dtype=torch.float32, device=dev) if want_bias else None
+    gb = (gb_out if gb_out is not None else torch.empty(C, dtype=torch.float32, device=dev)) if want_bias else None
     wpart = torch.empty(N.lib().fz_gemm_dw_workspace_bytes(B, V) // 4, dtype=torch.float32, device=dev)
     d = N.GemmDwDesc()
     d.g, d.q, d.w, d.y = g.data_ptr(), q.data_ptr(), w2.data_ptr(), y.data_ptr()
@@ -783,6 +783,88 @@ def act_linear_res(z, w, b, res, act="none"):
     _warn_composed("Linear+residual", z, w, b, res)
     y = linear_cf(F.gelu(z) if act == "gelu" else z, w, b)
     return y if res is None else res + y
+
+
+# ---- ConvTranspose3d(k2, s2) + virtual concat + Linear as ONE autograd node ---------------------------------------
+class UpCatLinearFn(torch.autograd.Function):
+    """out = adapter(cat([skip, upsample(deep)], 1)) — the first three lines of a decoder level (unet.py:125-128 with
+    the FactorizerStage adapter, factorizer.py:116).  Forward: the two existing launches (the up-sampled tensor is a
+    temporary).  Backward: the adapter's up half W_b and the transposed convolution W_t are both linear with nothing in
+    between, so every gradient is formed from the COMPOSED weights  Wc[k][m][tap] = Σ_c W_t[k][c][tap]·W_b[m][c]:
+      g_deep = k2s2-correlation of g with Wc          (reads g once — not W_bᵀg written, then read back)
+      Gt[k][m][tap] = Σ_n deep[k][n]·g[m][fine(n,tap)]  (the transposed-convolution weight-gradient launch, on g itself)
+      dW_b = Σ_{k,tap} Gt·W_t + (Σ_v g)⊗b_t ,  dW_t = Σ_m W_b·Gt ,  db_t = W_bᵀ·Σ_v g          (tiny contractions)
+    and the up-sampled tensor, its gradient and the row-sum pass over it never exist in the backward: 6 U of traffic per
+    level instead of 10 U (U = one full-resolution activation tensor of the level)."""
+
+    @staticmethod
+    def forward(ctx, skip, deep, w_t, b_t, w_ad, b_ad):
+        skip, deep = skip.contiguous(), deep.contiguous()
+        B, Cd, D, H, W = deep.shape
+        O = w_t.shape[1]
+        V = D * H * W
+        up = torch.empty((B, O, 2 * D, 2 * H, 2 * W), dtype=deep.dtype, device=deep.device)
+        _gemm([deep], w_t, up, B=B, Cin=Cd, Vin=V, M=8 * O, K=Cd, Ncol=V, w_t=True, ldw=8 * O, bias=b_t,
+              epilogue=EPI_D2S, Ho=H, Wo=W, name="tconv_k2s2")
+        C1 = skip.shape[1]
+        M = w_ad.shape[0]
+        w2 = w_ad.reshape(M, C1 + O)
+        y = torch.empty((B, M, *skip.shape[2:]), dtype=skip.dtype, device=skip.device)
+        _gemm([skip, up], w2, y, B=B, Cin=C1 + O, Vin=8 * V, M=M, K=C1 + O, Ncol=8 * V, bias=b_ad, c0=C1, name="cat_linear")
+        ctx.save_for_backward(skip, deep, w_t, w2, b_t)
+        ctx.has_bt, ctx.has_bad, ctx.wshape = b_t is not None, b_ad is not None, w_ad.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        skip, deep, w_t, w2, b_t = ctx.saved_tensors
+        g = g.contiguous()
+        B, Cd, D, H, W = deep.shape
+        O = w_t.shape[1]
+        V = D * H * W
+        Vf = 8 * V
+        C1 = skip.shape[1]
+        M = w2.shape[0]
+        dev = g.device
+        gw_ad = _GB.out_like(w2)
+        gb_ad = torch.empty(M, dtype=torch.float32, device=dev)
+        # --- skip half: input gradient + W_a weight gradient (+ Σ_v g) ---
+        if M == 32 and C1 == 32 and _dw_fused_ok(M, Vf):
+            g_skip, _, _, _, _ = _gemm_dw(g, w2[:, :C1].contiguous(), skip, want_bias=True, name="dgrad_wgrad",
+                                          gw_out=gw_ad[:, :C1], gb_out=gb_ad)
+        else:
+            g_skip = torch.empty_like(skip)
+            _gemm([g], w2, g_skip, B=B, Cin=M, Vin=Vf, M=C1, K=M, Ncol=Vf, w_t=True, ldw=C1 + O, name="linear_dgrad")
+            gwa = torch.empty((M, C1), dtype=torch.float32, device=dev)
+            _wgrad(g, [skip], gwa, B=B, M=M, Cin=C1, K=C1, Vq=Vf, Ncols=Vf, gbias=gb_ad, name="wgrad_linear")
+            gw_ad[:, :C1].copy_(gwa)
+        with torch.autocast("cuda", enabled=False):
+            w_b = w2[:, C1:]                                   # (M, O)
+            wt3 = w_t.reshape(Cd, O, 8)
+            wc = torch.einsum("kct,mc->kmt", wt3, w_b).reshape(Cd, M, 2, 2, 2).contiguous()
+        # --- deep half: input gradient and the (deep x g) correlation, both on g itself ---
+        g_deep = None
+        if ctx.needs_input_grad[1]:
+            g_deep = torch.empty_like(deep)
+            _gemm([g], wc, g_deep, B=B, Cin=M, Vin=Vf, M=Cd, K=8 * M, Ncol=V, loader=LOAD_S2D,
+                  Di=2 * D, Hi=2 * H, Wi=2 * W, Ho=H, Wo=W, name="tconv_k2s2_dgrad")
+        gt = torch.empty((Cd, M, 8), dtype=torch.float32, device=dev)
+        _wgrad(deep, [g], gt, B=B, M=Cd, Cin=M, K=8 * M, Vq=Vf, Ncols=V, loader=LOAD_S2D, D=2 * D, H=2 * H,
+               W=2 * W, Ho=H, Wo=W, name="wgrad_tconv_k2s2")
+        with torch.autocast("cuda", enabled=False):
+            gwb = torch.einsum("kmt,kct->mc", gt, wt3)
+            if ctx.has_bt:   # up = T(deep) + b_t: the constant part meets Σ_v g
+                gwb = gwb + gb_ad[:, None] * b_t[None, :]
+            gw_ad[:, C1:].copy_(gwb)
+            gw_t = _GB.out_like(w_t)   # (its slice of the flat gradient buffer when one is attached)
+            gw_t.view(Cd, O, 8).copy_(torch.einsum("mc,kmt->kct", w_b, gt))
+            gb_t = (gb_ad @ w_b) if ctx.has_bt else None
+        return (g_skip, g_deep, gw_t, gb_t, gw_ad.reshape(ctx.wshape), gb_ad if ctx.has_bad else None)
+
+
+def up_cat_linear(skip, deep, w_t, b_t, w_ad, b_ad=None):
+    """adapter(cat([skip, ConvTranspose3d(k2, s2)(deep)], 1)) as one autograd node (UpCatLinearFn)."""
+    return UpCatLinearFn.apply(skip, deep, w_t, b_t, w_ad, b_ad)
 
 
 def cat_linear(x1, x2, w, b=None):

@@ -131,6 +131,11 @@ class UNetDecoderBlock(nn.Module):
         self.block = partialize(block)(2 * out_channels, out_channels, depth=depth, **kwargs)
 
     def forward(self, deep, skip):
+        fused = getattr(self.block, "forward_up_pair", None)
+        if fused is not None:
+            out = fused(skip, deep, self.upsample)
+            if out is not None:
+                return out
         up = self.upsample(deep)
         pair = getattr(self.block, "forward_pair", None)
         if pair is not None:

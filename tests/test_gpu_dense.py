@@ -528,6 +528,55 @@ def test_grouped_weight_gradients_equal_single_launches(C, Hd, S, dt):
     assert ((grouped["w2"].double() - ref).abs().max() / ref.abs().max()).item() < (1e-4 if dt == torch.float32 else 2e-2)
 
 
+@pytest.mark.parametrize("C,Cd,S,bias_ad,dt", [(32, 64, (8, 8, 8), False, torch.float32), (64, 128, (4, 4, 8), True, torch.float32),
+                                                (32, 64, (8, 8, 8), False, torch.bfloat16), (16, 32, (4, 4, 4), False, torch.float32)])
+def test_up_cat_linear_node_vs_separate_nodes_and_fp64(C, Cd, S, bias_ad, dt):
+    """pointwise.UpCatLinearFn — ConvTranspose3d(k2, s2) + virtual concat + adapter Linear as one autograd node whose
+    backward works from the composed weights (unet.py:125-128, factorizer.py:116) — against (a) the two separate nodes it
+    replaces (same forward kernels: identical output; gradients to rounding) and (b) a float64 evaluation of
+    adapter(cat([skip, conv_transpose3d(deep)])) with autograd."""
+    torch.manual_seed(4)
+    B = 2
+    fine = tuple(2 * d for d in S)
+    skip = torch.randn(B, C, *fine)
+    deep = torch.randn(B, Cd, *S)
+    w_t = torch.randn(Cd, C, 2, 2, 2) * 0.2
+    b_t = torch.randn(C) * 0.1
+    w_ad = torch.randn(C, 2 * C, 1) * 0.2
+    b_ad = torch.randn(C) * 0.1 if bias_ad else None
+    g = torch.randn(B, C, *fine)
+    # float64 reference
+    r = [t.double().requires_grad_(True) for t in (skip, deep, w_t, b_t, w_ad)]
+    rb = b_ad.double().requires_grad_(True) if bias_ad else None
+    up = F.conv_transpose3d(r[1], r[2], r[3], stride=2)
+    yr = F.conv1d(torch.cat([r[0], up], 1).flatten(2), r[4], rb).reshape(B, C, *fine)
+    gr = torch.autograd.grad(yr, r + ([rb] if bias_ad else []), g.double())
+
+    def dev_inputs():
+        t = [v.to(DEV) for v in (skip, deep, w_t, b_t, w_ad)]
+        t[0], t[1] = t[0].to(dt), t[1].to(dt)
+        t = [v.requires_grad_(True) for v in t]
+        bd = b_ad.to(DEV).requires_grad_(True) if bias_ad else None
+        return t, bd
+    (a, bd) = dev_inputs()
+    n0 = _native.launch_count()
+    y1 = PW.up_cat_linear(a[0], a[1], a[2], a[3], a[4], bd)
+    assert _native.launch_count() > n0
+    g1 = torch.autograd.grad(y1, a + ([bd] if bias_ad else []), g.to(DEV).to(dt))
+    (c, bc) = dev_inputs()
+    y2 = PW.CatLinearFn.apply(c[0], PW.TConvK2S2Fn.apply(c[1], c[2], c[3]), c[4], bc)
+    g2 = torch.autograd.grad(y2, c + ([bc] if bias_ad else []), g.to(DEV).to(dt))
+    assert torch.equal(y1, y2)
+    tol = 1e-4 if dt == torch.float32 else 2e-2
+    names = ["skip", "deep", "w_t", "b_t", "w_ad"] + (["b_ad"] if bias_ad else [])
+    for n, u, v, ref in zip(names, g1, g2, gr):
+        scale = ref.abs().max().item() + 1e-30
+        assert (u.double().cpu() - ref).abs().max().item() <= tol * scale, (n, "vs fp64")
+        assert (u.double() - v.double()).abs().max().item() <= tol * scale, (n, "vs separate nodes")
+    if dt == torch.float32:
+        P.close(f"up_cat_linear {Cd}->{C} y", y1, yr.float())
+
+
 def test_weight_gradients_land_in_the_flat_buffer():
     """With a FlatAdamW / FlatGradSync attached, every weight-gradient launch writes into its parameter's slice of the flat
     gradient buffer (factorizer_amd/gradbuf.py): after backward p.grad of every matrix / convolution weight IS that slice (no
