@@ -803,14 +803,31 @@ class UpCatLinearFn(torch.autograd.Function):
         B, Cd, D, H, W = deep.shape
         O = w_t.shape[1]
         V = D * H * W
-        up = torch.empty((B, O, 2 * D, 2 * H, 2 * W), dtype=deep.dtype, device=deep.device)
-        _gemm([deep], w_t, up, B=B, Cin=Cd, Vin=V, M=8 * O, K=Cd, Ncol=V, w_t=True, ldw=8 * O, bias=b_t,
-              epilogue=EPI_D2S, Ho=H, Wo=W, name="tconv_k2s2")
         C1 = skip.shape[1]
         M = w_ad.shape[0]
         w2 = w_ad.reshape(M, C1 + O)
         y = torch.empty((B, M, *skip.shape[2:]), dtype=skip.dtype, device=skip.device)
-        _gemm([skip, up], w2, y, B=B, Cin=C1 + O, Vin=8 * V, M=M, K=C1 + O, Ncol=8 * V, bias=b_ad, c0=C1, name="cat_linear")
+        if (M == 32 and C1 == 32 and O == 32 and _UPCAT_FWD and N.lib().fz_upcat_supported(C1, Cd, D, H, W)):
+            # one pass over (skip, deep) -> out with the composed weights (csrc/upcat.hip): no up-sampled tensor at all
+            with torch.autocast("cuda", enabled=False):
+                w_b = w2[:, C1:]
+                wbt = torch.einsum("mc,kct->tmk", w_b, w_t.reshape(Cd, O, 8)).contiguous()
+                bias = b_ad
+                if b_t is not None:
+                    bias = w_b @ b_t if b_ad is None else b_ad + w_b @ b_t
+            es = skip.element_size()
+            with torch.cuda.device(skip.device):
+                rc = Fn._timed(f"upcat_{Cd}->{M}", es * (skip.numel() + deep.numel() + y.numel()),
+                               lambda: N.lib().fz_upcat(skip.data_ptr(), deep.data_ptr(), w2.data_ptr(), C1 + O, wbt.data_ptr(),
+                                                        _p(bias), y.data_ptr(), B, C1, Cd, D, H, W, N.act_dtype(skip),
+                                                        N.stream_ptr(skip)),
+                               cols=B * 8 * V, flops=2 * B * 8 * V * M * (C1 + Cd))
+            N.check(rc, "fz_upcat")
+        else:
+            up = torch.empty((B, O, 2 * D, 2 * H, 2 * W), dtype=deep.dtype, device=deep.device)
+            _gemm([deep], w_t, up, B=B, Cin=Cd, Vin=V, M=8 * O, K=Cd, Ncol=V, w_t=True, ldw=8 * O, bias=b_t,
+                  epilogue=EPI_D2S, Ho=H, Wo=W, name="tconv_k2s2")
+            _gemm([skip, up], w2, y, B=B, Cin=C1 + O, Vin=8 * V, M=M, K=C1 + O, Ncol=8 * V, bias=b_ad, c0=C1, name="cat_linear")
         ctx.save_for_backward(skip, deep, w_t, w2, b_t)
         ctx.has_bt, ctx.has_bad, ctx.wshape = b_t is not None, b_ad is not None, w_ad.shape
         return y
@@ -860,6 +877,9 @@ class UpCatLinearFn(torch.autograd.Function):
             gw_t.view(Cd, O, 8).copy_(torch.einsum("mc,kmt->kct", w_b, gt))
             gb_t = (gb_ad @ w_b) if ctx.has_bt else None
         return (g_skip, g_deep, gw_t, gb_t, gw_ad.reshape(ctx.wshape), gb_ad if ctx.has_bad else None)
+
+
+_UPCAT_FWD = os.environ.get("FZ_UPCAT_FWD", "1") != "0"   # diagnostics: 0 = the two forward launches
 
 
 def up_cat_linear(skip, deep, w_t, b_t, w_ad, b_ad=None):

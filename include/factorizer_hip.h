@@ -306,6 +306,15 @@ int fz_gemm_dw_rows(int B, int64_t V);
 int64_t fz_gemm_dw_workspace_bytes(int B, int64_t V);
 int fz_gemm_dw(const fz_gemm_dw_desc* desc, fz_stream_t stream);
 
+/* ---- decoder level forward in one pass ---------------------------------------------------
+ * out = adapter(cat([skip, ConvTranspose3d(k2, s2)(deep)], 1))  (factorizer/unet.py:125-127 with the stage adapter of
+ * factorizer.py:116) without forming the up-sampled tensor: the caller passes the composed weights
+ * wbt[tap][m][k] = sum_c W_b[m][c] W_t[k][c][tap] (tap = kd*4 + kh*2 + kw), the skip half W_a (row stride lda) and
+ * bias' = b_ad + W_b b_t (or NULL).  C = 32 skip / output channels, Cd = 64 deep channels, (D, H, W) = coarse extent. */
+int fz_upcat_supported(int C, int Cd, int D, int H, int W);
+int fz_upcat(const void* skip, const void* deep, const float* wa, int lda, const float* wbt, const float* bias, void* out,
+             int B, int C, int Cd, int D, int H, int W, int act_dtype, fz_stream_t stream);
+
 int fz_mlp_supported(int C, int H, int64_t V);
 int64_t fz_mlp_partials(int B, int64_t V);
 int fz_mlp_wgrad_rows(int B, int64_t V);

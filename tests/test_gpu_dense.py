@@ -529,6 +529,8 @@ def test_grouped_weight_gradients_equal_single_launches(C, Hd, S, dt):
 
 
 @pytest.mark.parametrize("C,Cd,S,bias_ad,dt", [(32, 64, (8, 8, 8), False, torch.float32), (64, 128, (4, 4, 8), True, torch.float32),
+                                                (32, 64, (4, 8, 32), False, torch.float32), (32, 64, (2, 4, 64), True, torch.float32),
+                                                (32, 64, (4, 8, 32), False, torch.bfloat16),
                                                 (32, 64, (8, 8, 8), False, torch.bfloat16), (16, 32, (4, 4, 4), False, torch.float32)])
 def test_up_cat_linear_node_vs_separate_nodes_and_fp64(C, Cd, S, bias_ad, dt):
     """pointwise.UpCatLinearFn — ConvTranspose3d(k2, s2) + virtual concat + adapter Linear as one autograd node whose
@@ -566,8 +568,11 @@ def test_up_cat_linear_node_vs_separate_nodes_and_fp64(C, Cd, S, bias_ad, dt):
     (c, bc) = dev_inputs()
     y2 = PW.CatLinearFn.apply(c[0], PW.TConvK2S2Fn.apply(c[1], c[2], c[3]), c[4], bc)
     g2 = torch.autograd.grad(y2, c + ([bc] if bias_ad else []), g.to(DEV).to(dt))
-    assert torch.equal(y1, y2)
     tol = 1e-4 if dt == torch.float32 else 2e-2
+    # (C = 32, 64 deep channels, rows of >= 64 fine voxels: one fused forward pass on composed weights, csrc/upcat.hip;
+    # other shapes: the two forward launches of the separate nodes — identical output)
+    assert (y1.double() - y2.double()).abs().max().item() <= (1e-5 if dt == torch.float32 else 2e-2) * yr.abs().max().item()
+    assert (y1.double().cpu() - yr).abs().max().item() <= tol * yr.abs().max().item()
     names = ["skip", "deep", "w_t", "b_t", "w_ad"] + (["b_ad"] if bias_ad else [])
     for n, u, v, ref in zip(names, g1, g2, gr):
         scale = ref.abs().max().item() + 1e-30
