@@ -172,6 +172,9 @@ class FactorizerStage(nn.Module):
               and self.adapter.linear.weight.dtype == torch.float32
               and tuple(skip.shape[2:]) == tuple(2 * d for d in deep.shape[2:])
               and self.adapter.linear.weight.shape[1] == skip.shape[1] + upsample.out_channels
+              # (the node saves 4 full-resolution tensor passes of the level and costs ~10 tiny launches for the weight
+              # compositions: it pays from 2^18 voxels x batch on — the two shallow levels of the README model)
+              and skip.shape[0] * skip[0, 0].numel() >= int(os.environ.get("FZ_UP_FUSED_MIN", 1 << 18))
               and os.environ.get("FZ_UP_FUSED", "1") != "0")
         if not ok:
             return None
