@@ -167,6 +167,8 @@ _SIGS.update({
     "fz_mlp_wgrad_workspace_bytes": ([_i, _i64], _i64),
     "fz_mlp_chain": ([_c.POINTER(MlpDesc), _vp], _i),
     "fz_upcat_supported": ([_i] * 5, _i),
+    "fz_upcat_compose": ([_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp], _i),
+    "fz_upcat_wgrads": ([_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp], _i),
     "fz_upcat": ([_vp, _vp, _vp, _i, _vp, _vp, _vp] + [_i] * 7 + [_vp], _i),
     "fz_wgrad": ([_c.POINTER(WgradDesc), _vp, _vp], _i),
     "fz_wgrad_group": ([_c.POINTER(_c.POINTER(WgradDesc)), _c.POINTER(_vp), _i, _vp], _i),

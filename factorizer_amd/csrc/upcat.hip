@@ -158,9 +158,94 @@ __global__ __launch_bounds__(256, 2) void upcat_bx_kernel(UpcatArgsT<AT> p) {
   }
 }
 
+// ---- the weight compositions of the node (tiny: a few hundred kflop .. Mflop; one launch each instead of ~10 framework ops) ----
+// wc[k][m][t] = Σ_c w_t[k][c][t]·w_b[m][c]  (backward: correlation weights),  wbt[t][m][k] = the same value (forward layout),
+// bias'[m] = b_ad[m] + Σ_c w_b[m][c]·b_t[c].  One workgroup per deep channel k (+ one for the bias).
+__global__ __launch_bounds__(256) void upcat_compose_kernel(const float* __restrict__ w_t, const float* __restrict__ w_b, int ldb,
+                                                            const float* __restrict__ b_t, const float* __restrict__ b_ad,
+                                                            float* __restrict__ wc, float* __restrict__ wbt,
+                                                            float* __restrict__ bias, int Cd, int O, int M) {
+  const int k = blockIdx.x;
+  if (k == Cd) {
+    if (bias == nullptr) return;
+    for (int m = threadIdx.x; m < M; m += 256) {
+      float t = b_ad != nullptr ? b_ad[m] : 0.f;
+      if (b_t != nullptr)
+        for (int c = 0; c < O; ++c) t += w_b[(int64_t)m * ldb + c] * b_t[c];
+      bias[m] = t;
+    }
+    return;
+  }
+  const float* wk = w_t + (int64_t)k * O * 8;
+  for (int i = threadIdx.x; i < M * 8; i += 256) {
+    const int m = i >> 3, t = i & 7;
+    float acc = 0.f;
+    for (int c = 0; c < O; ++c) acc += wk[c * 8 + t] * w_b[(int64_t)m * ldb + c];
+    if (wc != nullptr) wc[((int64_t)k * M + m) * 8 + t] = acc;
+    if (wbt != nullptr) wbt[((int64_t)t * M + m) * Cd + k] = acc;
+  }
+}
+
+// gw_t[k][c][t] = Σ_m w_b[m][c]·gt[k][m][t]  (blocks 0 .. Cd-1);  gw_b[m][c] = Σ_{k,t} gt[k][m][t]·w_t[k][c][t] + gb_ad[m]·b_t[c]
+// (blocks Cd .. Cd+M-1, written with row stride ldg into the adapter's weight gradient);  gb_t[c] = Σ_m gb_ad[m]·w_b[m][c] (last block)
+__global__ __launch_bounds__(256) void upcat_wgrads_kernel(const float* __restrict__ gt, const float* __restrict__ w_t,
+                                                           const float* __restrict__ w_b, int ldb, const float* __restrict__ gb_ad,
+                                                           const float* __restrict__ b_t, float* __restrict__ gw_t,
+                                                           float* __restrict__ gw_b, int ldg, float* __restrict__ gb_t, int Cd, int O,
+                                                           int M) {
+  const int blk = blockIdx.x;
+  if (blk < Cd) {
+    const float* gk = gt + (int64_t)blk * M * 8;
+    for (int i = threadIdx.x; i < O * 8; i += 256) {
+      const int c = i >> 3, t = i & 7;
+      float acc = 0.f;
+      for (int m = 0; m < M; ++m) acc += w_b[(int64_t)m * ldb + c] * gk[m * 8 + t];
+      gw_t[((int64_t)blk * O + c) * 8 + t] = acc;
+    }
+  } else if (blk < Cd + M) {
+    const int m = blk - Cd;
+    for (int c = threadIdx.x; c < O; c += 256) {
+      float acc = 0.f;
+      for (int k = 0; k < Cd; ++k) {
+        const float* g8 = gt + ((int64_t)k * M + m) * 8;
+        const float* w8 = w_t + ((int64_t)k * O + c) * 8;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc += g8[t] * w8[t];
+      }
+      if (b_t != nullptr) acc += gb_ad[m] * b_t[c];
+      gw_b[(int64_t)m * ldg + c] = acc;
+    }
+  } else if (gb_t != nullptr) {
+    for (int c = threadIdx.x; c < O; c += 256) {
+      float acc = 0.f;
+      for (int m = 0; m < M; ++m) acc += gb_ad[m] * w_b[(int64_t)m * ldb + c];
+      gb_t[c] = acc;
+    }
+  }
+}
+
 }  // namespace fz
 
 using namespace fz;
+
+extern "C" int fz_upcat_compose(const float* w_t, const float* w_b, int ldb, const float* b_t, const float* b_ad, float* wc, float* wbt,
+                                float* bias, int Cd, int O, int M, fz_stream_t stream) {
+  if (!w_t || !w_b || (!wc && !wbt && !bias) || Cd < 1 || O < 1 || M < 1 || ldb < O) return fail(FZ_E_ARG, "fz_upcat_compose: bad arguments");
+  hipLaunchKernelGGL(upcat_compose_kernel, dim3((unsigned)(Cd + 1)), dim3(256), 0, (hipStream_t)stream, w_t, w_b, ldb, b_t, b_ad, wc, wbt,
+                     bias, Cd, O, M);
+  FZ_LAUNCH_CHECK();
+  return FZ_OK;
+}
+
+extern "C" int fz_upcat_wgrads(const float* gt, const float* w_t, const float* w_b, int ldb, const float* gb_ad, const float* b_t,
+                               float* gw_t, float* gw_b, int ldg, float* gb_t, int Cd, int O, int M, fz_stream_t stream) {
+  if (!gt || !w_t || !w_b || !gb_ad || !gw_t || !gw_b || Cd < 1 || O < 1 || M < 1 || ldb < O || ldg < O)
+    return fail(FZ_E_ARG, "fz_upcat_wgrads: bad arguments");
+  hipLaunchKernelGGL(upcat_wgrads_kernel, dim3((unsigned)(Cd + M + 1)), dim3(256), 0, (hipStream_t)stream, gt, w_t, w_b, ldb, gb_ad, b_t,
+                     gw_t, gw_b, ldg, gb_t, Cd, O, M);
+  FZ_LAUNCH_CHECK();
+  return FZ_OK;
+}
 
 extern "C" int fz_upcat_supported(int C, int Cd, int D, int H, int W) {
   // (coarse extent) fine rows of 2W voxels in 64-voxel wave tiles, 256-voxel workgroups inside one d

@@ -809,12 +809,12 @@ class UpCatLinearFn(torch.autograd.Function):
         y = torch.empty((B, M, *skip.shape[2:]), dtype=skip.dtype, device=skip.device)
         if (M == 32 and C1 == 32 and O == 32 and _UPCAT_FWD and N.lib().fz_upcat_supported(C1, Cd, D, H, W)):
             # one pass over (skip, deep) -> out with the composed weights (csrc/upcat.hip): no up-sampled tensor at all
-            with torch.autocast("cuda", enabled=False):
-                w_b = w2[:, C1:]
-                wbt = torch.einsum("mc,kct->tmk", w_b, w_t.reshape(Cd, O, 8)).contiguous()
-                bias = b_ad
-                if b_t is not None:
-                    bias = w_b @ b_t if b_ad is None else b_ad + w_b @ b_t
+            w_b = w2[:, C1:]
+            wbt = torch.empty((8, M, Cd), dtype=torch.float32, device=skip.device)
+            bias = torch.empty(M, dtype=torch.float32, device=skip.device) if (b_t is not None or b_ad is not None) else None
+            with torch.cuda.device(skip.device):
+                N.check(N.lib().fz_upcat_compose(w_t.data_ptr(), w_b.data_ptr(), C1 + O, _p(b_t), _p(b_ad), None, wbt.data_ptr(),
+                                                 _p(bias), Cd, O, M, N.stream_ptr(skip)), "fz_upcat_compose")
             es = skip.element_size()
             with torch.cuda.device(skip.device):
                 rc = Fn._timed(f"upcat_{Cd}->{M}", es * (skip.numel() + deep.numel() + y.numel()),
@@ -855,10 +855,11 @@ class UpCatLinearFn(torch.autograd.Function):
             gwa = torch.empty((M, C1), dtype=torch.float32, device=dev)
             _wgrad(g, [skip], gwa, B=B, M=M, Cin=C1, K=C1, Vq=Vf, Ncols=Vf, gbias=gb_ad, name="wgrad_linear")
             gw_ad[:, :C1].copy_(gwa)
-        with torch.autocast("cuda", enabled=False):
-            w_b = w2[:, C1:]                                   # (M, O)
-            wt3 = w_t.reshape(Cd, O, 8)
-            wc = torch.einsum("kct,mc->kmt", wt3, w_b).reshape(Cd, M, 2, 2, 2).contiguous()
+        w_b = w2[:, C1:]                                       # (M, O), row stride C1 + O
+        wc = torch.empty((Cd, M, 2, 2, 2), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            N.check(N.lib().fz_upcat_compose(w_t.data_ptr(), w_b.data_ptr(), C1 + O, None, None, wc.data_ptr(), None, None,
+                                             Cd, O, M, N.stream_ptr(g)), "fz_upcat_compose")
         # --- deep half: input gradient and the (deep x g) correlation, both on g itself ---
         g_deep = None
         if ctx.needs_input_grad[1]:
@@ -868,14 +869,12 @@ class UpCatLinearFn(torch.autograd.Function):
         gt = torch.empty((Cd, M, 8), dtype=torch.float32, device=dev)
         _wgrad(deep, [g], gt, B=B, M=Cd, Cin=M, K=8 * M, Vq=Vf, Ncols=V, loader=LOAD_S2D, D=2 * D, H=2 * H,
                W=2 * W, Ho=H, Wo=W, name="wgrad_tconv_k2s2")
-        with torch.autocast("cuda", enabled=False):
-            gwb = torch.einsum("kmt,kct->mc", gt, wt3)
-            if ctx.has_bt:   # up = T(deep) + b_t: the constant part meets Σ_v g
-                gwb = gwb + gb_ad[:, None] * b_t[None, :]
-            gw_ad[:, C1:].copy_(gwb)
-            gw_t = _GB.out_like(w_t)   # (its slice of the flat gradient buffer when one is attached)
-            gw_t.view(Cd, O, 8).copy_(torch.einsum("mc,kmt->kct", w_b, gt))
-            gb_t = (gb_ad @ w_b) if ctx.has_bt else None
+        gw_t = _GB.out_like(w_t)       # (its slice of the flat gradient buffer when one is attached)
+        gb_t = torch.empty(O, dtype=torch.float32, device=dev) if ctx.has_bt else None
+        with torch.cuda.device(dev):   # up = T(deep) + b_t: the constant part of up meets Σ_v g in dW_b
+            N.check(N.lib().fz_upcat_wgrads(gt.data_ptr(), w_t.data_ptr(), w_b.data_ptr(), C1 + O, gb_ad.data_ptr(), _p(b_t),
+                                            gw_t.data_ptr(), gw_ad[:, C1:].data_ptr(), C1 + O, _p(gb_t), Cd, O, M,
+                                            N.stream_ptr(g)), "fz_upcat_wgrads")
         return (g_skip, g_deep, gw_t, gb_t, gw_ad.reshape(ctx.wshape), gb_ad if ctx.has_bad else None)
 
 

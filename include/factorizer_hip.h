@@ -311,6 +311,14 @@ int fz_gemm_dw(const fz_gemm_dw_desc* desc, fz_stream_t stream);
  * factorizer.py:116) without forming the up-sampled tensor: the caller passes the composed weights
  * wbt[tap][m][k] = sum_c W_b[m][c] W_t[k][c][tap] (tap = kd*4 + kh*2 + kw), the skip half W_a (row stride lda) and
  * bias' = b_ad + W_b b_t (or NULL).  C = 32 skip / output channels, Cd = 64 deep channels, (D, H, W) = coarse extent. */
+/* the weight compositions of that node (a few Mflop; device pointers, fp32):
+ *   compose: wc[k][m][t] = sum_c w_t[k][c][t] w_b[m][c] (and/or wbt[t][m][k], bias'[m] = b_ad[m] + sum_c w_b[m][c] b_t[c]; outputs may be NULL)
+ *   wgrads : from gt[k][m][t] = sum_n deep[k][n] g[m][fine(n,t)]:  gw_t = w_b^T gt,  gw_b = gt . w_t + gb_ad (x) b_t (row stride ldg),
+ *            gb_t = w_b^T gb_ad                                                                      */
+int fz_upcat_compose(const float* w_t, const float* w_b, int ldb, const float* b_t, const float* b_ad, float* wc, float* wbt, float* bias,
+                     int Cd, int O, int M, fz_stream_t stream);
+int fz_upcat_wgrads(const float* gt, const float* w_t, const float* w_b, int ldb, const float* gb_ad, const float* b_t, float* gw_t,
+                    float* gw_b, int ldg, float* gb_t, int Cd, int O, int M, fz_stream_t stream);
 int fz_upcat_supported(int C, int Cd, int D, int H, int W);
 int fz_upcat(const void* skip, const void* deep, const float* wa, int lda, const float* wbt, const float* bias, void* out,
              int B, int C, int Cd, int D, int H, int W, int act_dtype, fz_stream_t stream);
