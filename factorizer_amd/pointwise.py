@@ -466,6 +466,23 @@ class ActLinearResFn(torch.autograd.Function):
         V = _vox(z)
         M = w2.shape[0]
         gz = torch.empty_like(z)
+        if M <= 4 and C == 32 and ctx.bact == "none" and V % 4 == 0 and _HEAD_BWD:
+            # the head (32 -> out_channels): input, weight and bias gradient in one bandwidth-bound pass (csrc/headbwd.hip)
+            lib = N.lib()
+            rows = lib.fz_head_bwd_rows()
+            part = torch.empty(lib.fz_head_bwd_workspace_bytes() // 4, dtype=torch.float32, device=z.device)
+            out = torch.empty(132, dtype=torch.float32, device=z.device)
+            es = z.element_size()
+            with torch.cuda.device(z.device):
+                rc = Fn._timed(f"head_bwd_{C}->{M}", es * (gy.numel() + 2 * z.numel()),
+                               lambda: lib.fz_head_bwd(gy.data_ptr(), z.data_ptr(), w2.data_ptr(), gz.data_ptr(), part.data_ptr(),
+                                                       B, M, C, V, N.act_dtype(z), N.stream_ptr(z)), cols=B * V)
+                N.check(rc, "fz_head_bwd")
+                N.check(lib.fz_chunk_reduce(part.data_ptr(), rows, 132, out.data_ptr(), 0, N.stream_ptr(z)), "fz_chunk_reduce")
+            gw = _GB.out_like(w2)
+            gw.copy_(out[:M * 32].view(M, 32))
+            gb = out[128:128 + M]
+            return gz, gw.reshape(ctx.wshape), (gb if ctx.has_bias else None), (gy if ctx.has_res else None), None
         _gemm([gy], w2, gz, B=B, Cin=M, Vin=V, M=C, K=M, Ncol=V, w_t=True, ldw=C,
               emul=(z if ctx.bact != "none" else None), emul_kind=ACT[ctx.bact], name="linear_dgrad")
         gw = _GB.out_like(w2)
@@ -879,6 +896,7 @@ class UpCatLinearFn(torch.autograd.Function):
 
 
 _UPCAT_FWD = os.environ.get("FZ_UPCAT_FWD", "1") != "0"   # diagnostics: 0 = the two forward launches
+_HEAD_BWD = os.environ.get("FZ_HEAD_BWD", "1") != "0"     # diagnostics: 0 = separate input- and weight-gradient launches
 
 
 def up_cat_linear(skip, deep, w_t, b_t, w_ad, b_ad=None):

@@ -306,6 +306,14 @@ int fz_gemm_dw_rows(int B, int64_t V);
 int64_t fz_gemm_dw_workspace_bytes(int B, int64_t V);
 int fz_gemm_dw(const fz_gemm_dw_desc* desc, fz_stream_t stream);
 
+/* ---- backward of a Linear(32 -> M), M <= 4, in one pass (the network's head: factorizer/unet.py:253) ----
+ * gx = W^T gy (activation, (B, 32, V)); weight and bias gradient as fz_head_bwd_rows() partial rows of 132 floats
+ * (gW[m][c] at m*32 + c, gb[m] at 128 + m) for fz_chunk_reduce(part, rows, 132, out132, 0, stream). */
+int fz_head_bwd_rows(void);
+int64_t fz_head_bwd_workspace_bytes(void);
+int fz_head_bwd(const void* gy, const void* x, const float* w, void* gx, float* part, int B, int M, int C, int64_t V,
+                int act_dtype, fz_stream_t stream);
+
 /* ---- decoder level forward in one pass ---------------------------------------------------
  * out = adapter(cat([skip, ConvTranspose3d(k2, s2)(deep)], 1))  (factorizer/unet.py:125-127 with the stage adapter of
  * factorizer.py:116) without forming the up-sampled tensor: the caller passes the composed weights

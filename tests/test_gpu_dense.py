@@ -582,6 +582,31 @@ def test_up_cat_linear_node_vs_separate_nodes_and_fp64(C, Cd, S, bias_ad, dt):
         P.close(f"up_cat_linear {Cd}->{C} y", y1, yr.float())
 
 
+@pytest.mark.parametrize("M", [1, 2, 3, 4])
+@pytest.mark.parametrize("B,S,dt", [(2, (8, 8, 8), torch.float32), (1, (16, 16, 12), torch.float32), (3, (32, 32, 40), torch.float32),
+                                   (2, (16, 16, 16), torch.bfloat16)])
+def test_head_backward_one_pass_fp64(M, B, S, dt):
+    """fz_head_bwd (csrc/headbwd.hip): backward of the network's head Linear(32 -> out_channels <= 4) (unet.py:253 through
+    linear.py:53-58) — input, weight and bias gradient from one pass over (gy, x) — against a float64 evaluation."""
+    torch.manual_seed(9)
+    x = torch.randn(B, 32, *S)
+    w = torch.randn(M, 32, 1) * 0.3
+    b = torch.randn(M) * 0.1
+    g = torch.randn(B, M, *S)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    yr = F.conv1d(xr.flatten(2), wr, br).reshape(B, M, *S)
+    gr = torch.autograd.grad(yr, [xr, wr, br], g.double())
+    xd = x.to(DEV).to(dt).requires_grad_(True)
+    wd, bd = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    n0 = _native.launch_count()
+    y = PW.linear_cf(xd, wd, bd)
+    gd = torch.autograd.grad(y, [xd, wd, bd], g.to(DEV).to(dt))
+    assert _native.launch_count() > n0
+    tol = 1e-4 if dt == torch.float32 else 2e-2
+    for n, u, r in zip(("gx", "gw", "gb"), gd, gr):
+        assert (u.double().cpu() - r).abs().max().item() <= tol * (r.abs().max().item() + 1e-30), n
+
+
 def test_weight_gradients_land_in_the_flat_buffer():
     """With a FlatAdamW / FlatGradSync attached, every weight-gradient launch writes into its parameter's slice of the flat
     gradient buffer (factorizer_amd/gradbuf.py): after backward p.grad of every matrix / convolution weight IS that slice (no
