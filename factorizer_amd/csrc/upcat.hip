@@ -11,11 +11,9 @@
 // Mapping.  A wave owns 64 consecutive fine voxels of one (d, h) row (W_fine % 64 == 0): lane (j, half) holds the two
 // voxels w = w0 + 2j + q, q = 0, 1 — the two fine voxels of ONE coarse voxel along W, i.e. tap tw = q — so the deep
 // operand is loaded once per lane and channel and multiplied with the weights of tap (td, th, q) into accumulator q:
-// no masked or duplicated MFMA.  (td, th) = (d & 1, h & 1) is wave-uniform; the four waves of a workgroup cover 256
-// consecutive voxels = whole rows of one d (H_fine % 4 == 0), so the workgroup stages the four taps (td, th ∈ {0,1},
-// tw ∈ {0,1}) of Wbt next to W_a: 54 KB of pre-split bf16 levels (gemm_bx.h: six exact bf16 products per fp32
-// product; bf16 storage: the activations are exact single terms).  One tile per workgroup, every operand load issued
-// before the first product; operand reads from LDS through one opaque per-lane base per image (see gemm_chain64).
+// no masked or duplicated MFMA.  (td, th) = (d & 1, h & 1) is wave-uniform per tile.  All eight taps of Wbt and W_a sit
+// pre-split in LDS (gemm_bx.h: six exact bf16 products per fp32 product; bf16 storage: the activations are exact single
+// terms); operand reads from LDS through one opaque per-lane base per image (see gemm_chain64).
 #include "gemm_bx.h"
 
 namespace fz {
@@ -32,29 +30,32 @@ struct UpcatArgsT {
   int B, D, H, W;     // coarse extent
 };
 
+// One PERSISTENT workgroup of 256 threads per CU (one wave per SIMD): W_a and all eight taps of Wbt are split into bf16
+// levels and staged ONCE (102 KB of LDS), every wave then walks 64-voxel tiles with a stride of the grid, the operands of
+// its next tile in flight while the products of the current one run.  (A first form staged four taps per 256-voxel
+// workgroup: the staging — 1 152 weight items per tile of 24 KB of operand data — was half of the kernel.)
+// Four waves, not eight: the same program as a 512-thread workgroup (two waves of one workgroup per SIMD) returned run-to-run
+// different values in a few hundred elements at 128^3 — also with the tap images beyond 64 KB unused — while the 256-thread
+// form replays bit for bit (tools/probes/upcat_check.py, profiles/r03_two_stream_interaction.md); cause not found.
+#define UPCAT_WAVES 4
+#define UPCAT_THREADS (UPCAT_WAVES * 64)
 template <typename AT>
-__global__ __launch_bounds__(256, 2) void upcat_bx_kernel(UpcatArgsT<AT> p) {
+__global__ __launch_bounds__(UPCAT_THREADS, 2) void upcat_bx_kernel(UpcatArgsT<AT> p, int64_t ntiles) {
   constexpr int C = 32, CD = 64;
   constexpr int GS = C / 16, GD = CD / 16;          // K16-groups of the two segments
   constexpr int NTB = bx_terms_b<AT>(BXPRO_NONE);   // 3 (fp32 storage) / 1 (bf16 storage: exact)
-  // LDS images: [slot][level][lane] x 16 B; skip: slot = g (2); deep: slot = (tapsel * GD + g), tapsel = th * 2 + tw (16)
-  __shared__ __attribute__((aligned(16))) float As[(GS + 4 * GD) * 3 * 64 * 4];
+  // LDS images: [slot][level][lane] x 16 B; skip: slot = g (2); deep: slot = GS + tap * GD + g, tap = td*4 + th*2 + tw (32)
+  extern __shared__ __attribute__((aligned(16))) float As[];
   __shared__ float sBias[32];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int j = lane & 31, hk = lane >> 5;
   const int Wf = 2 * p.W, Hf = 2 * p.H, Df = 2 * p.D;
   const int64_t Vf = (int64_t)Df * Hf * Wf, Vc = (int64_t)p.D * p.H * p.W;
-  const int64_t tiles_per_sample = Vf / 256;
-  const int b = (int)(blockIdx.x / tiles_per_sample);
-  const int64_t n0 = (blockIdx.x % tiles_per_sample) * 256 + (int64_t)wave * 64;   // first fine voxel of this wave
-  const int w0 = (int)(n0 % Wf);
-  const int64_t row = n0 / Wf;
-  const int hf = (int)(row % Hf), df = (int)(row / Hf);
-  const int td = __builtin_amdgcn_readfirstlane((int)((blockIdx.x % tiles_per_sample) * 256 / ((int64_t)Wf * Hf)) & 1);   // workgroup-uniform
+  const int64_t tiles_per_sample = Vf / 64;
 
   // ---- weights -> three bf16 levels -> LDS (once per workgroup) ----
-  for (int item = threadIdx.x; item < (GS + 4 * GD) * 64; item += 256) {
+  for (int item = threadIdx.x; item < (GS + 8 * GD) * 64; item += UPCAT_THREADS) {
     const int l = item & 63, slot = item >> 6;
     const int m = l & 31, kh = l >> 5;
     float a8[8];
@@ -62,8 +63,7 @@ __global__ __launch_bounds__(256, 2) void upcat_bx_kernel(UpcatArgsT<AT> p) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) a8[e] = p.wa[(int64_t)m * p.lda + 16 * slot + 8 * kh + e];
     } else {
-      const int s2 = slot - GS, tapsel = s2 / GD, g = s2 % GD;
-      const int tap = td * 4 + (tapsel >> 1) * 2 + (tapsel & 1);
+      const int s2 = slot - GS, tap = s2 / GD, g = s2 % GD;
 #pragma unroll
       for (int e = 0; e < 8; ++e) a8[e] = p.wbt[((int64_t)tap * 32 + m) * CD + 16 * g + 8 * kh + e];
     }
@@ -73,88 +73,111 @@ __global__ __launch_bounds__(256, 2) void upcat_bx_kernel(UpcatArgsT<AT> p) {
     dst[0] = t3[0]; dst[64] = t3[1]; dst[128] = t3[2];
   }
   if (threadIdx.x < 32) sBias[threadIdx.x] = p.bias != nullptr ? p.bias[threadIdx.x] : 0.f;
-
-  // ---- operand loads: skip (two fine voxels per lane and channel), deep (their one coarse voxel) ----
-  const int th = hf & 1;
-  const unsigned soff = (unsigned)((((int64_t)8 * hk) * Vf + n0 + 2 * j) * (int64_t)sizeof(AT));
-  const int64_t ncoarse = ((int64_t)(df >> 1) * p.H + (hf >> 1)) * p.W + (w0 >> 1) + j;
-  const unsigned doff = (unsigned)((((int64_t)8 * hk) * Vc + ncoarse) * (int64_t)sizeof(AT));
-  float xs[GS][8][2], xd[GD][8];
-#pragma unroll
-  for (int g = 0; g < GS; ++g) {
-    const AT* ub = p.skip + ((int64_t)b * C + 16 * g) * Vf;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) uload<2>(ub + (int64_t)e * Vf, soff, xs[g][e]);
-  }
-#pragma unroll
-  for (int g = 0; g < GD; ++g) {
-    const AT* ub = p.deep + ((int64_t)b * CD + 16 * g) * Vc;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float t[1];
-      uload<1>(ub + (int64_t)e * Vc, doff, t);
-      xd[g][e] = t[0];
-    }
-  }
   __syncthreads();
 
-  f32x16 acc[2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
-  int lane4 = lane * 4;
+  int lane4 = lane * 4, lane4d = lane * 4 + GS * 3 * 256;   // opaque per-lane float indices of the two images (64 KB immediates)
   asm volatile("" : "+v"(lane4));
-  auto ld_a = [&](int slot3) { return *reinterpret_cast<const bx8*>(As + slot3 * 256 + lane4); };
+  asm volatile("" : "+v"(lane4d));
 
-  // ---- skip segment: out += W_a · skip ----
+  // ---- operand loads of one tile: skip (two fine voxels per lane and channel), deep (their one coarse voxel) ----
+  float xs[GS][8][2], xd[GD][8];
+  auto fetch = [&](int64_t t) {
+    const int b = (int)(t / tiles_per_sample);
+    const int64_t n0 = (t % tiles_per_sample) * 64;
+    const int w0 = (int)(n0 % Wf);
+    const int64_t row = n0 / Wf;
+    const int hf = (int)(row % Hf), df = (int)(row / Hf);
+    const unsigned soff = (unsigned)((((int64_t)8 * hk) * Vf + n0 + 2 * j) * (int64_t)sizeof(AT));
+    const int64_t ncoarse = ((int64_t)(df >> 1) * p.H + (hf >> 1)) * p.W + (w0 >> 1) + j;
+    const unsigned doff = (unsigned)((((int64_t)8 * hk) * Vc + ncoarse) * (int64_t)sizeof(AT));
 #pragma unroll
-  for (int g = 0; g < GS; ++g) {
+    for (int g = 0; g < GS; ++g) {
+      const AT* ub = p.skip + ((int64_t)b * C + 16 * g) * Vf;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      float x8[8];
+      for (int e = 0; e < 8; ++e) uload<2>(ub + (int64_t)e * Vf, soff, xs[g][e]);
+    }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) x8[e] = xs[g][e][q];
-      bx8 bop[NTB];
-      bx_split<NTB>(x8, bop);
+    for (int g = 0; g < GD; ++g) {
+      const AT* ub = p.deep + ((int64_t)b * CD + 16 * g) * Vc;
 #pragma unroll
-      for (int t = 2; t >= 0; --t) {
-        const bx8 a = ld_a(g * 3 + t);
-#pragma unroll
-        for (int jj = NTB - 1; jj >= 0; --jj)
-          if (t + jj <= 2) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bop[jj], acc[q], 0, 0, 0);
+      for (int e = 0; e < 8; ++e) {
+        float t1[1];
+        uload<1>(ub + (int64_t)e * Vc, doff, t1);
+        xd[g][e] = t1[0];
       }
     }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  // ---- deep segment: out[.., voxel q] += Wbt[tap (td, th, q)] · deep[coarse voxel] ----
-  const int tbase = __builtin_amdgcn_readfirstlane(GS + th * 2 * GD);   // slot of (th, tw = 0, g = 0)
+  };
+
+  const int64_t tstep = (int64_t)gridDim.x * UPCAT_WAVES;
+  int64_t tile = (int64_t)blockIdx.x * UPCAT_WAVES + wave;
+  if (tile < ntiles) fetch(tile);
+  for (; tile < ntiles; tile += tstep) {
+    const int b = (int)(tile / tiles_per_sample);
+    const int64_t n0 = (tile % tiles_per_sample) * 64;
+    const int64_t row = n0 / Wf;
+    const int hf = (int)(row % Hf), df = (int)(row / Hf);
+    const int tap0 = __builtin_amdgcn_readfirstlane(((df & 1) * 4 + (hf & 1) * 2) * GD);   // slot of (td, th, tw = 0, g = 0) inside the deep image
+
+    // ---- split the column operands (the registers are then free for the next tile's loads) ----
+    bx8 bs[GS][2][NTB], bd[GD][NTB];
 #pragma unroll
-  for (int g = 0; g < GD; ++g) {
-    bx8 bop[NTB];
-    bx_split<NTB>(xd[g], bop);
+    for (int g = 0; g < GS; ++g)
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+      for (int q = 0; q < 2; ++q) {
+        float x8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x8[e] = xs[g][e][q];
+        bx_split<NTB>(x8, bs[g][q]);
+      }
+#pragma unroll
+    for (int g = 0; g < GD; ++g) bx_split<NTB>(xd[g], bd[g]);
+    if (tile + tstep < ntiles) fetch(tile + tstep);
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    // ---- skip segment: out += W_a · skip ----
+#pragma unroll
+    for (int g = 0; g < GS; ++g) {
 #pragma unroll
       for (int t = 2; t >= 0; --t) {
-        const bx8 a = *reinterpret_cast<const bx8*>(As + ((tbase + q * GD + g) * 3 + t) * 256 + lane4);
+        const bx8 a = *reinterpret_cast<const bx8*>(As + (g * 3 + t) * 256 + lane4);
 #pragma unroll
-        for (int jj = NTB - 1; jj >= 0; --jj)
-          if (t + jj <= 2) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bop[jj], acc[q], 0, 0, 0);
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int jj = NTB - 1; jj >= 0; --jj)
+            if (t + jj <= 2) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bs[g][q][jj], acc[q], 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-
-  // ---- epilogue: rows (r & 3) + 8 (r >> 2) + 4 hk, the lane's two voxels as one 8-byte (4-byte) store ----
-  const unsigned yoff = (unsigned)((((int64_t)4 * hk) * Vf + n0 + 2 * j) * (int64_t)sizeof(AT));
-  AT* yb = p.out + (int64_t)b * C * Vf;
+    // ---- deep segment: out[.., voxel q] += Wbt[tap (td, th, q)] · deep[coarse voxel] ----
+    const float* Ad = As + tap0 * 3 * 256;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int rb = (r & 3) + 8 * (r >> 2);
-    const float add = sBias[rb + 4 * hk];
-    const float v[2] = {acc[0][r] + add, acc[1][r] + add};
-    vstore<2>(reinterpret_cast<AT*>(reinterpret_cast<char*>(yb + (int64_t)rb * Vf) + yoff), v);
+    for (int g = 0; g < GD; ++g) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int t = 2; t >= 0; --t) {
+          const bx8 a = *reinterpret_cast<const bx8*>(Ad + ((q * GD + g) * 3 + t) * 256 + lane4d);
+#pragma unroll
+          for (int jj = NTB - 1; jj >= 0; --jj)
+            if (t + jj <= 2) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bd[g][jj], acc[q], 0, 0, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- epilogue: rows (r & 3) + 8 (r >> 2) + 4 hk, the lane's two voxels as one 8-byte (4-byte) store ----
+    const unsigned yoff = (unsigned)((((int64_t)4 * hk) * Vf + n0 + 2 * j) * (int64_t)sizeof(AT));
+    AT* yb = p.out + (int64_t)b * C * Vf;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rb = (r & 3) + 8 * (r >> 2);
+      const float add = sBias[rb + 4 * hk];
+      const float v[2] = {acc[0][r] + add, acc[1][r] + add};
+      vstore<2>(reinterpret_cast<AT*>(reinterpret_cast<char*>(yb + (int64_t)rb * Vf) + yoff), v);
+    }
   }
 }
 
@@ -259,8 +282,12 @@ static int upcat_launch(const void* skip, const void* deep, const float* wa, int
   UpcatArgsT<AT> a;
   a.skip = (const AT*)skip; a.deep = (const AT*)deep; a.wa = wa; a.wbt = wbt; a.bias = bias; a.out = (AT*)out;
   a.lda = lda; a.B = B; a.D = D; a.H = H; a.W = W;
-  const int64_t tiles = (int64_t)8 * D * H * W / 256 * B;
-  hipLaunchKernelGGL((upcat_bx_kernel<AT>), dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, a);
+  const int64_t ntiles = (int64_t)8 * D * H * W / 64 * B;   // 64-voxel wave tiles
+  constexpr int lds = (2 + 8 * 4) * 3 * 64 * 16;            // 34 slots x 3 levels x 64 lanes x 16 B = 102 KB
+  auto kern = upcat_bx_kernel<AT>;
+  FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  const int64_t wgs = (ntiles + UPCAT_WAVES - 1) / UPCAT_WAVES;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(wgs < 256 ? wgs : 256)), dim3(UPCAT_THREADS), lds, (hipStream_t)stream, a, ntiles);
   FZ_LAUNCH_CHECK();
   return FZ_OK;
 }
