@@ -46,7 +46,6 @@ __global__ __launch_bounds__(UPCAT_THREADS, 1) void upcat_bx_kernel(UpcatArgsT<A
   constexpr int NTB = bx_terms_b<AT>(BXPRO_NONE);   // 3 (fp32 storage) / 1 (bf16 storage: exact)
   // LDS images: [slot][level][lane] x 16 B; skip: slot = g (2); deep: slot = GS + tap * GD + g, tap = td*4 + th*2 + tw (32)
   extern __shared__ __attribute__((aligned(16))) float As[];
-  __shared__ float sBias[32];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int j = lane & 31, hk = lane >> 5;
@@ -73,8 +72,10 @@ __global__ __launch_bounds__(UPCAT_THREADS, 1) void upcat_bx_kernel(UpcatArgsT<A
     bx8* dst = reinterpret_cast<bx8*>(As) + (slot * 3) * 64 + l;
     dst[0] = t3[0]; dst[64] = t3[1]; dst[128] = t3[2];
   }
-  if (threadIdx.x < 32) sBias[threadIdx.x] = p.bias != nullptr ? p.bias[threadIdx.x] : 0.f;
   __syncthreads();
+  float badd[16];   // the bias' entries of this lane's 16 output rows
+#pragma unroll
+  for (int r = 0; r < 16; ++r) badd[r] = p.bias != nullptr ? p.bias[(r & 3) + 8 * (r >> 2) + 4 * hk] : 0.f;
 
   int lane4 = lane * 4, lane4d = lane * 4 + GS * 3 * 256;   // opaque per-lane float indices of the two images (64 KB immediates)
   asm volatile("" : "+v"(lane4));
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(UPCAT_THREADS, 1) void upcat_bx_kernel(UpcatArgsT<A
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int rb = (r & 3) + 8 * (r >> 2);
-      const float add = sBias[rb + 4 * hk];
+      const float add = badd[r];
       const float v[2] = {acc[0][r] + add, acc[1][r] + add};
       vstore<2>(reinterpret_cast<AT*>(reinterpret_cast<char*>(yb + (int64_t)rb * Vf) + yoff), v);
     }
