@@ -141,9 +141,11 @@ __device__ __forceinline__ void lnbwd_block(const GemmArgsT<AT>& p, const f32x16
 // workgroup sequentially with one accumulator set: the input is read from HBM exactly once for
 // all output rows and 10+ KiB per wave are in flight.
 // =================================================================================================
-template <int NSTEP, int EPI, bool BMUL, bool GADD = false, typename AT = float, int PF = 3>
+// RESPF (one 32-row block, plain epilogue): the residual tile is requested with the operand, before the products — in the
+// epilogue its loads were a second exposed round trip per workgroup (wait share 0.72 of the wave lifetime, round-3 profile 8)
+template <int NSTEP, int EPI, bool BMUL, bool GADD = false, typename AT = float, int PF = 3, bool RESPF = false>
 // (waves per SIMD chosen so that NO variant needs scratch: see the note on scratch and concurrent streams in nmf_pcf.hip)
-__global__ __launch_bounds__(256, ((NSTEP <= 16 && EPI == EPI_PLAIN && !BMUL && !(PF & 2)) ? 3 : (NSTEP <= 16 ? 2 : 1))) void gemm_resident_kernel(GemmArgsT<AT> p, int RB) {
+__global__ __launch_bounds__(256, ((NSTEP <= 16 && EPI == EPI_PLAIN && !BMUL && !(PF & 2) && !RESPF) ? 3 : (NSTEP <= 16 ? 2 : 1))) void gemm_resident_kernel(GemmArgsT<AT> p, int RB) {
   // PF: prologue code compiled in — bit 0 input activation, bit 1 LayerNorm.  A runtime branch alone keeps a second copy
   // of the operand registers alive (normalised / activated next to raw): the K <= 32 form spilled because of it.
   constexpr bool ACTIN = (PF & 1) != 0, LNP = (PF & 2) != 0;
@@ -165,6 +167,24 @@ __global__ __launch_bounds__(256, ((NSTEP <= 16 && EPI == EPI_PLAIN && !BMUL && 
   const int b = bid / tiles_per_sample;
   const int64_t n0 = ((int64_t)(bid % tiles_per_sample) * 4 + wave) * 128;
   const int m0 = blockIdx.y * 32 * RB;
+
+  // the column operand (and the residual tile) first: the weight fill below runs under their latency
+  const int64_t col_off = n0 + 4 * j;
+  const bool col_ok = col_off < p.Ncol;
+  // (K <= 32 forms; the K <= 64 ones keep the loads behind the fill: one of them needed scratch with the operand live across it)
+  constexpr bool kEarly = NSTEP <= 16;
+  float bv[NSTEP][4];
+  float rv[RESPF ? 16 : 1][4];
+  auto load_operands = [&]() {
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) fetch_plain<4, BMUL>(p, b, 2 * s + h, col_off, col_ok, bv[s]);
+    if (RESPF) {   // host-checked: M == 32, p.res != null
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        vload<4>(p.res + ((int64_t)b * p.M + (r & 3) + 8 * (r >> 2) + 4 * h) * p.Ncol + (col_ok ? col_off : 0), rv[RESPF ? r : 0]);
+    }
+  };
+  if (kEarly) load_operands();
 
   // batched fill (8 independent loads per thread before the LDS stores)
   constexpr int kFill = (NSTEP <= 16 && EPI == EPI_PLAIN && !BMUL) ? 4 : 8;   // independent loads per thread and round
@@ -206,11 +226,7 @@ __global__ __launch_bounds__(256, ((NSTEP <= 16 && EPI == EPI_PLAIN && !BMUL && 
     if (threadIdx.x < 32) tW[threadIdx.x] = p.lnb_g[threadIdx.x];
   }
 
-  const int64_t col_off = n0 + 4 * j;
-  const bool col_ok = col_off < p.Ncol;
-  float bv[NSTEP][4];
-#pragma unroll
-  for (int s = 0; s < NSTEP; ++s) fetch_plain<4, BMUL>(p, b, 2 * s + h, col_off, col_ok, bv[s]);
+  if (!kEarly) load_operands();
 
   if (LNP && p.ln) {
     // exact two-pass statistics over the Cin channels (this lane holds the parity-h half)
@@ -285,6 +301,25 @@ __global__ __launch_bounds__(256, ((NSTEP <= 16 && EPI == EPI_PLAIN && !BMUL && 
     }
     if (EPI == EPI_LNBWD) {
       lnbwd_block<4, GADD>(p, acc, b, col_off, col_ok, lane, wave, tW + 32 * RB, blockIdx.x, tW);
+    } else if (RESPF) {   // store_block's plain form with the residual already in registers (same order of additions)
+      if (col_ok) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
+          float add = p.bias ? p.bias[rl] : 0.f;
+          if (LNP && p.ln) add += tW[rl];
+          float v[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = acc[q][r] + add;
+          if (p.eact) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = act_f(p.eact, v[q]);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] += rv[RESPF ? r : 0][q];
+          vstore<4>(p.y + ((int64_t)b * p.M + rl) * p.Ncol + col_off, v);
+        }
+      }
     } else {
       if (col_ok) store_block<4, (EPI == EPI_LNBWD ? EPI_PLAIN : EPI), false>(p, acc, b, m0 + rb * 32, col_off, h, (LNP && p.ln) ? tW + rb * 32 : nullptr);
     }
@@ -2337,6 +2372,7 @@ static int env_pos_once(const char* name, int dflt) {
 static int knob_mlp_wg_wgs() { static const int v = env_pos_once("FZ_MLP_WG_WGS", 512); return v; }
 static int knob_gemm_dw_wgs() { static const int v = env_pos_once("FZ_GEMM_DW_WGS", 512); return v; }
 static int knob_chain64_p512() { static const int v = env_pos_once("FZ_CHAIN64_P512", 1); return v == 1; }   // 2 = off (diagnostics)
+static int knob_res_prefetch() { static const int v = env_pos_once("FZ_RES_PREFETCH", 1); return v == 1; }   // 2 = off (diagnostics)
 static int knob_mlp_wgs(int dflt) { static const int v = env_pos_once("FZ_MLP_WGS", 0); return v > 0 ? v : dflt; }
 
 static int gemm_bx_enabled() {
@@ -2466,6 +2502,9 @@ static int gemm_launch(const fz_gemm_desc* d, fz_stream_t stream) {
       if (nA <= 16) FZ_RES(16, EPI_D2S, false); else FZ_RES(32, EPI_D2S, false);
     } else if (d->bmul) {
       if (nA <= 16) FZ_RES(16, EPI_PLAIN, true); else FZ_RES(32, EPI_PLAIN, true);
+    } else if (d->res && !d->emul && d->M == 32 && nA <= 16 && !d->ln && knob_res_prefetch()) {
+      if (d->bact) hipLaunchKernelGGL((gemm_resident_kernel<16, EPI_PLAIN, false, false, AT, 1, true>), grid, block, lds, st, a, RB);
+      else hipLaunchKernelGGL((gemm_resident_kernel<16, EPI_PLAIN, false, false, AT, 0, true>), grid, block, lds, st, a, RB);
     } else {
       if (nA <= 16) FZ_RES(16, EPI_PLAIN, false); else FZ_RES(32, EPI_PLAIN, false);
     }
