@@ -327,6 +327,140 @@ __global__ __launch_bounds__(256, ((NSTEP <= 16 && EPI == EPI_PLAIN && !BMUL && 
 }
 
 // =================================================================================================
+// Kernel A' — the 32 -> 32 layers of stage 0 without a residual (LayerNorm + Linear in-projection, plain projections):
+// PERSISTENT waves.  The weights are this lane's 16 A operands for the whole walk (registers, no LDS image, no barrier in
+// the loop), every wave walks 128-column tiles with the operand of its next TWO tiles in flight — the one-tile-per-workgroup
+// forms (Kernel A, the streaming ring) pay the load round trip of every tile in the open (wait share 0.4-0.7, profile 8).
+// Arithmetic as Kernel A: exact two-pass LayerNorm, K-steps in ascending order on v_mfma_f32_32x32x2_f32.
+// Host-checked: M == K == Cin == 32, plain loader and epilogue, no gate, no residual, Ncol % 4 == 0.
+// =================================================================================================
+template <int PF, typename AT>
+__global__ __launch_bounds__(256, 2) void gemm_p32_kernel(GemmArgsT<AT> p, unsigned ntiles) {
+  constexpr bool ACTIN = (PF & 1) != 0, LNP = (PF & 2) != 0;
+  __shared__ float tW[32];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int j = lane & 31, h = lane >> 5;
+  const unsigned tps = (unsigned)((p.Ncol + 127) / 128);
+
+  if (threadIdx.x < 32) {
+    float t = p.bias ? p.bias[threadIdx.x] : 0.f;
+    if (LNP)
+      for (int k = 0; k < 32; ++k) t += weight_at(p, (int)threadIdx.x, k) * p.ln_b[k];
+    tW[threadIdx.x] = t;
+  }
+  float aw[16];   // A operand of K-step s: W[row j][channel 2s + h] (x gamma)
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    aw[s] = weight_at(p, j, 2 * s + h);
+    if (LNP) aw[s] *= p.ln_g[2 * s + h];
+  }
+  __syncthreads();
+  float add[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) add[r] = tW[(r & 3) + 8 * (r >> 2) + 4 * h];
+
+  typedef float BvT[16][4];
+  auto fetch = [&](unsigned t, BvT& bv) {
+    // every address = wave-uniform base (sample, channel pair: SGPRs) + ONE 32-bit lane offset (channel parity h, column)
+    const unsigned b = t / tps;
+    const int64_t col = (int64_t)(t - b * tps) * 128 + 4 * j;
+    const unsigned xoff = (unsigned)(((int64_t)h * p.Vin + (col < p.Ncol ? col : 0)) * (int64_t)sizeof(AT));
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int c = 2 * s;   // (c0 is even: both channels of the pair come from the same source)
+      const bool first = c < p.c0;
+      const AT* base = first ? p.x[0] : p.x[1];
+      const int cs = first ? p.c0 : 32 - p.c0;
+      const int ci = first ? c : c - p.c0;
+      uload<4>(base + ((int64_t)b * cs + ci) * p.Vin, xoff, bv[s]);
+    }
+  };
+  const unsigned tstep = gridDim.x * 4;
+  auto run = [&](unsigned t, BvT& bv) {
+    const unsigned b = t / tps;
+    const int64_t col_off = (int64_t)(t - b * tps) * 128 + 4 * j;
+    const bool col_ok = col_off < p.Ncol;
+    if (LNP) {
+      float mu[4], rs[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) v += bv[s][e];
+        v += __shfl_xor(v, 32, 64);
+        mu[e] = v / 32.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          const float d = bv[s][e] - mu[e];
+          v += d * d;
+        }
+        v += __shfl_xor(v, 32, 64);
+        rs[e] = 1.0f / sqrtf(v / 32.f + p.ln_eps);
+      }
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[s][e] = (bv[s][e] - mu[e]) * rs[e];
+      if (p.stats_out != nullptr && h == 0 && col_ok) {
+        float* so = p.stats_out + (int64_t)b * 2 * p.Vin;
+        *reinterpret_cast<float4*>(so + col_off) = make_float4(mu[0], mu[1], mu[2], mu[3]);
+        *reinterpret_cast<float4*>(so + p.Vin + col_off) = make_float4(rs[0], rs[1], rs[2], rs[3]);
+      }
+    }
+    if (ACTIN && p.bact == ACT_GELU) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[s][e] = gelu_f(bv[s][e]);
+    } else if (ACTIN && p.bact == ACT_RELU) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[s][e] = bv[s][e] > 0.f ? bv[s][e] : 0.f;
+    }
+    f32x16 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[s], bv[s][q], acc[q], 0, 0, 0);
+    if (t + 2 * tstep < ntiles) fetch(t + 2 * tstep, bv);   // the operand registers are free: the tile two steps ahead
+    if (col_ok) {
+      const unsigned yoff = (unsigned)(((int64_t)4 * h * p.Ncol + col_off) * (int64_t)sizeof(AT));
+      AT* yb = p.y + (int64_t)b * 32 * p.Ncol;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = acc[q][r] + add[r];
+        if (p.eact) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = act_f(p.eact, v[q]);
+        }
+        vstore<4>(reinterpret_cast<AT*>(reinterpret_cast<char*>(yb + (int64_t)((r & 3) + 8 * (r >> 2)) * p.Ncol) + yoff), v);
+      }
+    }
+  };
+
+  BvT bvA, bvB;
+  unsigned tile = blockIdx.x * 4 + (unsigned)wave;
+  if (tile < ntiles) fetch(tile, bvA);
+  if (tile + tstep < ntiles) fetch(tile + tstep, bvB);
+  for (; tile < ntiles; tile += 2 * tstep) {
+    run(tile, bvA);
+    if (tile + tstep < ntiles) run(tile + tstep, bvB);
+  }
+}
+
+// =================================================================================================
 // Kernel C — two chained GEMMs for the C = 32 MLP (layers/mlp.py:54-63 behind the second pre-norm
 // residual, factorizer.py:76): the 64-row hidden tensor is produced in the accumulators of GEMM 1,
 // transformed in registers and consumed as the B operand of GEMM 2 WITHOUT leaving the wave.
@@ -2373,6 +2507,7 @@ static int knob_mlp_wg_wgs() { static const int v = env_pos_once("FZ_MLP_WG_WGS"
 static int knob_gemm_dw_wgs() { static const int v = env_pos_once("FZ_GEMM_DW_WGS", 512); return v; }
 static int knob_chain64_p512() { static const int v = env_pos_once("FZ_CHAIN64_P512", 1); return v == 1; }   // 2 = off (diagnostics)
 static int knob_res_prefetch() { static const int v = env_pos_once("FZ_RES_PREFETCH", 1); return v == 1; }   // 2 = off (diagnostics)
+static int knob_p32() { static const int v = env_pos_once("FZ_GEMM_P32", 1); return v == 1; }   // 2 = off (diagnostics)
 static int knob_mlp_wgs(int dflt) { static const int v = env_pos_once("FZ_MLP_WGS", 0); return v > 0 ? v : dflt; }
 
 static int gemm_bx_enabled() {
@@ -2461,6 +2596,21 @@ static int gemm_launch(const fz_gemm_desc* d, fz_stream_t stream) {
       const int rc = gemm_bx_launch<AT>(a, d->loader, d->epilogue, pro_bx, stream);
       if (rc != FZ_E_UNSUPPORTED) return rc;   // shapes outside the family (K % 64, M % 32, alignment): the kernels below
     }
+  }
+
+  // ---- Kernel A': persistent 32 -> 32 without a residual (stage 0: LayerNorm + in-projection, plain projections) ----
+  if (knob_p32() && d->loader == LOAD_PLAIN && d->epilogue == EPI_PLAIN && d->M == 32 && d->K == 32 && d->Cin == 32 && (a.c0 & 1) == 0 && d->Vin < ((int64_t)1 << 28) && !d->res && !d->bmul &&
+      !d->emul && d->Ncol % 4 == 0 && d->Ncol == d->Vin && d->B * ((d->Ncol + 127) / 128) >= 4096 && d->B * ((d->Ncol + 127) / 128) < ((int64_t)1 << 30) &&
+      !(d->bact && !d->ln) /* the activation-only form needs scratch at two waves per SIMD: Kernel A keeps it */) {
+    const unsigned ntiles = (unsigned)(d->B * ((d->Ncol + 127) / 128));
+    const unsigned wgs = (ntiles + 3) / 4 < 512 ? (ntiles + 3) / 4 : 512;
+    const int pf = (d->bact ? 1 : 0) | (d->ln ? 2 : 0);
+    dim3 grid(wgs), block(256);
+    if (pf == 0) hipLaunchKernelGGL((gemm_p32_kernel<0, AT>), grid, block, 0, st, a, ntiles);
+    else if (pf == 2) hipLaunchKernelGGL((gemm_p32_kernel<2, AT>), grid, block, 0, st, a, ntiles);
+    else hipLaunchKernelGGL((gemm_p32_kernel<3, AT>), grid, block, 0, st, a, ntiles);
+    FZ_LAUNCH_CHECK();
+    return FZ_OK;
   }
 
   // ---- Kernel A: whole operand in registers (K <= 64, plain loader) ----
