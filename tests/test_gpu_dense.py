@@ -91,6 +91,44 @@ def test_ln_linear_large_mean():
     _cmp(y, yc, "ln large mean")
 
 
+@pytest.mark.parametrize("kind", ["ln", "ln_relu", "plain", "plain_nobias"])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_stage0_persistent_32_to_32(kind, dt):
+    """gemm_p32_kernel (persistent waves, >= 4096 wave tiles): 32 -> 32 at 81 x 81 x 80 voxels — 4100.6 tiles of 128 columns,
+    so the last tile is partial — against float64 on the host; forward values and the LayerNorm statistics it leaves for
+    the backward (through the input gradient)."""
+    torch.manual_seed(11)
+    S = (81, 81, 80)
+    x = (torch.randn(1, 32, *S) * 2 + 0.5)
+    g, bt = torch.rand(32) + 0.5, torch.randn(32) * 0.3
+    w = torch.randn(32, 32, 1) / 32 ** 0.5
+    b = None if kind == "plain_nobias" else torch.randn(32)
+    xd = x.to(DEV, dt).requires_grad_(True)
+    n0 = _native.launch_count()
+    if kind.startswith("ln"):
+        y = PW.ln_linear(xd, g.to(DEV), bt.to(DEV), 1e-5, w.to(DEV), b.to(DEV), "relu" if kind == "ln_relu" else "none")
+    else:
+        y = PW.linear_cf(xd, w.to(DEV), None if b is None else b.to(DEV))
+    assert _native.launch_count() > n0
+    x64 = xd.detach().double().cpu().requires_grad_(True)
+    if kind.startswith("ln"):
+        z = F.layer_norm(x64.movedim(1, -1), (32,), g.double(), bt.double(), 1e-5).movedim(-1, 1)
+    else:
+        z = x64
+    y64 = _lin_cpu(z, w.double(), None if b is None else b.double())
+    if kind == "ln_relu":
+        y64 = torch.relu(y64)
+    tol = 1e-4 if dt == torch.float32 else 8e-3
+    why = None if dt == torch.float32 else "bf16 storage: the output (and the gradient) is rounded to 8 bits of mantissa"
+    _cmp(y.float().cpu(), y64.float(), f"p32 {kind} forward", rtol=tol, why=why)
+    torch.manual_seed(12)
+    gy = torch.randn(y64.shape, dtype=torch.float64)
+    (gx,) = torch.autograd.grad(y, xd, gy.to(DEV, dt))
+    (gx64,) = torch.autograd.grad(y64, x64, gy.to(dt).double())
+    _cmp(gx.float().cpu(), gx64.float(), f"p32 {kind} input gradient", rtol=tol * 2,
+         why=why or "input gradient of LayerNorm + Linear: two chained fp32 kernels against float64")
+
+
 @pytest.mark.parametrize("B,Cin,Cout,S", SHAPES[:4])
 @pytest.mark.parametrize("act", ["gelu", "none"])
 @pytest.mark.parametrize("res", [True, False])
