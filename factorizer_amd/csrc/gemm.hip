@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256, ((NSTEP <= 16 && EPI == EPI_PLAIN && !BMUL && 
 // the loop), every wave walks 128-column tiles with the operand of its next TWO tiles in flight — the one-tile-per-workgroup
 // forms (Kernel A, the streaming ring) pay the load round trip of every tile in the open (wait share 0.4-0.7, profile 8).
 // Arithmetic as Kernel A: exact two-pass LayerNorm, K-steps in ascending order on v_mfma_f32_32x32x2_f32.
-// Host-checked: M == K == Cin == 32, plain loader and epilogue, no gate, no residual, Ncol % 4 == 0.
+// Host-checked: M <= 32, K == Cin == 32, plain loader and epilogue, no gate, no residual, Ncol % 4 == 0.
 // =================================================================================================
 template <int PF, typename AT>
 __global__ __launch_bounds__(256, 2) void gemm_p32_kernel(GemmArgsT<AT> p, unsigned ntiles) {
@@ -343,16 +343,20 @@ __global__ __launch_bounds__(256, 2) void gemm_p32_kernel(GemmArgsT<AT> p, unsig
   const int j = lane & 31, h = lane >> 5;
   const unsigned tps = (unsigned)((p.Ncol + 127) / 128);
 
+  // (M <= 32: rows beyond M have zero weights and are not stored — the 32 -> 3 head)
   if (threadIdx.x < 32) {
-    float t = p.bias ? p.bias[threadIdx.x] : 0.f;
-    if (LNP)
-      for (int k = 0; k < 32; ++k) t += weight_at(p, (int)threadIdx.x, k) * p.ln_b[k];
+    float t = 0.f;
+    if ((int)threadIdx.x < p.M) {
+      t = p.bias ? p.bias[threadIdx.x] : 0.f;
+      if (LNP)
+        for (int k = 0; k < 32; ++k) t += weight_at(p, (int)threadIdx.x, k) * p.ln_b[k];
+    }
     tW[threadIdx.x] = t;
   }
   float aw[16];   // A operand of K-step s: W[row j][channel 2s + h] (x gamma)
 #pragma unroll
   for (int s = 0; s < 16; ++s) {
-    aw[s] = weight_at(p, j, 2 * s + h);
+    aw[s] = j < p.M ? weight_at(p, j, 2 * s + h) : 0.f;
     if (LNP) aw[s] *= p.ln_g[2 * s + h];
   }
   __syncthreads();
@@ -435,9 +439,10 @@ __global__ __launch_bounds__(256, 2) void gemm_p32_kernel(GemmArgsT<AT> p, unsig
     if (t + 2 * tstep < ntiles) fetch(t + 2 * tstep, bv);   // the operand registers are free: the tile two steps ahead
     if (col_ok) {
       const unsigned yoff = (unsigned)(((int64_t)4 * h * p.Ncol + col_off) * (int64_t)sizeof(AT));
-      AT* yb = p.y + (int64_t)b * 32 * p.Ncol;
+      AT* yb = p.y + (int64_t)b * p.M * p.Ncol;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
+        if ((r & 3) + 8 * (r >> 2) + 4 * h >= p.M) continue;
         float v[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = acc[q][r] + add[r];
@@ -2599,7 +2604,7 @@ static int gemm_launch(const fz_gemm_desc* d, fz_stream_t stream) {
   }
 
   // ---- Kernel A': persistent 32 -> 32 without a residual (stage 0: LayerNorm + in-projection, plain projections) ----
-  if (knob_p32() && d->loader == LOAD_PLAIN && d->epilogue == EPI_PLAIN && d->M == 32 && d->K == 32 && d->Cin == 32 && (a.c0 & 1) == 0 && d->Vin < ((int64_t)1 << 28) && !d->res && !d->bmul &&
+  if (knob_p32() && d->loader == LOAD_PLAIN && d->epilogue == EPI_PLAIN && d->M <= 32 && d->K == 32 && d->Cin == 32 && (a.c0 & 1) == 0 && d->Vin < ((int64_t)1 << 28) && !d->res && !d->bmul &&
       !d->emul && d->Ncol % 4 == 0 && d->Ncol == d->Vin && d->B * ((d->Ncol + 127) / 128) >= 4096 && d->B * ((d->Ncol + 127) / 128) < ((int64_t)1 << 30) &&
       !(d->bact && !d->ln) /* the activation-only form needs scratch at two waves per SIMD: Kernel A keeps it */) {
     const unsigned ntiles = (unsigned)(d->B * ((d->Ncol + 127) / 128));

@@ -91,7 +91,7 @@ def test_ln_linear_large_mean():
     _cmp(y, yc, "ln large mean")
 
 
-@pytest.mark.parametrize("kind", ["ln", "ln_relu", "plain", "plain_nobias"])
+@pytest.mark.parametrize("kind", ["ln", "ln_relu", "plain", "plain_nobias", "head3"])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_stage0_persistent_32_to_32(kind, dt):
     """gemm_p32_kernel (persistent waves, >= 4096 wave tiles): 32 -> 32 at 81 x 81 x 80 voxels — 4100.6 tiles of 128 columns,
@@ -101,8 +101,9 @@ def test_stage0_persistent_32_to_32(kind, dt):
     S = (81, 81, 80)
     x = (torch.randn(1, 32, *S) * 2 + 0.5)
     g, bt = torch.rand(32) + 0.5, torch.randn(32) * 0.3
-    w = torch.randn(32, 32, 1) / 32 ** 0.5
-    b = None if kind == "plain_nobias" else torch.randn(32)
+    M = 3 if kind == "head3" else 32   # (M < 32: the 32 -> 3 head; rows beyond M are neither computed into nor stored)
+    w = torch.randn(M, 32, 1) / 32 ** 0.5
+    b = None if kind == "plain_nobias" else torch.randn(M)
     xd = x.to(DEV, dt).requires_grad_(True)
     n0 = _native.launch_count()
     if kind.startswith("ln"):
