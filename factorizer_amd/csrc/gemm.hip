@@ -2513,6 +2513,7 @@ static int knob_gemm_dw_wgs() { static const int v = env_pos_once("FZ_GEMM_DW_WG
 static int knob_chain64_p512() { static const int v = env_pos_once("FZ_CHAIN64_P512", 1); return v == 1; }   // 2 = off (diagnostics)
 static int knob_res_prefetch() { static const int v = env_pos_once("FZ_RES_PREFETCH", 1); return v == 1; }   // 2 = off (diagnostics)
 static int knob_p32() { static const int v = env_pos_once("FZ_GEMM_P32", 1); return v == 1; }   // 2 = off (diagnostics)
+static int knob_p32_wgs() { static const int v = env_pos_once("FZ_GEMM_P32_WGS", 512); return v; }   // resident: 2 per CU
 static int knob_mlp_wgs(int dflt) { static const int v = env_pos_once("FZ_MLP_WGS", 0); return v > 0 ? v : dflt; }
 
 static int gemm_bx_enabled() {
@@ -2608,7 +2609,8 @@ static int gemm_launch(const fz_gemm_desc* d, fz_stream_t stream) {
       !d->emul && d->Ncol % 4 == 0 && d->Ncol == d->Vin && d->B * ((d->Ncol + 127) / 128) >= 4096 && d->B * ((d->Ncol + 127) / 128) < ((int64_t)1 << 30) &&
       !(d->bact && !d->ln) /* the activation-only form needs scratch at two waves per SIMD: Kernel A keeps it */) {
     const unsigned ntiles = (unsigned)(d->B * ((d->Ncol + 127) / 128));
-    const unsigned wgs = (ntiles + 3) / 4 < 512 ? (ntiles + 3) / 4 : 512;
+    const unsigned cap = (unsigned)knob_p32_wgs();
+    const unsigned wgs = (ntiles + 3) / 4 < cap ? (ntiles + 3) / 4 : cap;
     const int pf = (d->bact ? 1 : 0) | (d->ln ? 2 : 0);
     dim3 grid(wgs), block(256);
     if (pf == 0) hipLaunchKernelGGL((gemm_p32_kernel<0, AT>), grid, block, 0, st, a, ntiles);
