@@ -16,6 +16,21 @@ from .nmf import NMF, MatrixFactorization, RandomInit
 from .utils import partialize
 
 
+def _env_int(name, default):
+    """diagnostic knob, read ONCE at import and validated (a malformed value must not surface in the middle of training)"""
+    v = os.environ.get(name)
+    if v is None:
+        return default
+    try:
+        return int(v, 0)
+    except ValueError:
+        raise ValueError(f"{name}={v!r}: expected an integer") from None
+
+
+_UP_FUSED = _env_int("FZ_UP_FUSED", 1) != 0            # 0 = decoder levels as separate autograd nodes
+_UP_FUSED_MIN = _env_int("FZ_UP_FUSED_MIN", 1 << 18)   # voxels x batch from which the one-node decoder level pays
+
+
 class FactMixer(nn.Module):
     """in_proj → reshape (matricize) → act → factorize → reshape⁻¹ → out_proj → dropout
     (factorizer.py:34-57).  ``reshape`` and ``factorize`` are duck-typed slots
@@ -174,8 +189,11 @@ class FactorizerStage(nn.Module):
               and self.adapter.linear.weight.shape[1] == skip.shape[1] + upsample.out_channels
               # (the node saves 4 full-resolution tensor passes of the level and costs ~10 tiny launches for the weight
               # compositions: it pays from 2^18 voxels x batch on — the two shallow levels of the README model)
-              and skip.shape[0] * skip[0, 0].numel() >= int(os.environ.get("FZ_UP_FUSED_MIN", 1 << 18))
-              and os.environ.get("FZ_UP_FUSED", "1") != "0")
+              and _UP_FUSED and skip.shape[0] * skip[0, 0].numel() >= _UP_FUSED_MIN
+              # forward hooks on the two modules the node replaces must keep firing: leave such stages to the module path
+              and not (upsample._forward_hooks or upsample._forward_pre_hooks
+                       or self.adapter._forward_hooks or self.adapter._forward_pre_hooks
+                       or self.adapter.linear._forward_hooks or self.adapter.linear._forward_pre_hooks))
         if not ok:
             return None
         out = PW.up_cat_linear(skip, deep, upsample.weight, upsample.bias, self.adapter.linear.weight, self.adapter.linear.bias)

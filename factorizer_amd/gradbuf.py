@@ -22,21 +22,30 @@ _DST = {}   # data_ptr of the parameter -> _Entry
 
 
 class _Entry:
-    __slots__ = ("param", "flat", "off", "n", "claimed")
+    __slots__ = ("param", "_flat", "off", "n", "claimed")
 
     def __init__(self, param, flat, off):
-        self.param, self.flat, self.off, self.n, self.claimed = weakref.ref(param), flat, int(off), param.numel(), False
+        # both references are weak: the table must not keep the buffers of a dead model / optimizer allocated
+        self.param, self._flat, self.off, self.n, self.claimed = weakref.ref(param), weakref.ref(flat), int(off), param.numel(), False
+
+    @property
+    def flat(self):
+        return self._flat()
 
 
 def register(flat: torch.Tensor, views: dict) -> None:
     """views: {parameter: its view inside `flat`}.  Re-registering a parameter replaces its entry; entries whose
     parameter has died or moved (``p.data`` re-pointed) are dropped."""
-    for k in [k for k, e in _DST.items() if e.param() is None or e.param().data_ptr() != k]:
-        del _DST[k]
+    _sweep()
     base = flat.storage_offset()
     for p, v in views.items():
         if p.dtype == flat.dtype and v.is_contiguous() and v.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr():
             _DST[p.data_ptr()] = _Entry(p, flat, v.storage_offset() - base)
+
+
+def _sweep() -> None:
+    for k in [k for k, e in _DST.items() if e.param() is None or e.flat is None or e.param().data_ptr() != k]:
+        del _DST[k]
 
 
 def release(flat: torch.Tensor = None) -> None:
@@ -56,9 +65,12 @@ def out_like(w: torch.Tensor, shape=None, dtype=None) -> torch.Tensor:
     shape = tuple(w.shape) if shape is None else tuple(shape)
     dtype = w.dtype if dtype is None else dtype
     e = _DST.get(w.data_ptr())
-    if e is not None and not e.claimed and e.n == w.numel() and e.flat.device == w.device and e.flat.dtype == dtype:
+    flat = e.flat if e is not None else None
+    if flat is None and e is not None:
+        del _DST[w.data_ptr()]       # the buffer's owner is gone
+    if flat is not None and not e.claimed and e.n == w.numel() and flat.device == w.device and flat.dtype == dtype:
         p = e.param()
         if p is not None and p.data_ptr() == w.data_ptr() and p.grad is None:
             e.claimed = True
-            return e.flat[e.off:e.off + e.n].view(shape)
+            return flat[e.off:e.off + e.n].view(shape)
     return torch.empty(shape, dtype=dtype, device=w.device)

@@ -97,6 +97,7 @@ class FlatAdamW:
             for q in new.order:
                 lo, n = new.offsets[q], q.numel()
                 q.data = new.flat_param[lo:lo + n].view_as(q)
+        _GB.register(new.flat_grad, new.grad_views)   # the copy's weight gradients land in the copy's buffer
         return new
 
     @property

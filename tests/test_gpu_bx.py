@@ -209,3 +209,43 @@ def test_stem_conv_k3_fp64(B, S):
         return g
     g_bx, g_f32 = _both(run)
     _check("conv_k3 wgrad 32x108", g_bx, g_f32, gref, gmag, slack=4.0)   # sum over B·V = 8-16 K voxels in tile / chunk order
+
+
+@pytest.mark.parametrize("case", ["x*2^60", "x*2^-60", "w*2^60, x*2^-60", "w*2^-40, x*2^-40", "mixed 1e-20..1e20"])
+def test_split_bf16_dynamic_range_fp64(case):
+    """Range of the three-level split (VERDICT r3 next-4 iii).  bf16 has fp32's exponent range, so scaling an operand by
+    2^±60 must leave the RELATIVE error (in units of Σ|a||b|) where it was: the lower levels are 2^-8 / 2^-16 of the value
+    and stay normal numbers down to |x| ~ 2^-110.  A tensor whose elements span 1e-20 .. 1e20 must err by fp32 roundings of
+    its LARGEST products (the split is per element, not per tensor: a small element next to a large one keeps its own three
+    levels).  Against float64, next to the fp32-MFMA kernel on the same inputs; plain linear, its input gradient and the
+    LayerNorm-prologue form (whose statistics see the same range)."""
+    torch.manual_seed(11)
+    B, Cin, Cout, S = 2, 128, 64, (8, 8, 8)
+    x = torch.randn(B, Cin, *S)
+    w = torch.randn(Cout, Cin, 1) / Cin ** 0.5
+    if case == "x*2^60":
+        x = x * 2.0 ** 60
+    elif case == "x*2^-60":
+        x = x * 2.0 ** -60
+    elif case == "w*2^60, x*2^-60":
+        w, x = w * 2.0 ** 60, x * 2.0 ** -60
+    elif case == "w*2^-40, x*2^-40":
+        w, x = w * 2.0 ** -40, x * 2.0 ** -40       # products ~2^-80, third-level products ~2^-96: still normal
+    else:
+        x = x.sign() * 10.0 ** (torch.rand_like(x) * 40 - 20)
+    ref = F.conv1d(x.double().flatten(2), w.double()).reshape(B, Cout, *S)
+    xd, wd = x.to(DEV), w.to(DEV)
+    y_bx, y_f32 = _both(lambda: PW.linear_cf(xd, wd, None))
+    assert torch.isfinite(y_bx).all() and torch.isfinite(y_f32).all()
+    _check(f"range[{case}] linear", y_bx, y_f32, ref, _lin_mag(x, w))
+    # input gradient with the incoming gradient carrying the same range
+    gy = torch.randn(B, Cout, *S) * float(x.abs().median())
+    gref = torch.einsum("oc,bov->bcv", w[:, :, 0].double(), gy.double().flatten(2)).reshape(B, Cin, *S)
+    xg, gd = xd.clone().requires_grad_(True), gy.to(DEV)
+
+    def run():
+        (g,) = torch.autograd.grad(PW.linear_cf(xg, wd, None), xg, gd)
+        return g
+    g_bx, g_f32 = _both(run)
+    mag = torch.einsum("oc,bov->bcv", w[:, :, 0].double().abs(), gy.double().abs().flatten(2)).reshape(B, Cin, *S)
+    _check(f"range[{case}] linear dgrad", g_bx, g_f32, gref, mag)
