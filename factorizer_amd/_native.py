@@ -19,6 +19,29 @@ FZ_OK = 0
 FZ_E_UNSUPPORTED = -2
 SOLVER_ID = {"mu": 0, "hals": 1}
 STORE_F32, STORE_BF16 = 0, 1   # include/factorizer_hip.h: FZ_STORE_*
+PRODUCTS_DEFAULT, PRODUCTS_SPLIT_BF16, PRODUCTS_FP32_MFMA = 0, 1, 2   # FZ_PRODUCTS_*: the `products` field of the descriptors
+_products = [PRODUCTS_DEFAULT]
+
+
+def products() -> int:
+    """the FZ_PRODUCTS_* value this package's layers put in their descriptors (default: the library's own default)"""
+    return _products[0]
+
+
+class use_products:
+    """with use_products(PRODUCTS_FP32_MFMA): ...  — fp32 products of every dense layer launched inside the block (forward AND
+    the backward passes run inside it: autograd's worker threads read the same setting) on the named pipe, through the
+    descriptors' `products` field.  The C ABI has no switch to flip for this: a caller of the library sets the field per call."""
+
+    def __init__(self, value):
+        self.value = int(value)
+
+    def __enter__(self):
+        self.prev = products()
+        _products[0] = self.value
+
+    def __exit__(self, *exc):
+        _products[0] = self.prev
 
 
 def act_dtype(t: torch.Tensor) -> int:
@@ -110,14 +133,14 @@ class GemmDesc(_c.Structure):
                 ("bias", _vp), ("ln", _i), ("ln_g", _vp), ("ln_b", _vp), ("ln_eps", _f), ("stats_out", _vp),
                 ("bact", _i), ("bmul", _vp), ("bmul_kind", _i), ("eact", _i), ("res", _vp), ("emul", _vp), ("emul_kind", _i), ("y", _vp),
                 ("Ncol", _i64), ("Ho", _i), ("Wo", _i), ("B", _i), ("loader", _i), ("epilogue", _i), ("lnb_x", _vp), ("lnb_stats", _vp), ("lnb_g", _vp),
-                ("lnb_gadd", _vp), ("lnb_part", _vp), ("act_dtype", _i)]
+                ("lnb_gadd", _vp), ("lnb_part", _vp), ("act_dtype", _i), ("products", _i)]
 
 
 class MlpDesc(_c.Structure):
     _fields_ = [("mode", _i), ("inp", _vp), ("w1", _vp), ("w2", _vp), ("b1", _vp), ("b2", _vp), ("ln_g", _vp),
                 ("ln_b", _vp), ("ln_eps", _f), ("stats", _vp), ("z1", _vp), ("gz1", _vp), ("x1", _vp), ("out", _vp),
                 ("part", _vp), ("B", _i), ("C", _i), ("H", _i), ("V", _i64), ("act_dtype", _i), ("wpart", _vp),
-                ("gw1", _vp), ("gb1", _vp), ("gw2", _vp), ("gb2", _vp), ("gln", _vp), ("glp", _vp)]
+                ("gw1", _vp), ("gb1", _vp), ("gw2", _vp), ("gb2", _vp), ("gln", _vp), ("glp", _vp), ("products", _i)]
 
 
 class GemmDwDesc(_c.Structure):
@@ -131,7 +154,7 @@ class WgradDesc(_c.Structure):
                 ("src_mode", _i), ("c0", _i), ("Cin", _i), ("K", _i), ("Vq", _i64), ("D", _i), ("H", _i),
                 ("W", _i), ("N", _i64), ("Ho", _i), ("Wo", _i), ("stats", _vp), ("qact", _i), ("ln_g", _vp),
                 ("ln_b", _vp), ("gw", _vp), ("gbias", _vp), ("accumulate", _i), ("B", _i), ("loader", _i),
-                ("act_dtype", _i)]
+                ("act_dtype", _i), ("products", _i)]
 
 
 _SIGS.update({
@@ -180,9 +203,9 @@ _SIGS.update({
     "fz_wgrad": ([_c.POINTER(WgradDesc), _vp, _vp], _i),
     "fz_wgrad_group": ([_c.POINTER(_c.POINTER(WgradDesc)), _c.POINTER(_vp), _i, _vp], _i),
     "fz_wgrad_workspace_bytes": ([_c.POINTER(WgradDesc)], _i64),
-    "fz_conv3_fwd": ([_vp] * 4 + [_i] * 7 + [_vp], _i),
+    "fz_conv3_fwd": ([_vp] * 4 + [_i] * 8 + [_vp], _i),
     "fz_conv3_wgrad_chunks": ([_i] * 4, _i),
-    "fz_conv3_wgrad_partials": ([_vp] * 4 + [_i] * 7 + [_vp], _i),
+    "fz_conv3_wgrad_partials": ([_vp] * 4 + [_i] * 8 + [_vp], _i),
     "fz_chunk_reduce": ([_vp, _i, _i64, _vp, _i, _vp], _i),
     "fz_dice_bce_chunks": ([_i64], _i),
     "fz_dice_bce_sums": ([_vp, _vp, _vp, _i, _i64, _vp], _i),

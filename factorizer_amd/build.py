@@ -18,14 +18,29 @@ LIB = os.path.join(HERE, "libfactorizer_hip.so")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-comment",
          "-ffp-contract=fast"]
-# gemm.hip: the SLP vectorizer pairs accumulator elements of DIFFERENT MFMA tiles for v_pk_* math,
-# which needs register-to-register copies of whole accumulator tiles (adjacent VGPRs hold the same
-# column group, not the same row) — +64..128 VGPRs and scratch spills in the fused epilogues.
-# -fno-slp-vectorize: the SLP vectorizer pairs elements of different MFMA tiles (gemm.hip) and, in the NMF wave programs, forms
-# v_pk_fma_f32 / v_pk_mul_f32 pairs whose 64-bit register alignment costs more v_mov than the packing saves: the rank-2 HALS
-# backward of the generic-patch core went from 234 to 154 VGPRs and 43.9 -> 38.3 ms per cfg-5 step without it (round 3)
+# -fno-slp-vectorize is the DEFAULT (round 4).  Three measured reasons:
+#  * correctness: the SLP vectorizer packs pairs of scalar fp32 adds into `v_pk_add_f32 ... op_sel:[0,1]` (low result from a
+#    HIGH source half).  Four of those in a store epilogue made an eight-wave MFMA kernel return run-to-run different values in
+#    lanes 48-63 on gfx950; replacing exactly those four instructions by scalar adds in the assembly restores bitwise replay,
+#    s_nop padding around them does not (tools/probes/upcat_asm_variants.py, profiles/r04_nondeterminism.md).
+#    tools/pk_opsel_audit.py counts such instructions in the built objects; tests/test_no_spills.py keeps the count at zero.
+#  * gemm.hip: it pairs accumulator elements of DIFFERENT MFMA tiles for v_pk_* math, which needs register-to-register copies of
+#    whole accumulator tiles — +64..128 VGPRs and scratch spills in the fused epilogues (round 1);
+#  * the NMF wave programs: v_pk_fma_f32 / v_pk_mul_f32 pairs whose 64-bit register alignment costs more v_mov than the packing
+#    saves: the rank-2 HALS backward of the generic-patch core went from 234 to 154 VGPRs and 43.9 -> 38.3 ms per cfg-5 step (round 3).
+# Exceptions (SLP left on): gemm_bx.hip — without it the compile does not finish in five minutes, and the audit finds no such
+# instruction in it; the standalone ft.NMF kernels nmf_r*.hip — without it they spill more (they are the one exemption of the
+# no-scratch policy as well) and they run one launch at a time, never beside an MFMA kernel of this library.
 _NO_SLP = ["-fno-slp-vectorize"]
-PER_FILE_FLAGS = {"gemm.hip": _NO_SLP, "nmf_pcf.hip": _NO_SLP, "nmf_cf.hip": _NO_SLP}
+_SLP_ON = {"gemm_bx.hip"} | {f"nmf_r{r}{sfx}.hip" for r in (1, 2, 3, 4) for sfx in ("", "_bf16")}
+
+
+class _PerFile(dict):
+    def get(self, src, default=None):
+        return [] if src in _SLP_ON else _NO_SLP
+
+
+PER_FILE_FLAGS = _PerFile()
 
 
 def _hipcc() -> str:
@@ -63,12 +78,17 @@ def _hdr_mtime() -> float:
 
 def _compile(src: str) -> str:
     obj = os.path.join(OBJ, src[:-4] + ".o")
-    if os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(os.path.join(CSRC, src)), _hdr_mtime()):
+    flags = [*FLAGS, *PER_FILE_FLAGS.get(src, [])]
+    stamp, want = obj + ".flags", " ".join(flags)   # an object built with other flags is stale, whatever its age
+    fresh = os.path.exists(stamp) and open(stamp).read() == want
+    if fresh and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(os.path.join(CSRC, src)), _hdr_mtime()):
         return obj
-    cmd = [_hipcc(), *FLAGS, *PER_FILE_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
+    cmd = [_hipcc(), *flags, "-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-4000:]}")
+    with open(stamp, "w") as f:
+        f.write(want)
     return obj
 
 

@@ -443,7 +443,7 @@ using namespace fz;
 
 template <typename AT>
 static int conv3_fwd_launch(const void* x, const float* w, const float* bias, void* y, int B, int Cin, int M, int D,
-                            int H, int W, fz_stream_t stream) {
+                            int H, int W, int products, fz_stream_t stream) {
   Conv3ArgsT<AT> p{(const AT*)x, w, bias, (AT*)y, B, Cin, M, D, H, W};
   const int64_t V = (int64_t)D * H * W;
   const int mblocks = (M + 31) / 32;
@@ -452,7 +452,7 @@ static int conv3_fwd_launch(const void* x, const float* w, const float* bias, vo
   if (lds > 65536) return fail(FZ_E_UNSUPPORTED, "fz_conv3_fwd: C_in too large for the stem kernel");
   dim3 grid((unsigned)(((V + 511) / 512) * B), (unsigned)((mblocks + MB - 1) / MB)), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (Cin == 4 && fz_gemm_bx_enable(-1)) {   // the stem of the README model: split-bf16 form (fz_gemm_bx_enable(0): fp32 MFMAs)
+  if (Cin == 4 && products_split(products)) {   // the stem of the README model: split-bf16 form (FZ_PRODUCTS_FP32_MFMA: fp32 MFMAs)
     if (MB == 2) hipLaunchKernelGGL((conv3_fwd_bx_kernel<2, 2, AT>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((conv3_fwd_bx_kernel<1, 2, AT>), grid, block, 0, st, p);
     FZ_LAUNCH_CHECK();
@@ -465,13 +465,13 @@ static int conv3_fwd_launch(const void* x, const float* w, const float* bias, vo
 }
 
 extern "C" int fz_conv3_fwd(const void* x, const float* w, const float* bias, void* y, int B, int Cin, int M, int D,
-                            int H, int W, int act_dtype, fz_stream_t stream) {
+                            int H, int W, int act_dtype, int products, fz_stream_t stream) {
   if (!x || !w || !y) return fail(FZ_E_ARG, "fz_conv3_fwd: null pointer");
   if (B < 0 || Cin < 2 || (Cin & 1) || M < 1 || D < 1 || H < 1 || W < 4 || (W & 3))
     return fail(FZ_E_UNSUPPORTED, "fz_conv3_fwd: needs even C_in and W % 4 == 0");
   if (B == 0) return FZ_OK;
-  if (act_dtype == FZ_STORE_F32) return conv3_fwd_launch<float>(x, w, bias, y, B, Cin, M, D, H, W, stream);
-  if (act_dtype == FZ_STORE_BF16) return conv3_fwd_launch<bf16>(x, w, bias, y, B, Cin, M, D, H, W, stream);
+  if (act_dtype == FZ_STORE_F32) return conv3_fwd_launch<float>(x, w, bias, y, B, Cin, M, D, H, W, products, stream);
+  if (act_dtype == FZ_STORE_BF16) return conv3_fwd_launch<bf16>(x, w, bias, y, B, Cin, M, D, H, W, products, stream);
   return fail(FZ_E_ARG, "fz_conv3_fwd: bad act_dtype");
 }
 
@@ -492,13 +492,13 @@ extern "C" int fz_conv3_wgrad_chunks(int B, int D, int H, int W) {
 
 template <typename AT>
 static int conv3_wgrad_launch(const void* gy, const void* x, float* part, float* part_bias, int B, int Cin,
-                              int M, int D, int H, int W, fz_stream_t stream) {
+                              int M, int D, int H, int W, int products, fz_stream_t stream) {
   Conv3WgradArgsT<AT> a{(const AT*)gy, (const AT*)x, part, part_bias, B, Cin, M, D, H, W, 1};
   const int nchunk = conv3_units(((int64_t)D * H * W / 32) * B, &a.tiles_per_unit);
   const size_t lds = (size_t)4 * (32 * 36 + 36 * kXs) * sizeof(float);
   const size_t lds_red = 4096 * sizeof(float);
   dim3 grid(nchunk, (M + 31) / 32), block(256);
-  if (fz_gemm_bx_enable(-1))
+  if (products_split(products))
     hipLaunchKernelGGL((conv3_wgrad_kernel<4, AT, true>), grid, block, lds > lds_red ? lds : lds_red, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL((conv3_wgrad_kernel<4, AT, false>), grid, block, lds > lds_red ? lds : lds_red, (hipStream_t)stream, a);
@@ -507,11 +507,11 @@ static int conv3_wgrad_launch(const void* gy, const void* x, float* part, float*
 }
 
 extern "C" int fz_conv3_wgrad_partials(const void* gy, const void* x, float* part, float* part_bias, int B, int Cin,
-                                       int M, int D, int H, int W, int act_dtype, fz_stream_t stream) {
+                                       int M, int D, int H, int W, int act_dtype, int products, fz_stream_t stream) {
   if (!gy || !x || !part || !part_bias) return fail(FZ_E_ARG, "fz_conv3_wgrad: null pointer");
   if (B < 1 || Cin < 1 || M < 1 || (W % 32) || 27 * Cin > 128 || Cin * 9 > 36)
     return fail(FZ_E_UNSUPPORTED, "fz_conv3_wgrad: needs W % 32 == 0 and C_in <= 4");
-  if (act_dtype == FZ_STORE_F32) return conv3_wgrad_launch<float>(gy, x, part, part_bias, B, Cin, M, D, H, W, stream);
-  if (act_dtype == FZ_STORE_BF16) return conv3_wgrad_launch<bf16>(gy, x, part, part_bias, B, Cin, M, D, H, W, stream);
+  if (act_dtype == FZ_STORE_F32) return conv3_wgrad_launch<float>(gy, x, part, part_bias, B, Cin, M, D, H, W, products, stream);
+  if (act_dtype == FZ_STORE_BF16) return conv3_wgrad_launch<bf16>(gy, x, part, part_bias, B, Cin, M, D, H, W, products, stream);
   return fail(FZ_E_ARG, "fz_conv3_wgrad: bad act_dtype");
 }

@@ -5,6 +5,7 @@
 #include <atomic>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 
 #include "../../include/factorizer_hip.h"
@@ -18,6 +19,21 @@ std::atomic<int64_t>& launch_counter();
 inline int fail(int code, const char* msg) {
   last_error() = msg;
   return code;
+}
+
+// Diagnostic environment knobs are read ONCE per process, at the first launch that consults them (a function-local static
+// at the call site): no getenv on a launch path after that, and a knob cannot change between a workspace-size query and the
+// launch that fills the workspace.  `str` stays valid for the life of the process (the environment block is not modified).
+struct EnvKnob { bool set; int val; const char* str; };
+inline EnvKnob env_knob(const char* name) {
+  const char* e = getenv(name);
+  return EnvKnob{e != nullptr, e ? atoi(e) : 0, e};
+}
+#define FZ_ENV_KNOB(name) ([]() -> const fz::EnvKnob& { static const fz::EnvKnob k_ = fz::env_knob(name); return k_; }())
+
+// fp32 products of a layer: the descriptor's `products` field, or the process default (fz_gemm_bx_enable) when it is unset
+inline bool products_split(int field) {
+  return field == FZ_PRODUCTS_SPLIT_BF16 ? true : (field == FZ_PRODUCTS_FP32_MFMA ? false : fz_gemm_bx_enable(-1) != 0);
 }
 
 #define FZ_HIP_OK(expr)                                                             \

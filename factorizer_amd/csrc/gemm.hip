@@ -1499,6 +1499,20 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
       __builtin_amdgcn_sched_barrier(0);
     }
 
+    // the residual rows g2 in the ACCUMULATOR layout, read back from Bf before x̂ replaces it there (rounds 2-3 re-read them
+    // from global memory before GEMM 2: 0.54 GB per launch that did not hit the caches — PMC traffic 1.22x algorithmic)
+    // (BX form only: the fp32-MFMA form of the kernel — fz_gemm_bx_enable(0), diagnostics — has no 32 registers to spare
+    // across pass B and keeps the global re-read)
+    float ga[2][8][NACC];
+    if (last && BX) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float2 gv = *reinterpret_cast<const float2*>(Bf + ((r & 3) + 8 * (r >> 2) + 4 * h) * kTS + 2 * j);
+        ga[r >> 3][r & 7][0] = gv.x; ga[r >> 3][r & 7][1] = gv.y;
+      }
+      asm volatile("" ::: "memory");   // (the reads must stay ahead of the x̂ stores below: same addresses)
+    }
+
     // ---- Bf <- LN-normalised x1 (requested during the last z1 block) ----
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf)
@@ -1539,9 +1553,8 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
       __builtin_amdgcn_sched_barrier(0);
     }
 
-    // residual rows (g2 again: L2 / MALL), requested before GEMM 2
-    float ga[2][8][NACC];
-    if (last) {
+
+    if (last && !BX) {   // residual rows (g2 again: L2 / MALL), requested before GEMM 2
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         vload<NACC>(p.lnb_gadd + sample + (int64_t)((r & 3) + 8 * (r >> 2)) * p.Ncol + lane_row, ga[r >> 3][r & 7]);
@@ -2566,8 +2579,8 @@ static int gemm_launch(const fz_gemm_desc* d, fz_stream_t stream) {
   a.bias = d->bias; a.ln = d->ln; a.ln_g = d->ln_g; a.ln_b = d->ln_b; a.ln_eps = d->ln_eps;
   a.stats_out = d->stats_out; a.bact = d->bact; a.eact = d->eact; a.res = (const AT*)d->res; a.emul = (const AT*)d->emul;
   a.emul_kind = d->emul_kind; a.y = (AT*)d->y; a.Ncol = d->Ncol; a.Ho = d->Ho; a.Wo = d->Wo; a.B = d->B;
-  { const char* e = getenv("FZ_GEMM_DBG"); a.dbg = e ? atoi(e) : 0; }
-  { const char* e = getenv("FZ_GEMM_TILEMAP"); a.tile_map = e ? atoi(e) : 1; }
+  { const auto& k = FZ_ENV_KNOB("FZ_GEMM_DBG"); a.dbg = k.set ? k.val : 0; }
+  { const auto& k = FZ_ENV_KNOB("FZ_GEMM_TILEMAP"); a.tile_map = k.set ? k.val : 1; }
   a.ygroups = 0; a.xtiles = 0;
   a.lnb_x = (const AT*)d->lnb_x; a.lnb_stats = d->lnb_stats; a.lnb_g = d->lnb_g; a.lnb_gadd = (const AT*)d->lnb_gadd; a.lnb_part = d->lnb_part;
   hipStream_t st = (hipStream_t)stream;
@@ -2578,7 +2591,7 @@ static int gemm_launch(const fz_gemm_desc* d, fz_stream_t stream) {
     ChainArgsT<AT> c = {};
     const int ntiles = (int)fz_mlp_partials(d->B, d->Ncol);
     constexpr int lds64 = (8192 + 8192 + 128 + 64 + 512) * (int)sizeof(float);
-    auto kern = gemm_bx_enabled() ? gemm_chain64_kernel<true, AT, true, true> : gemm_chain64_kernel<true, AT, true, false>;
+    auto kern = products_split(d->products) ? gemm_chain64_kernel<true, AT, true, true> : gemm_chain64_kernel<true, AT, true, false>;
     FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds64));
     hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles < 512 ? ntiles : 512)), dim3(256), lds64, st, a, c, ntiles);
     FZ_LAUNCH_CHECK();
@@ -2589,7 +2602,7 @@ static int gemm_launch(const fz_gemm_desc* d, fz_stream_t stream) {
   // fp32 products as six exact bf16 products on the bf16 matrix pipe (6/16 of the fp32-MFMA time, error <= the fp32
   // MFMA's own: tools/probes/bx6_accuracy.hip); FZ_GEMM_BX=0 keeps every GEMM on v_mfma_f32_32x32x2_f32
   {
-    const int bx_on = gemm_bx_enabled();
+    const int bx_on = products_split(d->products);
     const int pro_bx = d->ln ? 1 : (d->bact == ACT_GELU ? 2 : (d->bmul ? 3 : 0));
     const bool one_pro = (d->ln != 0) + (d->bact != 0) + (d->bmul != nullptr) <= 1;
     // (bf16 storage, no prologue: from K = 32 — three bf16 products per fp32 product; the stage-0 layers are matrix-pipe
@@ -2605,7 +2618,8 @@ static int gemm_launch(const fz_gemm_desc* d, fz_stream_t stream) {
   }
 
   // ---- Kernel A': persistent 32 -> 32 without a residual (stage 0: LayerNorm + in-projection, plain projections) ----
-  if (knob_p32() && d->loader == LOAD_PLAIN && d->epilogue == EPI_PLAIN && d->M <= 32 && d->K == 32 && d->Cin == 32 && (a.c0 & 1) == 0 && d->Vin < ((int64_t)1 << 28) && !d->res && !d->bmul &&
+  if (knob_p32() && d->loader == LOAD_PLAIN && d->epilogue == EPI_PLAIN && d->M <= 32 && d->K == 32 && d->Cin == 32 && (a.c0 & 1) == 0 && d->Vin < ((int64_t)1 << 28) &&
+      (int64_t)5 * d->Ncol * (int64_t)sizeof(AT) < ((int64_t)1 << 32) /* 32-bit store offsets (4·h·Ncol + col)·es */ && !d->res && !d->bmul &&
       !d->emul && d->Ncol % 4 == 0 && d->Ncol == d->Vin && d->B * ((d->Ncol + 127) / 128) >= 4096 && d->B * ((d->Ncol + 127) / 128) < ((int64_t)1 << 30) &&
       !(d->bact && !d->ln) /* the activation-only form needs scratch at two waves per SIMD: Kernel A keeps it */) {
     const unsigned ntiles = (unsigned)(d->B * ((d->Ncol + 127) / 128));
@@ -2624,7 +2638,7 @@ static int gemm_launch(const fz_gemm_desc* d, fz_stream_t stream) {
   // measured (round-1/2 probe `gemm_probe5`): the register-resident kernel wins for K <= 32, the
   // streaming ring for K = 64 (4.4 vs 3.3 TB/s at 64->32, 128^3)
   int res_maxk = 32;
-  { const char* e = getenv("FZ_GEMM_RESMAXK"); if (e) res_maxk = atoi(e); }
+  { const auto& k = FZ_ENV_KNOB("FZ_GEMM_RESMAXK"); if (k.set) res_maxk = k.val; }
   if (d->epilogue == EPI_LNBWD) res_maxk = 64;
   // ... except one 32-row block without a residual or gate: with the ring refills pinned the streaming
   // kernel overlaps its MFMAs with the loads still in flight, which the LayerNorm prologue of the
@@ -2632,7 +2646,7 @@ static int gemm_launch(const fz_gemm_desc* d, fz_stream_t stream) {
   // plain 278 -> 248 us; with a residual (357 vs 362 us) or two row blocks (391 vs 439 us) the resident
   // kernel stays ahead (round-1/2 probe `gemm_probe9`)
   const bool stream_small = mblocks == 1 && d->K >= 16 && d->K <= 32 && !d->res && !d->bmul && !d->emul &&
-                            d->epilogue == EPI_PLAIN && d->bact == 0 && !getenv("FZ_GEMM_RESMAXK");
+                            d->epilogue == EPI_PLAIN && d->bact == 0 && !FZ_ENV_KNOB("FZ_GEMM_RESMAXK").set;
   if (d->loader == LOAD_PLAIN && d->K <= res_maxk && !stream_small) {
     const int nA = (d->K + 1) / 2;
     int RB = mblocks < 8 ? mblocks : 8;
@@ -2691,7 +2705,7 @@ static int gemm_launch(const fz_gemm_desc* d, fz_stream_t stream) {
       // (when even 32-voxel tiles cannot give one workgroup per CU — the 8^3 bottleneck — stay with 64-voxel tiles and
       // let the K-split below fill the chip: 8-byte lane loads; 512->1024 at 2 x 8^3: 33 against 43 us, round-1/2 probe `gemm_deep`)
       if (wgs(nacc, MBsel) < 256 && !(wgs(1, MBsel) < 256 && d->K >= 256)) nacc = 1;
-      const char* e = getenv("FZ_GEMM_CFG");  // diagnostics: "<nacc><mb>", e.g. 42
+      const char* e = FZ_ENV_KNOB("FZ_GEMM_CFG").str;  // diagnostics: "<nacc><mb>", e.g. 42
       if (e && e[0] && e[1]) { nacc = e[0] - '0'; MBsel = e[1] - '0'; if (MBsel == 2 && (nacc != 4 || mblocks < 2)) MBsel = 1; }
     }
   }
@@ -2704,14 +2718,14 @@ static int gemm_launch(const fz_gemm_desc* d, fz_stream_t stream) {
     const bool shape_ok = MBsel == 1 && ((d->loader == LOAD_PLAIN && d->epilogue == EPI_PLAIN && nacc <= 2) ||
                                          d->loader == LOAD_S2D);
     if (shape_ok && wg1 < 256 && d->K >= 256) ks = 4;
-    const char* e = getenv("FZ_GEMM_KS");
-    if (e) ks = (atoi(e) == 4 && shape_ok) ? 4 : 1;
+    const auto& kk = FZ_ENV_KNOB("FZ_GEMM_KS");
+    if (kk.set) ks = (kk.val == 4 && shape_ok) ? 4 : 1;
   }
   const int WT = ks > 1 ? 1 : 4;
   const int64_t tiles = (d->Ncol + TN * WT - 1) / (TN * WT);
   const int ygr = (mblocks + MBsel - 1) / MBsel;
   int xcd_grid = 1;
-  { const char* e = getenv("FZ_GEMM_XCDGRID"); if (e) xcd_grid = atoi(e); }
+  { const auto& k = FZ_ENV_KNOB("FZ_GEMM_XCDGRID"); if (k.set) xcd_grid = k.val; }
   // (only where the COLUMN operand dominates the traffic: few row-block groups, many column tiles;
   // with e.g. 32 groups x 16 tiles — the deep transposed convs — the weights dominate and the
   // x-fastest order, which runs equal-weight workgroups together, is the better one: 61 vs 105 us)
@@ -2823,7 +2837,7 @@ static int mlp_launch(const fz_mlp_desc* d, fz_stream_t stream) {
     constexpr int lds64 = (8192 + 8192 + 128 + 64 + 512) * (int)sizeof(float);
     // fp32 storage with split-bf16 products: one 512-thread workgroup per CU around a pre-split weight image
     constexpr int lds512 = (12288 + 12288 + 128 + 64 + 1024) * (int)sizeof(float);
-    const bool p512 = gemm_bx_enabled() && ntiles % 2 == 0 && knob_chain64_p512();
+    const bool p512 = products_split(d->products) && ntiles % 2 == 0 && knob_chain64_p512();
     dim3 grid512((unsigned)(ntiles / 2 < 256 ? ntiles / 2 : 256));
     if (d->mode == 0) {
       a.w = d->w1; a.w_t = 0; a.ldw = 64;
@@ -2877,7 +2891,7 @@ static int mlp_launch(const fz_mlp_desc* d, fz_stream_t stream) {
     a.lnb_x = (const AT*)d->x1; a.lnb_stats = d->stats; a.lnb_g = d->ln_g; a.lnb_gadd = (const AT*)d->in; a.lnb_part = d->part;
     c.wB = d->w1; c.wB_t = 1; c.ldwB = 32;
     const int rows = fz_mlp_wgrad_rows(d->B, d->V);
-    const bool bxon = gemm_bx_enabled() != 0;
+    const bool bxon = products_split(d->products);
     const int lds = (2 * (bxon ? 3072 : 2048) + 32 + 256 + 4 * 48 * kTS) * (int)sizeof(float);
     if (d->H == 64) {
       auto kern = bxon ? gemm_chain_bwd_wg_kernel<AT, 1, 0, true> : gemm_chain_bwd_wg_kernel<AT, 1, 0, false>;

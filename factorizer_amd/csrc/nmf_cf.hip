@@ -764,14 +764,14 @@ static int cf_fwd_launch(const AT* t, const float* u0, const float* v0, AT* out,
   // measured on MI355X (round-1/2 probe `cf_probe`): a workgroup = one full row of patches along W
   // (up to 16 waves) consumes whole 128-B lines inside one CU: 0.856 -> 0.725 ms at stage 0
   int wpb = 16;
-  { const char* e = getenv("FZ_CF_WPB"); if (e) wpb = atoi(e); }
+  { const auto& k = FZ_ENV_KNOB("FZ_CF_WPB"); if (k.set) wpb = k.val; }
   if (wpb > q.G2) wpb = q.G2;
   if (wpb < 1) wpb = 1;
   int xr = 1;
-  { const char* e = getenv("FZ_CF_XCD"); if (e) xr = atoi(e); }
+  { const auto& k = FZ_ENV_KNOB("FZ_CF_XCD"); if (k.set) xr = k.val; }
   hipStream_t st = (hipStream_t)stream;
   int tile = 1;
-  { const char* e = getenv("FZ_CF_TILE"); if (e) tile = atoi(e); }
+  { const auto& k = FZ_ENV_KNOB("FZ_CF_TILE"); if (k.set) tile = k.val; }
   const bool half = (q.s2 % 4) != 0;  // W-axis shift ≡ 2 (mod 4): only the line-coalesced kernels handle it
   if (half || (tile && (q.G2 % 8) == 0)) {
     // line-coalesced kernel: WPB patches along W per workgroup.  8 patches per workgroup, two
@@ -833,15 +833,15 @@ static int cf_bwd_launch(const AT* t, const float* u0, const float* v0, const AT
   if (per_wave > 160 * 1024) return fail(FZ_E_UNSUPPORTED, "fz_nmf_cf_bwd: history exceeds LDS");
   int wpb = 65536 / per_wave;
   if (wpb > 4) wpb = 4;
-  { const char* e = getenv("FZ_CF_WPB_BWD"); if (e) { wpb = atoi(e); if (wpb * per_wave > 160 * 1024) wpb = 160 * 1024 / per_wave; } }
+  { const auto& k = FZ_ENV_KNOB("FZ_CF_WPB_BWD"); if (k.set) { wpb = k.val; if (wpb * per_wave > 160 * 1024) wpb = 160 * 1024 / per_wave; } }
   if (wpb > 8) wpb = 8;
   if (wpb < 1) wpb = 1;
   // patch neighbours on the same XCD share its L2 (shifted windows straddle lines): 1.31 -> 1.17 ms
   int xr = 1;
-  { const char* e = getenv("FZ_CF_XCD"); if (e) xr = atoi(e); }
+  { const auto& k = FZ_ENV_KNOB("FZ_CF_XCD"); if (k.set) xr = k.val; }
   hipStream_t st = (hipStream_t)stream;
   int tile = 1;
-  { const char* e = getenv("FZ_CF_TILE_BWD"); if (e) tile = atoi(e); }
+  { const auto& k = FZ_ENV_KNOB("FZ_CF_TILE_BWD"); if (k.set) tile = k.val; }
   const bool half = (q.s2 % 4) != 0;
   if (half || (tile && (q.G2 % 4) == 0)) {
     const int twpb = (q.G2 % 4) == 0 ? 4 : 1;
@@ -900,14 +900,10 @@ extern "C" int fz_nmf_cf_bwd(const void* t, const float* u0, const float* v0, co
 
 // ---- two windows in one launch: host side ------------------------------------------------------------------------------
 namespace fz {
-static int env_int_once(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e && *e ? atoi(e) : dflt;
-}
-static int knob_cf2_group() { static const int v = env_int_once("FZ_CF2_GROUP", 0); return v; }  // slices per group (0 = auto)
-static int knob_cf2_lag() { static const int v = env_int_once("FZ_CF2_LAG", 0); return v; }
-static int knob_cf2_nowait() { static const int v = env_int_once("FZ_CF2_NOWAIT", 0); return v; }  // TIMING PROBES ONLY: results invalid
-static int knob_cf2_wgs() { static const int v = env_int_once("FZ_CF2_WGS", 0); return v; }      // persistent workgroups (0 = resident)
+static int knob_cf2_group() { return FZ_ENV_KNOB("FZ_CF2_GROUP").val; }    // slices per group (0 = auto)
+static int knob_cf2_lag() { return FZ_ENV_KNOB("FZ_CF2_LAG").val; }
+static int knob_cf2_nowait() { return FZ_ENV_KNOB("FZ_CF2_NOWAIT").val; }  // TIMING PROBES ONLY: results invalid
+static int knob_cf2_wgs() { return FZ_ENV_KNOB("FZ_CF2_WGS").val; }        // persistent workgroups (0 = resident)
 
 // WPB: patches per tile (8 forward, 4 backward); passes: tensor passes one (plane, both windows) step moves (5 forward, 7 backward)
 static int cf2_plan(Cf2Plan& p, int B, int C, int D, int H, int W, const int* shifts, int WPB, int es, int passes,

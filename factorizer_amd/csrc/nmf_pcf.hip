@@ -251,7 +251,7 @@ static int pcf_bwd_launch(const AT* t, const float* u0, const float* v0, const A
   const int per_wave = pcf_per_wave(q.P, R, G);
   if (per_wave > 160 * 1024) return fail(FZ_E_UNSUPPORTED, "fz_nmf_pcf_bwd: history exceeds LDS");
   int wpb = fz_hist_waves_per_block(per_wave);
-  { const char* e = getenv("FZ_PCF_WPB"); if (e && atoi(e) >= 1 && atoi(e) <= 4) wpb = atoi(e); }   // diagnostics
+  { const auto& k = FZ_ENV_KNOB("FZ_PCF_WPB"); if (k.set && k.val >= 1 && k.val <= 4) wpb = k.val; }   // diagnostics
   const int lds = per_wave * wpb;
   dim3 grid((unsigned)((nmat + wpb - 1) / wpb)), block(64 * wpb);
 #define FZ_PCF_BWD(NN, RR, SS)                                                                                \

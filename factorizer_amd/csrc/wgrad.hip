@@ -611,8 +611,7 @@ static bool use_fast(const fz_wgrad_desc* d) {
   bool fast = PR == 64 && QR == 64 && d->loader == QL_PLAIN && !d->pmul && (d->M % PR) == 0 && (d->K % QR) == 0 &&
               (d->N % kTile) == 0 && d->N == d->Vq && (c0 % 8) == 0 && d->src_mode == 0 && !(d->stats && d->qact) &&
               (int64_t)8 * d->N < ((int64_t)1 << 30);
-  const char* e = getenv("FZ_WGRAD_FAST");
-  if (e && atoi(e) == 0) fast = false;
+  { const auto& k = FZ_ENV_KNOB("FZ_WGRAD_FAST"); if (k.set && k.val == 0) fast = false; }
   return fast;
 }
 
@@ -624,7 +623,7 @@ static int pick_chunks(int64_t total_tiles, int out_blocks, bool fast, int* tile
   // optimum for the register-operand kernel (64x64 at 64^3: 83 us against 107 with 4 per CU), two per CU
   // for the HBM-bound generic kernel (32x64 at 128^3: 370 against 400 us); 1.5 per CU loses to both.
   int64_t total_units = fast ? 1024 : 2048;
-  { const char* e = getenv("FZ_WGRAD_UNITS"); if (e && atoi(e) > 0) total_units = atoi(e); }
+  { const auto& k = FZ_ENV_KNOB("FZ_WGRAD_UNITS"); if (k.set && k.val > 0) total_units = k.val; }
   int64_t units_target = total_units / (out_blocks > 0 ? out_blocks : 1);
   if (units_target < 16) units_target = 16;
   int64_t tpc = (total_tiles + units_target - 1) / units_target;
@@ -701,7 +700,7 @@ static int wgrad_main_launch(const fz_wgrad_desc* d, const WgradPlan<AT>& pl, hi
   const size_t lds = (size_t)4 * (PR + QR) * kStride * sizeof(float);
   constexpr bool kBf16 = !std::is_same<AT, float>::value;  // bf16 activations: plain bf16 MFMAs
   // fp32 activations: six-term split-bf16 products unless the split-bf16 family is switched off (fz_gemm_bx_enable)
-  const int bf3g = fz_gemm_bx_enable(-1);
+  const int bf3g = products_split(d->products);
 #define FZ_WG(MBP, MBQ, QL)                                                                        \
   do {                                                                                             \
     if (kBf16) hipLaunchKernelGGL((wgrad_kernel<MBP, MBQ, QL, 1>), grid, block, lds, st, a);       \
@@ -786,7 +785,8 @@ static int wgrad_group_launch(const fz_wgrad_desc* const* ds, void* const* ws, i
   for (int i = 0; i < n; ++i) {
     const int rc = wgrad_plan<AT>(ds[i], ws[i], pl[i]);
     if (rc != FZ_OK) return rc;
-    groupable = groupable && pl[i].fast && pl[i].PR == 64 && pl[i].QR == 64 && ds[i]->B > 0;
+    groupable = groupable && pl[i].fast && pl[i].PR == 64 && pl[i].QR == 64 && ds[i]->B > 0 &&
+                products_split(ds[i]->products) == products_split(ds[0]->products);   // one kernel instantiation per grid
   }
   hipStream_t st = (hipStream_t)stream;
   if (!groupable) {
@@ -812,7 +812,7 @@ static int wgrad_group_launch(const fz_wgrad_desc* const* ds, void* const* ws, i
   g.n = n;
   const size_t ldsz = wgrad_fast_lds(64, 64);
   constexpr bool kBf16 = !std::is_same<AT, float>::value;
-  const int bf3 = fz_gemm_bx_enable(-1);
+  const int bf3 = products_split(ds[0]->products);
   if (kBf16) hipLaunchKernelGGL((wgrad_fast_group_kernel<2, 2, 1, AT>), dim3(total), dim3(256), ldsz, st, g);
   else if (bf3) hipLaunchKernelGGL((wgrad_fast_group_kernel<2, 2, 6, AT>), dim3(total), dim3(256), ldsz, st, g);
   else hipLaunchKernelGGL((wgrad_fast_group_kernel<2, 2, 0, AT>), dim3(total), dim3(256), ldsz, st, g);

@@ -43,6 +43,7 @@ def _gemm(xs, w, y, *, B, Cin, Vin, M, K, Ncol, w_t=False, ldw=None, bias=None, 
           bact=0, bmul=None, bmul_kind=0, eact=0, res=None, emul=None, emul_kind=0, src_mode=0, c0=0,
           loader=LOAD_PLAIN, epilogue=EPI_PLAIN, Di=0, Hi=0, Wi=0, Ho=0, Wo=0, name="gemm"):
     d = N.GemmDesc()
+    d.products = N.products()
     for i in range(4):
         d.x[i] = _p(xs[i]) if i < len(xs) else None
     d.nsrc, d.src_mode, d.c0, d.Cin, d.Vin = len(xs), src_mode, c0, Cin, Vin
@@ -71,6 +72,7 @@ def _wgrad_desc(p, qs, gw, *, B, M, Cin, K, Vq, Ncols, gbias=None, pmul=None, pm
                 stats=None, qact=0, ln=None, loader=0, D=0, H=0, W=0, Ho=0, Wo=0, accumulate=False, name="wgrad"):
     """(descriptor, workspace, timer key, algorithmic bytes, columns, flops) of one weight-gradient problem"""
     d = N.WgradDesc()
+    d.products = N.products()
     d.p, d.M, d.pmul, d.pmul_kind = _p(p), M, _p(pmul), pmul_kind
     for i in range(4):
         d.q[i] = _p(qs[i]) if i < len(qs) else None
@@ -145,6 +147,7 @@ def _dgrad_lnbwd(gz, w2, x, stats, ln_w, gadd):
         return _ln_backward(gl, x, stats, ln_w, gadd=gadd)
     gx = torch.empty_like(x)
     d = N.GemmDesc()
+    d.products = N.products()
     d.x[0] = gz.data_ptr()
     d.nsrc, d.src_mode, d.c0, d.Cin, d.Vin = 1, 0, 0, Mz, V
     d.w, d.w_t, d.ldw, d.M, d.K = w2.data_ptr(), 1, C, C, Mz
@@ -217,6 +220,7 @@ def _mlp_fwd_chain(x1, ln_w, ln_b, eps, w12, b1, w22, b2):
     st = torch.empty((B, 2, V), dtype=torch.float32, device=x1.device)
     x2 = torch.empty_like(x1)
     d = N.MlpDesc()
+    d.products = N.products()
     d.mode, d.inp, d.w1, d.w2, d.b1, d.b2 = 0, x1.data_ptr(), w12.data_ptr(), w22.data_ptr(), _p(b1), _p(b2)
     d.ln_g, d.ln_b, d.ln_eps = ln_w.data_ptr(), ln_b.data_ptr(), float(eps)
     d.stats, d.z1, d.out = st.data_ptr(), z1.data_ptr(), x2.data_ptr()
@@ -241,6 +245,7 @@ def _mlp_bwd_chain(g2, z1, w12, w22, x1, st, ln_w):
     gpar = torch.empty(2 * C, dtype=torch.float32, device=x1.device)
     tmp = torch.empty((64, 2 * C), dtype=torch.float32, device=x1.device)
     d = N.MlpDesc()
+    d.products = N.products()
     d.mode, d.inp, d.w1, d.w2 = 1, g2.data_ptr(), w12.data_ptr(), w22.data_ptr()
     d.ln_g, d.stats, d.z1, d.gz1, d.x1 = ln_w.data_ptr(), st.data_ptr(), z1.data_ptr(), gz1.data_ptr(), x1.data_ptr()
     d.out, d.part = gx1.data_ptr(), part.data_ptr()
@@ -275,6 +280,7 @@ def _mlp_bwd_chain_wgrad(g2, z1, w12, w22, x1, st, ln_w, ln_b):
     gb1 = torch.empty(Hd, dtype=torch.float32, device=dev)
     gb2 = torch.empty(C, dtype=torch.float32, device=dev)
     d = N.MlpDesc()
+    d.products = N.products()
     d.mode, d.inp, d.w1, d.w2 = 2, g2.data_ptr(), w12.data_ptr(), w22.data_ptr()
     d.ln_g, d.ln_b, d.stats, d.z1, d.x1 = ln_w.data_ptr(), ln_b.data_ptr(), st.data_ptr(), z1.data_ptr(), x1.data_ptr()
     d.out, d.gln, d.wpart = gx1.data_ptr(), gpar.data_ptr(), wpart.data_ptr()
@@ -687,7 +693,7 @@ class ConvK3Fn(torch.autograd.Function):
         if C * 27 * 64 * 4 <= 65536:
             with torch.cuda.device(x.device):
                 rc = Fn._timed(f"conv_k3_{C}->{O}", x.element_size() * (x.numel() + y.numel()), lambda: N.lib().fz_conv3_fwd(
-                    x.data_ptr(), w.data_ptr(), _p(b), y.data_ptr(), B, C, O, D, H, W, N.act_dtype(x), N.stream_ptr(x)),
+                    x.data_ptr(), w.data_ptr(), _p(b), y.data_ptr(), B, C, O, D, H, W, N.act_dtype(x), N.products(), N.stream_ptr(x)),
                     cols=B * V, flops=2 * B * V * 27 * C * O)
             N.check(rc, "fz_conv3_fwd")
         else:
@@ -726,10 +732,11 @@ class ConvK3Fn(torch.autograd.Function):
             pbias = torch.empty(nchunk * O, dtype=torch.float32, device=x.device)
             with torch.cuda.device(x.device):
                 st = N.stream_ptr(x)
+                prod = N.products()
 
                 def run():
                     rc = lib.fz_conv3_wgrad_partials(gy.data_ptr(), x.data_ptr(), part.data_ptr(), pbias.data_ptr(),
-                                                     B, C, O, D, H, W, N.act_dtype(x), st)
+                                                     B, C, O, D, H, W, N.act_dtype(x), prod, st)
                     if rc == 0:
                         rc = lib.fz_chunk_reduce(part.data_ptr(), nchunk, O * K, gw.data_ptr(), 0, st)
                     if rc == 0:

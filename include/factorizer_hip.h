@@ -200,6 +200,12 @@ int fz_nmf_pcf_bwd(const void* t, const float* u0, const float* v0, const void* 
 #define FZ_ACT_RELU 1
 #define FZ_ACT_GELU 2 /* exact erf GELU, layers/mlp.py:56 */
 
+/* How a layer forms its fp32 products: field `products` of fz_gemm_desc / fz_mlp_desc / fz_wgrad_desc and the last int of
+ * fz_conv3_fwd / fz_conv3_wgrad_partials.  A descriptor left zero-initialised follows the process default. */
+#define FZ_PRODUCTS_DEFAULT 0    /* fz_gemm_bx_enable()'s setting (environment FZ_GEMM_BX read once, else split-bf16) */
+#define FZ_PRODUCTS_SPLIT_BF16 1 /* six exact bf16 products per fp32 product on the bf16 matrix cores (csrc/gemm_bx.h)  */
+#define FZ_PRODUCTS_FP32_MFMA 2  /* v_mfma_f32_32x32x2_f32 / _16x16x4_f32                                               */
+
 typedef struct fz_gemm_desc {
   const void* x[4];    /* activation: input source tensors (B, C_i, Vin)                                */
   int nsrc;            /* number of sources                                                    */
@@ -240,6 +246,7 @@ typedef struct fz_gemm_desc {
   const void* lnb_gadd;   /* activation */
   float* lnb_part;
   int act_dtype;          /* FZ_STORE_F32 / FZ_STORE_BF16: element type of every "activation" pointer */
+  int products;           /* FZ_PRODUCTS_* */
 } fz_gemm_desc;
 
 /* number of 64-float partial rows fz_gemm writes to lnb_part for this descriptor */
@@ -252,7 +259,8 @@ int fz_gemm(const fz_gemm_desc* desc, fz_stream_t stream);
 /* fz_gemm runs layers with a reduction length >= 64 on the bf16 matrix cores with every fp32 operand split into three
  * bf16 values and six exact products per fp32 product (csrc/gemm_bx.hip: fp32 accuracy at 6/16 of the fp32-MFMA time).
  * on = 0 keeps them on v_mfma_f32_32x32x2_f32, on = 1 enables, on < 0 only queries; returns the previous setting.
- * Default: environment FZ_GEMM_BX (read once), else enabled. */
+ * Default: environment FZ_GEMM_BX (read once), else enabled.  This is only the DEFAULT for descriptors whose `products`
+ * field is FZ_PRODUCTS_DEFAULT: a caller that wants two models of one process to differ sets the field. */
 int fz_gemm_bx_enable(int on);
 
 /* ---- MLP chain ((C, H) = (32, 64), (32, 128) or (64, 128)): two GEMMs, hidden tensor stays in the accumulators
@@ -296,6 +304,7 @@ typedef struct fz_mlp_desc {
   float* gb2;         /* mode 2: (C)                                                         */
   float* gln;         /* mode 2: (2*C) dgamma | dbeta of the LayerNorm (part is not used)    */
   float* glp;         /* mode 2, H = 128: (B, C, V) fp32 scratch (the first half's part of W1^T gz1) */
+  int products;       /* FZ_PRODUCTS_* */
 } fz_mlp_desc;
 
 /* ---- input gradient AND weight gradient of a 32 -> 32 1x1 layer in one pass (in_proj behind LayerNorm, out_proj;
@@ -392,6 +401,7 @@ typedef struct fz_wgrad_desc {
   int B;
   int loader;
   int act_dtype;      /* FZ_STORE_F32 / FZ_STORE_BF16; with bf16 the products run on bf16 MFMAs (fp32 accumulation) */
+  int products;       /* FZ_PRODUCTS_* (fp32 activations) */
 } fz_wgrad_desc;
 
 int64_t fz_wgrad_workspace_bytes(const fz_wgrad_desc* desc);
@@ -423,10 +433,10 @@ int fz_ln_bwd(const void* gl, const void* x, const float* stats, const float* ga
  * (nchunk = fz_conv3_wgrad_chunks), reduced in a fixed order by fz_chunk_reduce; needs
  * W % 32 == 0 and 27*C_in <= 128. */
 int fz_conv3_fwd(const void* x /* activation */, const float* w, const float* bias, void* y /* activation */,
-                 int B, int Cin, int M, int D, int H, int W, int act_dtype, fz_stream_t stream);
+                 int B, int Cin, int M, int D, int H, int W, int act_dtype, int products, fz_stream_t stream);
 int fz_conv3_wgrad_chunks(int B, int D, int H, int W);
 int fz_conv3_wgrad_partials(const void* gy, const void* x /* activations */, float* part, float* part_bias, int B,
-                            int Cin, int M, int D, int H, int W, int act_dtype, fz_stream_t stream);
+                            int Cin, int M, int D, int H, int W, int act_dtype, int products, fz_stream_t stream);
 int fz_chunk_reduce(const float* part, int nchunk, int64_t n, float* out, int accumulate, fz_stream_t stream);
 
 /* out[c] = sum over batch and voxels of x[b,c,v] (bias gradient of ConvTranspose3d, unet.py:123);

@@ -17,16 +17,12 @@ DEV = "cuda:0"
 
 def _both(fn):
     """fn() -> tensor, evaluated with the split-bf16 family on and off"""
-    lib = _native.lib()
-    prev = lib.fz_gemm_bx_enable(1)
-    try:
-        n0 = _native.launch_count()
+    n0 = _native.launch_count()
+    with _native.use_products(_native.PRODUCTS_SPLIT_BF16):     # the descriptors' own field: no process-wide switch is touched
         y_bx = fn().double().cpu()
-        assert _native.launch_count() > n0
-        lib.fz_gemm_bx_enable(0)
+    assert _native.launch_count() > n0
+    with _native.use_products(_native.PRODUCTS_FP32_MFMA):
         y_f32 = fn().double().cpu()
-    finally:
-        lib.fz_gemm_bx_enable(prev)
     return y_bx, y_f32
 
 

@@ -705,7 +705,7 @@ def test_weight_gradients_land_in_the_flat_buffer():
 def test_wgrad_split_bf16_mode(M, K, S):
     """The weight-gradient kernels (register-operand and generic) form each fp32 product from a three-level bf16 split of both
     operands: six exact bf16 products on the bf16 matrix pipe, fp32 accumulation (the default; csrc/wgrad.hip BF = 6).
-    Against float64 its error must be at the level of the fp32-MFMA kernels' own (fz_gemm_bx_enable(0)): both <= 2e-6 of
+    Against float64 its error must be at the level of the fp32-MFMA kernels' own (products = FZ_PRODUCTS_FP32_MFMA): both <= 2e-6 of
     the largest entry, the split form within 1.5x of the fp32 form (different summation order: + one rounding)."""
     torch.manual_seed(5)
     V = S[0] * S[1] * S[2]
@@ -713,18 +713,15 @@ def test_wgrad_split_bf16_mode(M, K, S):
     q = torch.randn(2, K, V, device=DEV)
     ref = torch.einsum("bmv,bkv->mk", p.double(), q.double())
     errs = {}
-    lib = _native.lib()
-    prev = lib.fz_gemm_bx_enable(-1)
-    try:
-        for mode in (0, 1):
-            lib.fz_gemm_bx_enable(mode)
+    assert _native.lib().fz_gemm_bx_enable(-1) == 1                      # the process default stays untouched ...
+    for mode, prod in ((0, _native.PRODUCTS_FP32_MFMA), (1, _native.PRODUCTS_SPLIT_BF16)):
+        with _native.use_products(prod):                                  # ... the descriptor's own field selects the pipe
             gw = torch.empty(M, K, device=DEV)
             gb = torch.empty(M, device=DEV)
             PW._wgrad(p, [q], gw, B=2, M=M, Cin=K, K=K, Vq=V, Ncols=V, gbias=gb)
-            errs[mode] = ((gw.double() - ref).abs().max() / ref.abs().max()).item()
-            assert torch.allclose(gb.double(), p.double().sum((0, 2)), rtol=1e-4, atol=1e-3)
-    finally:
-        lib.fz_gemm_bx_enable(prev)
+        errs[mode] = ((gw.double() - ref).abs().max() / ref.abs().max()).item()
+        assert torch.allclose(gb.double(), p.double().sum((0, 2)), rtol=1e-4, atol=1e-3)
+    assert _native.lib().fz_gemm_bx_enable(-1) == 1
     P.note(f"wgrad {M}x{K}", err_f32_mfma=errs[0], err_split_bf16=errs[1])
     assert errs[0] <= 2e-6 and errs[1] <= max(1.5 * errs[0], 3e-7), errs
 

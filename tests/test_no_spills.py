@@ -61,3 +61,20 @@ def test_no_kernel_of_the_module_path_uses_scratch():
     bad = {tu: [k for k in ks if k[1] > 0] for tu, ks in res.items() if not tu.startswith("nmf_r")}
     bad = {tu: ks for tu, ks in bad.items() if ks}
     assert not bad, {tu: [(n[:80], ps) for n, ps, _, _ in ks[:4]] for tu, ks in bad.items()}
+
+
+def test_no_low_from_high_packed_fp32_instruction_outside_the_exempt_units():
+    """`v_pk_{add,mul,fma}_f32 ... op_sel:[..1..]` (low result from a HIGH source half) is the instruction form whose four
+    instances made an eight-wave MFMA kernel stop replaying bit for bit on gfx950 (assembly-level bisect,
+    profiles/r04_nondeterminism.md): hipcc's SLP vectorizer forms it, so the build uses -fno-slp-vectorize and no built object
+    may contain one — except gemm_bx (SLP kept for compile time; none found) and the standalone ft.NMF units nmf_r* (exempt
+    from the no-scratch policy for the same reason: they run one launch at a time)."""
+    import importlib.util
+    B.build(verbose=False)
+    spec = importlib.util.spec_from_file_location("pk_opsel_audit", os.path.join(ROOT, "tools", "pk_opsel_audit.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.audit()
+    assert "gemm" in res and "upcat" in res and res["gemm"][1] > 0          # the disassembly really was read
+    bad = {tu: n for tu, (n, _) in res.items() if n and not tu.startswith("nmf_r")}
+    assert not bad, bad

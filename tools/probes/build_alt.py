@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from factorizer_amd import build as B  # noqa: E402
 
-out, flag, files = sys.argv[1], sys.argv[2], sys.argv[3:]
+out, flag, files = sys.argv[1], sys.argv[2].split(","), sys.argv[3:]   # several flags: comma-separated
 B.build(verbose=False)
 alt = os.path.join(B.OBJ, "alt")
 os.makedirs(alt, exist_ok=True)
@@ -21,7 +21,7 @@ def one(src):
     if src not in files:
         return os.path.join(B.OBJ, src[:-4] + ".o")
     obj = os.path.join(alt, src[:-4] + ".o")
-    cmd = [B._hipcc(), *B.FLAGS, *B.PER_FILE_FLAGS.get(src, []), flag, "-c", os.path.join(B.CSRC, src), "-o", obj]
+    cmd = [B._hipcc(), *B.FLAGS, *B.PER_FILE_FLAGS.get(src, []), *flag, "-c", os.path.join(B.CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode:
         sys.exit(r.stderr[-3000:])

@@ -1,3 +1,5 @@
+// REPRODUCER — csrc/upcat.hip as of commit 9bf9197 (round 3), the program whose eight-wave form (-DUPCAT_WAVES=8) returned
+// run-to-run different values at 128^3; built into alternative libraries by tools/probes/upcat_variants.sh.  Not part of the product.
 // upcat.hip — decoder level forward in ONE pass:  out = W_a·skip + D2S(W_bt·deep) + bias'
 //
 // Replaces, for the full-resolution decoder level (C = 32 adapter outputs, 32 skip channels, 64 deep channels):
@@ -32,29 +34,29 @@ struct UpcatArgsT {
 
 // One PERSISTENT workgroup of 256 threads per CU (one wave per SIMD): W_a and all eight taps of Wbt are split into bf16
 // levels and staged ONCE (102 KB of LDS), every wave then walks 64-voxel tiles with a stride of the grid, the operands of
-// its next TWO tiles in flight while the products of the current one run.  (A first form staged four taps per 256-voxel
+// its next tile in flight while the products of the current one run.  (A first form staged four taps per 256-voxel
 // workgroup: the staging — 1 152 weight items per tile of 24 KB of operand data — was half of the kernel.)
 // Four waves, not eight: the same program as a 512-thread workgroup (two waves of one workgroup per SIMD) returned run-to-run
 // different values in a few hundred elements at 128^3 — also with the tap images beyond 64 KB unused — while the 256-thread
 // form replays bit for bit (tools/probes/upcat_check.py, profiles/r03_two_stream_interaction.md); cause not found.
-#ifndef UPCAT_WAVES   // (-DUPCAT_WAVES=8: the eight-wave form, for tools/probes/upcat_variants.sh only)
-#define UPCAT_WAVES 4
+#ifndef UPCAT_WAVES   // this file is the round-3 program kept as a REPRODUCER (tools/probes/upcat_variants.sh): 8 = the form that
+#define UPCAT_WAVES 4   // did not replay bit for bit
 #endif
 #define UPCAT_THREADS (UPCAT_WAVES * 64)
 template <typename AT>
-__global__ __launch_bounds__(UPCAT_THREADS, 1) void upcat_bx_kernel(UpcatArgsT<AT> p, unsigned ntiles) {
+__global__ __launch_bounds__(UPCAT_THREADS, 2) void upcat_bx_kernel(UpcatArgsT<AT> p, int64_t ntiles) {
   constexpr int C = 32, CD = 64;
   constexpr int GS = C / 16, GD = CD / 16;          // K16-groups of the two segments
   constexpr int NTB = bx_terms_b<AT>(BXPRO_NONE);   // 3 (fp32 storage) / 1 (bf16 storage: exact)
   // LDS images: [slot][level][lane] x 16 B; skip: slot = g (2); deep: slot = GS + tap * GD + g, tap = td*4 + th*2 + tw (32)
   extern __shared__ __attribute__((aligned(16))) float As[];
+  __shared__ float sBias[32];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int j = lane & 31, hk = lane >> 5;
   const int Wf = 2 * p.W, Hf = 2 * p.H, Df = 2 * p.D;
   const int64_t Vf = (int64_t)Df * Hf * Wf, Vc = (int64_t)p.D * p.H * p.W;
-  const unsigned tiles_per_sample = (unsigned)(Vf / 64);   // 32-bit index arithmetic throughout (fz_upcat_supported bounds the extent): the
-                                                             // 64-bit scalar divisions were a visible share of a tile with one wave per SIMD
+  const int64_t tiles_per_sample = Vf / 64;
 
   // ---- weights -> three bf16 levels -> LDS (once per workgroup) ----
   for (int item = threadIdx.x; item < (GS + 8 * GD) * 64; item += UPCAT_THREADS) {
@@ -74,24 +76,21 @@ __global__ __launch_bounds__(UPCAT_THREADS, 1) void upcat_bx_kernel(UpcatArgsT<A
     bx8* dst = reinterpret_cast<bx8*>(As) + (slot * 3) * 64 + l;
     dst[0] = t3[0]; dst[64] = t3[1]; dst[128] = t3[2];
   }
+  if (threadIdx.x < 32) sBias[threadIdx.x] = p.bias != nullptr ? p.bias[threadIdx.x] : 0.f;
   __syncthreads();
-  float badd[16];   // the bias' entries of this lane's 16 output rows
-#pragma unroll
-  for (int r = 0; r < 16; ++r) badd[r] = p.bias != nullptr ? p.bias[(r & 3) + 8 * (r >> 2) + 4 * hk] : 0.f;
 
   int lane4 = lane * 4, lane4d = lane * 4 + GS * 3 * 256;   // opaque per-lane float indices of the two images (64 KB immediates)
   asm volatile("" : "+v"(lane4));
   asm volatile("" : "+v"(lane4d));
 
   // ---- operand loads of one tile: skip (two fine voxels per lane and channel), deep (their one coarse voxel) ----
-  typedef float XsT[GS][8][2];
-  typedef float XdT[GD][8];
-  auto fetch = [&](unsigned t, XsT& xs, XdT& xd) {
-    const unsigned b = t / tiles_per_sample;
-    const unsigned n0 = (t - b * tiles_per_sample) * 64u;
-    const unsigned row = n0 / (unsigned)Wf;
-    const unsigned w0 = n0 - row * (unsigned)Wf;
-    const unsigned df = row / (unsigned)Hf, hf = row - df * (unsigned)Hf;
+  float xs[GS][8][2], xd[GD][8];
+  auto fetch = [&](int64_t t) {
+    const int b = (int)(t / tiles_per_sample);
+    const int64_t n0 = (t % tiles_per_sample) * 64;
+    const int w0 = (int)(n0 % Wf);
+    const int64_t row = n0 / Wf;
+    const int hf = (int)(row % Hf), df = (int)(row / Hf);
     const unsigned soff = (unsigned)((((int64_t)8 * hk) * Vf + n0 + 2 * j) * (int64_t)sizeof(AT));
     const int64_t ncoarse = ((int64_t)(df >> 1) * p.H + (hf >> 1)) * p.W + (w0 >> 1) + j;
     const unsigned doff = (unsigned)((((int64_t)8 * hk) * Vc + ncoarse) * (int64_t)sizeof(AT));
@@ -113,34 +112,17 @@ __global__ __launch_bounds__(UPCAT_THREADS, 1) void upcat_bx_kernel(UpcatArgsT<A
     }
   };
 
-  const unsigned tstep = gridDim.x * UPCAT_WAVES;
-  // The row operands live in REGISTERS: W_a (6 x 16 B per lane) for the whole walk, the two taps (td, th, tw = 0 / 1) of Wbt
-  // (24 x 16 B) until a tile with another (td, th) comes — with one wave per SIMD nothing would hide an LDS read per product
-  // group, and the tiles a wave walks are a whole number of row pairs apart in the common extents, so the reload is rare.
-  bx8 wsk[GS][3], wdp[2][GD][3];
-#pragma unroll
-  for (int g = 0; g < GS; ++g)
-#pragma unroll
-    for (int t = 0; t < 3; ++t) wsk[g][t] = *reinterpret_cast<const bx8*>(As + (g * 3 + t) * 256 + lane4);
-  int tap_cur = -1;
-  // one tile: split the operands, refill their registers with the tile two steps ahead, products, epilogue
-  auto run = [&](unsigned tile, XsT& xs, XdT& xd) {
-    const unsigned b = tile / tiles_per_sample;
-    const unsigned n0 = (tile - b * tiles_per_sample) * 64u;
-    const unsigned row = n0 / (unsigned)Wf;
-    const unsigned df = row / (unsigned)Hf, hf = row - df * (unsigned)Hf;
+  const int64_t tstep = (int64_t)gridDim.x * UPCAT_WAVES;
+  int64_t tile = (int64_t)blockIdx.x * UPCAT_WAVES + wave;
+  if (tile < ntiles) fetch(tile);
+  for (; tile < ntiles; tile += tstep) {
+    const int b = (int)(tile / tiles_per_sample);
+    const int64_t n0 = (tile % tiles_per_sample) * 64;
+    const int64_t row = n0 / Wf;
+    const int hf = (int)(row % Hf), df = (int)(row / Hf);
     const int tap0 = __builtin_amdgcn_readfirstlane(((df & 1) * 4 + (hf & 1) * 2) * GD);   // slot of (td, th, tw = 0, g = 0) inside the deep image
-    if (tap0 != tap_cur) {   // wave-uniform
-      tap_cur = tap0;
-      const float* Ad = As + tap0 * 3 * 256;
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int g = 0; g < GD; ++g)
-#pragma unroll
-          for (int t = 0; t < 3; ++t) wdp[q][g][t] = *reinterpret_cast<const bx8*>(Ad + ((q * GD + g) * 3 + t) * 256 + lane4d);
-    }
 
+    // ---- split the column operands (the registers are then free for the next tile's loads) ----
     bx8 bs[GS][2][NTB], bd[GD][NTB];
 #pragma unroll
     for (int g = 0; g < GS; ++g)
@@ -153,7 +135,7 @@ __global__ __launch_bounds__(UPCAT_THREADS, 1) void upcat_bx_kernel(UpcatArgsT<A
       }
 #pragma unroll
     for (int g = 0; g < GD; ++g) bx_split<NTB>(xd[g], bd[g]);
-    if (tile + 2 * tstep < ntiles) fetch(tile + 2 * tstep, xs, xd);
+    if (tile + tstep < ntiles) fetch(tile + tstep);
 
     f32x16 acc[2];
 #pragma unroll
@@ -165,26 +147,29 @@ __global__ __launch_bounds__(UPCAT_THREADS, 1) void upcat_bx_kernel(UpcatArgsT<A
     for (int g = 0; g < GS; ++g) {
 #pragma unroll
       for (int t = 2; t >= 0; --t) {
-        const bx8 a = wsk[g][t];
+        const bx8 a = *reinterpret_cast<const bx8*>(As + (g * 3 + t) * 256 + lane4);
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
           for (int jj = NTB - 1; jj >= 0; --jj)
             if (t + jj <= 2) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bs[g][q][jj], acc[q], 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
     // ---- deep segment: out[.., voxel q] += Wbt[tap (td, th, q)] · deep[coarse voxel] ----
+    const float* Ad = As + tap0 * 3 * 256;
 #pragma unroll
     for (int g = 0; g < GD; ++g) {
 #pragma unroll
       for (int q = 0; q < 2; ++q)
 #pragma unroll
         for (int t = 2; t >= 0; --t) {
-          const bx8 a = wdp[q][g][t];
+          const bx8 a = *reinterpret_cast<const bx8*>(Ad + ((q * GD + g) * 3 + t) * 256 + lane4d);
 #pragma unroll
           for (int jj = NTB - 1; jj >= 0; --jj)
             if (t + jj <= 2) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bd[g][jj], acc[q], 0, 0, 0);
         }
+      __builtin_amdgcn_sched_barrier(0);
     }
 
 #ifdef FZ_UPCAT_NOP   // probe: extra wait states between the last MFMA and the first reader of its result
@@ -196,21 +181,10 @@ __global__ __launch_bounds__(UPCAT_THREADS, 1) void upcat_bx_kernel(UpcatArgsT<A
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int rb = (r & 3) + 8 * (r >> 2);
-      const float add = badd[r];
+      const float add = sBias[rb + 4 * hk];
       const float v[2] = {acc[0][r] + add, acc[1][r] + add};
       vstore<2>(reinterpret_cast<AT*>(reinterpret_cast<char*>(yb + (int64_t)rb * Vf) + yoff), v);
     }
-  };
-
-  // two tiles of operands in flight per wave (one wave per SIMD: up to 512 registers are this wave's)
-  XsT xsA, xsB;
-  XdT xdA, xdB;
-  unsigned tile = blockIdx.x * UPCAT_WAVES + (unsigned)wave;
-  if (tile < ntiles) fetch(tile, xsA, xdA);
-  if (tile + tstep < ntiles) fetch(tile + tstep, xsB, xdB);
-  for (; tile < ntiles; tile += 2 * tstep) {
-    run(tile, xsA, xdA);
-    if (tile + tstep < ntiles) run(tile + tstep, xsB, xdB);
   }
 }
 
@@ -316,12 +290,11 @@ static int upcat_launch(const void* skip, const void* deep, const float* wa, int
   a.skip = (const AT*)skip; a.deep = (const AT*)deep; a.wa = wa; a.wbt = wbt; a.bias = bias; a.out = (AT*)out;
   a.lda = lda; a.B = B; a.D = D; a.H = H; a.W = W;
   const int64_t ntiles = (int64_t)8 * D * H * W / 64 * B;   // 64-voxel wave tiles
-  if (ntiles >= ((int64_t)1 << 30)) return fail(FZ_E_ARG, "fz_upcat: more than 2^30 wave tiles (32-bit tile arithmetic)");
   constexpr int lds = (2 + 8 * 4) * 3 * 64 * 16;            // 34 slots x 3 levels x 64 lanes x 16 B = 102 KB
   auto kern = upcat_bx_kernel<AT>;
   FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   const int64_t wgs = (ntiles + UPCAT_WAVES - 1) / UPCAT_WAVES;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(wgs < 256 ? wgs : 256)), dim3(UPCAT_THREADS), lds, (hipStream_t)stream, a, (unsigned)ntiles);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(wgs < 256 ? wgs : 256)), dim3(UPCAT_THREADS), lds, (hipStream_t)stream, a, ntiles);
   FZ_LAUNCH_CHECK();
   return FZ_OK;
 }
