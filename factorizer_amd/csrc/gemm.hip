@@ -641,8 +641,14 @@ __global__ __launch_bounds__(256, (NACC == 2 && HB == 2 && !BWD) ? 3 : 2) void g
 #pragma unroll
           for (int q = 0; q < NACC; ++q) v[q] = acc1[rb][q][r] + add;
           if (col_ok) vstore<NACC>(c.side + ob + lane_row, v);
+          if constexpr (NACC == 2) {
+            float gq[2];
+            gelu2_f(v, gq);
+            acc1[rb][0][r] = gq[0]; acc1[rb][1][r] = gq[1];
+          } else {
 #pragma unroll
-          for (int q = 0; q < NACC; ++q) acc1[rb][q][r] = gelu_f(v[q]);
+            for (int q = 0; q < NACC; ++q) acc1[rb][q][r] = gelu_f(v[q]);
+          }
         }
     } else {
       // groups of 8 rows: 8 loads of the saved pre-activation in flight, then 8 transforms + stores
@@ -1044,8 +1050,14 @@ __global__ __launch_bounds__(P512 ? 512 : 256, 2) void gemm_chain64_kernel(GemmA
 #pragma unroll
             for (int q = 0; q < NACC; ++q) v[q] = acc1[rbl][q][r] + add;
             if (col_ok) vstore<NACC>(c.side + ((int64_t)b * HID + rbase) * p.Ncol + lane_row, v);
+            if constexpr (NACC == 2) {
+              float gq[2];
+              gelu2_f(v, gq);
+              acc1[rbl][0][r] = gq[0]; acc1[rbl][1][r] = gq[1];
+            } else {
 #pragma unroll
-            for (int q = 0; q < NACC; ++q) acc1[rbl][q][r] = gelu_f(v[q]);
+              for (int q = 0; q < NACC; ++q) acc1[rbl][q][r] = gelu_f(v[q]);
+            }
           }
       } else {
 #pragma unroll
