@@ -488,7 +488,18 @@ struct ChainArgsT {
   int wB_t, ldwB;
   const float* biasB;  // forward: [32] or null
   AT* side;            // (B, 64, V)
+  int stagger;         // start delay of the workgroups beyond the first 256, in units of 8 192 cycles per 256 workgroups (timing only)
 };
+
+// Resident workgroups of one launch start together and walk tiles of equal length: the waves that share a SIMD then sit in
+// the same phase of the tile (all in their MFMA chains, or all in the GELU / epilogue VALU phase), and the matrix pipe idles
+// while the vector pipe is contended (MI355X_MICROARCH.md "two waves that run the SAME program ... try a stagger").  Workgroups
+// 256 .. 511 (the second resident workgroup of every CU under round-robin placement: speed only) start `stagger` sleep
+// quanta later, workgroups 512 .. twice that.  Results do not depend on it.
+__device__ __forceinline__ void chain_stagger(int stagger) {
+  const int n = stagger * (int)(blockIdx.x >> 8);
+  for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+}
 
 // HB = 32-row blocks of the hidden tensor: 2 (mlp_ratio 2, the README model) or 4 (mlp_ratio 4, the
 // BraTS bundle, train.yaml:62)
@@ -507,6 +518,7 @@ __global__ __launch_bounds__(256, (NACC == 2 && HB == 2 && !BWD) ? 3 : 2) void g
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, h = lane >> 5;
   const int tiles_per_sample = (int)((p.Ncol + 128 * NACC - 1) / (128 * NACC));
+  chain_stagger(c.stagger);
 
   // weights in operand order (8 independent loads per thread before the LDS stores)
   for (int base = threadIdx.x; base < 2 * N1; base += 256 * 8) {
@@ -1300,6 +1312,7 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
   float* Bf = R + wave * kWave;
   float* T = Bf + 32 * kTS;
   const int tiles_per_sample = (int)((p.Ncol + 128 * NACC - 1) / (128 * NACC));
+  chain_stagger(c.stagger);
 
   if constexpr (BX) {
     // 512 operand items of 8 steps each: As1x[g (2)][rb (2)][term][lane], As2x[g (4)][term][lane]
@@ -2539,6 +2552,7 @@ static int knob_chain64_p512() { static const int v = env_pos_once("FZ_CHAIN64_P
 static int knob_res_prefetch() { static const int v = env_pos_once("FZ_RES_PREFETCH", 1); return v == 1; }   // 2 = off (diagnostics)
 static int knob_p32() { static const int v = env_pos_once("FZ_GEMM_P32", 1); return v == 1; }   // 2 = off (diagnostics)
 static int knob_p32_wgs() { static const int v = env_pos_once("FZ_GEMM_P32_WGS", 512); return v; }   // resident: 2 per CU
+static int knob_chain_stagger(int dflt) { const auto& k = FZ_ENV_KNOB("FZ_CHAIN_STAGGER"); return k.set ? k.val : dflt; }
 static int knob_mlp_wgs(int dflt) { static const int v = env_pos_once("FZ_MLP_WGS", 0); return v > 0 ? v : dflt; }
 
 static int gemm_bx_enabled() {
@@ -2887,6 +2901,7 @@ static int mlp_launch(const fz_mlp_desc* d, fz_stream_t stream) {
     FZ_LAUNCH_CHECK();
     return FZ_OK;
   }
+  c.stagger = knob_chain_stagger(0);
   const int wgs = knob_mlp_wgs(d->H == 128 ? 512 : 768);  // resident workgroups (2 or 3 per CU), each walking tiles with a stride of the grid
   dim3 grid((unsigned)(ntiles < wgs ? ntiles : wgs)), block(256);
   if (d->mode == 0) {
