@@ -77,7 +77,24 @@ MFMA_FLOP_PER_BYTE = {"mlp_chain_bwd_wgrad_": 16384 / 640}
 # read from inside the benchmark: the committed summary of the profiled run is quoted, and
 # `traffic_source` says which file (with its content hash and the commit it was measured at), so a stale
 # number is visible as such.
-PMC_TRAFFIC = os.path.join(ROOT, "profiles", os.environ.get("FZ_PMC_TRAFFIC", "r03_pmc_traffic.json"))
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", os.environ.get("FZ_PMC_TRAFFIC", "r04_pmc_traffic.json"))
+PMC_TRAFFIC_BF16 = os.path.join(ROOT, "profiles", os.environ.get("FZ_PMC_TRAFFIC_BF16", "r04_pmc_traffic_bf16.json"))   # the --dtype bf16 command
+# What a hand-written streaming kernel of the same read : write mix reaches on MI355X (tools/probes/mem_ceilings.hip, 16 B per
+# lane, best over 4 / 8 / 16 waves per CU: profiles/r04_memory_ceilings.json).  `roofline.peak` stays the 8 TB/s of the
+# spec sheet; `stream_ceiling_GBps` is the number a memory-bound kernel can actually be held against.
+STREAM_CEILINGS = os.path.join(ROOT, "profiles", "r04_memory_ceilings.json")
+STREAM_MIX = {"nmf_cf_bwd_": "2:1", "nmf_cf_fwd_": "2:1", "mlp_chain_bwd_wgrad_": "3:1", "mlp_chain_fwd_": "1:1", "dgrad_": "3:1"}
+
+
+def stream_ceiling(timer_name):
+    """(GB/s, mix) of the bare access pattern closest to this launch's read : write mix, or (None, None)"""
+    try:
+        d = json.load(open(STREAM_CEILINGS))
+        mix = next((m for k, m in STREAM_MIX.items() if timer_name.startswith(k)), "2:1")
+        best = max(r["GBps"] for r in d["streams"] if r["mix"] == mix and r["footprint_MiB_per_stream"] == 1024)
+        return float(best), mix
+    except Exception:
+        return None, None
 # timer key of a BASELINE-size (stage-0) launch -> kernel-name prefix in the PMC summary; the summary averages
 # the launches with the largest grid of each kernel, i.e. the same stage-0 launches the key times
 PMC_KERNEL = {"nmf_cf_bwd_32x128x128x128": "fz::nmf_cf_bwd_tile_kernel<",
@@ -89,10 +106,11 @@ PMC_KERNEL = {"nmf_cf_bwd_32x128x128x128": "fz::nmf_cf_bwd_tile_kernel<",
               "mlp_chain_fwd_32": "fz::gemm_chain_kernel<false"}
 
 
-def pmc_traffic(timer_name):
+def pmc_traffic(timer_name, path=None):
     """(bytes per launch or None, traffic_source string).  Loud on stderr when the summary has no entry for
     the kernel the roofline line is about."""
     import hashlib
+    PMC_TRAFFIC = path or globals()["PMC_TRAFFIC"]
     try:
         raw = open(PMC_TRAFFIC, "rb").read()
         d = json.loads(raw)
@@ -386,9 +404,9 @@ def main():
             name, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
             avg_ms = a["ms"] / a["calls"]
             gbs = a["bytes"] / a["calls"] / (avg_ms * 1e-3) / 1e9
-            traffic, traffic_source = pmc_traffic(name)
-            if args.dtype != "f32":   # the committed counter passes are of the fp32 (headline) command
-                traffic, traffic_source = None, traffic_source + " (fp32 command: not applicable to this bf16 line)"
+            # (the counter passes are committed per command: the fp32 headline and the --dtype bf16 secondary line)
+            traffic, traffic_source = pmc_traffic(name, PMC_TRAFFIC if args.dtype == "f32" else PMC_TRAFFIC_BF16)
+            ceil_gbs, ceil_mix = stream_ceiling(name)
             # which roof binds: the one with the larger minimum time for this launch's algorithmic work
             fpb = next((v for k, v in MFMA_FLOP_PER_BYTE.items() if name.startswith(k)), 0.0)
             tflops = fpb * gbs / 1e3
@@ -400,6 +418,11 @@ def main():
             else:
                 head = {"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
+            if head["bound"] == "hbm" and ceil_gbs:
+                es = 1.0 if args.dtype == "f32" else 1.0   # (ceilings are in bytes: storage type does not matter)
+                head["stream_ceiling_GBps"] = ceil_gbs
+                head["stream_ceiling_mix"] = ceil_mix
+                head["frac_of_stream_ceiling"] = round(gbs * es / ceil_gbs, 4)
             roof = {**head, "traffic": traffic,
                     "traffic_source": traffic_source,
                     "avg_launch_ms": round(avg_ms, 4), "launches": a["calls"],

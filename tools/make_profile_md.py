@@ -44,8 +44,8 @@ def main():
     alg = {"fz::nmf_cf_bwd_tile_kernel<1, 1, 4, false, float>": (3.5 * 536.87, " (avg over the 2 windows)"),
            "fz::nmf_cf_fwd_tile_kernel<1, 1, 8, false, float>": (2.5 * 536.87, " (avg over the 2 windows)"),
            "fz::gemm_chain_kernel<true, 2, 2, float>": (7 * 536.87, ""), "fz::gemm_chain_kernel<false, 2, 2, float>": (4 * 536.87, ""),
-           "fz::gemm_chain_bwd_wg_kernel<float>": (5 * 536.87, " (+ 537: g2 is read a second time for the residual)"),
-           "fz::gemm_chain_bwd_wg_kernel<float, 1, 0, true>": (5 * 536.87, " (+ 537: g2 is read a second time for the residual)"),
+           "fz::gemm_chain_bwd_wg_kernel<float>": (5 * 536.87, " (round 4: the residual rows g2 come from LDS; rounds 2-3 read them a second time, +537)"),
+           "fz::gemm_chain_bwd_wg_kernel<float, 1, 0, true>": (5 * 536.87, " (round 4: the residual rows g2 come from LDS; rounds 2-3 read them a second time, +537)"),
            "fz::gemm_dw_kernel<true, float>": (4 * 536.87, ""), "fz::gemm_dw_kernel<false, float>": (3 * 536.87, "")}
     for k, (a, note) in alg.items():
         if k in pmc:

@@ -14,12 +14,25 @@ import re
 import sys
 
 
+def plain_name(name):
+    """rocprofv3 leaves names with a __bf16 template argument mangled (`_ZN2fz22nmf_cf_bwd_tile_kernelILi1E...DF16bEEv...`):
+    turn them into `fz::nmf_cf_bwd_tile_kernel<mangled:Li1E...DF16b>` so that the bf16 instantiations are listed like the others"""
+    m = re.match(r"_ZN2fz(\d+)", name)
+    if not m:
+        return name
+    n = int(m.group(1))
+    ident = name[m.end():m.end() + n]
+    rest = name[m.end() + n:]
+    targs = rest[1:rest.index("EEv")] if rest.startswith("I") and "EEv" in rest else ""
+    return f"fz::{ident}<mangled:{targs}>" if targs else f"fz::{ident}"
+
+
 def load(path, cname):
     d = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != cname:
             continue
-        name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").strip()
+        name = plain_name(re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").strip())
         d[name].append((int(r["Grid_Size"]), float(r["Counter_Value"])))
     return d
 
