@@ -133,7 +133,7 @@ class GemmDesc(_c.Structure):
                 ("bias", _vp), ("ln", _i), ("ln_g", _vp), ("ln_b", _vp), ("ln_eps", _f), ("stats_out", _vp),
                 ("bact", _i), ("bmul", _vp), ("bmul_kind", _i), ("eact", _i), ("res", _vp), ("emul", _vp), ("emul_kind", _i), ("y", _vp),
                 ("Ncol", _i64), ("Ho", _i), ("Wo", _i), ("B", _i), ("loader", _i), ("epilogue", _i), ("lnb_x", _vp), ("lnb_stats", _vp), ("lnb_g", _vp),
-                ("lnb_gadd", _vp), ("lnb_part", _vp), ("act_dtype", _i), ("products", _i)]
+                ("lnb_gadd", _vp), ("lnb_part", _vp), ("act_dtype", _i), ("products", _i), ("tune", _i)]
 
 
 class MlpDesc(_c.Structure):

@@ -2607,7 +2607,7 @@ static int gemm_launch(const fz_gemm_desc* d, fz_stream_t stream) {
   a.emul_kind = d->emul_kind; a.y = (AT*)d->y; a.Ncol = d->Ncol; a.Ho = d->Ho; a.Wo = d->Wo; a.B = d->B;
   { const auto& k = FZ_ENV_KNOB("FZ_GEMM_DBG"); a.dbg = k.set ? k.val : 0; }
   { const auto& k = FZ_ENV_KNOB("FZ_GEMM_TILEMAP"); a.tile_map = k.set ? k.val : 1; }
-  a.ygroups = 0; a.xtiles = 0;
+  a.ygroups = 0; a.xtiles = 0; a.tune = d->tune;
   a.lnb_x = (const AT*)d->lnb_x; a.lnb_stats = d->lnb_stats; a.lnb_g = d->lnb_g; a.lnb_gadd = (const AT*)d->lnb_gadd; a.lnb_part = d->lnb_part;
   hipStream_t st = (hipStream_t)stream;
   const int mblocks = (d->M + 31) / 32;

@@ -45,6 +45,7 @@ struct GemmArgsT {
   int B;
   int dbg;             // diagnostics (FZ_GEMM_DBG): 3 = skip the weight staging
   int tile_map;        // workgroup -> column-tile order: 0 linear, 1 XCD-contiguous, 2 scattered
+  int tune;            // host only: fz_gemm_desc.tune (tile choice of the split-bf16 family for timing probes)
   int ygroups, xtiles; // streaming kernel: > 1 row-block groups -> 1-D XCD-aware grid of xtiles column tiles
   // EPI_LNBWD (M == 32): the result is gl = dL/d(LN output); the epilogue applies the LayerNorm
   // backward in registers: y = rstd*(gl*g - mean_c(gl*g) - n*mean_c(gl*g*n)) + lnb_gadd

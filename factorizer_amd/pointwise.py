@@ -41,9 +41,10 @@ def _vox(x):
 # ---- raw launches ---------------------------------------------------------------------------
 def _gemm(xs, w, y, *, B, Cin, Vin, M, K, Ncol, w_t=False, ldw=None, bias=None, ln=None, stats_out=None,
           bact=0, bmul=None, bmul_kind=0, eact=0, res=None, emul=None, emul_kind=0, src_mode=0, c0=0,
-          loader=LOAD_PLAIN, epilogue=EPI_PLAIN, Di=0, Hi=0, Wi=0, Ho=0, Wo=0, name="gemm"):
+          loader=LOAD_PLAIN, epilogue=EPI_PLAIN, Di=0, Hi=0, Wi=0, Ho=0, Wo=0, name="gemm", tune=0):
     d = N.GemmDesc()
     d.products = N.products()
+    d.tune = tune
     for i in range(4):
         d.x[i] = _p(xs[i]) if i < len(xs) else None
     d.nsrc, d.src_mode, d.c0, d.Cin, d.Vin = len(xs), src_mode, c0, Cin, Vin

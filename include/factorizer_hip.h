@@ -247,6 +247,9 @@ typedef struct fz_gemm_desc {
   float* lnb_part;
   int act_dtype;          /* FZ_STORE_F32 / FZ_STORE_BF16: element type of every "activation" pointer */
   int products;           /* FZ_PRODUCTS_* */
+  int tune;               /* 0 = the library chooses the tile.  Timing probes (tools/probes/gemm_bx_bench.py; results do not depend
+                             on it): split-bf16 family only — 100 + 10*nacc + mb = streaming form with that tile (nacc 2|4, mb 1|2),
+                             200 + 10*nacc + mb = K-split form (nacc 1|2, mb 1|2), 300 = streaming form, library's tile */
 } fz_gemm_desc;
 
 /* number of 64-float partial rows fz_gemm writes to lnb_part for this descriptor */

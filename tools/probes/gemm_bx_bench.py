@@ -60,13 +60,13 @@ def main():
             st = torch.empty(B, 2, V, device=DEV)
             w2 = w.reshape(M, Cin)
             if kind == "lin":
-                fn = lambda: PW._gemm([x], w2, y, B=B, Cin=Cin, Vin=V, M=M, K=Cin, Ncol=V, bias=b)  # noqa: E731
+                fn = lambda t: PW._gemm([x], w2, y, B=B, Cin=Cin, Vin=V, M=M, K=Cin, Ncol=V, bias=b, tune=t)  # noqa: E731
                 nbytes = 4 * (x.numel() + y.numel())
             elif kind == "ln":
-                fn = lambda: PW._gemm([x], w2, y, B=B, Cin=Cin, Vin=V, M=M, K=Cin, Ncol=V, bias=b, ln=(g, bt, 1e-5), stats_out=st, eact=1)  # noqa: E731
+                fn = lambda t: PW._gemm([x], w2, y, B=B, Cin=Cin, Vin=V, M=M, K=Cin, Ncol=V, bias=b, ln=(g, bt, 1e-5), stats_out=st, eact=1, tune=t)  # noqa: E731
                 nbytes = 4 * (x.numel() + y.numel())
             else:
-                fn = lambda: PW._gemm([x], w2, y, B=B, Cin=Cin, Vin=V, M=M, K=Cin, Ncol=V, bias=b, bact=2, res=res)  # noqa: E731
+                fn = lambda t: PW._gemm([x], w2, y, B=B, Cin=Cin, Vin=V, M=M, K=Cin, Ncol=V, bias=b, bact=2, res=res, tune=t)  # noqa: E731
                 nbytes = 4 * (x.numel() + 2 * y.numel())
             flops = 2.0 * B * V * Cin * M
         elif kind == "conv":
@@ -74,36 +74,35 @@ def main():
             b = torch.randn(M, device=DEV)
             Eo = E // 2
             y = torch.empty(B, M, Eo, Eo, Eo, device=DEV)
-            fn = lambda: PW._gemm([x], w, y, B=B, Cin=Cin, Vin=V, M=M, K=8 * Cin, Ncol=Eo ** 3, bias=b, loader=PW.LOAD_S2D,  # noqa: E731
-                                  Di=E, Hi=E, Wi=E, Ho=Eo, Wo=Eo)
+            fn = lambda t: PW._gemm([x], w, y, B=B, Cin=Cin, Vin=V, M=M, K=8 * Cin, Ncol=Eo ** 3, bias=b, loader=PW.LOAD_S2D,  # noqa: E731
+                                    Di=E, Hi=E, Wi=E, Ho=Eo, Wo=Eo, tune=t)
             nbytes = 4 * (x.numel() + y.numel())
             flops = 2.0 * B * Eo ** 3 * 8 * Cin * M
         else:
             w = torch.randn(Cin, M, 2, 2, 2, device=DEV) / Cin ** 0.5
             b = torch.randn(M, device=DEV)
             y = torch.empty(B, M, 2 * E, 2 * E, 2 * E, device=DEV)
-            fn = lambda: PW._gemm([x], w, y, B=B, Cin=Cin, Vin=V, M=8 * M, K=Cin, Ncol=V, w_t=True, ldw=8 * M, bias=b,  # noqa: E731
-                                  epilogue=PW.EPI_D2S, Ho=E, Wo=E)
+            fn = lambda t: PW._gemm([x], w, y, B=B, Cin=Cin, Vin=V, M=8 * M, K=Cin, Ncol=V, w_t=True, ldw=8 * M, bias=b,  # noqa: E731
+                                    epilogue=PW.EPI_D2S, Ho=E, Wo=E, tune=t)
             nbytes = 4 * (x.numel() + y.numel())
             flops = 2.0 * B * V * Cin * 8 * M
         for variant in ["f32mfma"] + cfgs:
-            os.environ.pop("FZ_BX_CFG", None)
-            os.environ.pop("FZ_BX_KS", None)
+            # per-call settings only: the descriptor's `products` and `tune` fields (no environment, no process-wide switch)
+            prod, tune = N.PRODUCTS_SPLIT_BF16, 0
             if variant == "f32mfma":
-                lib.fz_gemm_bx_enable(0)
-            else:
-                lib.fz_gemm_bx_enable(1)
-                if variant.startswith("n"):      # streaming form, tile <nacc><mb>
-                    if kind == "conv":
-                        continue
-                    os.environ["FZ_BX_KS"] = "0"
-                    os.environ["FZ_BX_CFG"] = variant[1:]
-                elif variant.startswith("k"):    # K-split form, tile <nacc><mb>
-                    if kind == "conv" and variant[1] != "2":
-                        continue
-                    os.environ["FZ_BX_KS"] = "1" + variant[1:]
+                prod = N.PRODUCTS_FP32_MFMA
+            elif variant.startswith("n"):      # streaming form, tile <nacc><mb>
+                if kind == "conv":
+                    continue
+                tune = 100 + int(variant[1:])
+            elif variant.startswith("k"):      # K-split form, tile <nacc><mb>
+                if kind == "conv" and variant[1] != "2":
+                    continue
+                tune = 200 + int(variant[1:])
+            run = (lambda f, t: (lambda: f(t)))(fn, tune)
             try:
-                us = timeit(fn)
+                with N.use_products(prod):
+                    us = timeit(run)
             except Exception as ex:  # unsupported tile for this shape
                 print(f"# {kind} {Cin}->{M}@{E} {variant}: {ex}", file=sys.stderr)
                 continue
@@ -113,9 +112,6 @@ def main():
             print(line, flush=True)
             if out:
                 out.write(line + "\n")
-        os.environ.pop("FZ_BX_CFG", None)
-        os.environ.pop("FZ_BX_KS", None)
-        lib.fz_gemm_bx_enable(1)
 
 
 if __name__ == "__main__":
