@@ -922,16 +922,17 @@ static int cf2_plan(Cf2Plan& p, int B, int C, int D, int H, int W, const int* sh
   const int64_t tensor_bytes = nslice * 8 * (int64_t)D * H * W * es;
   if (tensor_bytes >= ((int64_t)1 << 31)) return 0;   // 32-bit buffer offsets
   p.GQ = G2 / WPB; p.tpp = G1 * p.GQ;
-  // slices per group: the bytes between the two uses of a plane (about two steps of `passes` plane-sets of the group) must
-  // stay well inside the 256 MiB Infinity Cache — 96 MB — and a bundle should be at least one round of resident workgroups
-  const int64_t plane_bytes = (int64_t)8 * 8 * H * W * es;
+  // slices per group.  The design intent was a group small enough for the Infinity Cache (two steps of `passes` plane-sets
+  // of the group within ~96 MB); measured (profiles/r04_cf2_sweep.json) small groups only make window-1 workgroups wait on a
+  // resident slot — the 4 096 matrices in flight are 164 MB by themselves — so the library's own choice is the whole tensor
+  // as ONE group with window 1 a plane further behind (the least slow setting: within 6 % of the one-window launches).
+  (void)passes;
   int group = (int)nslice;
   if (tune && tune[0] > 0) group = tune[0];
   else if (knob_cf2_group() > 0) group = knob_cf2_group();
-  else while (group > 1 && (group * plane_bytes * passes * 2 > ((int64_t)96 << 20)) && (group % 2) == 0) group /= 2;
   if (group < 1 || nslice % group) return 0;
   p.group = group; p.items_w = group * p.tpp;
-  int lag = (tune && tune[1] >= 0) ? tune[1] : knob_cf2_lag();
+  int lag = (tune && tune[1] >= 0) ? tune[1] : (FZ_ENV_KNOB("FZ_CF2_LAG").set ? knob_cf2_lag() : 1);
   if (lag < 0) lag = 0;
   if (lag > G0 - 1) lag = G0 - 1;
   p.lag = lag;
