@@ -652,7 +652,7 @@ __global__ __launch_bounds__(256, (NACC == 2 && HB == 2 && !BWD) ? 3 : 2) void g
           const float add = tW[row];
 #pragma unroll
           for (int q = 0; q < NACC; ++q) v[q] = acc1[rb][q][r] + add;
-          if (col_ok) vstore<NACC>(c.side + ob + lane_row, v);
+          if (col_ok && c.side != nullptr) vstore<NACC>(c.side + ob + lane_row, v);   // (null: timing probe FZ_CHAIN_NOZ1)
           if constexpr (NACC == 2) {
             float gq[2];
             gelu2_f(v, gq);
@@ -2909,7 +2909,7 @@ static int mlp_launch(const fz_mlp_desc* d, fz_stream_t stream) {
     a.bias = d->b1; a.ln = 1; a.ln_g = d->ln_g; a.ln_b = d->ln_b; a.ln_eps = d->ln_eps; a.stats_out = d->stats;
     a.res = (const AT*)d->in; a.y = (AT*)d->out;
     c.wB = d->w2; c.wB_t = 0; c.ldwB = d->H;         // A2[m][k] = W2[m][k]
-    c.biasB = d->b2; c.side = (AT*)d->z1;
+    c.biasB = d->b2; c.side = FZ_ENV_KNOB("FZ_CHAIN_NOZ1").val ? nullptr : (AT*)d->z1;   // (knob: timing probe, z1 not written)
     if (d->H == 128) hipLaunchKernelGGL((gemm_chain_kernel<false, 2, 4>), grid, block, 0, st, a, c, ntiles);
     else hipLaunchKernelGGL((gemm_chain_kernel<false, 2, 2>), grid, block, 0, st, a, c, ntiles);
   } else if (d->mode == 2) {
