@@ -28,11 +28,12 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
 #    whole accumulator tiles — +64..128 VGPRs and scratch spills in the fused epilogues (round 1);
 #  * the NMF wave programs: v_pk_fma_f32 / v_pk_mul_f32 pairs whose 64-bit register alignment costs more v_mov than the packing
 #    saves: the rank-2 HALS backward of the generic-patch core went from 234 to 154 VGPRs and 43.9 -> 38.3 ms per cfg-5 step (round 3).
-# Exceptions (SLP left on): gemm_bx.hip — without it the compile does not finish in five minutes, and the audit finds no such
-# instruction in it; the standalone ft.NMF kernels nmf_r*.hip — without it they spill more (they are the one exemption of the
-# no-scratch policy as well) and they run one launch at a time, never beside an MFMA kernel of this library.
+# Exception (SLP left on): gemm_bx.hip — without it the compile does not finish in five minutes, and the audit finds no such
+# instruction in it.  (The standalone ft.NMF units nmf_r*.hip were an exception at first — round 3 believed they spill more
+# without SLP; measured in round 4 they spill LESS: 34 kernels / 12.6 KB of scratch against 51 / 49 KB — and carried 17 000 of
+# the op_sel'd instructions.)
 _NO_SLP = ["-fno-slp-vectorize"]
-_SLP_ON = {"gemm_bx.hip"} | {f"nmf_r{r}{sfx}.hip" for r in (1, 2, 3, 4) for sfx in ("", "_bf16")}
+_SLP_ON = {"gemm_bx.hip"}
 
 
 class _PerFile(dict):
@@ -63,8 +64,21 @@ def _deps_mtime() -> float:
     return m
 
 
+def _flags_of(src):
+    return " ".join([*FLAGS, *PER_FILE_FLAGS.get(src, [])])
+
+
+def _stale_flags() -> bool:
+    """an object compiled with other flags than today's (the .flags stamp beside it) makes the library stale"""
+    for src in sources():
+        stamp = os.path.join(OBJ, src[:-4] + ".o.flags")
+        if not os.path.exists(stamp) or open(stamp).read() != _flags_of(src):
+            return True
+    return False
+
+
 def needs_build() -> bool:
-    return not os.path.exists(LIB) or os.path.getmtime(LIB) < _deps_mtime()
+    return not os.path.exists(LIB) or os.path.getmtime(LIB) < _deps_mtime() or _stale_flags()
 
 
 def _hdr_mtime() -> float:

@@ -67,8 +67,8 @@ def test_no_low_from_high_packed_fp32_instruction_outside_the_exempt_units():
     """`v_pk_{add,mul,fma}_f32 ... op_sel:[..1..]` (low result from a HIGH source half) is the instruction form whose four
     instances made an eight-wave MFMA kernel stop replaying bit for bit on gfx950 (assembly-level bisect,
     profiles/r04_nondeterminism.md): hipcc's SLP vectorizer forms it, so the build uses -fno-slp-vectorize and no built object
-    may contain one — except gemm_bx (SLP kept for compile time; none found) and the standalone ft.NMF units nmf_r* (exempt
-    from the no-scratch policy for the same reason: they run one launch at a time)."""
+    may contain one — no exemption (gemm_bx keeps SLP for compile time and contains none; the standalone ft.NMF units nmf_r* are
+    built without SLP as well since round 4: they spill less that way)."""
     import importlib.util
     B.build(verbose=False)
     spec = importlib.util.spec_from_file_location("pk_opsel_audit", os.path.join(ROOT, "tools", "pk_opsel_audit.py"))
@@ -76,5 +76,5 @@ def test_no_low_from_high_packed_fp32_instruction_outside_the_exempt_units():
     spec.loader.exec_module(mod)
     res = mod.audit()
     assert "gemm" in res and "upcat" in res and res["gemm"][1] > 0          # the disassembly really was read
-    bad = {tu: n for tu, (n, _) in res.items() if n and not tu.startswith("nmf_r")}
+    bad = {tu: n for tu, (n, _) in res.items() if n}
     assert not bad, bad

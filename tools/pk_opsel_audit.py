@@ -2,7 +2,7 @@
 half (`v_pk_{add,mul,fma}_f32 ... op_sel:[..1..]`).  Four such instructions — formed by the SLP vectorizer in a store
 epilogue — are what made the eight-wave upcat kernel stop replaying bit for bit beside MFMA waves on gfx950
 (assembly-level bisect: profiles/r04_nondeterminism.md).  The build therefore compiles with -fno-slp-vectorize
-(factorizer_amd/build.py) and tests/test_no_spills.py asserts that this audit finds none outside the exempt units.
+(factorizer_amd/build.py) and tests/test_no_spills.py asserts that this audit finds none, in any unit.
 Reads the objects in factorizer_amd/csrc/build (llvm-objdump of the embedded gfx950 code object; no recompilation).
 usage: python tools/pk_opsel_audit.py"""
 import os
