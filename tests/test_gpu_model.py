@@ -33,26 +33,43 @@ def _model(spatial, patch, **kw):
     return ft.Factorizer(**args)
 
 
-@pytest.mark.parametrize("S,patch,B", [
-    ((64, 64, 64), 4, 2),
-    # KNOWN SHORTFALL, kept visible: at 32^3 / patch 2 (8 x 8 matrices, B = 1) four of the 123 gradients — norm1.weight / .bias and
-    # in_proj.weight of encoder block 0 and stem.weight, i.e. everything upstream of that block's core backward — sit 1.5e-4 ..
-    # 3.5e-4 of max|g| from the float64 oracle where ATen's fp32 arithmetic sits 1.3e-5 .. 2.8e-5 (the other 119: <= 4e-6 against
-    # <= 8e-7).  This configuration amplifies a perturbation that enters at the last decoder block ~40x on its way back to the
-    # stem, and the device's per-kernel errors, while <= 4e-6 everywhere, are 3-10x ATen's in the voxel-sum reductions (fixed-order
-    # partial rows instead of pairwise sums).  Exonerated in isolation, each at ATen's own accuracy on the tensors the model
-    # really produces: the fused core forward + backward (tools/probes/core_model_input.py, core_model_grad.py), the whole
-    # FactorizerBlock with every parameter gradient (tools/probes/block_grad_table.py); table of all 123 tensors:
-    # profiles/r04_model_grad_table_32.txt.  Not met: 1e-4 at the MODEL level for this configuration.
-    pytest.param((32, 32, 32), 2, 1, marks=pytest.mark.xfail(strict=False, reason="32^3 / patch 2: four stage-0 gradients at 1.5e-4 .. "
-                 "3.5e-4 of float64 (ATen fp32: 1.3e-5 .. 2.8e-5); see the comment and profiles/r04_model_grad_table_32.txt"))])
+def _device_relu_gates(model, x):
+    """Forward of the device model with a pre-hook on every FactorizerBlock: the block input is captured and the block's FIRST
+    launch — t = relu(in_proj(LayerNorm1(x))), the very kernel and arguments the fused node uses — is repeated on it, so the
+    returned masks [t > 0] are bit for bit the ReLU gates the device run had (execution order: encoder stages, then decoder)."""
+    from factorizer_amd.blocks import FactorizerBlock
+    inputs, hooks = [], []
+    for m in model.modules():
+        if isinstance(m, FactorizerBlock):
+            hooks.append(m.register_forward_pre_hook(lambda mod, args: inputs.append((mod, args[0].detach()))))
+    y = model(x)
+    for h in hooks:
+        h.remove()
+    gates = []
+    with torch.no_grad():
+        for mod, xin in inputs:
+            n1, lin = mod.norm1.norm, mod.fact.in_proj.linear
+            t = PW.ln_linear(xin, n1.weight, n1.bias, n1.eps, lin.weight, None, "relu")
+            gates.append((t > 0).cpu())
+    return y, gates
+
+
+@pytest.mark.parametrize("S,patch,B", [((64, 64, 64), 4, 2), ((32, 32, 32), 2, 1)])
 def test_five_stage_model_vs_oracle_every_gradient(S, patch, B):
-    """widths (32, 64, 128, 256, 512) at 64^3 with patch 4 (bottleneck 4^3 = one patch per head and window) and at 32^3
-    with patch 2: output to 1e-4 of the fp32 oracle; each parameter gradient to 1e-4 of the fp32 oracle.  Where that fails AND
-    the fp32 oracle itself is further than 5e-5 from its float64 evaluation, the tensor is compared with the float64 oracle
-    instead: RMS distance <= 2 x and maximum distance <= 4 x the fp32 oracle's own (cf. tests/test_gpu_cfg5.py); such tensors
-    must stay exceptions (< 1/4 of the list; measured: 1 of 123 at 64^3, and the device is on average 4 x CLOSER to float64
-    than ATen's fp32 CPU arithmetic — tools/probes/model_grad_table.py)."""
+    """widths (32, 64, 128, 256, 512) at 64^3 / patch 4 (B = 2) and 32^3 / patch 2 (B = 1): output against the fp32 oracle, every
+    parameter gradient against the FLOAT64 oracle, at 1e-4.
+
+    One thing has to be handled, and round 4 found it the hard way (tools/probes/block_model_grad.py): the network has ~2 M ReLU
+    pre-activations z = in_proj(LN(x)) (factorizer.py:38-44), and in every draw a handful lie within fp32 rounding of zero
+    (|z| < 1e-7 of max|z|; seed 3 at 32^3: z = +8.6e-8 in float64, -5.9e-8 in ATen's fp32).  Two correct fp32 evaluations can put
+    such an element on different sides; the gate of ONE element moves the input gradient of its voxel by 1e-3 relative and every
+    voxel-sum gradient upstream by ~1e-4 — a discontinuity of the function, not an error of either evaluation.  So the float64
+    oracle is run with the ReLU gates the DEVICE had ([t > 0] of the device's own t, obtained bit for bit by repeating the block's
+    first launch on the hooked block input): where the device's gate differs from float64's own sign the element must be such a
+    tie (|z64| <= 1e-6 max|z64|, asserted, counted), everywhere else nothing changes.  (The VALUE stays float64's own relu(z): a
+    negative z let through an open gate would leave NMF's domain, and a row of X whose only non-zero is that element then trips
+    the solver's own relu((Xv + eps) / (v'v + eps)) — measured: 2.6e-4 on in_proj.weight from that alone.)  With the ties resolved
+    one way, the device must match float64 to 1e-4 with no further allowance."""
     torch.manual_seed(3)
     model = _model(S, patch)
     sd = {k: v.clone() for k, v in model.state_dict().items()}
@@ -60,55 +77,60 @@ def test_five_stage_model_vs_oracle_every_gradient(S, patch, B):
     x = torch.rand(B, 4, *S)
     gy = torch.randn(B, 3, *S)
 
-    def oracle(dt):
-        prm = {k: v.clone().to(dt).requires_grad_(True) for k, v in sd.items()
-               if v.is_floating_point() and not k.endswith(("u0", "v0"))}
-        full = {k: (v.to(dt) if v.is_floating_point() else v) for k, v in sd.items()}
-        full.update(prm)
-        yo = O.factorizer_forward(x.to(dt), full, cfg)
-        return yo.detach(), dict(zip(prm.keys(), torch.autograd.grad(yo, list(prm.values()), gy.to(dt))))
-
-    y32, g32 = oracle(torch.float32)
-    y64, g64 = oracle(torch.float64)
     model = model.to(DEV)
     n0 = _native.launch_count()
     with warnings.catch_warnings():
         warnings.simplefilter("error", RuntimeWarning)     # no composed-ATen branch anywhere in the model
-        yd = model(x.to(DEV))
+        yd, gates = _device_relu_gates(model, x.to(DEV))
         yd.backward(gy.to(DEV))
-    assert _native.launch_count() > n0
+    assert _native.launch_count() > n0 and len(gates) == 9
+
+    with torch.no_grad():
+        y32 = O.factorizer_forward(x, sd, cfg)
     P.close(f"five-stage model {S} y", yd, y32)
+
+    # float64 oracle with the device's gates (oracle/cpu_ref.py:fact_mixer restated with the gate injected)
+    ties, it = [], iter(gates)
+
+    def fact_mixer_gated(xx, sdd, prefix, c):
+        C, spatial = xx.shape[1], tuple(xx.shape[2:])
+        z = O.linear_cf(xx, sdd[prefix + "in_proj.linear.weight"])
+        gate = next(it)
+        own = z.detach() > 0
+        diff = own != gate
+        if diff.any():
+            zt = z.detach()[diff].abs()
+            assert float(zt.max()) <= 1e-6 * float(z.detach().abs().max()), (prefix, float(zt.max()))   # a tie, not a disagreement
+        ties.append(int(diff.sum()))
+        t = torch.relu(z).detach() + gate.to(z.dtype) * (z - z.detach())     # value relu(z) (float64's own), derivative = the device's gate
+        m = O.swm_forward(t, **c["reshape"])
+        m = O.nmf_forward(m, sdd[prefix + "factorize.init.u0"], sdd[prefix + "factorize.init.v0"], c.get("num_iters", 5),
+                          c.get("solver", "hals"), c.get("num_grad_steps"))
+        a = O.swm_inverse(m, C, spatial, **c["reshape"])
+        return O.linear_cf(a, sdd[prefix + "out_proj.linear.weight"], sdd[prefix + "out_proj.linear.bias"])
+
+    prm = {k: v.clone().double().requires_grad_(True) for k, v in sd.items()
+           if v.is_floating_point() and not k.endswith(("u0", "v0"))}
+    full = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    full.update(prm)
+    orig = O.fact_mixer
+    O.fact_mixer = fact_mixer_gated
+    try:
+        y64 = O.factorizer_forward(x.double(), full, cfg)
+        g64 = dict(zip(prm.keys(), torch.autograd.grad(y64, list(prm.values()), gy.double())))
+    finally:
+        O.fact_mixer = orig
+    assert len(ties) == 9 and sum(ties) <= 64, ties
+    P.note("five_stage_model_relu_ties", spatial=list(S), ties_per_block=ties,
+           meaning="ReLU pre-activations within 1e-6 of zero that the device and float64 put on different sides")
+    P.close(f"five-stage model {S} y (float64, device gates)", yd, y64.float())
     names = [n for n, _ in model.named_parameters()]
-    assert set(names) == set(g32.keys())
-    n_fp64_rule, worst = 0, 0.0
+    assert set(names) == set(g64.keys())
+    worst = 0.0
     for n, p in model.named_parameters():
-        scale = g64[n].abs().max().item() + 1e-30
-        e32 = (g32[n].double() - g64[n]).abs().max().item() / scale
-        d = p.grad.double().cpu() - g64[n]
-        ed = d.abs().max().item() / scale
-        worst = max(worst, ed)
-        e_dev32 = (p.grad.double().cpu() - g32[n].double()).abs().max().item() / (g32[n].abs().max().item() + 1e-30)
-        if e_dev32 <= 1e-4 or e32 <= 5e-5:     # the rule: 1e-4 of the reference's fp32 result
-            P.close(f"five-stage model {S} grad {n}", p.grad, g32[n])
-        else:
-            # ill-conditioned tensor (so far only the stage-0 encoder block's in_proj / norm1, whose gradient passes through
-            # every HALS sweep of the network): two fp32 evaluations differ from each other by as much as each differs from
-            # float64.  The device must be as close to float64 as the reference's fp32 arithmetic is — in RMS (x 2) and,
-            # because the error has a heavy tail (a ReLU gate of HALS flipping in one patch moves single elements), in
-            # maximum (x 4)
-            n_fp64_rule += 1
-            r32 = (g32[n].double() - g64[n]).pow(2).mean().sqrt().item() / scale
-            rd = d.pow(2).mean().sqrt().item() / scale
-            P.note(f"five-stage model {S} grad {n}: distances to the fp64 oracle", device_max=ed, fp32_oracle_max=e32,
-                   device_rms=rd, fp32_oracle_rms=r32)
-            assert rd <= max(2.0 * r32, 2e-5), (n, rd, r32)
-            P.close(f"five-stage model {S} grad {n} (vs fp64 oracle; fp32 oracle is {e32:.1e} away)", p.grad, g64[n].float(),
-                    rel=max(1e-4, 4.0 * e32),
-                    why="the reference's own fp32 arithmetic is further than 5e-5 from its float64 evaluation for this tensor; "
-                        "RMS distance held to 2x the fp32 oracle's")
-    P.note("five_stage_model_gradients", spatial=list(S), tensors=len(names), held_to_fp64_rule=n_fp64_rule,
-           worst_distance_to_fp64=worst)
-    assert n_fp64_rule <= len(names) // 4, n_fp64_rule   # the 1e-4-of-the-fp32-oracle bar must stay the rule, not the exception
+        worst = max(worst, P.close(f"five-stage model {S} grad {n} (float64 oracle, device gates)", p.grad, g64[n].float())
+                    / (g64[n].abs().max().item() + 1e-30))
+    P.note("five_stage_model_gradients", spatial=list(S), tensors=len(names), worst_distance_to_fp64=worst)
 
 
 def _readme_step(model, x, t):

@@ -26,7 +26,11 @@ def oracle(dt):
     return yo.detach(), dict(zip(prm.keys(), torch.autograd.grad(yo, list(prm.values()), gy.to(dt))))
 y32, g32 = oracle(torch.float32); y64, g64 = oracle(torch.float64)
 model = model.cuda()
-yd = model(x.cuda()); yd.backward(gy.cuda())
+from factorizer_amd import _native as _N
+_prod = {"split": _N.PRODUCTS_SPLIT_BF16, "fp32": _N.PRODUCTS_FP32_MFMA}.get(os.environ.get("FZ_TABLE_PRODUCTS", ""), _N.PRODUCTS_DEFAULT)
+print("products:", _prod)
+with _N.use_products(_prod):
+    yd = model(x.cuda()); yd.backward(gy.cuda())
 print("y: dev-64 %.2e  32-64 %.2e" % ((yd.double().cpu() - y64).abs().max() / y64.abs().max(), (y32.double() - y64).abs().max() / y64.abs().max()))
 rows = []
 for n, p in model.named_parameters():
