@@ -1259,7 +1259,7 @@ __device__ __forceinline__ void gelu_both(float x, float& g, float& dg) {
   const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
   const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
   const float r = 1.0f - poly * E;                       // erf(|x|/√2)
-  const float cdf = 0.5f * (1.0f + (x < 0.f ? -r : r));
+  const float cdf = 0.5f * (1.0f + __builtin_copysignf(r, x));
   g = x * cdf;
   dg = cdf + x * (0.3989422804014327f * E);
 }
@@ -1268,6 +1268,7 @@ __device__ __forceinline__ void gelu_both(float x, float& g, float& dg) {
 // issue slot; the exponentials and reciprocals stay scalar) — same operations in the same order, so the results are
 // those of gelu_both; ≈ 23 instead of 44 VALU instructions per voxel pair in the VALU-heaviest phase of the fused kernel.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <bool SEL = false>   // SEL: sign by compare + select (the two-launch hidden-128 form keeps its round-3 register allocation)
 __device__ __forceinline__ void gelu_both2(const float (&x)[2], float (&g)[2], float (&dg)[2]) {
   const f32x2 xv = {x[0], x[1]};
   const f32x2 ax = f32x2{fabsf(x[0]), fabsf(x[1])} * 0.70710678118654752f;
@@ -1277,7 +1278,9 @@ __device__ __forceinline__ void gelu_both2(const float (&x)[2], float (&g)[2], f
   const f32x2 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
   const f32x2 poly = t * (t * (t * (t * (t * 1.061405429f + -1.453152027f) + 1.421413741f) + -0.284496736f) + 0.254829592f);
   const f32x2 r = 1.0f - poly * E;
-  const f32x2 rs = {x[0] < 0.f ? -r[0] : r[0], x[1] < 0.f ? -r[1] : r[1]};
+  f32x2 rs;
+  if constexpr (SEL) rs = f32x2{x[0] < 0.f ? -r[0] : r[0], x[1] < 0.f ? -r[1] : r[1]};
+  else rs = f32x2{__builtin_copysignf(r[0], x[0]), __builtin_copysignf(r[1], x[1])};   // one v_bfi_b32 instead of compare + select (fast_erf, fz_common.h)
   const f32x2 cdf = (rs + 1.0f) * 0.5f;
   const f32x2 gv = xv * cdf;
   const f32x2 dv = cdf + xv * (E * 0.3989422804014327f);
@@ -1401,10 +1404,22 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
     const unsigned lane_par = (unsigned)h * (unsigned)p.Ncol + (unsigned)nc;
     const int64_t sample = (int64_t)b * 32 * p.Ncol;
 
-    // ---- Bf <- g2 (lanes past the last column contribute zero to the voxel sums) ----
+    // Lanes past the last column (ragged last tile only: their loads are clamped to column 0) must contribute zero to the
+    // voxel sums.  Zeroing g2 HERE, once, does it for every sum of the tile: gh = W2ᵀ·0 = 0 makes gz1 = gh∘gelu' = 0 (db1, dW1,
+    // and through GEMM 2 the LayerNorm sums), g2 = 0 itself covers dW2 and db2 — gelu(z1) and x̂ of such a lane stay finite and
+    // meet a zero factor.  (Rounds 2-3 selected on every LDS store instead: 224 v_cndmask per tile, 10 % of the VALU stream.)
+    // (hidden 128, two launches: the second half adds to a parked part read at a clamped address, and its register
+    // allocation does not survive the change — that form keeps the per-store selects, ZSEL)
+    constexpr bool ZSEL = HALVES == 2;
+    auto zs = [&](float v) { return (ZSEL && !col_ok) ? 0.f : v; };
+    if (!ZSEL && __builtin_amdgcn_ballot_w64(!col_ok) != 0) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) { bv[s][0] = col_ok ? bv[s][0] : 0.f; bv[s][1] = col_ok ? bv[s][1] : 0.f; }
+    }
+    // ---- Bf <- g2 ----
 #pragma unroll
     for (int s = 0; s < 16; ++s)
-      *reinterpret_cast<float2*>(Bf + (2 * s + h) * kTS + 2 * j) = make_float2(col_ok ? bv[s][0] : 0.f, col_ok ? bv[s][1] : 0.f);
+      *reinterpret_cast<float2*>(Bf + (2 * s + h) * kTS + 2 * j) = make_float2(zs(bv[s][0]), zs(bv[s][1]));
 
     // Every global operand of the tile is requested one phase AHEAD of its use (two waves per SIMD cannot hide a
     // memory round trip per phase): z1 block g+1 during block g, x1 during the last z1 block, the residual rows before
@@ -1486,7 +1501,7 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
       for (int i = 0; i < 8; ++i) {
         const int rr = g8 * 8 + i, rb = rr >> 4, r = rr & 15;
         float gl[NACC], dg[NACC];
-        gelu_both2(e[g8 & 1][i], gl, dg);
+        gelu_both2<HALVES == 2>(e[g8 & 1][i], gl, dg);
 #pragma unroll
         for (int q = 0; q < NACC; ++q) {
           float gz = acc1[rb][q][r] * dg[q];
@@ -1496,7 +1511,7 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
           acc1[rb][q][r] = gz;
         }
         const int loc = (i & 3) + 8 * (i >> 2) + 4 * h;
-        *reinterpret_cast<float2*>(T + loc * kTS + 2 * j) = make_float2(col_ok ? gl[0] : 0.f, col_ok ? gl[1] : 0.f);
+        *reinterpret_cast<float2*>(T + loc * kTS + 2 * j) = make_float2(zs(gl[0]), zs(gl[1]));
       }
 #pragma unroll
       for (int tc = 0; tc < 2; ++tc) {   // 8 voxel quads at a time: 24 LDS operands in flight, then 16 MFMAs
@@ -1544,7 +1559,7 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
 #pragma unroll
       for (int s8 = 0; s8 < 8; ++s8)
         *reinterpret_cast<float2*>(Bf + (2 * (hf * 8 + s8) + h) * kTS + 2 * j) =
-            make_float2(col_ok ? (xv[hf][s8][0] - mu[0]) * rs[0] : 0.f, col_ok ? (xv[hf][s8][1] - mu[1]) * rs[1] : 0.f);
+            make_float2(zs((xv[hf][s8][0] - mu[0]) * rs[0]), zs((xv[hf][s8][1] - mu[1]) * rs[1]));
 
     // ---- pass B: gz1 block -> T; S1 += gz1 ⊗ x̂, db1 += Σ gz1 ----
 #pragma unroll
@@ -1554,7 +1569,7 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
       for (int i = 0; i < 8; ++i) {
         const int rr = g8 * 8 + i, rb = rr >> 4, r = rr & 15;
         const int loc = (i & 3) + 8 * (i >> 2) + 4 * h;
-        *reinterpret_cast<float2*>(T + loc * kTS + 2 * j) = make_float2(col_ok ? acc1[rb][0][r] : 0.f, col_ok ? acc1[rb][1][r] : 0.f);
+        *reinterpret_cast<float2*>(T + loc * kTS + 2 * j) = make_float2(zs(acc1[rb][0][r]), zs(acc1[rb][1][r]));
       }
 #pragma unroll
       for (int tc = 0; tc < 2; ++tc) {
@@ -1670,8 +1685,10 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
         v[0] = rs[0] * (acc2[0][r] * gc - m1[0] - xh.x * m2[0]) + ga[r8][i][0];
         v[1] = rs[1] * (acc2[1][r] * gc - m1[1] - xh.y * m2[1]) + ga[r8][i][1];
         if (col_ok) vstore<NACC>(p.y + sample + (int64_t)rbase * p.Ncol + lane_row, v);
-        float sg = col_ok ? acc2[0][r] * xh.x + acc2[1][r] * xh.y : 0.f;
-        float sb = col_ok ? acc2[0][r] + acc2[1][r] : 0.f;
+        float sg = acc2[0][r] * xh.x + acc2[1][r] * xh.y;   // (lanes past the last column: acc2 = 0, see the top of the tile)
+        float sb = acc2[0][r] + acc2[1][r];
+        sg = zs(sg);
+        sb = zs(sb);
         sg = half_sum32(sg);
         sb = half_sum32(sb);
         if ((lane & 31) == 31) {

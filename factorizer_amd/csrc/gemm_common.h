@@ -77,7 +77,7 @@ __device__ __forceinline__ void gelu2_f(const float (&x)[2], float (&g)[2]) {
   const fz_f32x2 nax2 = -ax * ax;
   const fz_f32x2 E = {__expf(nax2[0]), __expf(nax2[1])};
   const fz_f32x2 r = 1.0f - poly * E;
-  const fz_f32x2 rs = {xs[0] < 0.f ? -r[0] : r[0], xs[1] < 0.f ? -r[1] : r[1]};
+  const fz_f32x2 rs = {__builtin_copysignf(r[0], xs[0]), __builtin_copysignf(r[1], xs[1])};   // one v_bfi_b32 each (r >= -1 ulp)
   const fz_f32x2 gv = (xv * 0.5f) * (rs + 1.0f);
   g[0] = gv[0]; g[1] = gv[1];
 }
