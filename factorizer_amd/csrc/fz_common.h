@@ -219,6 +219,46 @@ __device__ __forceinline__ float wave_group_sum(float v) {
   const fz_u32x2 b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
+// ---- the same reductions over the 32 lanes of each wave HALF (two independent problems per wave: nmf_pcf.hip) ----
+// total of v over the lane's half (rows 0-1 resp. 2-3 of the DPP network), in every lane of that half
+__device__ __forceinline__ float half_sum_all(float v) {
+  v += dpp_take<0xB1, 0xf>(v);   // xor 1
+  v += dpp_take<0x4E, 0xf>(v);   // xor 2
+  v += dpp_take<0x141, 0xf>(v);  // row_half_mirror
+  v += dpp_take<0x140, 0xf>(v);  // row_mirror -> 16-lane row totals
+  const fz_u32x2 a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(a[0]) + __uint_as_float(a[1]);   // row + its neighbour (lane ^ 16)
+}
+// EIGHT half totals at once, left distributed: every lane of the 4-lane group i = (lane >> 2) & 7 of a half holds total i
+// of THAT half.  Multi-value butterfly as in wave_sum8_dist, one stage shorter:
+//   distance 16: v_permlane16_swap (v[k] | v[k+4]) -> 4 registers; distance 8: select + row_ror:8 -> 2; distance 4:
+//   select + row_half_mirror (lane i <-> 7 - i of its 8-lane group: the partner is always in the other quad) -> 1;
+//   distances 1, 2: quad_perm.  19 vector operations for the sixteen sums of a wave.
+__device__ __forceinline__ float half_sum8_dist(const float (&v)[8], int lane) {
+  float y[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const fz_u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[k]), __float_as_uint(v[k + 4]), false, false);
+    y[k] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  const bool hi8 = (lane & 8) != 0;
+  float z[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const float keep = hi8 ? y[k + 2] : y[k], give = hi8 ? y[k] : y[k + 2];
+    z[k] = keep + dpp_take<0x128, 0xf>(give);   // row_ror:8
+  }
+  const bool hi4 = (lane & 4) != 0;
+  const float keep = hi4 ? z[1] : z[0], give = hi4 ? z[0] : z[1];
+  float w = keep + dpp_take<0x141, 0xf>(give);  // row_half_mirror
+  w += dpp_take<0xB1, 0xf>(w);                  // quad_perm [1,0,3,2]
+  w += dpp_take<0x4E, 0xf>(w);                  // quad_perm [2,3,0,1]
+  return w;
+}
+// the value lane `src` (0..31) of the lane's own half holds, in every lane (LDS crossbar, no LDS memory)
+__device__ __forceinline__ float half_take(float d, int lane, int src) {
+  return __int_as_float(__builtin_amdgcn_ds_bpermute(((lane & 32) + src) << 2, __float_as_int(d)));
+}
 __device__ __forceinline__ void wave_sum8(float (&v)[8], int lane) {
   float y[4];
 #pragma unroll

@@ -67,7 +67,7 @@ struct PcfWave {
 };
 
 // plane base of the wave's (sample, head) and the in-plane element offset of each of the lane's columns
-template <int NPL>
+template <int NPL, int LW = 64>   // LW: lanes per matrix (64, or 32 for the two-matrices-per-wave kernel: `lane` is then lane & 31)
 __device__ __forceinline__ void pcf_decode(const PcfGeom& q, int64_t mat, int lane, int64_t& base, int64_t& V,
                                            int (&voff)[NPL], bool (&ok)[NPL]) {
   unsigned t = (unsigned)mat;  // the host rejects > 2^31 matrices
@@ -80,7 +80,7 @@ __device__ __forceinline__ void pcf_decode(const PcfGeom& q, int64_t mat, int la
   base = ((int64_t)b * q.C + (int64_t)hh * 8) * V;
 #pragma unroll
   for (int j = 0; j < NPL; ++j) {
-    const int n = j * 64 + lane;
+    const int n = j * LW + lane;
     ok[j] = n < q.P;
     const int nn = ok[j] ? n : 0;
     const int c2 = nn % q.p2, c1 = (nn / q.p2) % q.p1, c0 = nn / (q.p2 * q.p1);
@@ -126,6 +126,88 @@ __global__ __launch_bounds__(256) void nmf_pcf_fwd_kernel(const AT* __restrict__
 #pragma unroll
     for (int j = 0; j < NPL; ++j) {
       if (!ok[j]) continue;
+      AT* p = out + base + m * V + voff[j];
+      float o = q.accumulate ? aget(p) + x[m][j] : 0.0f + x[m][j];
+      if (q.divisor > 1) o = pow2 ? o * inv : o / dv;
+      aput(p, o);
+    }
+}
+
+// ---- TWO matrices per wave (forward) ------------------------------------------------------------------------
+// 150 columns (patch (5,6,5), BASELINE configs[4]) on 64 lanes are three passes at 78 % lane use; on the 32 lanes of a wave
+// HALF they are five at 94 %, and everything the wave program does per ROW — the eight-row reductions, the U half-step on
+// distributed rows, the Gram matrix — serves the two matrices of the wave in one instruction stream.  Policy of nmf_core.h
+// with every "uniform" value uniform per half: reductions over 32 lanes (fz_common.h half_*), factor row m of a half in
+// its 4-lane group m, row values fetched through the LDS crossbar (ds_bpermute) instead of v_readlane.
+template <int NPL>
+struct PcfHalf {
+  using F = float;
+  int lane, nreal;
+  __device__ __forceinline__ int l32() const { return lane & 31; }
+  __device__ __forceinline__ int grp() const { return (lane >> 2) & 7; }
+  __device__ __forceinline__ int col(int j) const { return j * 32 + l32(); }
+  __device__ __forceinline__ float sum(float v) const { return half_sum_all(v); }
+  __device__ __forceinline__ void sum8(float (&v)[8]) const {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = half_sum_all(v[i]);
+  }
+  // (history accessors: the caller carves one history per HALF; only the backward uses them)
+  __device__ __forceinline__ void st_priv(float* base, int idx, float v) const { base[idx * 32 + l32()] = v; }
+  __device__ __forceinline__ float ld_priv(const float* base, int idx) const { return base[idx * 32 + l32()]; }
+  __device__ __forceinline__ void st_uni(float* base, int idx, float v) const {
+    if (l32() == 0) base[idx] = v;
+  }
+  __device__ __forceinline__ float ld_uni(const float* base, int idx) const { return base[idx]; }
+  __device__ __forceinline__ float ld_uni_global(const float* p, int idx) const { return p[idx]; }
+  __device__ __forceinline__ float ld_v0(const float* v0, int j, int r, int R) const {
+    const int n = col(j);
+    return n < nreal ? v0[n * R + r] : 0.f;
+  }
+  __device__ __forceinline__ float keep_col(int j, float v) const { return col(j) < nreal ? v : 0.f; }
+  __device__ __forceinline__ void fence() const { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+  static constexpr bool kDistRows = true;
+  __device__ __forceinline__ float sum8_dist(const float (&v)[8]) const { return half_sum8_dist(v, lane); }
+  __device__ __forceinline__ float grp_take(float d, int m) const { return half_take(d, lane, 4 * m); }
+  __device__ __forceinline__ bool grp_below(int n) const { return grp() < n; }
+  __device__ __forceinline__ void st_grp(float* base, int i0, int stride, float d) const {
+    if ((lane & 3) == 0) base[i0 + grp() * stride] = d;
+  }
+  __device__ __forceinline__ float ld_grp_global(const float* p, int i0, int stride) const { return p[i0 + grp() * stride]; }
+  __device__ __forceinline__ float ld_grp(const float* base, int i0, int stride) const { return base[i0 + grp() * stride]; }
+  __device__ __forceinline__ float grp_sum(float d) const {   // total over the eight 4-lane groups of a group-constant value
+    d += dpp_take<0x141, 0xf>(d);                 // the other quad of the 8-lane group
+    d += dpp_take<0x128, 0xf>(d);                 // row_ror:8
+    const fz_u32x2 a = __builtin_amdgcn_permlane16_swap(__float_as_uint(d), __float_as_uint(d), false, false);
+    return __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  }
+};
+
+template <int NPL, int R, int SOLVER, typename AT>
+__global__ __launch_bounds__(256) void nmf_pcf_fwd2_kernel(const AT* __restrict__ t, const float* __restrict__ u0,
+                                                           const float* __restrict__ v0, AT* __restrict__ out, PcfGeom q,
+                                                           int64_t nmat, int T, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t pair = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (2 * pair >= nmat) return;
+  int64_t mat = 2 * pair + (lane >> 5);
+  const bool live = mat < nmat;          // an odd last matrix leaves the upper half idle: it repeats the lower half's work
+  if (!live) mat = nmat - 1;             // (the exchanges of the wave program need all 64 lanes) and stores nothing
+  PcfHalf<NPL> w{lane, q.P};
+  int64_t base, V;
+  int voff[NPL];
+  bool ok[NPL];
+  pcf_decode<NPL, 32>(q, mat, lane & 31, base, V, voff, ok);
+  float x[8][NPL], u[8][R], v[NPL][R];
+  pcf_load<NPL>(t, base, V, voff, ok, x);
+  nmf_forward_wave<8, NPL, R, SOLVER>(w, u0, v0, x, u, v, 8, T, eps);
+  const float dv = (float)q.divisor;
+  const bool pow2 = (__float_as_uint(dv) & 0x007fffffu) == 0u;
+  const float inv = 1.0f / dv;
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      if (!ok[j] || !live) continue;
       AT* p = out + base + m * V + voff[j];
       float o = q.accumulate ? aget(p) + x[m][j] : 0.0f + x[m][j];
       if (q.divisor > 1) o = pow2 ? o * inv : o / dv;
@@ -227,6 +309,17 @@ static int pcf_fwd_launch(const AT* t, const float* u0, const float* v0, AT* out
   const int64_t nmat = (int64_t)q.B * q.h * q.G0 * q.G1 * q.G2;
   if (nmat >= (int64_t)1 << 31) return fail(FZ_E_UNSUPPORTED, "fz_nmf_pcf: more than 2^31 matrices");
   dim3 grid((unsigned)((nmat + 3) / 4)), block(256);
+  // 129..160 voxels per patch: two matrices per wave, five columns per lane (FZ_PCF_HALF=0: the one-matrix form, diagnostics)
+  static const bool half_on = !(FZ_ENV_KNOB("FZ_PCF_HALF").set && FZ_ENV_KNOB("FZ_PCF_HALF").val == 0);
+  if (half_on && q.P > 128 && q.P <= 160) {
+    dim3 grid2((unsigned)(((nmat + 1) / 2 + 3) / 4));
+#define FZ_PCF_FWD2(RR, SS) hipLaunchKernelGGL((nmf_pcf_fwd2_kernel<5, RR, SS, AT>), grid2, block, 0, st, t, u0, v0, out, q, nmat, T, eps)
+    if (R == 1) { if (solver == FZ_SOLVER_MU) FZ_PCF_FWD2(1, SOLVER_MU); else FZ_PCF_FWD2(1, SOLVER_HALS); }
+    else { if (solver == FZ_SOLVER_MU) FZ_PCF_FWD2(2, SOLVER_MU); else FZ_PCF_FWD2(2, SOLVER_HALS); }
+#undef FZ_PCF_FWD2
+    FZ_LAUNCH_CHECK();
+    return FZ_OK;
+  }
 #define FZ_PCF_FWD(NN, RR, SS) hipLaunchKernelGGL((nmf_pcf_fwd_kernel<NN, RR, SS, AT>), grid, block, 0, st, t, u0, v0, out, q, nmat, T, eps)
 #define FZ_PCF_FWD_RS(NN)                                                                                    \
   do {                                                                                                       \

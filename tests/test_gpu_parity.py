@@ -433,6 +433,38 @@ def test_fact_core_any_patch_vs_modular(S, patch, shifts, solver, R):
     assert torch.allclose(g3, g1 * (t > 0), rtol=0, atol=0)
 
 
+@pytest.mark.parametrize("solver,R", [("hals", 1), ("mu", 2), ("hals", 2)])
+@pytest.mark.parametrize("S,B,C", [((15, 6, 5), 1, 8), ((5, 18, 25), 1, 8), ((10, 12, 10), 3, 24)])
+def test_fact_core_two_matrices_per_wave(S, B, C, solver, R):
+    """The 8 x 150 forward of nmf_pcf.hip runs TWO matrices per wave (32 lanes x 5 columns each; BASELINE configs[4], patch
+    (5, 6, 5)).  Matrix counts 3 and 15 (odd: the last wave's upper half is idle and must store nothing) and 72, two windows,
+    against the modular chain SWMatricize -> NMF -> inverse AND against the CPU oracle's NMF on the device-matricized input."""
+    from factorizer_amd import functional as Fn
+    torch.manual_seed(29)
+    m = ft.SWMatricize((None, C, *S), head_dim=8, patch_size=(5, 6, 5), shifts=[None, (2, 3, 1)])
+    geo = m.geometry
+    assert geo.P == 150
+    nmf = ft.NMF(size=(8, geo.P), rank=R, num_iters=6, num_grad_steps=2, init="uniform", solver=solver).to(DEV)
+    t = torch.rand(B, C, *S, device=DEV)
+    t1 = t.clone().requires_grad_(True)
+    t2 = t.clone().requires_grad_(True)
+    sentinel = torch.full((4096,), 7.0, device=DEV)        # allocated right behind: a stray store of the idle half would show
+    with Launches():
+        a1 = Fn.FactCoreFn.apply(t1, nmf.init.u0, nmf.init.v0, geo, 6, 2, solver, 1e-16, False)
+    a2 = m.inverse_forward(nmf(m(t2)))
+    P.close("a two-per-wave vs modular", a1, a2, rel=1e-5)
+    assert torch.equal(sentinel, torch.full_like(sentinel, 7.0))
+    xm = m(t).cpu()                                          # (W·B·heads·patches, 8, 150)
+    yo = O.nmf_forward(xm, nmf.init.u0.cpu(), nmf.init.v0.cpu(), 6, solver, None)
+    P.close("a two-per-wave vs oracle", a1, m.inverse_forward(yo.to(DEV)), rel=1e-4)
+    ga = torch.rand_like(a1)
+    (g1,) = torch.autograd.grad(a1, t1, ga)
+    (g2,) = torch.autograd.grad(a2, t2, ga)
+    P.close("gt two-per-wave vs modular", g1, g2)
+    b1 = Fn.FactCoreFn.apply(t.clone(), nmf.init.u0, nmf.init.v0, geo, 6, 2, solver, 1e-16, False)
+    assert torch.equal(a1, b1)                               # replay
+
+
 # ---------------------------------------------------------------- other BASELINE / §8f configs ------
 def _block_vs_oracle(C, S, reshape_kw, nmf_kw, mlp_ratio=2, B=1, tol=1e-4, why=None):
     torch.manual_seed(0)
