@@ -103,6 +103,30 @@ __device__ __forceinline__ void pcf_load(const AT* __restrict__ t, int64_t base,
     }
 }
 
+// window w > 0 adds to what the earlier windows left: the old values of FOUR rows are requested together, then added and
+// stored (a load per store, in program order, is a chain of 8·NPL dependent round trips per lane — the compiler may not move
+// a load above a store it cannot prove disjoint — and cost the shifted windows up to 25 % of their launch)
+template <int NPL, typename AT, class Fin>
+__device__ __forceinline__ void pcf_rmw_store(AT* __restrict__ dst, int64_t base, int64_t V, const int (&voff)[NPL],
+                                              const bool (&ok)[NPL], bool live, bool accumulate, float (&val)[8][NPL], Fin finish) {
+#pragma unroll
+  for (int m0 = 0; m0 < 8; m0 += 4) {
+    float old[4][NPL];
+#pragma unroll
+    for (int mm = 0; mm < 4; ++mm)
+#pragma unroll
+      for (int j = 0; j < NPL; ++j)
+        old[mm][j] = (accumulate && ok[j] && live) ? aget(dst + base + (m0 + mm) * V + voff[j]) : 0.0f;
+#pragma unroll
+    for (int mm = 0; mm < 4; ++mm)
+#pragma unroll
+      for (int j = 0; j < NPL; ++j) {
+        if (!ok[j] || !live) continue;
+        aput(dst + base + (m0 + mm) * V + voff[j], finish(old[mm][j] + val[m0 + mm][j]));
+      }
+  }
+}
+
 template <int NPL, int R, int SOLVER, typename AT>
 __global__ __launch_bounds__(256) void nmf_pcf_fwd_kernel(const AT* __restrict__ t, const float* __restrict__ u0,
                                                           const float* __restrict__ v0, AT* __restrict__ out, PcfGeom q,
@@ -121,16 +145,8 @@ __global__ __launch_bounds__(256) void nmf_pcf_fwd_kernel(const AT* __restrict__
   const float dv = (float)q.divisor;
   const bool pow2 = (__float_as_uint(dv) & 0x007fffffu) == 0u;   // 2 or 4 windows: exact scaling, no IEEE division
   const float inv = 1.0f / dv;
-#pragma unroll
-  for (int m = 0; m < 8; ++m)
-#pragma unroll
-    for (int j = 0; j < NPL; ++j) {
-      if (!ok[j]) continue;
-      AT* p = out + base + m * V + voff[j];
-      float o = q.accumulate ? aget(p) + x[m][j] : 0.0f + x[m][j];
-      if (q.divisor > 1) o = pow2 ? o * inv : o / dv;
-      aput(p, o);
-    }
+  pcf_rmw_store<NPL>(out, base, V, voff, ok, true, q.accumulate != 0, x,
+                     [&](float o) { return q.divisor > 1 ? (pow2 ? o * inv : o / dv) : o; });
 }
 
 // ---- TWO matrices per wave (forward) ------------------------------------------------------------------------
@@ -203,16 +219,8 @@ __global__ __launch_bounds__(256) void nmf_pcf_fwd2_kernel(const AT* __restrict_
   const float dv = (float)q.divisor;
   const bool pow2 = (__float_as_uint(dv) & 0x007fffffu) == 0u;
   const float inv = 1.0f / dv;
-#pragma unroll
-  for (int m = 0; m < 8; ++m)
-#pragma unroll
-    for (int j = 0; j < NPL; ++j) {
-      if (!ok[j] || !live) continue;
-      AT* p = out + base + m * V + voff[j];
-      float o = q.accumulate ? aget(p) + x[m][j] : 0.0f + x[m][j];
-      if (q.divisor > 1) o = pow2 ? o * inv : o / dv;
-      aput(p, o);
-    }
+  pcf_rmw_store<NPL>(out, base, V, voff, ok, live, q.accumulate != 0, x,
+                     [&](float o) { return q.divisor > 1 ? (pow2 ? o * inv : o / dv) : o; });
 }
 
 // backward: gY = gather_w(ga) / W ; gt (+)= [t > 0] ∘ scatter_w(gX)
@@ -269,13 +277,68 @@ __global__ __launch_bounds__(256, (pcf_bwd_waves_per_simd<NPL, R, SOLVER>())) vo
 #pragma unroll
   for (int m = 0; m < 8; ++m)
 #pragma unroll
-    for (int j = 0; j < NPL; ++j) {
-      if (!ok[j]) continue;
-      AT* p = gt + base + m * V + voff[j];
-      float r = (!relu_gate || x[m][j] > 0.f) ? g[m][j] : 0.f;
-      if (q.accumulate) r += aget(p);
-      aput(p, r);
-    }
+    for (int j = 0; j < NPL; ++j) g[m][j] = (!relu_gate || x[m][j] > 0.f) ? g[m][j] : 0.f;
+  pcf_rmw_store<NPL>(gt, base, V, voff, ok, true, q.accumulate != 0, g, [](float r) { return r; });
+}
+
+// backward, two matrices per wave: one history per HALF (lane-private part 32 lanes wide)
+static inline int pcf_half_hist_floats(int NPL, int R, int G) {
+  return (G + 1) * R * NPL * 32 + (G + 1) * 8 * R + G * (8 * R + R * R);
+}
+template <int NPL, int R, int SOLVER, typename AT>
+__global__ __launch_bounds__(256, 2) void nmf_pcf_bwd2_kernel(const AT* __restrict__ t, const float* __restrict__ u0,
+                                                                const float* __restrict__ v0, const AT* __restrict__ ga,
+                                                                AT* __restrict__ gt, PcfGeom q, int64_t nmat, int T, int G,
+                                                                float eps, int relu_gate) {
+  extern __shared__ __attribute__((aligned(16))) float fz_lds_pcf2[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t pair = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+  if (2 * pair >= nmat) return;
+  int64_t mat = 2 * pair + (lane >> 5);
+  const bool live = mat < nmat;
+  if (!live) mat = nmat - 1;
+  PcfHalf<NPL> w{lane, q.P};
+  Hist<8, NPL, R> h;
+  {
+    const int per_half = (G + 1) * R * NPL * 32 + (G + 1) * 8 * R + G * (8 * R + R * R);
+    float* base = fz_lds_pcf2 + (wave * 2 + (lane >> 5)) * per_half;
+    h.vh = base;
+    h.uh = h.vh + (G + 1) * R * NPL * 32;
+    h.ah = h.uh + (G + 1) * 8 * R;
+    h.bh = h.ah + G * 8 * R;
+  }
+  float x[8][NPL], g[8][NPL];
+  {
+    int64_t base, V;
+    int voff[NPL];
+    bool ok[NPL];
+    pcf_decode<NPL, 32>(q, mat, lane & 31, base, V, voff, ok);
+    pcf_load<NPL>(t, base, V, voff, ok, x);
+    pcf_load<NPL>(ga, base, V, voff, ok, g);
+  }
+  if (q.gscale_div != 1.0f) {
+    const float dv = q.gscale_div;
+    const bool pow2 = (__float_as_uint(dv) & 0x007fffffu) == 0u;
+    const float inv = 1.0f / dv;
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+      for (int j = 0; j < NPL; ++j) g[m][j] = pow2 ? g[m][j] * inv : g[m][j] / dv;
+  }
+  nmf_backward_wave<8, NPL, R, SOLVER>(w, u0, v0, x, g, h, 8, T, G, eps, nullptr, nullptr);
+  int64_t base, V;
+  int voff[NPL];
+  bool ok[NPL];
+  {
+    int64_t mat2 = mat;
+    asm volatile("" : "+v"(mat2));   // as in nmf_pcf_bwd_kernel: the decode is repeated, not carried across the wave program
+    pcf_decode<NPL, 32>(q, mat2, lane & 31, base, V, voff, ok);
+  }
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) g[m][j] = (!relu_gate || x[m][j] > 0.f) ? g[m][j] : 0.f;
+  pcf_rmw_store<NPL>(gt, base, V, voff, ok, live, q.accumulate != 0, g, [](float r) { return r; });
 }
 
 static int pcf_geom(PcfGeom& q, int B, int C, int D, int H, int W, int pd, int ph, int pw, const int* shift, int accumulate,
@@ -341,6 +404,28 @@ static int pcf_bwd_launch(const AT* t, const float* u0, const float* v0, const A
                           int G, int solver, float eps, int relu_gate, hipStream_t st) {
   const int64_t nmat = (int64_t)q.B * q.h * q.G0 * q.G1 * q.G2;
   if (nmat >= (int64_t)1 << 31) return fail(FZ_E_UNSUPPORTED, "fz_nmf_pcf: more than 2^31 matrices");
+  static const bool half_on = !(FZ_ENV_KNOB("FZ_PCF_HALF").set && FZ_ENV_KNOB("FZ_PCF_HALF").val == 0);
+  // (windows w > 0 — read-modify-write of the running gradient — keep the one-matrix form: at the two-matrix form's 5 waves per
+  // CU the extra scattered read costs more than the form saves, 9.5 against 8.9 ms at the cfg-5 stage-0 launch; window 0: 6.3 / 7.1)
+  if (half_on && !q.accumulate && q.P > 128 && q.P <= 160 && 2 * pcf_half_hist_floats(5, R, G) * (int)sizeof(float) <= 160 * 1024) {
+    const int per_wave2 = 2 * pcf_half_hist_floats(5, R, G) * (int)sizeof(float);
+    const int wpb2 = fz_hist_waves_per_block(per_wave2);
+    const int lds2 = per_wave2 * wpb2;
+    const int64_t npair = (nmat + 1) / 2;
+    dim3 grid2((unsigned)((npair + wpb2 - 1) / wpb2)), block2(64 * wpb2);
+#define FZ_PCF_BWD2(RR, SS)                                                                                   \
+  do {                                                                                                        \
+    auto kern = nmf_pcf_bwd2_kernel<5, RR, SS, AT>;                                                            \
+    if (lds2 > 65536)                                                                                         \
+      FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds2)); \
+    hipLaunchKernelGGL(kern, grid2, block2, lds2, st, t, u0, v0, ga, gt, q, nmat, T, G, eps, relu_gate);      \
+  } while (0)
+    if (R == 1) { if (solver == FZ_SOLVER_MU) FZ_PCF_BWD2(1, SOLVER_MU); else FZ_PCF_BWD2(1, SOLVER_HALS); }
+    else { if (solver == FZ_SOLVER_MU) FZ_PCF_BWD2(2, SOLVER_MU); else FZ_PCF_BWD2(2, SOLVER_HALS); }
+#undef FZ_PCF_BWD2
+    FZ_LAUNCH_CHECK();
+    return FZ_OK;
+  }
   const int per_wave = pcf_per_wave(q.P, R, G);
   if (per_wave > 160 * 1024) return fail(FZ_E_UNSUPPORTED, "fz_nmf_pcf_bwd: history exceeds LDS");
   int wpb = fz_hist_waves_per_block(per_wave);

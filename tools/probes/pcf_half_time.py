@@ -25,5 +25,17 @@ for dt, ad in ((torch.float32, N.STORE_F32), (torch.bfloat16, N.STORE_BF16)):
     e0.record()
     for _ in range(10): run()
     e1.record(); torch.cuda.synchronize()
-    res[str(dt)] = {"ms": round(e0.elapsed_time(e1) / 10, 4), "checksum": float(out.float().double().sum())}
+    fwd_ms = e0.elapsed_time(e1) / 10
+    ga = torch.rand(B, C, *S, device=dev).to(dt)
+    gt = torch.empty_like(t)
+    def runb():
+        N.check(N.lib().fz_nmf_pcf_bwd(t.data_ptr(), u0.data_ptr(), v0.data_ptr(), ga.data_ptr(), gt.data_ptr(), B, C, *S, *P, arr, 0, 1, 1,
+                                       R, T, T, N.SOLVER_ID["hals"], 1e-8, ad, N.stream_ptr(t)), "pcf bwd")
+    for _ in range(2): runb()
+    e0.record()
+    for _ in range(5): runb()
+    e1.record(); torch.cuda.synchronize()
+    res[str(dt)] = {"fwd_ms": round(fwd_ms, 4), "bwd_ms": round(e0.elapsed_time(e1) / 5, 4), "checksum": float(out.float().double().sum()),
+                    "checksum_bwd": float(gt.float().double().sum())}
+    del ga, gt
 print(json.dumps({"FZ_PCF_HALF": os.environ.get("FZ_PCF_HALF", "default(1)"), "B": B, **res}))
