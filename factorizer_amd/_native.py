@@ -177,6 +177,8 @@ _SIGS.update({
     "fz_nmf_pcf_supported": ([_i] * 11, _i),
     "fz_nmf_pcf_fwd": ([_vp] * 4 + [_i] * 8 + [_c.POINTER(_i)] + [_i] * 5 + [_f, _i, _vp], _i),
     "fz_nmf_pcf_bwd": ([_vp] * 5 + [_i] * 8 + [_c.POINTER(_i)] + [_i] * 7 + [_f, _i, _vp], _i),
+    "fz_nmf_pcf_bwd_prefers_separate": ([_i] * 4, _i),
+    "fz_act_add": ([_vp, _vp, _i64, _i, _vp], _i),
     "fz_gemm": ([_c.POINTER(GemmDesc), _vp], _i),
     "fz_gemm_bx_enable": ([_i], _i),
     "fz_gemm_lnbwd_partials": ([_c.POINTER(GemmDesc)], _i64),

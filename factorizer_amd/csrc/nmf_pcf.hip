@@ -454,6 +454,26 @@ static int pcf_bwd_launch(const AT* t, const float* u0, const float* v0, const A
   return FZ_OK;
 }
 
+// dst += src, elementwise on activations (16 bytes per lane and step; the sum is formed in fp32 and stored once).  Used where a
+// window w > 0 of the generic-patch backward is cheaper into its own buffer than as a scattered read-modify-write (below).
+template <typename AT>
+__global__ __launch_bounds__(256) void act_add_kernel(AT* __restrict__ dst, const AT* __restrict__ src, int64_t n) {
+  constexpr int VEC = 16 / (int)sizeof(AT);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * VEC;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC; i < n; i += stride) {
+    if (i + VEC <= n) {
+      float a[VEC], b[VEC];
+      aload<VEC>(dst + i, a);
+      aload<VEC>(src + i, b);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) a[e] += b[e];
+      astore<VEC>(dst + i, a);
+    } else {
+      for (int64_t e = i; e < n; ++e) aput(dst + e, aget(dst + e) + aget(src + e));
+    }
+  }
+}
+
 }  // namespace fz
 
 using namespace fz;
@@ -500,4 +520,31 @@ extern "C" int fz_nmf_pcf_bwd(const void* t, const float* u0, const float* v0, c
   if (act_dtype == FZ_STORE_BF16)
     return pcf_bwd_launch<bf16>((const bf16*)t, u0, v0, (const bf16*)ga, (bf16*)gt, q, R, T, G, solver, eps, relu_gate, st);
   return fail(FZ_E_ARG, "fz_nmf_pcf_bwd: bad act_dtype");
+}
+
+/* 1 when a window w > 0 of the backward is faster written to its OWN buffer (accumulate = 0) and added with fz_act_add than
+ * as the read-modify-write of accumulate = 1: the two-matrices-per-wave shapes (129..160 voxels per patch) in bf16 storage
+ * (cfg-5 step, B = 4: 100.3 -> 96.2 ms; fp32 storage, where the add moves twice the bytes: 116.9 -> 120.9, so not there). */
+extern "C" int fz_nmf_pcf_bwd_prefers_separate(int pd, int ph, int pw, int act_dtype) {
+  static const bool half_on = !(FZ_ENV_KNOB("FZ_PCF_HALF").set && FZ_ENV_KNOB("FZ_PCF_HALF").val == 0);
+  static const bool sep_on = !(FZ_ENV_KNOB("FZ_PCF_SEPARATE").set && FZ_ENV_KNOB("FZ_PCF_SEPARATE").val == 0);
+  const int64_t P = (int64_t)pd * ph * pw;
+  return (half_on && sep_on && act_dtype == FZ_STORE_BF16 && P > 128 && P <= 160) ? 1 : 0;
+}
+
+extern "C" int fz_act_add(void* dst, const void* src, int64_t n, int act_dtype, fz_stream_t stream) {
+  if (!dst || !src) return fail(FZ_E_ARG, "fz_act_add: null pointer");
+  if (n < 0) return fail(FZ_E_ARG, "fz_act_add: negative length");
+  if (n == 0) return FZ_OK;
+  if ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) return fail(FZ_E_ARG, "fz_act_add: 16-byte alignment");
+  hipStream_t st = (hipStream_t)stream;
+  const int vec = act_dtype == FZ_STORE_F32 ? 4 : 8;
+  int64_t nb = (n / vec + 255) / 256;
+  if (nb < 1) nb = 1;
+  if (nb > 256 * 8) nb = 256 * 8;
+  if (act_dtype == FZ_STORE_F32) hipLaunchKernelGGL(act_add_kernel<float>, dim3((unsigned)nb), dim3(256), 0, st, (float*)dst, (const float*)src, n);
+  else if (act_dtype == FZ_STORE_BF16) hipLaunchKernelGGL(act_add_kernel<bf16>, dim3((unsigned)nb), dim3(256), 0, st, (bf16*)dst, (const bf16*)src, n);
+  else return fail(FZ_E_ARG, "fz_act_add: bad act_dtype");
+  FZ_LAUNCH_CHECK();
+  return FZ_OK;
 }

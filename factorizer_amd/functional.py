@@ -483,6 +483,18 @@ class FactCoreFn(torch.autograd.Function):
                         t.data_ptr(), u0.data_ptr(), v0.data_ptr(), ga.data_ptr(), gt.data_ptr(), B, geo.C,
                         *geo.spatial, arr, int(w > 0), geo.nshift, int(relu_gate), R, T, G, N.SOLVER_ID[solver], eps,
                         ad, N.stream_ptr(t)))
+                elif w > 0 and N.lib().fz_nmf_pcf_bwd_prefers_separate(*geo.patch, ad):
+                    # the window's gradient into its own buffer, then one coalesced add (include/factorizer_hip.h)
+                    tmp = torch.empty_like(gt)
+                    rc = _timed(f"nmf_pcf_bwd_{geo.C}x" + "x".join(str(v) for v in geo.spatial), nb, cols=t.numel() // geo.C, fn=lambda: N.lib().fz_nmf_pcf_bwd(
+                        t.data_ptr(), u0.data_ptr(), v0.data_ptr(), ga.data_ptr(), tmp.data_ptr(), B, geo.C,
+                        *geo.spatial, *geo.patch, arr, 0, geo.nshift, int(relu_gate), R, T, G, N.SOLVER_ID[solver], eps,
+                        ad, N.stream_ptr(t)))
+                    N.check(rc, "fz_nmf_pcf_bwd")
+                    rc = _timed(f"window_add_{geo.C}x" + "x".join(str(v) for v in geo.spatial), nb, cols=t.numel() // geo.C, fn=lambda: N.lib().fz_act_add(
+                        gt.data_ptr(), tmp.data_ptr(), gt.numel(), ad, N.stream_ptr(t)))
+                    N.check(rc, "fz_act_add")
+                    del tmp
                 else:
                     rc = _timed(f"nmf_pcf_bwd_{geo.C}x" + "x".join(str(v) for v in geo.spatial), nb + (es * t.numel() if w else 0), cols=t.numel() // geo.C, fn=lambda: N.lib().fz_nmf_pcf_bwd(
                         t.data_ptr(), u0.data_ptr(), v0.data_ptr(), ga.data_ptr(), gt.data_ptr(), B, geo.C,

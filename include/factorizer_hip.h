@@ -176,6 +176,13 @@ int fz_nmf_pcf_fwd(const void* t, const float* u0, const float* v0, void* out, i
 int fz_nmf_pcf_bwd(const void* t, const float* u0, const float* v0, const void* ga, void* gt, int B, int C, int D,
                    int H, int W, int pd, int ph, int pw, const int* shift, int accumulate, int nshift, int relu_gate,
                    int R, int T, int Tgrad, int solver, float eps, int act_dtype, fz_stream_t stream);
+/* Windows w > 0 of the generic-patch backward: accumulate = 1 is a scattered read-modify-write of gt.  Where
+ * fz_nmf_pcf_bwd_prefers_separate() returns 1 (129..160 voxels per patch, bf16 storage: measured) it is cheaper to
+ * give the window its own buffer (accumulate = 0) and add it with fz_act_add (dst += src, n elements of act_dtype, both
+ * 16-byte aligned) — what the reference's modular chain does anyway: every window's inverse_forward term is a tensor of its
+ * own before the sum (factorizer/layers/reshape/operations.py:423-434, autograd of it). */
+int fz_nmf_pcf_bwd_prefers_separate(int pd, int ph, int pw, int act_dtype);
+int fz_act_add(void* dst, const void* src, int64_t n, int act_dtype, fz_stream_t stream);
 
 /* ---- channels-first GEMM family (1x1 layers, k2s2 conv / transposed conv, input grads) ----
  * Out[m, n] = epilogue( sum_k A[m,k] * prologue(In)[k,n] ), n = voxel.  One descriptor drives

@@ -465,6 +465,39 @@ def test_fact_core_two_matrices_per_wave(S, B, C, solver, R):
     assert torch.equal(a1, b1)                               # replay
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_act_add_and_separate_window_backward(dt):
+    """fz_act_add (dst += src, 16 bytes per lane, ragged tail) against torch, and the backward of a two-window 8 x 150 core —
+    window 1 into its own buffer + fz_act_add where fz_nmf_pcf_bwd_prefers_separate() says so — against the modular chain."""
+    from factorizer_amd import functional as Fn
+    from factorizer_amd import _native as N
+    torch.manual_seed(5)
+    for n in (8 * 1000 + 3, 16, 5):
+        a = torch.randn(n + 8, device=DEV).to(dt)[:n]        # (a view at offset 0 of a 16-byte aligned allocation)
+        b = torch.randn(n + 8, device=DEV).to(dt)[:n]
+        ref = (a.float() + b.float()).to(dt)
+        N.check(N.lib().fz_act_add(a.data_ptr(), b.data_ptr(), n, N.act_dtype(a), N.stream_ptr(a)), "fz_act_add")
+        assert torch.equal(a, ref), n
+    bad = torch.zeros(64, device=DEV).to(dt)
+    assert N.lib().fz_act_add(bad.data_ptr() + bad.element_size(), bad.data_ptr(), 8, N.act_dtype(bad), N.stream_ptr(bad)) != 0
+    assert N.lib().fz_nmf_pcf_bwd_prefers_separate(5, 6, 5, N.STORE_BF16) == 1 and N.lib().fz_nmf_pcf_bwd_prefers_separate(4, 4, 4, N.STORE_BF16) == 0
+    assert N.lib().fz_nmf_pcf_bwd_prefers_separate(5, 6, 5, N.STORE_F32) == 0
+    S, C = (10, 12, 10), 16
+    m = ft.SWMatricize((None, C, *S), head_dim=8, patch_size=(5, 6, 5), shifts=[None, (2, 3, 1), (1, 0, 2)])
+    nmf = ft.NMF(size=(8, 150), rank=2, num_iters=5, num_grad_steps=3, init="uniform", solver="hals").to(DEV)
+    t = torch.rand(2, C, *S, device=DEV).to(dt)          # bf16: windows 1, 2 go to their own buffers; fp32: read-modify-write
+    t1, t2 = t.clone().requires_grad_(True), t.float().requires_grad_(True)
+    a1 = Fn.FactCoreFn.apply(t1, nmf.init.u0, nmf.init.v0, m.geometry, 5, 3, "hals", 1e-16, True)
+    a2 = m.inverse_forward(nmf(m(t2)))
+    ga = torch.randn_like(a2).to(dt).float()
+    (g1,) = torch.autograd.grad(a1, t1, ga.to(dt))
+    (g2,) = torch.autograd.grad(a2, t2, ga)
+    if dt == torch.float32:
+        P.close("gt three windows", g1, g2 * (t > 0))
+    else:   # three stored bf16 terms and their bf16 sums: 2^-8 of the largest element per rounding
+        P.close("gt three windows, own buffers (bf16 storage)", g1.float(), g2 * (t > 0), rel=2e-2, why="bf16 storage of the three window terms")
+
+
 # ---------------------------------------------------------------- other BASELINE / §8f configs ------
 def _block_vs_oracle(C, S, reshape_kw, nmf_kw, mlp_ratio=2, B=1, tol=1e-4, why=None):
     torch.manual_seed(0)
