@@ -26,3 +26,6 @@ tot = sum(a["ms"] for a in agg.values())
 rows = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])
 print(json.dumps({"FZ_PCF_HALF": os.environ.get("FZ_PCF_HALF", "1"), "kernel_ms_total": round(tot, 2),
                   "nmf": {k: [a["calls"], round(a["ms"], 3)] for k, a in rows if k.startswith("nmf_")}}))
+if len(sys.argv) > 2:
+    for k, a in rows[:40]:
+        print("%-44s %3d calls %8.3f ms  %7.1f GB/s" % (k, a["calls"], a["ms"], a["bytes"] / (a["ms"] * 1e-3) / 1e9 if a["ms"] > 0 else 0))
