@@ -215,24 +215,34 @@ struct CfTile {
 // HALF (W-axis shift ≡ 2 mod 4, e.g. the production windows [None, 2, 4, 6]): a 16-byte chunk of the
 // shifted run starts 8 bytes into an aligned quad of the tensor and may straddle the cyclic wrap, so
 // it moves as two 8-byte halves with separately wrapped addresses (off2 = offset of voxels +2, +3).
-template <bool HALF, typename AT>
-__device__ __forceinline__ float4 cf_ld4(const AT* p, int64_t o, int64_t o2) {
-  if (HALF) {
-    float a[2], b[2];
-    aload<2>(p + o, a);
-    aload<2>(p + o2, b);
-    return make_float4(a[0], a[1], b[0], b[1]);
-  }
-  return ld4(p + o);
+// (p is wave-uniform — a channel plane of the workgroup's (sample, head) — and o a 32-bit element offset: the access
+// compiles to `global_load_dwordx4 v, v_off, s[p:p+1]`, no 64-bit address arithmetic per lane and access)
+template <typename AT>
+__device__ __forceinline__ const AT* cf_at(const AT* p, unsigned o) {
+  return reinterpret_cast<const AT*>(reinterpret_cast<const char*>(p) + o * (unsigned)sizeof(AT));
+}
+template <typename AT>
+__device__ __forceinline__ AT* cf_at(AT* p, unsigned o) {
+  return reinterpret_cast<AT*>(reinterpret_cast<char*>(p) + o * (unsigned)sizeof(AT));
 }
 template <bool HALF, typename AT>
-__device__ __forceinline__ void cf_st4(AT* p, int64_t o, int64_t o2, float4 v) {
+__device__ __forceinline__ float4 cf_ld4(const AT* p, unsigned o, unsigned o2) {
+  if (HALF) {
+    float a[2], b[2];
+    aload<2>(cf_at(p, o), a);
+    aload<2>(cf_at(p, o2), b);
+    return make_float4(a[0], a[1], b[0], b[1]);
+  }
+  return ld4(cf_at(p, o));
+}
+template <bool HALF, typename AT>
+__device__ __forceinline__ void cf_st4(AT* p, unsigned o, unsigned o2, float4 v) {
   if (HALF) {
     const float a[2] = {v.x, v.y}, b[2] = {v.z, v.w};
-    astore<2>(p + o, a);
-    astore<2>(p + o2, b);
+    astore<2>(cf_at(p, o), a);
+    astore<2>(cf_at(p, o2), b);
   } else {
-    st4(p + o, v);
+    st4(cf_at(p, o), v);
   }
 }
 
@@ -254,7 +264,7 @@ __device__ __forceinline__ CfTileId cf_tile_id(const CfGeom& q, int64_t blk) {
 
 template <int WPB>
 __device__ __forceinline__ void cf_tile_decode(const CfGeom& q, const CfTileId& id, int tid, int64_t& base, int64_t& V,
-                                               int64_t (&off)[2], int (&lidx)[2], int64_t (&off2)[2]) {
+                                               unsigned (&off)[2], int (&lidx)[2], unsigned (&off2)[2]) {
   using TL = CfTile<WPB>;
   V = (int64_t)q.D * q.H * q.W;
   base = ((int64_t)id.b * q.C + (int64_t)id.hh * 8) * V;
@@ -265,9 +275,9 @@ __device__ __forceinline__ void cf_tile_decode(const CfGeom& q, const CfTileId& 
     int z0 = id.g0 * 8 + (row >> 3) - q.s0; if (z0 < 0) z0 += q.D;
     int z1 = id.g1 * 8 + (row & 7) - q.s1; if (z1 < 0) z1 += q.H;
     int z2 = id.gq * WPB * 8 + chunk * 4 - q.s2; if (z2 < 0) z2 += q.W;
-    off[k] = ((int64_t)z0 * q.H + z1) * q.W + z2;
+    off[k] = (unsigned)((z0 * q.H + z1) * q.W + z2);   // in-plane element offset < 2^30 (host-checked): 32 bits, so that every
     int z2b = z2 + 2; if (z2b >= q.W) z2b -= q.W;
-    off2[k] = ((int64_t)z0 * q.H + z1) * q.W + z2b;
+    off2[k] = (unsigned)((z0 * q.H + z1) * q.W + z2b); // access is `uniform plane pointer (SGPR pair) + one 32-bit lane offset`
     lidx[k] = TL::at(row, chunk);
   }
 }
@@ -371,7 +381,8 @@ __device__ __forceinline__ void cf_fwd_tile_body(const AT* __restrict__ t, const
                                                  const CfTileId& id, int T, float eps, float* S, int role, const CfSync& y, int ia, int ib) {
   using TL = CfTile<WPB>;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int64_t base, V, off[2], off2[2];
+  int64_t base, V;
+  unsigned off[2], off2[2];
   int lidx[2];
   cf_tile_decode<WPB>(q, id, tid, base, V, off, lidx, off2);
   const int own0 = cf_owner_lidx<WPB>(lane, wave, 0), own1 = cf_owner_lidx<WPB>(lane, wave, 1);
@@ -394,6 +405,9 @@ __device__ __forceinline__ void cf_fwd_tile_body(const AT* __restrict__ t, const
   // the running sum are issued at once (one exposed round trip)
   const float dv = (float)q.divisor;
   const bool dv_pow2 = cf_pow2(dv);
+  // (the plane base back in a scalar register pair: after the wave program the compiler otherwise carries it in vector
+  // registers and every epilogue access pays a 64-bit vector address)
+  asm volatile("" : "+s"(base));
   float4 old[8][2];
   if (q.accumulate) {
     if (SYNC && role == CF_CONSUME) {
@@ -505,7 +519,8 @@ __device__ __forceinline__ void cf_bwd_tile_body(const AT* __restrict__ t, const
                                                  int relu_gate, float* S, int role, const CfSync& y, int ia, int ib) {
   using TL = CfTile<WPB>;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int64_t base, V, off[2], off2[2];
+  int64_t base, V;
+  unsigned off[2], off2[2];
   int lidx[2];
   cf_tile_decode<WPB>(q, id, tid, base, V, off, lidx, off2);
   const int own0 = cf_owner_lidx<WPB>(lane, wave, 0), own1 = cf_owner_lidx<WPB>(lane, wave, 1);
@@ -540,6 +555,9 @@ __device__ __forceinline__ void cf_bwd_tile_body(const AT* __restrict__ t, const
 #pragma unroll
       for (int e = 0; e < 8; ++e) g[dd][e] = x[dd][e] > 0.f ? g[dd][e] : 0.f;
   }
+  // (the plane base back in a scalar register pair: after the wave program the compiler otherwise carries it in vector
+  // registers and every epilogue access pays a 64-bit vector address)
+  asm volatile("" : "+s"(base));
   float4 old[8][2];
   if (q.accumulate) {
     if (SYNC && role == CF_CONSUME) {
@@ -726,6 +744,7 @@ static int cf_geom(CfGeom& q, int B, int C, int D, int H, int W, const int* shif
   if (B < 0 || C < 8 || (C % 8) || D < 8 || H < 8 || W < 8 || (D % 8) || (H % 8) || (W % 8))
     return fail(FZ_E_SHAPE, "fz_nmf_cf: needs C % 8 == 0 and spatial dims multiples of 8");
   if (!shift) return fail(FZ_E_ARG, "fz_nmf_cf: shift is null");
+  if ((int64_t)D * H * W >= ((int64_t)1 << 30)) return fail(FZ_E_UNSUPPORTED, "fz_nmf_cf: 2^30 or more voxels per channel plane");   // 32-bit lane offsets
   q.B = B; q.C = C; q.D = D; q.H = H; q.W = W; q.h = C / 8; q.G0 = D / 8; q.G1 = H / 8; q.G2 = W / 8;
   int s[3];
   const int S[3] = {D, H, W};
@@ -742,7 +761,7 @@ using namespace fz;
 
 extern "C" int fz_nmf_cf_supported(int C, int D, int H, int W, int d, int pd, int ph, int pw, int R, int T, int Tgrad) {
   if (d != 8 || pd != 8 || ph != 8 || pw != 8 || (C % 8) || (D % 8) || (H % 8) || (W % 8)) return 0;
-  if (R < 1 || R > 2 || T < 0) return 0;
+  if (R < 1 || R > 2 || T < 0 || (int64_t)D * H * W >= ((int64_t)1 << 30)) return 0;
   const int G = Tgrad < 0 ? 0 : (Tgrad > T ? T : Tgrad);
   const int per_wave = ((G + 1) * R * 8 * 64 + (G + 1) * 8 * R + G * (8 * R + R * R)) * 4;
   return per_wave <= 160 * 1024 ? 1 : 0;
