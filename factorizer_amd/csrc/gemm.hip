@@ -334,6 +334,8 @@ __global__ __launch_bounds__(256, ((NSTEP <= 16 && EPI == EPI_PLAIN && !BMUL && 
 // Arithmetic as Kernel A: exact two-pass LayerNorm, K-steps in ascending order on v_mfma_f32_32x32x2_f32.
 // Host-checked: M <= 32, K == Cin == 32, plain loader and epilogue, no gate, no residual, Ncol % 4 == 0.
 // =================================================================================================
+// (The split-bf16 form of this kernel — 48 bf16 MFMAs + operand splits instead of 64 fp32 MFMAs, DESIGN §10.4a — needs ~20 registers
+// more than the 240 of two operand tiles in flight + 64 accumulators leave at two waves per SIMD: 10-16 spilled; not built in.)
 template <int PF, typename AT>
 __global__ __launch_bounds__(256, 2) void gemm_p32_kernel(GemmArgsT<AT> p, unsigned ntiles) {
   constexpr bool ACTIN = (PF & 1) != 0, LNP = (PF & 2) != 0;
@@ -503,23 +505,61 @@ __device__ __forceinline__ void chain_stagger(int stagger) {
 
 // HB = 32-row blocks of the hidden tensor: 2 (mlp_ratio 2, the README model) or 4 (mlp_ratio 4, the
 // BraTS bundle, train.yaml:62)
-template <bool BWD, int NACC, int HB, typename AT = float>
-__global__ __launch_bounds__(256, (NACC == 2 && HB == 2 && !BWD) ? 3 : 2) void gemm_chain_kernel(GemmArgsT<AT> p, ChainArgsT<AT> c, int ntiles) {
-  constexpr int HID = 32 * HB, N1 = 16 * HB * 64;  // hidden rows; floats of each staged weight block
-  __shared__ float As1[N1];
-  __shared__ float As2[N1];
+// BX: both GEMMs as split-bf16 products (gemm_bx.h: three-level operands, six products of v_mfma_f32_32x32x16_bf16), weights
+// pre-split in LDS as bf16x8 triples (12 KB per GEMM at HB = 2 instead of 8: two workgroups per CU instead of three).  Why: an fp32
+// MFMA blocks the SIMD's vector issue for its whole duration — the 128 fp32 MFMAs of a tile were 48 % of this
+// kernel's time with nothing running beside them — a bf16 MFMA for a quarter of its own.
+// (Six-wave workgroups — 73 KB, two per CU, three waves per SIMD again — were tried and are slower than these four-wave ones at two
+// waves per SIMD: 1.06 against 0.97 ms per step for the two launches, fp32 form 1.09; profiles/r04_chain_fwd_bx_ab.log.)
+template <bool BWD, int NACC, int HB, typename AT = float, bool BX = false>
+__global__ __launch_bounds__(256, (NACC == 2 && HB == 2 && !BWD && !BX) ? 3 : 2) void gemm_chain_kernel(GemmArgsT<AT> p, ChainArgsT<AT> c, int ntiles) {
+  constexpr int NW = 4;
+  constexpr int HID = 32 * HB, N1 = BX ? 1536 * HB : 16 * HB * 64;  // hidden rows; floats of each staged weight block
+  static_assert(!BX || (!BWD && NACC == 2), "the split-bf16 form is the forward chain");
+  __shared__ __attribute__((aligned(16))) float As1[N1];
+  __shared__ __attribute__((aligned(16))) float As2[N1];
   __shared__ float tW[HID];
   __shared__ float tB[32];
   __shared__ float red[256];
   // raw operand tile of each wave (32 channels x 32*NACC columns): the epilogue needs the SAME tensor
   // again in the accumulator layout (residual x1 / added gradient g2) — served from LDS instead of a
   // second global read (PMC: 1 of 5 resp. 8 plane-sets of traffic)
-  __shared__ __attribute__((aligned(16))) float stash[4][32][32 * NACC];
+  __shared__ __attribute__((aligned(16))) float stash[NW][32][32 * NACC];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, h = lane >> 5;
-  const int tiles_per_sample = (int)((p.Ncol + 128 * NACC - 1) / (128 * NACC));
+  const int tiles_per_sample = (int)((p.Ncol + 32 * NW * NACC - 1) / (32 * NW * NACC));
   chain_stagger(c.stagger);
 
+  if constexpr (BX) {
+    // operand items of 8 steps each: As1x[g (2)][rb (HB)][level][lane], As2x[g (2 HB)][level][lane]
+    for (int it = threadIdx.x; it < 4 * HB * 64; it += 64 * NW) {
+      float wv[8];
+      const int l = it & 63;
+      __bf16* dst;
+      if (it < 2 * HB * 64) {
+        const int rb = (it >> 6) % HB, g = it / (64 * HB);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int kk = 2 * (8 * g + e) + (l >> 5);
+          wv[e] = weight_at(p, rb * 32 + (l & 31), kk) * p.ln_g[kk];
+        }
+        dst = reinterpret_cast<__bf16*>(As1) + ((g * HB + rb) * 3 * 64 + l) * 8;
+      } else {
+        const int g = (it - 2 * HB * 64) >> 6;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int s2 = 8 * g + e, r = s2 & 15, rb = s2 >> 4;
+          const int kk = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), m = l & 31;
+          wv[e] = c.wB_t ? c.wB[(int64_t)kk * c.ldwB + m] : c.wB[(int64_t)m * c.ldwB + kk];
+        }
+        dst = reinterpret_cast<__bf16*>(As2) + (g * 3 * 64 + l) * 8;
+      }
+      bx8 t3[3];
+      bx_split<3>(wv, t3);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) *reinterpret_cast<bx8*>(dst + i * 64 * 8) = t3[i];
+    }
+  } else
   // weights in operand order (8 independent loads per thread before the LDS stores)
   for (int base = threadIdx.x; base < 2 * N1; base += 256 * 8) {
     float tmp[8];
@@ -565,7 +605,7 @@ __global__ __launch_bounds__(256, (NACC == 2 && HB == 2 && !BWD) ? 3 : 2) void g
   // operand loads: channel 2s + h → uniform part (b*32 + 2s)*V in scalar registers + ONE lane offset
   auto fetch_tile = [&](int t) {
     const int bt = t / tiles_per_sample;
-    const int64_t ct = ((int64_t)(t % tiles_per_sample) * 4 + wave) * (32 * NACC) + NACC * j;
+    const int64_t ct = ((int64_t)(t % tiles_per_sample) * NW + wave) * (32 * NACC) + NACC * j;
     const unsigned lo = (unsigned)h * (unsigned)p.Ncol + (unsigned)(ct < p.Ncol ? ct : 0);
     const AT* xb = p.x[0] + (int64_t)bt * 32 * p.Ncol;
 #pragma unroll
@@ -579,7 +619,7 @@ __global__ __launch_bounds__(256, (NACC == 2 && HB == 2 && !BWD) ? 3 : 2) void g
     // hoisted out of the tile loop and kept in VGPRs, which spills the accumulators
     asm volatile("" ::: "memory");
     const int b = tile / tiles_per_sample;
-    const int64_t col_off = ((int64_t)(tile % tiles_per_sample) * 4 + wave) * (32 * NACC) + NACC * j;
+    const int64_t col_off = ((int64_t)(tile % tiles_per_sample) * NW + wave) * (32 * NACC) + NACC * j;
     const bool col_ok = col_off < p.Ncol;
     const int64_t nc = col_ok ? col_off : 0;
     const unsigned lane_row = (unsigned)(4 * h) * (unsigned)p.Ncol + (unsigned)nc;
@@ -627,6 +667,28 @@ __global__ __launch_bounds__(256, (NACC == 2 && HB == 2 && !BWD) ? 3 : 2) void g
       for (int q = 0; q < NACC; ++q)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc1[rb][q][r] = 0.f;
+    if constexpr (BX) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {   // element e of lane half h = K-step 8g + e of the fp32 form (channel 2 (8g + e) + h)
+        bx8 bop[NACC][3];
+#pragma unroll
+        for (int q = 0; q < NACC; ++q) {
+          float x8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x8[e] = bv[8 * g + e][q];
+          bx_split<3>(x8, bop[q]);
+        }
+#pragma unroll
+        for (int rb = 0; rb < HB; ++rb) {
+          bx8 aop[3];
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+            aop[i] = *reinterpret_cast<const bx8*>(reinterpret_cast<const __bf16*>(As1) + (((g * HB + rb) * 3 + i) * 64 + lane) * 8);
+#pragma unroll
+          for (int q = 0; q < NACC; ++q) bx_mfma<3, 3>(acc1[rb][q], aop, bop[q]);
+        }
+      }
+    } else {
 #pragma unroll
     for (int s = 0; s < 16; ++s)
 #pragma unroll
@@ -635,6 +697,7 @@ __global__ __launch_bounds__(256, (NACC == 2 && HB == 2 && !BWD) ? 3 : 2) void g
 #pragma unroll
         for (int q = 0; q < NACC; ++q) acc1[rb][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[s][q], acc1[rb][q], 0, 0, 0);
       }
+    }
 
     // ---- prefetch the operand of the next tile (clamped re-read of this one on the last pass) ----
     fetch_tile(tile + gridDim.x < ntiles ? tile + gridDim.x : tile);
@@ -695,6 +758,24 @@ __global__ __launch_bounds__(256, (NACC == 2 && HB == 2 && !BWD) ? 3 : 2) void g
     for (int q = 0; q < NACC; ++q)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc2[q][r] = 0.f;
+    if constexpr (BX) {
+#pragma unroll
+      for (int g = 0; g < 2 * HB; ++g) {   // steps (rb, r) = (g >> 1, 8 (g & 1) + e): accumulator registers as the column operand
+        bx8 aop[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          aop[i] = *reinterpret_cast<const bx8*>(reinterpret_cast<const __bf16*>(As2) + ((g * 3 + i) * 64 + lane) * 8);
+#pragma unroll
+        for (int q = 0; q < NACC; ++q) {
+          float x8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x8[e] = acc1[g >> 1][q][8 * (g & 1) + e];
+          bx8 bop[3];
+          bx_split<3>(x8, bop);
+          bx_mfma<3, 3>(acc2[q], aop, bop);
+        }
+      }
+    } else {
 #pragma unroll
     for (int rb = 0; rb < HB; ++rb)
 #pragma unroll
@@ -703,6 +784,7 @@ __global__ __launch_bounds__(256, (NACC == 2 && HB == 2 && !BWD) ? 3 : 2) void g
 #pragma unroll
         for (int q = 0; q < NACC; ++q) acc2[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, acc1[rb][q][r], acc2[q], 0, 0, 0);
       }
+    }
 
     if (BWD) {
       lnbwd_block<NACC, true, true>(p, acc2, b, col_off, col_ok, lane, wave, red, tile, tB, &stash[wave][0][0]);
@@ -2569,6 +2651,7 @@ static int knob_chain64_p512() { static const int v = env_pos_once("FZ_CHAIN64_P
 static int knob_res_prefetch() { static const int v = env_pos_once("FZ_RES_PREFETCH", 1); return v == 1; }   // 2 = off (diagnostics)
 static int knob_p32() { static const int v = env_pos_once("FZ_GEMM_P32", 1); return v == 1; }   // 2 = off (diagnostics)
 static int knob_p32_wgs() { static const int v = env_pos_once("FZ_GEMM_P32_WGS", 512); return v; }   // resident: 2 per CU
+static int knob_chain_fwd_bx() { const auto& k = FZ_ENV_KNOB("FZ_CHAIN_FWD_BX"); return k.set ? k.val : 1; }   // 0: the fp32-MFMA forward chain (A/B runs)
 static int knob_chain_stagger(int dflt) { const auto& k = FZ_ENV_KNOB("FZ_CHAIN_STAGGER"); return k.set ? k.val : dflt; }
 static int knob_mlp_wgs(int dflt) { static const int v = env_pos_once("FZ_MLP_WGS", 0); return v > 0 ? v : dflt; }
 
@@ -2928,7 +3011,10 @@ static int mlp_launch(const fz_mlp_desc* d, fz_stream_t stream) {
     c.wB = d->w2; c.wB_t = 0; c.ldwB = d->H;         // A2[m][k] = W2[m][k]
     c.biasB = d->b2; c.side = FZ_ENV_KNOB("FZ_CHAIN_NOZ1").val ? nullptr : (AT*)d->z1;   // (knob: timing probe, z1 not written)
     if (d->H == 128) hipLaunchKernelGGL((gemm_chain_kernel<false, 2, 4>), grid, block, 0, st, a, c, ntiles);
-    else hipLaunchKernelGGL((gemm_chain_kernel<false, 2, 2>), grid, block, 0, st, a, c, ntiles);
+    else if (products_split(d->products) && knob_chain_fwd_bx()) {   // split-bf16 form: two workgroups per CU
+      const int wgs2 = knob_mlp_wgs(512);
+      hipLaunchKernelGGL((gemm_chain_kernel<false, 2, 2, AT, true>), dim3((unsigned)(ntiles < wgs2 ? ntiles : wgs2)), block, 0, st, a, c, ntiles);
+    } else hipLaunchKernelGGL((gemm_chain_kernel<false, 2, 2>), grid, block, 0, st, a, c, ntiles);
   } else if (d->mode == 2) {
     a.w = d->w2; a.w_t = 1; a.ldw = d->H;
     a.emul = (const AT*)d->z1; a.y = (AT*)d->out;
