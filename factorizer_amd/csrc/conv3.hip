@@ -312,45 +312,96 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(Conv3WgradArgsT<AT> a)
   // index math per lane and tile, not prefetched — was 2/3 of the kernel's time).
   float4 pv[4], hv[5];
   float ev[2];
-  auto issue = [&](int64_t t) {
-    const int b = (int)(t / tiles_per_sample);
-    const int64_t n0 = (t % tiles_per_sample) * 32;
-    const int w0 = (int)(n0 % a.W);
-    const int h0 = (int)((n0 / a.W) % a.H);
-    const int d0 = (int)(n0 / ((int64_t)a.W * a.H));
+  // Tile coordinates (sample, plane, row, first voxel of the 32 along W) are WAVE-UNIFORM and advance by one tile per call:
+  // carried as scalar state and stepped with compares.  Every load address is `scalar tile base + a lane offset that does
+  // not depend on the tile` (the halo taps as signed element offsets, biased by one plane row + 1 so that they are unsigned),
+  // and whether a tap falls outside the volume is a bit test of a per-lane tap mask against four scalar border flags.
+  // (Rounds 1-3 re-derived everything from the tile number per lane and tile — five 64-bit divisions, clamps and 64-bit
+  // multiplies for each of the 11 loads: several hundred vector instructions, more than the tile's arithmetic.)
+  int tb, td, th, tw;
+  {
+    const unsigned tps32 = (unsigned)tiles_per_sample;                       // < 2^26 (V < 2^31, host-checked)
+    const unsigned t0 = (unsigned)__builtin_amdgcn_readfirstlane((int)t_begin);   // < 2^31 (host-checked)
+    const unsigned rem = t0 % tps32, row = rem / (unsigned)(a.W / 32);
+    tb = (int)(t0 / tps32);
+    tw = (int)(rem % (unsigned)(a.W / 32)) * 32;
+    th = (int)(row % (unsigned)a.H);
+    td = (int)(row / (unsigned)a.H);
+  }
+  const unsigned bias = (unsigned)((a.H + 1) * a.W + 1);                     // -(smallest tap offset)
+  unsigned goff[4], xo[5], eo[2];     // element offsets of the lane's loads relative to the tile's scalar bases
+  unsigned xsafe[5], esafe[2];        // the centre tap of the same channel: always inside the volume
+  unsigned mask = 0;                  // bits 4i..4i+3: load i is tap (kd == 0, kd == 2, kh == 0, kh == 2)
+  bool gvalid[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + (lane >> 3) + 8 * i;
+    gvalid[i] = m < a.M;
+    goff[i] = (unsigned)((m < a.M ? m : a.M - 1) * V + (lane & 7) * 4);      // < 2^30 elements (host-checked)
+  }
+  auto tap_bits = [&](int kd, int kh) { return (unsigned)((kd == 0) | ((kd == 2) << 1) | ((kh == 0) << 2) | ((kh == 2) << 3)); };
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int q = lane + 64 * i;
+    const int rr = min(q >> 3, nrow - 1), cq = q & 7;
+    const int ci = rr / 9, kd = (rr % 9) / 3, kh = rr % 3;
+    xo[i] = (unsigned)(ci * V + ((kd - 1) * a.H + (kh - 1)) * a.W + cq * 4 + (int64_t)bias);
+    xsafe[i] = (unsigned)(ci * V + cq * 4 + (int64_t)bias);
+    mask |= tap_bits(kd, kh) << (4 * i);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int id = lane + 64 * i;
+    const int rr = min(id >> 1, nrow - 1), side = id & 1;
+    const int ci = rr / 9, kd = (rr % 9) / 3, kh = rr % 3;
+    eo[i] = (unsigned)(ci * V + ((kd - 1) * a.H + (kh - 1)) * a.W + (side ? 32 : -1) + (int64_t)bias);
+    esafe[i] = (unsigned)(ci * V + (int64_t)bias);
+  }
+  // the two edge voxels: their own tap bits + side bits (left edge outside when w0 == 0, right edge when w0 + 32 == W)
+  unsigned emask = 0, enever = 0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int id = lane + 64 * i;
+    const int rr = min(id >> 1, nrow - 1), side = id & 1;
+    const int kd = (rr % 9) / 3, kh = rr % 3;
+    emask |= (tap_bits(kd, kh) | (side ? 0x20u : 0x10u)) << (8 * i);
+    enever |= ((id >> 1) < nrow ? 0u : 1u) << i;
+  }
+  unsigned xnever = 0;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) xnever |= (((lane + 64 * i) >> 3) < nrow ? 0u : 1u) << i;
+  auto issue = [&]() {
+    const int b = tb, w0 = tw, h0 = th, d0 = td;
+    // border flags of this tile, in tap-bit order (kd == 0, kd == 2, kh == 0, kh == 2), replicated per load
+    const unsigned f4 = (unsigned)((d0 == 0) | ((d0 == a.D - 1) << 1) | ((h0 == 0) << 2) | ((h0 == a.H - 1) << 3));
+    const unsigned f20 = f4 * 0x11111u;
+    const unsigned fe = (f4 | ((w0 == 0) << 4) | ((w0 + 32 == a.W) << 5)) * 0x101u;
+    const int64_t n0 = ((int64_t)d0 * a.H + h0) * a.W + w0;
+    const AT* gbase = a.gy + (int64_t)b * a.M * V + n0;
+    const AT* xbase = a.x + (int64_t)b * a.Cin * V + n0 - (int64_t)bias;
+    tw += 32;                                                                // the NEXT call's tile
+    if (tw == a.W) { tw = 0; if (++th == a.H) { th = 0; if (++td == a.D) { td = 0; ++tb; } } }
+    const unsigned bad = mask & f20, ebad = emask & fe;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int r = (lane >> 3) + 8 * i, cq = lane & 7;
-      const int m = m0 + r;
-      const int mc = m < a.M ? m : a.M - 1;
-      const float4 v = ld4(a.gy + ((int64_t)b * a.M + mc) * V + n0 + cq * 4);
-      pv[i] = m < a.M ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 v = ld4(gbase + goff[i]);
+      pv[i] = gvalid[i] ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-      const int q = lane + 64 * i;
-      const int rr = min(q >> 3, nrow - 1), cq = q & 7;
-      const int ci = rr / 9, kd = (rr % 9) / 3, kh = rr % 3;
-      const int zd = d0 + kd - 1, zh = h0 + kh - 1;
-      const bool ok = (q >> 3) < nrow && zd >= 0 && zd < a.D && zh >= 0 && zh < a.H;
-      const int zdc = min(max(zd, 0), a.D - 1), zhc = min(max(zh, 0), a.H - 1);
-      const float4 v = ld4(a.x + ((int64_t)b * a.Cin + ci) * V + ((int64_t)zdc * a.H + zhc) * a.W + w0 + cq * 4);
+      const bool ok = ((bad >> (4 * i)) & 0xfu) == 0 && ((xnever >> i) & 1u) == 0;
+      const float4 v = ld4(xbase + (ok ? xo[i] : xsafe[i]));
       hv[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int id = lane + 64 * i;
-      const int rr = min(id >> 1, nrow - 1), side = id & 1;
-      const int ci = rr / 9, kd = (rr % 9) / 3, kh = rr % 3;
-      const int zd = d0 + kd - 1, zh = h0 + kh - 1, zw = side ? w0 + 32 : w0 - 1;
-      const bool ok = (id >> 1) < nrow && zd >= 0 && zd < a.D && zh >= 0 && zh < a.H && zw >= 0 && zw < a.W;
-      const int zdc = min(max(zd, 0), a.D - 1), zhc = min(max(zh, 0), a.H - 1), zwc = min(max(zw, 0), a.W - 1);
-      const float v = aget(a.x + ((int64_t)b * a.Cin + ci) * V + ((int64_t)zdc * a.H + zhc) * a.W + zwc);
+      const bool ok = ((ebad >> (8 * i)) & 0x3fu) == 0 && ((enever >> i) & 1u) == 0;
+      const float v = aget(xbase + (ok ? eo[i] : esafe[i]));
       ev[i] = ok ? v : 0.f;
     }
   };
 
-  if (t_begin < t_end) issue(t_begin);
+  if (t_begin < t_end) issue();
   for (int64_t t = t_begin; t < t_end; ++t) {
     // registers -> LDS
 #pragma unroll
@@ -367,7 +418,7 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(Conv3WgradArgsT<AT> a)
       if (id < 72) Xs[(id >> 1) * kXs + ((id & 1) ? 36 : 3)] = ev[i];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (t + 1 < t_end) issue(t + 1);  // in flight during the MFMA loop
+    if (t + 1 < t_end) issue();  // in flight during the MFMA loop
     if constexpr (BX) {
       constexpr int NTA = BxTerms<AT>::A;   // both operands are activations; gY may carry rounding of a bf16 tensor only
       constexpr int NT = sizeof(AT) == 4 ? 3 : 1;
@@ -511,6 +562,12 @@ extern "C" int fz_conv3_wgrad_partials(const void* gy, const void* x, float* par
   if (!gy || !x || !part || !part_bias) return fail(FZ_E_ARG, "fz_conv3_wgrad: null pointer");
   if (B < 1 || Cin < 1 || M < 1 || (W % 32) || 27 * Cin > 128 || Cin * 9 > 36)
     return fail(FZ_E_UNSUPPORTED, "fz_conv3_wgrad: needs W % 32 == 0 and C_in <= 4");
+  {
+    const int64_t V = (int64_t)D * H * W;   // 32-bit tile arithmetic and 32-bit lane offsets (elements) in the kernel
+    if ((V / 32) * B >= ((int64_t)1 << 31) || (int64_t)(M < 32 ? 32 : M) * V >= ((int64_t)1 << 32) ||
+        (int64_t)Cin * V + (int64_t)(H + 1) * W + 64 >= ((int64_t)1 << 32))
+      return fail(FZ_E_UNSUPPORTED, "fz_conv3_wgrad: volume too large for the kernel's 32-bit offsets");
+  }
   if (act_dtype == FZ_STORE_F32) return conv3_wgrad_launch<float>(gy, x, part, part_bias, B, Cin, M, D, H, W, products, stream);
   if (act_dtype == FZ_STORE_BF16) return conv3_wgrad_launch<bf16>(gy, x, part, part_bias, B, Cin, M, D, H, W, products, stream);
   return fail(FZ_E_ARG, "fz_conv3_wgrad: bad act_dtype");
