@@ -198,6 +198,7 @@ _SIGS.update({
     "fz_head_bwd_rows": ([], _i),
     "fz_head_bwd_workspace_bytes": ([], _i64),
     "fz_head_bwd": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i, _vp], _i),
+    "fz_head_fwd": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i, _vp], _i),
     "fz_upcat_supported": ([_i] * 5, _i),
     "fz_upcat_compose": ([_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp], _i),
     "fz_upcat_wgrads": ([_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp], _i),

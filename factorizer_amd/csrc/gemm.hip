@@ -2651,6 +2651,7 @@ static int knob_chain64_p512() { static const int v = env_pos_once("FZ_CHAIN64_P
 static int knob_res_prefetch() { static const int v = env_pos_once("FZ_RES_PREFETCH", 1); return v == 1; }   // 2 = off (diagnostics)
 static int knob_p32() { static const int v = env_pos_once("FZ_GEMM_P32", 1); return v == 1; }   // 2 = off (diagnostics)
 static int knob_p32_wgs() { static const int v = env_pos_once("FZ_GEMM_P32_WGS", 512); return v; }   // resident: 2 per CU
+static int knob_head_fwd() { const auto& k = FZ_ENV_KNOB("FZ_HEAD_FWD"); return k.set ? k.val : 1; }   // 0: the head through gemm_p32 (A/B runs)
 static int knob_chain_fwd_bx() { const auto& k = FZ_ENV_KNOB("FZ_CHAIN_FWD_BX"); return k.set ? k.val : 1; }   // 0: the fp32-MFMA forward chain (A/B runs)
 static int knob_chain_stagger(int dflt) { const auto& k = FZ_ENV_KNOB("FZ_CHAIN_STAGGER"); return k.set ? k.val : dflt; }
 static int knob_mlp_wgs(int dflt) { static const int v = env_pos_once("FZ_MLP_WGS", 0); return v > 0 ? v : dflt; }
@@ -2742,6 +2743,12 @@ static int gemm_launch(const fz_gemm_desc* d, fz_stream_t stream) {
       if (rc != FZ_E_UNSUPPORTED) return rc;   // shapes outside the family (K % 64, M % 32, alignment): the kernels below
     }
   }
+
+  // ---- the head: Linear(32 -> M <= 4), nothing fused: 32·M FMAs per voxel on the VALU, bandwidth-bound (headbwd.hip) ----
+  if (knob_head_fwd() && d->loader == LOAD_PLAIN && d->epilogue == EPI_PLAIN && d->M <= 4 && d->K == 32 && d->Cin == 32 && a.c0 == 32 &&
+      !d->ln && !d->bact && !d->eact && !d->res && !d->bmul && !d->emul && !d->w_t && d->ldw == 32 && d->Ncol == d->Vin && d->Ncol % 4 == 0 &&
+      d->Ncol / 4 < ((int64_t)1 << 31) && (int64_t)d->B * (d->Ncol / 4) < ((int64_t)1 << 31) && d->stats_out == nullptr)
+    return fz_head_fwd(d->x[0], d->w, d->bias, d->y, d->B, d->M, 32, d->Ncol, d->act_dtype, stream);
 
   // ---- Kernel A': persistent 32 -> 32 without a residual (stage 0: LayerNorm + in-projection, plain projections) ----
   if (knob_p32() && d->loader == LOAD_PLAIN && d->epilogue == EPI_PLAIN && d->M <= 32 && d->K == 32 && d->Cin == 32 && (a.c0 & 1) == 0 && d->Vin < ((int64_t)1 << 28) &&

@@ -354,6 +354,10 @@ int fz_head_bwd_rows(void);
 int64_t fz_head_bwd_workspace_bytes(void);
 int fz_head_bwd(const void* gy, const void* x, const float* w, void* gx, float* part, int B, int M, int C, int64_t V,
                 int act_dtype, fz_stream_t stream);
+/* forward of the same layer: y = W x + b (w row-major [M][32], bias [M] or null), (B, 32, V) -> (B, M, V); fz_gemm takes this
+ * path by itself for a plain Linear(32 -> M <= 4) without LayerNorm / activation / residual. */
+int fz_head_fwd(const void* x, const float* w, const float* bias, void* y, int B, int M, int C, int64_t V, int act_dtype,
+                fz_stream_t stream);
 
 /* ---- decoder level forward in one pass ---------------------------------------------------
  * out = adapter(cat([skip, ConvTranspose3d(k2, s2)(deep)], 1))  (factorizer/unet.py:125-127 with the stage adapter of

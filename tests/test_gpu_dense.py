@@ -646,6 +646,36 @@ def test_head_backward_one_pass_fp64(M, B, S, dt):
         assert (u.double().cpu() - r).abs().max().item() <= tol * (r.abs().max().item() + 1e-30), n
 
 
+@pytest.mark.parametrize("M,B,S,dt,bias", [(3, 2, (32, 32, 32), torch.float32, True), (1, 1, (8, 12, 20), torch.float32, False),
+                                          (4, 3, (8, 8, 8), torch.float32, True), (2, 2, (16, 16, 16), torch.bfloat16, True)])
+def test_head_forward_valu_kernel_fp64(M, B, S, dt, bias):
+    """fz_head_fwd (csrc/headbwd.hip): y = W x + b of the network's head Linear(32 -> out_channels <= 4) (unet.py:253) as 32·M
+    FMAs per voxel, through the module path (fz_gemm dispatches to it) and through the entry point itself, against float64;
+    a ragged quad count per workgroup (8·12·20 voxels), replay."""
+    torch.manual_seed(10)
+    x = torch.randn(B, 32, *S)
+    w = torch.randn(M, 32, 1) * 0.3
+    b = torch.randn(M) * 0.1 if bias else None
+    yr = F.conv1d(x.double().flatten(2), w.double(), None if b is None else b.double()).reshape(B, M, *S)
+    xd = x.to(DEV).to(dt)
+    wd = w.to(DEV)
+    bd = None if b is None else b.to(DEV)
+    n0 = _native.launch_count()
+    y = PW.linear_cf(xd, wd, bd)
+    assert _native.launch_count() > n0
+    y2 = torch.empty_like(y)
+    V = S[0] * S[1] * S[2]
+    _native.check(_native.lib().fz_head_fwd(xd.data_ptr(), wd.data_ptr(), 0 if bd is None else bd.data_ptr(), y2.data_ptr(), B, M, 32, V,
+                                            _native.act_dtype(xd), _native.stream_ptr(xd)), "fz_head_fwd")
+    assert torch.equal(y, y2)                      # the module path IS this kernel
+    xq = xd.double().cpu()                         # (bf16: the stored input is the reference's input)
+    yq = F.conv1d(xq.flatten(2), w.double(), None if b is None else b.double()).reshape(B, M, *S)
+    tol = 1e-5 if dt == torch.float32 else 1e-2
+    assert (y.double().cpu() - yq).abs().max().item() <= tol * yq.abs().max().item()
+    assert (yq - yr).abs().max().item() <= (1e-12 if dt == torch.float32 else 5e-2) * yr.abs().max().item() + 1e-12
+    assert _native.lib().fz_head_fwd(xd.data_ptr(), wd.data_ptr(), 0, y2.data_ptr(), B, 5, 32, V, _native.act_dtype(xd), _native.stream_ptr(xd)) != 0
+
+
 def test_weight_gradients_land_in_the_flat_buffer():
     """With a FlatAdamW / FlatGradSync attached, every weight-gradient launch writes into its parameter's slice of the flat
     gradient buffer (factorizer_amd/gradbuf.py): after backward p.grad of every matrix / convolution weight IS that slice (no
