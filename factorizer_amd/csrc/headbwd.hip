@@ -32,13 +32,13 @@ __global__ __launch_bounds__(256, 2) void head_bwd_kernel(const AT* __restrict__
 #pragma unroll
     for (int c = 0; c < 32; ++c) gw[m][c] = 0.f;
   }
-  const int64_t quads = V / 4, total = quads * B;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+  const unsigned quads = (unsigned)(V / 4), total = quads * (unsigned)B;   // host: below 2^31
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
     // compiler-only fence: without it the loop-invariant LDS reads of W (M·32 per lane) are hoisted into VGPRs next to
     // the M·32 accumulators and spill
     asm volatile("" ::: "memory");
-    const int b = (int)(i / quads);
-    const int64_t v = (i % quads) * 4;   // (a stepped (sample, quad) walk instead of this division spills 99 registers here: the allocator's choice)
+    const int b = (int)(i / quads);          // 32-bit division (the 64-bit one was ~200 vector instructions per iteration;
+    const int64_t v = (int64_t)(i - (unsigned)b * quads) * 4;   // a stepped walk without any division spills 99 registers here)
     float g4[M][4];
 #pragma unroll
     for (int m = 0; m < M; ++m) {
@@ -172,6 +172,7 @@ extern "C" int fz_head_bwd(const void* gy, const void* x, const float* w, void* 
                            int act_dtype, fz_stream_t stream) {
   if (!gy || !x || !w || !gx || !part) return fail(FZ_E_ARG, "fz_head_bwd: null pointer");
   if (C != 32 || M < 1 || M > 4 || V < 4 || V % 4 != 0) return fail(FZ_E_UNSUPPORTED, "fz_head_bwd: needs C == 32, 1 <= M <= 4, V % 4 == 0");
+  if ((int64_t)B * (V / 4) >= ((int64_t)1 << 31)) return fail(FZ_E_UNSUPPORTED, "fz_head_bwd: 2^31 or more voxel quads");
   if (B <= 0) return B == 0 ? FZ_OK : fail(FZ_E_SHAPE, "fz_head_bwd: negative batch");
   if (act_dtype == FZ_STORE_F32) return head_bwd_launch<float>(gy, x, w, gx, part, B, M, V, (hipStream_t)stream);
   if (act_dtype == FZ_STORE_BF16) return head_bwd_launch<bf16>(gy, x, w, gx, part, B, M, V, (hipStream_t)stream);
