@@ -1,3 +1,4 @@
+# round 3: which test file running before tests/test_gpu_wide_nmf.py makes its per-call timing jump (the pause between calls: profiles/r03_wide_nmf_timing.json)
 mkdir -p gpurun_out/r03
 for f in test_gpu_bf16 test_gpu_bx test_gpu_deconver test_gpu_dense test_gpu_parity; do
   python -m pytest tests/$f.py tests/test_gpu_wide_nmf.py -q -m gpu -k "not fp64 or wide" 2>&1 | tail -2

@@ -1,3 +1,4 @@
+# grouped weight-gradient launches: partial-sum units per problem (FZ_WGRAD_UNITS) against step time and the wgrad rows of bench.py
 for u in 1024 512 256 2048 1024; do
   FZ_WGRAD_UNITS=$u python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
 import sys,json
