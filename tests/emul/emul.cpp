@@ -25,6 +25,7 @@ inline V64 fz_gate(const V64& w, const V64& g) { V64 r; for (int i = 0; i < 64; 
 }  // namespace fz
 
 #include "../../factorizer_amd/csrc/nmf_core.h"
+#include "../../factorizer_amd/csrc/nmf_gram.h"
 
 
 template <int M, int NPL>
@@ -121,6 +122,78 @@ static void run_bwd(const float* x, const float* u0, const float* v0, const floa
     fz::nmf_backward_wave<M, NPL, R, S>(w, u0, v0, xm, g, h, mreal, T, G, eps,
                                         gu ? gu + k * mreal * R : nullptr, gv ? gv + k * nreal * R : nullptr);
     w.store_mat(gx + k * mreal * nreal, g);
+  }
+}
+
+
+// ---- the row-space (Gram) reverse mode of nmf_gram.h: HALS rank 1 on non-negative matrices -------------------------
+// The distributed-row capabilities of the device policy (CfWave in csrc/nmf_cf.hip) restated for 64-lane vectors:
+// lane group g = lanes 8g .. 8g+7 holds element g of an 8-vector.
+template <int NPL>
+struct EmuWaveDist : EmuWave<8, NPL> {
+  using F = V64;
+  using Base = EmuWave<8, NPL>;
+  F sum8_dist(const F (&v)[8]) const {
+    F tmp[8];
+    for (int i = 0; i < 8; ++i) tmp[i] = v[i];
+    Base::sum8(tmp);
+    F o;
+    for (int l = 0; l < 64; ++l) o.a[l] = tmp[l >> 3].a[0];
+    return o;
+  }
+  F grp_take(const F& d, int m) const { return F(d.a[8 * m]); }
+  // device order (fz_common.h wave_group_sum): distance 8, 16, 32
+  F grp_sum(const F& d) const {
+    float g[8], h[8];
+    for (int i = 0; i < 8; ++i) g[i] = d.a[8 * i];
+    for (int i = 0; i < 8; ++i) h[i] = g[i] + g[i ^ 1];
+    for (int i = 0; i < 8; ++i) g[i] = h[i] + h[i ^ 2];
+    for (int i = 0; i < 8; ++i) h[i] = g[i] + g[i ^ 4];
+    return F(h[0]);
+  }
+  F mask_rows(const F& d, int mreal) const { F o; for (int l = 0; l < 64; ++l) o.a[l] = (l >> 3) < mreal ? d.a[l] : 0.f; return o; }
+  F pick_call(int c, const F& tot, const F& mine) const { F o; for (int l = 0; l < 64; ++l) o.a[l] = (l & 7) == c ? tot.a[l] : mine.a[l]; return o; }
+  void k_unrotate(float* scratch, const F& mine, F (&Kd)[8]) const {
+    for (int l = 0; l < 64; ++l) { const int g = l >> 3, i = l & 7; scratch[g * 8 + ((g + i) & 7)] = mine.a[l]; }
+    for (int k = 0; k < 8; ++k) for (int l = 0; l < 64; ++l) Kd[k].a[l] = scratch[(l >> 3) * 8 + k];
+  }
+  void st_grp(float* base, int i0, int stride, const F& d) const { for (int g = 0; g < 8; ++g) base[i0 + g * stride] = d.a[8 * g]; }
+  F ld_grp(const float* base, int i0, int stride) const { F o; for (int l = 0; l < 64; ++l) o.a[l] = base[i0 + (l >> 3) * stride]; return o; }
+};
+
+template <int NPL>
+static void run_gram_bwd(const float* x, const float* v0, const float* gy, float* gx, int64_t nmat, int mreal, int nreal,
+                         int T, int G, float eps, float gscale) {
+  std::vector<float> lds(fz::gram_hist_floats(G - 1));
+  for (int64_t k = 0; k < nmat; ++k) {
+    EmuWaveDist<NPL> w;
+    w.mreal = mreal; w.nreal = nreal;
+    V64 xm[8][NPL], g[8][NPL];
+    w.load_mat(x + k * mreal * nreal, xm);
+    w.load_mat(gy + k * mreal * nreal, g);
+    fz::GramBwd<NPL, EmuWaveDist<NPL>> P;
+    P.forward(w, xm, v0, mreal, nreal, T, G, eps, lds.data(), [] {});
+    for (int m = 0; m < 8; ++m) P.out_row(m, g[m]);
+    P.reverse(w, xm, gscale, [] {});
+    for (int m = 0; m < 8; ++m) {
+      V64 srow[8], gsm, ga1m;
+      P.row_coeffs(w, m, srow, gsm, ga1m);
+      P.gx_row(m, xm, srow, gsm, ga1m, g[m]);
+    }
+    w.store_mat(gx + k * mreal * nreal, g);
+  }
+}
+
+extern "C" int emu_gram_bwd(const float* x, const float* v0, const float* gy, float* gx, int64_t nmat, int M, int N, int T,
+                            int G, float eps, float gscale) {
+  if (M > 8 || N > 512 || G < 1 || G > T) return -2;
+  switch ((N + 63) / 64) {
+    case 1: run_gram_bwd<1>(x, v0, gy, gx, nmat, M, N, T, G, eps, gscale); return 0;
+    case 2: run_gram_bwd<2>(x, v0, gy, gx, nmat, M, N, T, G, eps, gscale); return 0;
+    case 3: run_gram_bwd<3>(x, v0, gy, gx, nmat, M, N, T, G, eps, gscale); return 0;
+    case 4: run_gram_bwd<4>(x, v0, gy, gx, nmat, M, N, T, G, eps, gscale); return 0;
+    case 8: run_gram_bwd<8>(x, v0, gy, gx, nmat, M, N, T, G, eps, gscale); return 0;
+    default: return -2;
   }
 }
 
