@@ -170,10 +170,6 @@ _SIGS.update({
     "fz_nmf_cf_supported": ([_i] * 11, _i),
     "fz_nmf_cf_fwd": ([_vp] * 4 + [_i] * 5 + [_c.POINTER(_i)] + [_i] * 5 + [_f, _i, _vp], _i),
     "fz_nmf_cf_bwd": ([_vp] * 5 + [_i] * 5 + [_c.POINTER(_i)] + [_i] * 7 + [_f, _i, _vp], _i),
-    "fz_nmf_cf2_workspace_bytes": ([_i] * 3, _i64),
-    "fz_nmf_cf2_supported": ([_i] * 5 + [_c.POINTER(_i)] + [_i] * 5, _i),
-    "fz_nmf_cf_fwd2": ([_vp] * 4 + [_i] * 5 + [_c.POINTER(_i)] + [_i] * 3 + [_f, _i, _vp, _c.POINTER(_i), _vp], _i),
-    "fz_nmf_cf_bwd2": ([_vp] * 5 + [_i] * 5 + [_c.POINTER(_i)] + [_i] * 5 + [_f, _i, _vp, _c.POINTER(_i), _vp], _i),
     "fz_nmf_pcf_supported": ([_i] * 11, _i),
     "fz_nmf_pcf_fwd": ([_vp] * 4 + [_i] * 8 + [_c.POINTER(_i)] + [_i] * 5 + [_f, _i, _vp], _i),
     "fz_nmf_pcf_bwd": ([_vp] * 5 + [_i] * 8 + [_c.POINTER(_i)] + [_i] * 7 + [_f, _i, _vp], _i),

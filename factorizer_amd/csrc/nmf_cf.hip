@@ -17,73 +17,11 @@
 
 namespace fz {
 
-// ---- in-launch hand-off between the two shift windows (two-window kernels below) -----------------------------------
-// Window 0 writes its part of the running average WRITE-THROUGH (sc1) and signals a per-(slice, patch-plane) counter;
-// window 1 polls the counters of the planes its voxels lie in and then reads the running average with sc1 loads
-// (cdna_hip_programming.md Guideline 16, recipe R1 in its counter form; MI355X_MICROARCH.md § visibility, table row
-// "agent-scope atomic adds by one lane of each storing workgroup / sc1 poll / barrier / sc1 dwordx4 stores, whole lines /
-// sc1 dwordx4 loads").  Placement-independent: nothing assumes a dispatch order or a workgroup -> XCD map.
-typedef int cf_v4i __attribute__((__vector_size__(16)));
-typedef int cf_v2i __attribute__((__vector_size__(8)));
-enum { CF_PLAIN = 0, CF_PRODUCE = 1, CF_CONSUME = 2 };  // role of a tile in the two-window launch
-
-struct CfSync {
-  __amdgpu_buffer_rsrc_t rsrc;   // the tensor that is handed over (out / gt), as a buffer (32-bit byte offsets)
-  unsigned* done;                // [slice][patch-plane] completed window-0 tiles
-  unsigned* timeout;             // set to a code when a bounded spin gives up (never, unless the protocol is broken)
-  int need;                      // tiles per (slice, plane)
-};
-// (the counters a tile signals / waits for travel as plain ints beside the struct: a struct with a buffer resource in it is
-// not split into registers by the optimiser, and fields written per tile would live in scratch)
-
-__device__ __forceinline__ float4 cf_ld4_sc1(const CfSync& y, const float*, int64_t eoff) {
-  const cf_v4i r = __builtin_amdgcn_raw_buffer_load_b128(y.rsrc, (int)(eoff * 4), 0, 16);
-  return make_float4(__int_as_float(r[0]), __int_as_float(r[1]), __int_as_float(r[2]), __int_as_float(r[3]));
-}
-__device__ __forceinline__ float4 cf_ld4_sc1(const CfSync& y, const bf16*, int64_t eoff) {
-  const cf_v2i r = __builtin_amdgcn_raw_buffer_load_b64(y.rsrc, (int)(eoff * 2), 0, 16);
-  return make_float4(__uint_as_float((unsigned)r[0] << 16), __uint_as_float((unsigned)r[0] & 0xffff0000u),
-                     __uint_as_float((unsigned)r[1] << 16), __uint_as_float((unsigned)r[1] & 0xffff0000u));
-}
-__device__ __forceinline__ void cf_st4_sc1(const CfSync& y, const float*, int64_t eoff, float4 v) {
-  const cf_v4i r = {__float_as_int(v.x), __float_as_int(v.y), __float_as_int(v.z), __float_as_int(v.w)};
-  __builtin_amdgcn_raw_buffer_store_b128(r, y.rsrc, (int)(eoff * 4), 0, 16);
-}
-__device__ __forceinline__ void cf_st4_sc1(const CfSync& y, const bf16*, int64_t eoff, float4 v) {
-  const f32v4 f = {v.x, v.y, v.z, v.w};
-  const bf16v4 h = __builtin_convertvector(f, bf16v4);
-  __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const cf_v2i*>(&h), y.rsrc, (int)(eoff * 2), 0, 16);
-}
-
-// producer side: EVERY storing wave drains its stores, the workgroup meets, ONE lane signals
-__device__ __forceinline__ void cf_publish(const CfSync& y, int idx, int tid) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) __hip_atomic_fetch_add(y.done + idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// consumer side: ONE lane polls (relaxed, bounded), the workgroup meets, then every load of the handed-over bytes is sc1
-__device__ __forceinline__ void cf_await(const CfSync& y, int ia, int ib, int tid) {
-  if (tid == 0) {
-    unsigned spins = 0;
-    while (__hip_atomic_load(y.done + ia, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)y.need ||
-           __hip_atomic_load(y.done + ib, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)y.need) {
-      __builtin_amdgcn_s_sleep(8);
-      if (++spins > (1u << 24)) {   // ~ seconds: a producer with a lower ticket is resident or done, so this cannot happen
-        __hip_atomic_store(y.timeout, 0xdead0001u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-    }
-  }
-  __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // no instruction: keeps the sc1 loads below the poll
-}
-
-// One tile (WPB patches along W) of one window of the forward.  ROLE: CF_PLAIN — the one-window-per-launch kernel;
-// CF_PRODUCE / CF_CONSUME — window 0 / window 1 of the two-window launch (block-uniform at run time there: `role`).
-template <int R, int SOLVER, int WPB, bool HALF, typename AT, bool SYNC>
+// One tile (WPB patches along W) of one window of the forward.
+template <int R, int SOLVER, int WPB, bool HALF, typename AT>
 __device__ __forceinline__ void cf_fwd_tile_body(const AT* __restrict__ t, const float* __restrict__ u0,
                                                  const float* __restrict__ v0, AT* __restrict__ out, const CfGeom& q,
-                                                 const CfTileId& id, int T, float eps, float* S, int role, const CfSync& y, int ia, int ib) {
+                                                 const CfTileId& id, int T, float eps, float* S) {
   using TL = CfTile<WPB>;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int64_t base, V;
@@ -115,18 +53,10 @@ __device__ __forceinline__ void cf_fwd_tile_body(const AT* __restrict__ t, const
   asm volatile("" : "+s"(base));
   float4 old[8][2];
   if (q.accumulate) {
-    if (SYNC && role == CF_CONSUME) {
-      cf_await(y, ia, ib, tid);
 #pragma unroll
-      for (int dd = 0; dd < 8; ++dd)
+    for (int dd = 0; dd < 8; ++dd)
 #pragma unroll
-        for (int k = 0; k < 2; ++k) old[dd][k] = cf_ld4_sc1(y, out, base + dd * V + off[k]);
-    } else {
-#pragma unroll
-      for (int dd = 0; dd < 8; ++dd)
-#pragma unroll
-        for (int k = 0; k < 2; ++k) old[dd][k] = cf_ld4<HALF>(out + base + dd * V, off[k], off2[k]);
-    }
+      for (int k = 0; k < 2; ++k) old[dd][k] = cf_ld4<HALF>(out + base + dd * V, off[k], off2[k]);
   }
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
@@ -151,12 +81,10 @@ __device__ __forceinline__ void cf_fwd_tile_body(const AT* __restrict__ t, const
           o = make_float4(0.0f + z.x, 0.0f + z.y, 0.0f + z.z, 0.0f + z.w);
         }
         if (q.divisor > 1) o = cf_divide4(o, dv, dv_pow2);
-        if (SYNC && role == CF_PRODUCE) cf_st4_sc1(y, out, base + (2 * s + c) * V + off[k], o);
-        else cf_st4<HALF>(out + base + (2 * s + c) * V, off[k], off2[k], o);
+        cf_st4<HALF>(out + base + (2 * s + c) * V, off[k], off2[k], o);
       }
     __syncthreads();
   }
-  if (SYNC && role == CF_PRODUCE) cf_publish(y, ia, tid);
 }
 
 template <int R, int SOLVER, int WPB, bool HALF, typename AT>
@@ -169,9 +97,7 @@ __global__ __launch_bounds__(WPB * 64, (WPB == 8 || R >= 2) ? 2 : 4) void nmf_cf
                                                                    AT* __restrict__ out, CfGeom q, int T, float eps,
                                                                    int xcd_remap) {
   extern __shared__ __attribute__((aligned(16))) float fz_lds_tile[];
-  CfSync none{};
-  cf_fwd_tile_body<R, SOLVER, WPB, HALF, AT, false>(t, u0, v0, out, q, cf_tile_id<WPB>(q, cf_logical_block(xcd_remap)), T, eps,
-                                                    fz_lds_tile, CF_PLAIN, none, 0, 0);
+  cf_fwd_tile_body<R, SOLVER, WPB, HALF, AT>(t, u0, v0, out, q, cf_tile_id<WPB>(q, cf_logical_block(xcd_remap)), T, eps, fz_lds_tile);
 }
 
 // backward: gY = gather_w(ga) / W ; gt (+)= [t > 0] ∘ scatter_w(gX)
@@ -217,11 +143,11 @@ __global__ __launch_bounds__(256, (R == 1 && SOLVER == 1) ? 2 : 1) void nmf_cf_b
 
 // line-coalesced backward: same exchange for t and for the incoming gradient, ReLU gate applied on
 // the owner side before the exchange back, read-modify-write of gt with the coalesced map
-template <int R, int SOLVER, int WPB, bool HALF, typename AT, bool SYNC>
+template <int R, int SOLVER, int WPB, bool HALF, typename AT>
 __device__ __forceinline__ void cf_bwd_tile_body(const AT* __restrict__ t, const float* __restrict__ u0,
                                                  const float* __restrict__ v0, const AT* __restrict__ ga,
                                                  AT* __restrict__ gt, const CfGeom& q, const CfTileId& id, int T, int G, float eps,
-                                                 int relu_gate, float* S, int role, const CfSync& y, int ia, int ib) {
+                                                 int relu_gate, float* S) {
   using TL = CfTile<WPB>;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int64_t base, V;
@@ -265,18 +191,10 @@ __device__ __forceinline__ void cf_bwd_tile_body(const AT* __restrict__ t, const
   asm volatile("" : "+s"(base));
   float4 old[8][2];
   if (q.accumulate) {
-    if (SYNC && role == CF_CONSUME) {
-      cf_await(y, ia, ib, tid);
 #pragma unroll
-      for (int dd = 0; dd < 8; ++dd)
+    for (int dd = 0; dd < 8; ++dd)
 #pragma unroll
-        for (int k = 0; k < 2; ++k) old[dd][k] = cf_ld4_sc1(y, gt, base + dd * V + off[k]);
-    } else {
-#pragma unroll
-      for (int dd = 0; dd < 8; ++dd)
-#pragma unroll
-        for (int k = 0; k < 2; ++k) old[dd][k] = cf_ld4<HALF>(gt + base + dd * V, off[k], off2[k]);
-    }
+      for (int k = 0; k < 2; ++k) old[dd][k] = cf_ld4<HALF>(gt + base + dd * V, off[k], off2[k]);
   }
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
@@ -297,12 +215,10 @@ __device__ __forceinline__ void cf_bwd_tile_body(const AT* __restrict__ t, const
           const float4 o = old[2 * s + c][k];
           z.x += o.x; z.y += o.y; z.z += o.z; z.w += o.w;
         }
-        if (SYNC && role == CF_PRODUCE) cf_st4_sc1(y, gt, base + (2 * s + c) * V + off[k], z);
-        else cf_st4<HALF>(gt + base + (2 * s + c) * V, off[k], off2[k], z);
+        cf_st4<HALF>(gt + base + (2 * s + c) * V, off[k], off2[k], z);
       }
     __syncthreads();
   }
-  if (SYNC && role == CF_PRODUCE) cf_publish(y, ia, tid);
 }
 
 template <int R, int SOLVER, int WPB, bool HALF, typename AT>
@@ -311,140 +227,10 @@ __global__ __launch_bounds__(WPB * 64, (R == 1 && SOLVER == 1 && (WPB == 4 || WP
     const AT* __restrict__ ga, AT* __restrict__ gt, CfGeom q, int T, int G, float eps, int relu_gate,
     int xcd_remap) {
   extern __shared__ __attribute__((aligned(16))) float fz_lds_cf[];
-  CfSync none{};
-  cf_bwd_tile_body<R, SOLVER, WPB, HALF, AT, false>(t, u0, v0, ga, gt, q, cf_tile_id<WPB>(q, cf_logical_block(xcd_remap)), T, G, eps,
-                                                    relu_gate, fz_lds_cf, CF_PLAIN, none, 0, 0);
+  cf_bwd_tile_body<R, SOLVER, WPB, HALF, AT>(t, u0, v0, ga, gt, q, cf_tile_id<WPB>(q, cf_logical_block(xcd_remap)), T, G, eps,
+                                             relu_gate, fz_lds_cf);
 }
 
-
-// ---- BOTH shift windows in ONE launch, scheduled for the Infinity Cache ---------------------------------------------
-// The reference treats the windows as independent passes over the whole tensor (operations.py:417-434) and so did rounds
-// 1-3: window 1 re-read t and read-modify-wrote the running average from HBM (forward 2·U + 3·U, backward 3·U + 4·U).
-// A (sample, head) slice never interacts with another slice and window 1's patch-plane q only needs window 0's planes
-// q - 1 and q (a D-axis shift of 1 .. 7 voxels), so the launch walks the tensor SLAB-MAJOR: for a group of slices, window 0
-// of plane s, then window 1 of plane s - 1 - lag, ... — a few tens of MB between the two uses of every byte of t and of the
-// running average, which the 256 MiB Infinity Cache holds (profiles/r04_memory_ceilings.json: the bare access pattern moves
-// its 5·U at 8.1 TB/s this way against 5.4 TB/s layer-major).
-//
-// Work items are handed out by a TICKET counter in the order above (persistent workgroups; the next ticket is requested
-// before the current tile is processed), so every tile a window-1 item waits for has a LOWER ticket, i.e. is held by a
-// workgroup that is running or done: no assumption on dispatch order, timing or workgroup -> XCD placement, no deadlock.
-// The hand-off itself is CfSync above.  Ticket -> item: bundles of `group x tiles-per-plane` items; inside a bundle
-// consecutive tickets cycle over 8 lanes, each a contiguous run of tiles (neighbours along W, then H) of one slice, so the
-// workgroups of one XCD (round-robin placement: speed only) keep sharing lines in their L2.
-struct Cf2Plan {
-  int GQ;                  // tiles per patch row (G2 / WPB)
-  int tpp;                 // tiles per (slice, plane) = G1 * GQ
-  int group;               // slices per group
-  int items_w;             // group * tpp
-  int lag;                 // extra planes window 1 trails window 0 by
-  unsigned total;          // 2 * nslice * G0 * tpp
-  int s1d, s1h, s1w;       // window 1's shift (window 0 is unshifted)
-  int divisor;             // forward: number of windows (2)
-  int nowait;              // timing probes only (FZ_CF2_NOWAIT): window 1 does not wait — results invalid
-};
-
-struct Cf2Item { int win, slice; CfTileId id; };
-
-__device__ __forceinline__ Cf2Item cf2_decode(const CfGeom& q, const Cf2Plan& p, unsigned k) {
-  const int G0 = q.G0;
-  const unsigned per_group = 2u * (unsigned)G0 * (unsigned)p.items_w;
-  const unsigned g = k / per_group, rem = k % per_group;
-  const int bi = (int)(rem / (unsigned)p.items_w), i = (int)(rem % (unsigned)p.items_w);
-  Cf2Item it;
-  // bundle order of a group: w0(0..lag), then pairs w0(s), w1(s - 1 - lag) for s = lag + 1 .. G0 - 1, then the rest of w1
-  int plane, j = 0;   // j: window-1 order index, plane (j + 1) % G0 — plane 0 needs window 0's LAST plane, so it comes last
-  if (bi <= p.lag) { it.win = 0; plane = bi; }
-  else {
-    const int r = bi - (p.lag + 1), npair = 2 * (G0 - 1 - p.lag);
-    if (r < npair) { const int s = p.lag + 1 + (r >> 1); it.win = r & 1; plane = s; j = s - 1 - p.lag; }
-    else { it.win = 1; plane = 0; j = (G0 + (r - npair)) - 1 - p.lag; }
-  }
-  if (it.win) { plane = j + 1; if (plane == G0) plane = 0; }
-  int flat = i;
-  if ((p.items_w & 7) == 0) flat = (i & 7) * (p.items_w >> 3) + (i >> 3);
-  const int sl = flat / p.tpp, tile = flat % p.tpp;
-  it.slice = (int)g * p.group + sl;
-  it.id.b = it.slice / q.h; it.id.hh = it.slice % q.h;
-  it.id.g0 = plane; it.id.g1 = tile / p.GQ; it.id.gq = tile % p.GQ;
-  return it;
-}
-
-__device__ __forceinline__ void cf2_roles(const Cf2Plan& p, const Cf2Item& it, CfGeom& q, int& role, int& ia, int& ib) {
-  const int plane = it.id.g0;
-  if (it.win == 0) {
-    q.s0 = q.s1 = q.s2 = 0; q.accumulate = 0; q.divisor = 1;
-    role = CF_PRODUCE;
-    ia = ib = it.slice * q.G0 + plane;
-  } else {
-    q.s0 = p.s1d; q.s1 = p.s1h; q.s2 = p.s1w; q.accumulate = 1; q.divisor = p.divisor;
-    role = CF_CONSUME;
-    // voxels 8·plane - s0 .. 8·plane - s0 + 7 (0 < s0 < 8): window 0's planes plane - 1 and plane
-    ia = it.slice * q.G0 + (plane == 0 ? q.G0 - 1 : plane - 1);
-    ib = it.slice * q.G0 + plane;
-  }
-}
-
-// ws: [0] ticket, [1] timeout code, [2..15] unused, [16 ..] done[slice][plane]   (zeroed by the launch function)
-enum { CF2_WS_HEAD = 16 };
-
-template <int R, int SOLVER, typename AT>
-__global__ __launch_bounds__(512, 2) void nmf_cf_fwd2_kernel(const AT* __restrict__ t, const float* __restrict__ u0,
-                                                            const float* __restrict__ v0, AT* __restrict__ out, CfGeom q,
-                                                            Cf2Plan p, int T, float eps, unsigned* __restrict__ ws,
-                                                            unsigned out_bytes) {
-  constexpr int WPB = 8;
-  extern __shared__ __attribute__((aligned(16))) float fz_lds_tile[];
-  float* S = fz_lds_tile;
-  unsigned* slot = reinterpret_cast<unsigned*>(S + CfTile<WPB>::STAGE_FLOATS);
-  const int tid = threadIdx.x;
-  CfSync y;
-  y.rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)out_bytes, 0x00020000);
-  y.done = ws + CF2_WS_HEAD; y.timeout = ws + 1; y.need = p.nowait ? 0 : p.tpp;
-  if (tid == 0) *slot = __hip_atomic_fetch_add(ws, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  unsigned k = __builtin_amdgcn_readfirstlane(*slot);
-  while (k < p.total) {
-    unsigned nxt = 0;
-    if (tid == 0) nxt = __hip_atomic_fetch_add(ws, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // used after the tile
-    const Cf2Item it = cf2_decode(q, p, k);
-    int role, ia, ib;
-    cf2_roles(p, it, q, role, ia, ib);
-    cf_fwd_tile_body<R, SOLVER, WPB, false, AT, true>(t, u0, v0, out, q, it.id, T, eps, S, role, y, ia, ib);
-    if (tid == 0) *slot = nxt;
-    __syncthreads();
-    k = __builtin_amdgcn_readfirstlane(*slot);
-  }
-}
-
-template <int R, int SOLVER, typename AT>
-__global__ __launch_bounds__(256, 2) void nmf_cf_bwd2_kernel(const AT* __restrict__ t, const float* __restrict__ u0,
-                                                            const float* __restrict__ v0, const AT* __restrict__ ga,
-                                                            AT* __restrict__ gt, CfGeom q, Cf2Plan p, int T, int G, float eps,
-                                                            int relu_gate, unsigned* __restrict__ ws, unsigned gt_bytes) {
-  constexpr int WPB = 4;
-  extern __shared__ __attribute__((aligned(16))) float fz_lds_cf[];
-  float* S = fz_lds_cf;
-  unsigned* slot = reinterpret_cast<unsigned*>(S + CfTile<WPB>::STAGE_FLOATS + WPB * Hist<8, 8, R>::floats(G));
-  const int tid = threadIdx.x;
-  CfSync y;
-  y.rsrc = __builtin_amdgcn_make_buffer_rsrc(gt, 0, (int)gt_bytes, 0x00020000);
-  y.done = ws + CF2_WS_HEAD; y.timeout = ws + 1; y.need = p.nowait ? 0 : p.tpp;
-  if (tid == 0) *slot = __hip_atomic_fetch_add(ws, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  unsigned k = __builtin_amdgcn_readfirstlane(*slot);
-  while (k < p.total) {
-    unsigned nxt = 0;
-    if (tid == 0) nxt = __hip_atomic_fetch_add(ws, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const Cf2Item it = cf2_decode(q, p, k);
-    int role, ia, ib;
-    cf2_roles(p, it, q, role, ia, ib);
-    cf_bwd_tile_body<R, SOLVER, WPB, false, AT, true>(t, u0, v0, ga, gt, q, it.id, T, G, eps, relu_gate, S, role, y, ia, ib);
-    if (tid == 0) *slot = nxt;
-    __syncthreads();
-    k = __builtin_amdgcn_readfirstlane(*slot);
-  }
-}
 
 static int cf_geom(CfGeom& q, int B, int C, int D, int H, int W, const int* shift, int accumulate, int divisor) {
   if (B < 0 || C < 8 || (C % 8) || D < 8 || H < 8 || W < 8 || (D % 8) || (H % 8) || (W % 8))
@@ -576,7 +362,11 @@ static int cf_bwd_launch(const AT* t, const float* u0, const float* v0, const AT
     const int twpb = (q.G2 % 4) == 0 ? 4 : 1;
     // HALS rank 1 behind a ReLU (t >= 0 by the relu_gate contract): the row-space reverse mode, no per-column history
     static const bool gram_on = !(FZ_ENV_KNOB("FZ_CF_GRAM").set && FZ_ENV_KNOB("FZ_CF_GRAM").val == 0);
-    if (gram_on && R == 1 && solver == FZ_SOLVER_HALS && relu_gate && G >= 1) {
+    // (measured, tools/probes/gram_floor.sh: both kernels sit on the tile's memory skeleton; the row-space one is 6-11 % faster
+    //  everywhere except fp32 windows w > 0 of >= 2^15 matrices, where the general kernel's single late burst of
+    //  running-sum reads is 3-5 % ahead: 461-464 against 478-487 us at the README's stage 0)
+    const bool gram_wins = !(sizeof(AT) == 4 && accumulate && nmat >= 32768);
+    if (gram_on && gram_wins && R == 1 && solver == FZ_SOLVER_HALS && relu_gate && G >= 1) {
       rc = cf_bwd_gram_launch<AT>(t, v0, ga, gt, q, nmat, T, G, eps, xr, st);
       if (rc != FZ_E_UNSUPPORTED) return rc;
     }
@@ -631,181 +421,4 @@ extern "C" int fz_nmf_cf_bwd(const void* t, const float* u0, const float* v0, co
     return cf_bwd_launch<bf16>((const bf16*)t, u0, v0, (const bf16*)ga, (bf16*)gt, B, C, D, H, W, shift, accumulate,
                                nshift, relu_gate, R, T, Tgrad, solver, eps, stream);
   return fail(FZ_E_ARG, "fz_nmf_cf_bwd: bad act_dtype");
-}
-
-// ---- two windows in one launch: host side ------------------------------------------------------------------------------
-namespace fz {
-static int knob_cf2_group() { return FZ_ENV_KNOB("FZ_CF2_GROUP").val; }    // slices per group (0 = auto)
-static int knob_cf2_lag() { return FZ_ENV_KNOB("FZ_CF2_LAG").val; }
-static int knob_cf2_nowait() { return FZ_ENV_KNOB("FZ_CF2_NOWAIT").val; }  // TIMING PROBES ONLY: results invalid
-static int knob_cf2_wgs() { return FZ_ENV_KNOB("FZ_CF2_WGS").val; }        // persistent workgroups (0 = resident)
-
-// WPB: patches per tile (8 forward, 4 backward); passes: tensor passes one (plane, both windows) step moves (5 forward, 7 backward)
-static int cf2_plan(Cf2Plan& p, int B, int C, int D, int H, int W, const int* shifts, int WPB, int es, int passes,
-                    const int* tune = nullptr) {
-  if (C % 8 || D % 8 || H % 8 || W % 8) return 0;
-  const int G0 = D / 8, G1 = H / 8, G2 = W / 8;
-  if (G2 % WPB) return 0;
-  // window 0 unshifted (its stores are whole 128-B lines: the measured hand-off form), window 1 a D-axis shift of 1 .. 7
-  // voxels (so that it needs exactly window 0's planes q - 1 and q) and a W-axis shift that keeps 16-byte chunks whole
-  if (shifts[0] || shifts[1] || shifts[2]) return 0;
-  int s[3];
-  const int Sz[3] = {D, H, W};
-  for (int i = 0; i < 3; ++i) { s[i] = shifts[3 + i] % Sz[i]; if (s[i] < 0) s[i] += Sz[i]; }
-  if (s[0] < 1 || s[0] > 7 || (s[2] % 4) || G0 < 2) return 0;
-  const int64_t nslice = (int64_t)B * (C / 8);
-  const int64_t tensor_bytes = nslice * 8 * (int64_t)D * H * W * es;
-  if (tensor_bytes >= ((int64_t)1 << 31)) return 0;   // 32-bit buffer offsets
-  p.GQ = G2 / WPB; p.tpp = G1 * p.GQ;
-  // slices per group.  The design intent was a group small enough for the Infinity Cache (two steps of `passes` plane-sets
-  // of the group within ~96 MB); measured (profiles/r04_cf2_sweep.json) small groups only make window-1 workgroups wait on a
-  // resident slot — the 4 096 matrices in flight are 164 MB by themselves — so the library's own choice is the whole tensor
-  // as ONE group with window 1 a plane further behind (the least slow setting: within 6 % of the one-window launches).
-  (void)passes;
-  int group = (int)nslice;
-  if (tune && tune[0] > 0) group = tune[0];
-  else if (knob_cf2_group() > 0) group = knob_cf2_group();
-  if (group < 1 || nslice % group) return 0;
-  p.group = group; p.items_w = group * p.tpp;
-  int lag = (tune && tune[1] >= 0) ? tune[1] : (FZ_ENV_KNOB("FZ_CF2_LAG").set ? knob_cf2_lag() : 1);
-  if (lag < 0) lag = 0;
-  if (lag > G0 - 1) lag = G0 - 1;
-  p.lag = lag;
-  const int64_t total = 2 * nslice * G0 * p.tpp;
-  if (total >= ((int64_t)1 << 31)) return 0;
-  p.total = (unsigned)total;
-  p.s1d = s[0]; p.s1h = s[1]; p.s1w = s[2];
-  p.divisor = 2;
-  p.nowait = knob_cf2_nowait();
-  return 1;
-}
-}  // namespace fz
-
-extern "C" int64_t fz_nmf_cf2_workspace_bytes(int B, int C, int D) {
-  if (B < 0 || C < 8 || D < 8) return 0;
-  const int64_t n = CF2_WS_HEAD + (int64_t)B * (C / 8) * (D / 8);
-  return ((n * 4 + 15) / 16) * 16;
-}
-
-extern "C" int fz_nmf_cf2_supported(int B, int C, int D, int H, int W, const int* shifts, int nshift, int R, int T, int Tgrad,
-                                    int act_dtype) {
-  // rank 1 only: the rank-2 wave programs sit at the 256-register limit and would spill beside the ticket loop
-  if (nshift != 2 || !shifts || B < 1 || R != 1) return 0;
-  if (!fz_nmf_cf_supported(C, D, H, W, 8, 8, 8, 8, R, T, Tgrad)) return 0;
-  const int es = act_dtype == FZ_STORE_BF16 ? 2 : 4;
-  Cf2Plan p;
-  if (!cf2_plan(p, B, C, D, H, W, shifts, 8, es, 5)) return 0;
-  if (!cf2_plan(p, B, C, D, H, W, shifts, 4, es, 7)) return 0;
-  const int G = Tgrad < 0 ? 0 : (Tgrad > T ? T : Tgrad);
-  const int per_wave = Hist<8, 8, 1>::floats(G) * (int)sizeof(float);
-  return CfTile<4>::STAGE_FLOATS * (int)sizeof(float) + 4 * per_wave + 16 <= 160 * 1024;
-}
-
-template <typename AT>
-static int cf_fwd2_launch(const AT* t, const float* u0, const float* v0, AT* out, int B, int C, int D, int H, int W,
-                          const int* shifts, int R, int T, int solver, float eps, void* workspace, const int* tune,
-                          fz_stream_t stream) {
-  if (!t || !u0 || !v0 || !out || !shifts || !workspace) return fail(FZ_E_ARG, "fz_nmf_cf_fwd2: null pointer");
-  if (R != 1) return fail(FZ_E_UNSUPPORTED, "fz_nmf_cf_fwd2: rank 1 (see fz_nmf_cf2_supported)");
-  if (solver != FZ_SOLVER_MU && solver != FZ_SOLVER_HALS) return fail(FZ_E_ARG, "fz_nmf_cf_fwd2: bad solver");
-  CfGeom q;
-  const int zero[3] = {0, 0, 0};
-  int rc = cf_geom(q, B, C, D, H, W, zero, 0, 1);
-  if (rc != FZ_OK) return rc;
-  Cf2Plan p;
-  if (B < 1 || !cf2_plan(p, B, C, D, H, W, shifts, 8, (int)sizeof(AT), 5, tune))
-    return fail(FZ_E_UNSUPPORTED, "fz_nmf_cf_fwd2: geometry outside the two-window launch (see fz_nmf_cf2_supported)");
-  hipStream_t st = (hipStream_t)stream;
-  FZ_HIP_OK(hipMemsetAsync(workspace, 0, (size_t)fz_nmf_cf2_workspace_bytes(B, C, D), st));
-  const unsigned bytes = (unsigned)((int64_t)B * C * D * H * W * (int64_t)sizeof(AT));
-  const int lds = CfTile<8>::STAGE_FLOATS * (int)sizeof(float) + 16;
-#define FZ_CF_FWD2(RR, SS)                                                                                                  \
-  do {                                                                                                                      \
-    auto kern = nmf_cf_fwd2_kernel<RR, SS, AT>;                                                                             \
-    static int resident = 0;                                                                                                \
-    if (!resident) {                                                                                                        \
-      int per_cu = 0, dev = 0;                                                                                              \
-      hipDeviceProp_t prop;                                                                                                 \
-      FZ_HIP_OK(hipGetDevice(&dev));                                                                                        \
-      FZ_HIP_OK(hipGetDeviceProperties(&prop, dev));                                                                        \
-      FZ_HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 512, lds));      \
-      resident = (per_cu > 0 ? per_cu : 1) * prop.multiProcessorCount;                                                      \
-    }                                                                                                                       \
-    unsigned grid = (tune && tune[2] > 0) ? (unsigned)tune[2] : knob_cf2_wgs() > 0 ? (unsigned)knob_cf2_wgs() : (unsigned)resident;                                     \
-    if (grid > p.total) grid = p.total;                                                                                     \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, t, u0, v0, out, q, p, T, eps, (unsigned*)workspace, bytes);    \
-  } while (0)
-  if (solver == FZ_SOLVER_MU) FZ_CF_FWD2(1, SOLVER_MU); else FZ_CF_FWD2(1, SOLVER_HALS);
-  FZ_LAUNCH_CHECK();
-  return FZ_OK;
-}
-
-extern "C" int fz_nmf_cf_fwd2(const void* t, const float* u0, const float* v0, void* out, int B, int C, int D, int H, int W,
-                              const int* shifts, int R, int T, int solver, float eps, int act_dtype, void* workspace,
-                              const int* tune, fz_stream_t stream) {
-  if (act_dtype == FZ_STORE_F32)
-    return cf_fwd2_launch<float>((const float*)t, u0, v0, (float*)out, B, C, D, H, W, shifts, R, T, solver, eps, workspace, tune, stream);
-  if (act_dtype == FZ_STORE_BF16)
-    return cf_fwd2_launch<bf16>((const bf16*)t, u0, v0, (bf16*)out, B, C, D, H, W, shifts, R, T, solver, eps, workspace, tune, stream);
-  return fail(FZ_E_ARG, "fz_nmf_cf_fwd2: bad act_dtype");
-}
-
-template <typename AT>
-static int cf_bwd2_launch(const AT* t, const float* u0, const float* v0, const AT* ga, AT* gt, int B, int C, int D, int H,
-                          int W, const int* shifts, int relu_gate, int R, int T, int Tgrad, int solver, float eps,
-                          void* workspace, const int* tune, fz_stream_t stream) {
-  if (!t || !u0 || !v0 || !ga || !gt || !shifts || !workspace) return fail(FZ_E_ARG, "fz_nmf_cf_bwd2: null pointer");
-  if (R != 1) return fail(FZ_E_UNSUPPORTED, "fz_nmf_cf_bwd2: rank 1 (see fz_nmf_cf2_supported)");
-  if (solver != FZ_SOLVER_MU && solver != FZ_SOLVER_HALS) return fail(FZ_E_ARG, "fz_nmf_cf_bwd2: bad solver");
-  CfGeom q;
-  const int zero[3] = {0, 0, 0};
-  int rc = cf_geom(q, B, C, D, H, W, zero, 0, 1);
-  if (rc != FZ_OK) return rc;
-  q.gscale_div = 2.0f;
-  Cf2Plan p;
-  if (B < 1 || !cf2_plan(p, B, C, D, H, W, shifts, 4, (int)sizeof(AT), 7, tune))
-    return fail(FZ_E_UNSUPPORTED, "fz_nmf_cf_bwd2: geometry outside the two-window launch (see fz_nmf_cf2_supported)");
-  p.divisor = 1;
-  const int G = Tgrad < 0 ? 0 : (Tgrad > T ? T : Tgrad);
-  const int per_wave = Hist<8, 8, 1>::floats(G) * (int)sizeof(float);
-  const int lds = CfTile<4>::STAGE_FLOATS * (int)sizeof(float) + 4 * per_wave + 16;
-  if (lds > 160 * 1024) return fail(FZ_E_UNSUPPORTED, "fz_nmf_cf_bwd2: history exceeds LDS");
-  hipStream_t st = (hipStream_t)stream;
-  FZ_HIP_OK(hipMemsetAsync(workspace, 0, (size_t)fz_nmf_cf2_workspace_bytes(B, C, D), st));
-  const unsigned bytes = (unsigned)((int64_t)B * C * D * H * W * (int64_t)sizeof(AT));
-#define FZ_CF_BWD2(RR, SS)                                                                                                  \
-  do {                                                                                                                      \
-    auto kern = nmf_cf_bwd2_kernel<RR, SS, AT>;                                                                             \
-    static int resident = 0, resident_lds = -1;                                                                             \
-    if (lds > 65536)                                                                                                        \
-      FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
-    if (!resident || resident_lds != lds) {                                                                                 \
-      int per_cu = 0, dev = 0;                                                                                              \
-      hipDeviceProp_t prop;                                                                                                 \
-      FZ_HIP_OK(hipGetDevice(&dev));                                                                                        \
-      FZ_HIP_OK(hipGetDeviceProperties(&prop, dev));                                                                        \
-      FZ_HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 256, lds));      \
-      resident = (per_cu > 0 ? per_cu : 1) * prop.multiProcessorCount;                                                      \
-      resident_lds = lds;                                                                                                   \
-    }                                                                                                                       \
-    unsigned grid = (tune && tune[2] > 0) ? (unsigned)tune[2] : knob_cf2_wgs() > 0 ? (unsigned)knob_cf2_wgs() : (unsigned)resident;                                     \
-    if (grid > p.total) grid = p.total;                                                                                     \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, t, u0, v0, ga, gt, q, p, T, G, eps, relu_gate,                  \
-                       (unsigned*)workspace, bytes);                                                                        \
-  } while (0)
-  if (solver == FZ_SOLVER_MU) FZ_CF_BWD2(1, SOLVER_MU); else FZ_CF_BWD2(1, SOLVER_HALS);
-  FZ_LAUNCH_CHECK();
-  return FZ_OK;
-}
-
-extern "C" int fz_nmf_cf_bwd2(const void* t, const float* u0, const float* v0, const void* ga, void* gt, int B, int C, int D,
-                              int H, int W, const int* shifts, int relu_gate, int R, int T, int Tgrad, int solver, float eps,
-                              int act_dtype, void* workspace, const int* tune, fz_stream_t stream) {
-  if (act_dtype == FZ_STORE_F32)
-    return cf_bwd2_launch<float>((const float*)t, u0, v0, (const float*)ga, (float*)gt, B, C, D, H, W, shifts, relu_gate, R, T,
-                                 Tgrad, solver, eps, workspace, tune, stream);
-  if (act_dtype == FZ_STORE_BF16)
-    return cf_bwd2_launch<bf16>((const bf16*)t, u0, v0, (const bf16*)ga, (bf16*)gt, B, C, D, H, W, shifts, relu_gate, R, T, Tgrad,
-                                solver, eps, workspace, tune, stream);
-  return fail(FZ_E_ARG, "fz_nmf_cf_bwd2: bad act_dtype");
 }

@@ -382,30 +382,6 @@ def nmf_pcf_supported(geo: Geometry, R, T, G) -> bool:
     return bool(N.lib().fz_nmf_pcf_supported(geo.C, *geo.spatial, geo.d, *geo.patch, int(R), int(T), int(G)))
 
 
-# Both windows of the fused core in ONE slab-major launch (fz_nmf_cf_fwd2 / fz_nmf_cf_bwd2).  Bit-identical to the two
-# launches and measured SLOWER on MI355X (profiles/r04_cf2_sweep.json: the wave program keeps 4 096 matrices = 2/3 of the
-# Infinity Cache in flight, so a producer -> consumer distance of one tile lifetime is already the whole cache): off unless
-# FZ_CF2=1 (read once).
-_CF2 = os.environ.get("FZ_CF2", "0") == "1"
-
-
-def nmf_cf2_plan(geo: Geometry, B, R, T, G, ad):
-    """Both windows of the default two-window SWMatricize in ONE launch, scheduled for the Infinity Cache
-    (csrc/nmf_cf.hip, fz_nmf_cf_fwd2 / fz_nmf_cf_bwd2): the 2 x 3 host shift array when the geometry is covered, else None."""
-    if not _CF2 or geo.nshift != 2 or len(geo.spatial) != 3 or not nmf_cf_supported(geo, R, T, G):
-        return None
-    arr = (N._i * 6)(*geo.shifts[0], *geo.shifts[1])
-    ok = N.lib().fz_nmf_cf2_supported(int(B), geo.C, *geo.spatial, arr, 2, int(R), int(T), int(G), ad)
-    return arr if ok else None
-
-
-def _cf2_workspace(t, B, geo):
-    """counters of the in-launch hand-off (zeroed by the call, on the launch stream); from the caching allocator per call, so
-    launches on different streams never share one"""
-    nbytes = int(N.lib().fz_nmf_cf2_workspace_bytes(int(B), geo.C, geo.spatial[0]))
-    return torch.empty(nbytes // 4, dtype=torch.int32, device=t.device)
-
-
 def nmf_core_supported(geo: Geometry, R, T, G) -> bool:
     return nmf_cf_supported(geo, R, T, G) or nmf_pcf_supported(geo, R, T, G)
 
@@ -413,7 +389,8 @@ def nmf_core_supported(geo: Geometry, R, T, G) -> bool:
 class FactCoreFn(torch.autograd.Function):
     """a = SWMatricize⁻¹(NMF(SWMatricize(t))) for t >= 0 already activated (factorizer.py:41-50)
     without materialising the matricized tensors (csrc/nmf_cf.hip).  `relu_gate`: the caller's
-    t is relu(z); the backward then returns the gradient w.r.t. z (gated by [t > 0])."""
+    t is relu(z) (so t >= 0 — the library relies on it: HALS rank 1 then runs its backward in the row space,
+    csrc/nmf_gram.h); the backward returns the gradient w.r.t. z (gated by [t > 0])."""
 
     @staticmethod
     def forward(ctx, t, u0, v0, geo, T, G, solver, eps, relu_gate):
@@ -426,16 +403,8 @@ class FactCoreFn(torch.autograd.Function):
         nb = 2 * es * t.numel()
         ad = N.act_dtype(t)
         hot = nmf_cf_supported(geo, R, T, G)      # 8x8x8 patches: csrc/nmf_cf.hip; any other patch: csrc/nmf_pcf.hip
-        both = nmf_cf2_plan(geo, B, R, T, G, ad) if hot else None
         with _dev_guard(t):
-            if both is not None:   # the two windows as ONE slab-major launch: 5 tensor passes, 2 of them from HBM
-                ws = _cf2_workspace(t, B, geo)
-                rc = _timed(f"nmf_cf_fwd2_{geo.C}x" + "x".join(str(v) for v in geo.spatial), 5 * es * t.numel(), cols=t.numel() // geo.C,
-                            fn=lambda: N.lib().fz_nmf_cf_fwd2(t.data_ptr(), u0.data_ptr(), v0.data_ptr(), out.data_ptr(), B, geo.C,
-                                                              *geo.spatial, both, R, T, N.SOLVER_ID[solver], eps, ad, ws.data_ptr(),
-                                                              None, N.stream_ptr(t)))
-                N.check(rc, "fz_nmf_cf_fwd2")
-            for w, s in enumerate(geo.shifts if both is None else ()):
+            for w, s in enumerate(geo.shifts):
                 arr = (N._i * 3)(*s)
                 last = geo.nshift if w == geo.nshift - 1 else 1
                 if hot:
@@ -467,16 +436,8 @@ class FactCoreFn(torch.autograd.Function):
         nb = 3 * es * t.numel()
         ad = N.act_dtype(t)
         hot = nmf_cf_supported(geo, R, T, G)
-        both = nmf_cf2_plan(geo, B, R, T, G, ad) if hot else None
         with _dev_guard(t):
-            if both is not None:   # 7 tensor passes, 3 of them from HBM
-                ws = _cf2_workspace(t, B, geo)
-                rc = _timed(f"nmf_cf_bwd2_{geo.C}x" + "x".join(str(v) for v in geo.spatial), 7 * es * t.numel(), cols=t.numel() // geo.C,
-                            fn=lambda: N.lib().fz_nmf_cf_bwd2(t.data_ptr(), u0.data_ptr(), v0.data_ptr(), ga.data_ptr(), gt.data_ptr(),
-                                                              B, geo.C, *geo.spatial, both, int(relu_gate), R, T, G,
-                                                              N.SOLVER_ID[solver], eps, ad, ws.data_ptr(), None, N.stream_ptr(t)))
-                N.check(rc, "fz_nmf_cf_bwd2")
-            for w, s in enumerate(geo.shifts if both is None else ()):
+            for w, s in enumerate(geo.shifts):
                 arr = (N._i * 3)(*s)
                 if hot:
                     rc = _timed(f"nmf_cf_bwd_{geo.C}x" + "x".join(str(v) for v in geo.spatial), nb + (es * t.numel() if w else 0), cols=t.numel() // geo.C, fn=lambda: N.lib().fz_nmf_cf_bwd(

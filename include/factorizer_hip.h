@@ -130,7 +130,10 @@ int fz_gnmf_bwd(const float* x, const float* u0, const float* v0, const float* g
  *        call once per window in order with accumulate = (w > 0), divisor = nshift on the last
  *        window (1 otherwise).
  *   bwd: gt (+)= [t > 0 if relu_gate] * scatter_w(dNMF(gather_w(t); gather_w(ga) / nshift));
- *        call once per window with accumulate = (w > 0).
+ *        call once per window with accumulate = (w > 0).  relu_gate = 1 is the CONTRACT "t = relu(z) >= 0 and gt is the
+ *        gradient with respect to z" (factorizer.py:44): for HALS rank 1 the backward then runs in the 8-dimensional row space
+ *        (csrc/nmf_gram.h — for a non-negative matrix no ReLU of the iteration ever clips, and v can be eliminated); a t with
+ *        negative entries must be passed with relu_gate = 0.
  * t, out, ga, gt: (B, C, D, H, W) activations (act_dtype: fp32, or bf16 storage — the running window sum is
  * then rounded to bf16 between windows, the factorisation itself stays fp32); shift: HOST pointer to 3 ints
  * (W-axis shift even).
@@ -143,28 +146,6 @@ int fz_nmf_cf_bwd(const void* t, const float* u0, const float* v0, const void* g
                   int C, int D, int H, int W, const int* shift, int accumulate, int nshift,
                   int relu_gate, int R, int T, int Tgrad, int solver, float eps, int act_dtype,
                   fz_stream_t stream);
-
-/* BOTH shift windows of the default two-window SWMatricize (shifts [None, patch/2], operations.py:395-398) in ONE launch,
- * walked slab-major so that window 1's read of t and its read-modify-write of the running average are served by the
- * 256 MiB Infinity Cache instead of HBM (csrc/nmf_cf.hip "two windows in one launch").  Same values, bit for bit, as the
- * two fz_nmf_cf_fwd / fz_nmf_cf_bwd calls they replace: ((0 + z_0) + z_1) / 2 resp. gt = gate(g_0) + gate(g_1).
- *   shifts: HOST pointer to 2 x 3 ints, window 0 then window 1; supported when window 0 is unshifted, window 1's D-axis
- *           shift is 1..7 voxels and its W-axis shift a multiple of 4, rank 1, W / 8 a multiple of 8, tensor < 2 GiB
- *           (fz_nmf_cf2_supported; otherwise call the one-window entry points).
- *   workspace: fz_nmf_cf2_workspace_bytes(B, C, D) bytes of device memory, caller-owned, 16-byte aligned; zeroed by the call
- *           on `stream` (ticket counter, per-(slice, patch-plane) completion counters of the in-launch hand-off, a
- *           time-out word at byte 4 that stays 0 unless the hand-off protocol is broken).
- *   tune: NULL, or HOST pointer to 3 ints {slices per group, extra planes window 1 trails by, persistent workgroups}; a
- *           value <= 0 (lag: < 0) keeps the launch function's own choice.  Results do not depend on it. */
-int64_t fz_nmf_cf2_workspace_bytes(int B, int C, int D);
-int fz_nmf_cf2_supported(int B, int C, int D, int H, int W, const int* shifts, int nshift, int R, int T, int Tgrad,
-                         int act_dtype);
-int fz_nmf_cf_fwd2(const void* t, const float* u0, const float* v0, void* out, int B, int C, int D, int H, int W,
-                   const int* shifts, int R, int T, int solver, float eps, int act_dtype, void* workspace,
-                   const int* tune, fz_stream_t stream);
-int fz_nmf_cf_bwd2(const void* t, const float* u0, const float* v0, const void* ga, void* gt, int B, int C, int D,
-                   int H, int W, const int* shifts, int relu_gate, int R, int T, int Tgrad, int solver, float eps,
-                   int act_dtype, void* workspace, const int* tune, fz_stream_t stream);
 
 /* The same fused core for ANY patch (pd, ph, pw) with head_dim 8 and at most 256 voxels per patch (csrc/nmf_pcf.hip:
  * BASELINE configs[4] uses patch (5,6,5) because 160x192x160 is not divisible by 8; the p = 4 test configurations):

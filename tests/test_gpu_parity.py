@@ -395,7 +395,12 @@ def test_fact_core_fused_vs_modular(S, shifts, solver, R):
     t3 = t.clone().requires_grad_(True)
     a3 = Fn.FactCoreFn.apply(t3, nmf.init.u0, nmf.init.v0, m.geometry, 4, G, solver, 1e-16, True)
     (g3,) = torch.autograd.grad(a3, t3, ga)
-    assert torch.allclose(g3, g1 * (t > 0), rtol=0, atol=0)
+    if solver == "hals" and R == 1:
+        # relu_gate = True is the promise t >= 0: HALS rank 1 then runs its backward in the row space (csrc/nmf_gram.h) — the
+        # same function evaluated in another order (tests/test_gpu_gram.py holds it to the float64 oracle)
+        P.close("gt row-space vs general wave program", g3, g1 * (t > 0), rel=1e-5)
+    else:
+        assert torch.allclose(g3, g1 * (t > 0), rtol=0, atol=0)
 
 
 @pytest.mark.parametrize("S,patch", [((10, 12, 20), (5, 6, 5)), ((8, 8, 16), (4, 4, 4)), ((6, 10, 14), (3, 5, 7)),

@@ -15,7 +15,16 @@ HOT = {
                  "gemm_dw_kernelILb1Ef", "gemm_dw_kernelILb0Ef", "gemm_chain64_kernelILb0Ef", "gemm_chain64_kernelILb1Ef",
                  "gemm_chain_kernelILb0ELi2ELi2Ef"],
     "nmf_cf.hip": ["nmf_cf_bwd_tile_kernelILi1ELi1ELi4ELb0Ef", "nmf_cf_fwd_tile_kernelILi1ELi1ELi8ELb0Ef"],
+    "nmf_cf_gram.hip": ["nmf_cf_bwd_gram_kernelILi4ELb0EfLi0E", "nmf_cf_bwd_gram_kernelILi4ELb0EDF16bLi2E"],
 }
+
+
+def test_row_space_backward_fits_three_waves_per_simd(metadata):
+    """csrc/nmf_cf_gram.hip is designed for three 4-wave workgroups per CU: 512 / 3 -> at most 168 registers."""
+    hits = {k: v for k, v in metadata.items() if "nmf_cf_bwd_gram_kernelILi4E" in k}
+    assert len(hits) == 4
+    for name, (vgprs, spills) in hits.items():
+        assert vgprs <= 168 and spills == 0, (name, vgprs, spills)
 
 
 @pytest.fixture(scope="module")

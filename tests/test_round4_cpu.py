@@ -1,5 +1,4 @@
-"""CPU-side tests of the round-4 host logic (no GPU): the geometry rules of the two-window launch (pure host functions of the
-library), the per-call `products` / `tune` plumbing, the flat-gradient destination table holding buffers weakly, and the
+"""CPU-side tests of the round-4 host logic (no GPU): the per-call `products` / `tune` plumbing, the flat-gradient destination table holding buffers weakly, and the
 read-once diagnostic knobs of the Python layer.  Reference behaviour these serve: SWMatricize's default two windows
 (operations.py:395-398), DistributedDataParallel's bucket memory (train_multigpu.yaml:3-6)."""
 import copy
@@ -12,38 +11,6 @@ import torch
 
 from factorizer_amd import _native as N
 from factorizer_amd import gradbuf
-
-
-def _sup(B, C, S, sh, R=1, dt=0, nshift=2):
-    arr = (N._i * 6)(*sh[0], *sh[1])
-    return N.lib().fz_nmf_cf2_supported(B, C, *S, arr, nshift, R, 5, 5, dt)
-
-
-def test_two_window_launch_geometry_rules():
-    ok = [(0, 0, 0), (4, 4, 4)]
-    assert _sup(2, 32, (128, 128, 128), ok) == 1                      # README stage 0
-    assert _sup(2, 64, (64, 64, 64), ok) == 1                         # stage 1
-    assert _sup(2, 32, (128, 128, 128), ok, dt=1) == 1                # bf16 storage
-    assert _sup(2, 128, (32, 32, 32), ok) == 0                        # W / 8 = 4: no eight-patch tile
-    assert _sup(2, 32, (128, 128, 128), ok, R=2) == 0                 # rank 2 stays on the one-window launches
-    assert _sup(2, 32, (128, 128, 128), ok, nshift=4) == 0            # only the two-window default
-    assert _sup(2, 32, (128, 128, 128), [(4, 4, 4), (0, 0, 0)]) == 0  # window 0 must be the unshifted one
-    assert _sup(2, 32, (128, 128, 128), [(0, 0, 0), (0, 4, 4)]) == 0  # D shift 0: not the plane - 1 / plane dependency
-    assert _sup(2, 32, (128, 128, 128), [(0, 0, 0), (8, 4, 4)]) == 0
-    assert _sup(2, 32, (128, 128, 128), [(0, 0, 0), (4, 4, 6)]) == 0  # W shift 2 (mod 4)
-    assert _sup(2, 32, (128, 128, 128), [(0, 0, 0), (-4, 4, 4)]) == 0 # -4 = 124 (mod 128): needs planes plane + 15 / + 16, not built
-    assert _sup(16, 32, (128, 128, 128), ok) == 0                     # 4.3 GB tensor: beyond 32-bit buffer offsets
-
-
-def test_two_window_workspace_size():
-    lib = N.lib()
-    n = lib.fz_nmf_cf2_workspace_bytes(2, 32, 128)
-    assert n % 16 == 0 and n >= (16 + 2 * 4 * 16) * 4
-    assert lib.fz_nmf_cf2_workspace_bytes(-1, 32, 128) == 0
-    # null pointers are refused before anything is launched
-    arr = (N._i * 6)(0, 0, 0, 4, 4, 4)
-    rc = lib.fz_nmf_cf_fwd2(None, None, None, None, 2, 32, 128, 128, 128, arr, 1, 5, 1, 1e-16, 0, None, None, None)
-    assert rc != 0 and b"null" in lib.fz_last_error_string()
 
 
 def test_products_setting_nests_and_reaches_the_descriptors():

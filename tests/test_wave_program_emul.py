@@ -19,7 +19,7 @@ CORE = os.path.join(os.path.dirname(HERE), "factorizer_amd", "csrc", "nmf_core.h
 
 @pytest.fixture(scope="module")
 def emu():
-    newest = max(os.path.getmtime(SRC), os.path.getmtime(CORE))
+    newest = max(os.path.getmtime(SRC), os.path.getmtime(CORE), os.path.getmtime(CORE.replace("nmf_core.h", "nmf_gram.h")))
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < newest:
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-o", LIB, SRC])
     lib = ctypes.CDLL(LIB)
@@ -101,3 +101,56 @@ def test_emul_vs_oracle_shapes(emu, M, N, solver):
             kink = (gxo - gx64).abs().max().item()
             s = gxo.abs().max().item()
             assert (gx - gx64).abs().max().item() <= 2e-4 * s + 1e-5 + 30 * kink, (R, G)
+
+
+# ---- the row-space (Gram) reverse mode of csrc/nmf_gram.h: HALS rank 1 on non-negative matrices -------------------------
+def emu_gram_bwd(lib, x, v0, gy, T, G, gscale=1.0):
+    M, N = x.shape[-2:]
+    xn = np.ascontiguousarray(x.reshape(-1, M, N).numpy())
+    gyn = np.ascontiguousarray(gy.reshape(-1, M, N).numpy())
+    gx = np.empty_like(xn)
+    lib.emu_gram_bwd.argtypes = [ctypes.POINTER(ctypes.c_float)] * 4 + [ctypes.c_int64] + [ctypes.c_int] * 4 + [ctypes.c_float] * 2
+    rc = lib.emu_gram_bwd(_p(xn), _p(np.ascontiguousarray(v0.numpy())), _p(gyn), _p(gx), xn.shape[0], M, N, T, G, 1e-16, gscale)
+    assert rc == 0
+    return torch.from_numpy(gx).reshape(x.shape)
+
+
+@pytest.mark.parametrize("name", ["cfg2_hals_r1_t5", "hals_r1_t5_g1", "hals_r1_t5", "hals_r1_t10"])
+def test_gram_emul_vs_reference_goldens(emu, golden, name):
+    """The row-space backward reproduces the input gradients the REFERENCE's autograd gave for its own rank-1 HALS
+    iteration (matrix_factorization.py:210-229,506-533) — goldens generated by importing the reference; they include an
+    all-zero matrix, where every ε of the iteration matters."""
+    g = golden("g2_nmf").case(name)
+    kw = NMF_CASES[name]
+    assert (g["x"] >= 0).all() and g["u0"].shape[1] == 1
+    T = kw["num_iters"]
+    G = kw.get("num_grad_steps") or T
+    gx = emu_gram_bwd(emu, g["x"], g["v0"], g["gy"], T, G)
+    scale = g["gx"].abs().max().item()
+    assert (gx - g["gx"]).abs().max().item() <= 1e-4 * scale + 1e-5
+    # per matrix, against the float64 oracle: the row-space form is at least as accurate as the reference's own fp32 arithmetic
+    x, gy = g["x"].reshape(-1, *g["x"].shape[-2:]), g["gy"].reshape(-1, *g["x"].shape[-2:])
+    gx64 = O.nmf_backward(x.double(), g["u0"].double(), g["v0"].double(), gy.double(), T, "hals", G)
+    s = gx64.abs().amax(dim=(1, 2)).clamp_min(1e-30)
+    e = (gx.reshape(x.shape).double() - gx64).abs().amax(dim=(1, 2)) / s
+    assert e.max().item() <= 5e-6, e
+
+
+@pytest.mark.parametrize("M,N", [(8, 512), (8, 200), (8, 150), (8, 64), (5, 100)])
+@pytest.mark.parametrize("T,G", [(5, 5), (4, 3), (4, 1), (1, 1), (10, 10)])
+def test_gram_emul_vs_oracle(emu, M, N, T, G):
+    """Shapes with masked rows / columns, every relation of graded to total iterations, an all-zero matrix, zero rows and
+    zero column blocks, the 1 / windows scale of the fused core — against the float64 oracle, per matrix."""
+    torch.manual_seed(M * 1000 + N + T)
+    x = torch.rand(5, M, N)
+    x[1] = 0
+    x[2, :, : N // 2] = 0
+    x[3, 2] = 0
+    x[4] = x[4] * (torch.rand(M, N) > 0.7)
+    u0, v0 = torch.rand(M, 1), torch.rand(N, 1)
+    gy = torch.rand_like(x) - 0.3
+    gx = emu_gram_bwd(emu, x, v0, gy, T, G, gscale=0.5)
+    gx64 = O.nmf_backward(x.double(), u0.double(), v0.double(), 0.5 * gy.double(), T, "hals", G)
+    s = gx64.abs().amax(dim=(1, 2)).clamp_min(1e-30)
+    e = (gx.double() - gx64).abs().amax(dim=(1, 2)) / s
+    assert e.max().item() <= 5e-6, e
