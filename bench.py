@@ -265,6 +265,76 @@ def nmf_gflops(table, nsteps, B):
     return out
 
 
+
+def other_configs(dev):
+    """The other BASELINE.json configurations that fit one GPU, timed AFTER the headline's timed region so that the driver's
+    one JSON line carries them: configs[1] FactorizerBlock fwd+bwd, configs[2] README model eval
+    forward, configs[4] one GPU's share of the BraTS-shape stress case under bf16 autocast at its per-GPU batch of 4.
+    Synthetic inputs, HIP events on the current stream; a few seconds in total."""
+    import contextlib
+    from torch import nn
+    out = []
+
+    def gpu_ms(fn, iters, warm):
+        for _ in range(warm):
+            fn()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        s.record()
+        for _ in range(iters):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / iters
+
+    def record(name, dtype, B, ms, **kw):
+        out.append({"config": name, "dtype": dtype, "batch": B, "ms": round(ms, 3), "volumes_per_s": round(B / ms * 1e3, 2),
+                    "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1), **kw})
+
+    # configs[1]: single FactorizerBlock (C = 32, 128^3, head_dim 8, patch 8, HALS rank 1, 5 iterations), fwd + bwd, B = 2
+    torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
+    torch.manual_seed(0)
+    blk = ft.FactorizerBlock(channels=32, spatial_size=(128, 128, 128), norm=ft.LayerNorm,
+                             reshape=(ft.SWMatricize, {"head_dim": 8, "patch_size": 8}), act=nn.ReLU, factorize=ft.NMF, rank=1,
+                             num_iters=5, init="uniform", solver="hals", mlp_ratio=2, dropout=0.0).to(dev)
+    x = torch.rand(2, 32, 128, 128, 128, device=dev, requires_grad=True)
+    g = torch.rand(2, 32, 128, 128, 128, device=dev)
+    ps = [x] + list(blk.parameters())
+    record("configs[1] FactorizerBlock C=32 128^3 fwd+bwd", "f32", 2, gpu_ms(lambda: torch.autograd.grad(blk(x), ps, g), 20, 5))
+    del blk, x, g, ps
+    # configs[2]: README Swin Factorizer, eval forward, B = 2
+    torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
+    torch.manual_seed(0)
+    model = ft.Factorizer(**MODEL_KW).to(dev).eval()
+    x = torch.rand(2, 4, 128, 128, 128, device=dev)
+    with torch.no_grad():
+        record("configs[2] README Swin Factorizer eval forward", "f32", 2, gpu_ms(lambda: model(x), 15, 3))
+    del model, x
+    # configs[4], one GPU's share: 160x192x160, HALS rank 2, 10 iterations, patch (5,6,5) (p = 8 does not divide the shape,
+    # SURVEY headline 5), bf16 autocast, per-GPU batch 4, training forward + loss + backward
+    torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
+    torch.manual_seed(0)
+    kw = dict(MODEL_KW, spatial_size=(160, 192, 160), reshape=(ft.SWMatricize, {"head_dim": 8, "patch_size": (5, 6, 5)}),
+              rank=2, num_iters=10)
+    model = ft.Factorizer(**kw).to(dev).train()
+    x = torch.rand(4, 4, 160, 192, 160, device=dev)
+    t = (torch.rand(4, 3, 160, 192, 160, device=dev) > 0.5).float()
+
+    def fb():
+        for p in model.parameters():
+            p.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = ft.dice_ce_loss(model(x), t)
+        loss.backward()
+        return loss
+    loss = fb()
+    record("configs[4] BraTS-shape stress 160x192x160, HALS R2 T10, patch (5,6,5), fwd+loss+bwd", "bf16 activations (autocast), fp32 "
+           "parameters / statistics / NMF internals", 4, gpu_ms(fb, 5, 2), loss_finite=bool(torch.isfinite(loss).item()))
+    del model, x, t
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -272,6 +342,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch-per-gpu", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the BASELINE configs[1], [2], [4] timings appended to the JSON line as `other_configs`")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
                     help="f32 (the reference's precision: the headline line) or bf16 = torch.autocast(bfloat16): bf16 "
                          "activation storage, fp32 parameters / statistics / accumulation / NMF internals (BASELINE configs[4] mode)")
@@ -464,6 +536,9 @@ def main():
                      if use_dist and os.environ.get("FZ_BENCH_BACKEND", "nccl") == "nccl" else
                      ("gloo" if use_dist else "not initialised (single rank; --force-dist runs it)")),
         }
+        if world == 1 and not args.no_other_configs and args.dtype == "f32":
+            del model, opt, sync, x, target
+            out["other_configs"] = other_configs(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_sample()
         if json_fd is not None:

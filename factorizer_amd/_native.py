@@ -17,31 +17,56 @@ LIB_PATH = os.environ.get("FZ_LIB_PATH") or os.path.join(_HERE, "libfactorizer_h
 
 FZ_OK = 0
 FZ_E_UNSUPPORTED = -2
+ABI_VERSION = 5   # include/factorizer_hip.h: FZ_ABI_VERSION this binding's argument lists / descriptor layouts are written against
 SOLVER_ID = {"mu": 0, "hals": 1}
 STORE_F32, STORE_BF16 = 0, 1   # include/factorizer_hip.h: FZ_STORE_*
 PRODUCTS_DEFAULT, PRODUCTS_SPLIT_BF16, PRODUCTS_FP32_MFMA = 0, 1, 2   # FZ_PRODUCTS_*: the `products` field of the descriptors
-_products = [PRODUCTS_DEFAULT]
+_products = threading.local()   # per thread: two models driven from two threads may use different pipes
 
 
 def products() -> int:
     """the FZ_PRODUCTS_* value this package's layers put in their descriptors (default: the library's own default)"""
-    return _products[0]
+    return getattr(_products, "value", PRODUCTS_DEFAULT)
 
 
 class use_products:
-    """with use_products(PRODUCTS_FP32_MFMA): ...  — fp32 products of every dense layer launched inside the block (forward AND
-    the backward passes run inside it: autograd's worker threads read the same setting) on the named pipe, through the
-    descriptors' `products` field.  The C ABI has no switch to flip for this: a caller of the library sets the field per call."""
+    """with use_products(PRODUCTS_FP32_MFMA): ...  — fp32 products of every dense layer whose FORWARD runs inside the block on
+    the named pipe, through the descriptors' `products` field.  The setting is per thread; every autograd node records it in
+    its ctx at forward time and re-establishes it for its backward (`capture_products` / `with_products` below), so a backward
+    pass that runs after the block has exited, or on one of autograd's worker threads, multiplies on the same pipe as its
+    forward did.  The C ABI has no switch to flip for this: a caller of the library sets the field per call."""
 
     def __init__(self, value):
         self.value = int(value)
 
     def __enter__(self):
         self.prev = products()
-        _products[0] = self.value
+        _products.value = self.value
 
     def __exit__(self, *exc):
-        _products[0] = self.prev
+        _products.value = self.prev
+
+
+def capture_products(fwd):
+    """decorator of an autograd Function's forward(ctx, ...): remember the thread's products setting in the ctx"""
+    import functools
+
+    @functools.wraps(fwd)
+    def wrapper(ctx, *a, **kw):
+        ctx._fz_products = products()
+        return fwd(ctx, *a, **kw)
+    return wrapper
+
+
+def with_products(bwd):
+    """decorator of the matching backward(ctx, ...): run it under the setting its forward saw"""
+    import functools
+
+    @functools.wraps(bwd)
+    def wrapper(ctx, *a, **kw):
+        with use_products(getattr(ctx, "_fz_products", PRODUCTS_DEFAULT)):
+            return bwd(ctx, *a, **kw)
+    return wrapper
 
 
 def act_dtype(t: torch.Tensor) -> int:
@@ -61,6 +86,7 @@ _vp, _i, _i64, _f = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float
 
 _SIGS = {
     "fz_version": ([], _i),
+    "fz_abi_version": ([], _i),
     "fz_last_error_string": ([], _c.c_char_p),
     "fz_launch_count": ([], _i64),
     "fz_swm_fwd": ([_vp, _vp] + [_i] * 10 + [_c.POINTER(_i), _i, _i, _i, _vp], _i),
@@ -92,6 +118,14 @@ def lib():
                 f"{LIB_PATH} not found: build it with `python -m factorizer_amd.build` "
                 "(hipcc --offload-arch=gfx950). Device tensors have no fallback path.")
         h = ctypes.CDLL(LIB_PATH)
+        try:
+            h.fz_abi_version.restype = ctypes.c_int
+            abi = int(h.fz_abi_version())
+        except AttributeError:
+            abi = None
+        if abi != ABI_VERSION:
+            raise NativeError(f"{LIB_PATH} has ABI revision {abi}, this binding is written against {ABI_VERSION} "
+                              "(include/factorizer_hip.h: FZ_ABI_VERSION): rebuild with `python -m factorizer_amd.build`")
         for name, (args, res) in _SIGS.items():
             fn = getattr(h, name)  # AttributeError if the .so does not export it
             fn.argtypes = args

@@ -12,6 +12,7 @@ std::atomic<int64_t>& launch_counter() {
 }
 }  // namespace fz
 
-extern "C" int fz_version(void) { return 100; }  // 0.1.0
+extern "C" int fz_version(void) { return 500; }  // 0.5.0
+extern "C" int fz_abi_version(void) { return FZ_ABI_VERSION; }
 extern "C" const char* fz_last_error_string(void) { return fz::last_error().c_str(); }
 extern "C" int64_t fz_launch_count(void) { return fz::launch_counter().load(); }

@@ -21,15 +21,21 @@ inline int fail(int code, const char* msg) {
   return code;
 }
 
-// Diagnostic environment knobs are read ONCE per process, at the first launch that consults them (a function-local static
-// at the call site): no getenv on a launch path after that, and a knob cannot change between a workspace-size query and the
-// launch that fills the workspace.  `str` stays valid for the life of the process (the environment block is not modified).
+// Diagnostic environment knobs exist only in PROBE builds of the library (-DFZ_PROBE: tools/probes/build_alt.py builds a
+// second .so, loaded through FZ_LIB_PATH for same-box A/B runs).  The shipped library reads ONE environment variable,
+// FZ_GEMM_BX (the process default of the `products` descriptor field; both settings are valid results), and nothing else:
+// FZ_KNOB(name) is a compile-time "unset" there, so every tuning / A-B branch folds to its default.  In a probe build a knob
+// is read once per process, at the first launch that consults it (a function-local static at the call site).
 struct EnvKnob { bool set; int val; const char* str; };
+#ifdef FZ_PROBE
 inline EnvKnob env_knob(const char* name) {
   const char* e = getenv(name);
   return EnvKnob{e != nullptr, e ? atoi(e) : 0, e};
 }
-#define FZ_ENV_KNOB(name) ([]() -> const fz::EnvKnob& { static const fz::EnvKnob k_ = fz::env_knob(name); return k_; }())
+#define FZ_KNOB(name) ([]() -> const fz::EnvKnob& { static const fz::EnvKnob k_ = fz::env_knob(name); return k_; }())
+#else
+#define FZ_KNOB(name) (fz::EnvKnob{false, 0, nullptr})
+#endif
 
 // fp32 products of a layer: the descriptor's `products` field, or the process default (fz_gemm_bx_enable) when it is unset
 inline bool products_split(int field) {

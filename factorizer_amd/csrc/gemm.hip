@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256, ((NSTEP <= 16 && EPI == EPI_PLAIN && !BMUL && 
 
   // batched fill (8 independent loads per thread before the LDS stores)
   constexpr int kFill = (NSTEP <= 16 && EPI == EPI_PLAIN && !BMUL) ? 4 : 8;   // independent loads per thread and round
-  for (int base = threadIdx.x; base < (p.dbg == 3 ? 0 : nA * RB * 64); base += blockDim.x * kFill) {
+  for (int base = threadIdx.x; base < nA * RB * 64; base += blockDim.x * kFill) {
     float tmp[kFill];
 #pragma unroll
     for (int uu = 0; uu < kFill; ++uu) {
@@ -2444,7 +2444,7 @@ __global__ __launch_bounds__(256, ((MB == 2 && NACC == 4 && PRO == 3 /* gate ope
       const int a = a0 + idx / (64 * MB);
       const int m = m0 + mb * 32 + (l & 31);
       const int kk = a_k<LOADER>(a, l >> 5);
-      const bool ok = idx < an * MB * 64 && m < p.M && kk < p.K && p.dbg != 3;
+      const bool ok = idx < an * MB * 64 && m < p.M && kk < p.K;
       const int mc = m < p.M ? m : p.M - 1, kc = kk < p.K ? kk : p.K - 1;
       float wv = weight_at(p, mc, kc);
       if (PRO == PRO_LN) wv *= p.ln_g[kc];
@@ -2642,21 +2642,17 @@ static std::atomic<int> g_bx_on{-1};
 // Diagnostic environment knobs are read ONCE per process and validated (> 0): the row count that sizes a caller's
 // workspace and the grid of the launch that fills it can then never disagree, and an empty / zero value cannot produce
 // a zero-sized grid.
-static int env_pos_once(const char* name, int dflt) {
-  const char* e = getenv(name);
-  const int v = e ? atoi(e) : 0;
-  return v > 0 ? v : dflt;
-}
-static int knob_mlp_wg_wgs() { static const int v = env_pos_once("FZ_MLP_WG_WGS", 512); return v; }
-static int knob_gemm_dw_wgs() { static const int v = env_pos_once("FZ_GEMM_DW_WGS", 512); return v; }
-static int knob_chain64_p512() { static const int v = env_pos_once("FZ_CHAIN64_P512", 1); return v == 1; }   // 2 = off (diagnostics)
-static int knob_res_prefetch() { static const int v = env_pos_once("FZ_RES_PREFETCH", 1); return v == 1; }   // 2 = off (diagnostics)
-static int knob_p32() { static const int v = env_pos_once("FZ_GEMM_P32", 1); return v == 1; }   // 2 = off (diagnostics)
-static int knob_p32_wgs() { static const int v = env_pos_once("FZ_GEMM_P32_WGS", 512); return v; }   // resident: 2 per CU
-static int knob_head_fwd() { const auto& k = FZ_ENV_KNOB("FZ_HEAD_FWD"); return k.set ? k.val : 1; }   // 0: the head through gemm_p32 (A/B runs)
-static int knob_chain_fwd_bx() { const auto& k = FZ_ENV_KNOB("FZ_CHAIN_FWD_BX"); return k.set ? k.val : 1; }   // 0: the fp32-MFMA forward chain (A/B runs)
-static int knob_chain_stagger(int dflt) { const auto& k = FZ_ENV_KNOB("FZ_CHAIN_STAGGER"); return k.set ? k.val : dflt; }
-static int knob_mlp_wgs(int dflt) { static const int v = env_pos_once("FZ_MLP_WGS", 0); return v > 0 ? v : dflt; }
+// (probe builds only: FZ_KNOB is a compile-time "unset" in the shipped library — fz_common.h)
+static int knob_pos(const fz::EnvKnob& k, int dflt) { return k.set && k.val > 0 ? k.val : dflt; }
+static int knob_mlp_wg_wgs() { return knob_pos(FZ_KNOB("FZ_MLP_WG_WGS"), 512); }
+static int knob_gemm_dw_wgs() { return knob_pos(FZ_KNOB("FZ_GEMM_DW_WGS"), 512); }
+static int knob_chain64_p512() { return knob_pos(FZ_KNOB("FZ_CHAIN64_P512"), 1) == 1; }   // 2 = off (A/B runs)
+static int knob_res_prefetch() { return knob_pos(FZ_KNOB("FZ_RES_PREFETCH"), 1) == 1; }   // 2 = off
+static int knob_p32() { return knob_pos(FZ_KNOB("FZ_GEMM_P32"), 1) == 1; }                // 2 = off
+static int knob_p32_wgs() { return knob_pos(FZ_KNOB("FZ_GEMM_P32_WGS"), 512); }           // resident: 2 per CU
+static int knob_head_fwd() { const auto& k = FZ_KNOB("FZ_HEAD_FWD"); return k.set ? k.val : 1; }   // 0: the head through gemm_p32
+static int knob_chain_fwd_bx() { const auto& k = FZ_KNOB("FZ_CHAIN_FWD_BX"); return k.set ? k.val : 1; }   // 0: the fp32-MFMA forward chain
+static int knob_mlp_wgs(int dflt) { return knob_pos(FZ_KNOB("FZ_MLP_WGS"), dflt); }
 
 static int gemm_bx_enabled() {
   int v = g_bx_on.load(std::memory_order_relaxed);
@@ -2708,8 +2704,7 @@ static int gemm_launch(const fz_gemm_desc* d, fz_stream_t stream) {
   a.bias = d->bias; a.ln = d->ln; a.ln_g = d->ln_g; a.ln_b = d->ln_b; a.ln_eps = d->ln_eps;
   a.stats_out = d->stats_out; a.bact = d->bact; a.eact = d->eact; a.res = (const AT*)d->res; a.emul = (const AT*)d->emul;
   a.emul_kind = d->emul_kind; a.y = (AT*)d->y; a.Ncol = d->Ncol; a.Ho = d->Ho; a.Wo = d->Wo; a.B = d->B;
-  { const auto& k = FZ_ENV_KNOB("FZ_GEMM_DBG"); a.dbg = k.set ? k.val : 0; }
-  { const auto& k = FZ_ENV_KNOB("FZ_GEMM_TILEMAP"); a.tile_map = k.set ? k.val : 1; }
+  a.dbg = 0; a.tile_map = 1;
   a.ygroups = 0; a.xtiles = 0; a.tune = d->tune;
   a.lnb_x = (const AT*)d->lnb_x; a.lnb_stats = d->lnb_stats; a.lnb_g = d->lnb_g; a.lnb_gadd = (const AT*)d->lnb_gadd; a.lnb_part = d->lnb_part;
   hipStream_t st = (hipStream_t)stream;
@@ -2773,7 +2768,6 @@ static int gemm_launch(const fz_gemm_desc* d, fz_stream_t stream) {
   // measured (round-1/2 probe `gemm_probe5`): the register-resident kernel wins for K <= 32, the
   // streaming ring for K = 64 (4.4 vs 3.3 TB/s at 64->32, 128^3)
   int res_maxk = 32;
-  { const auto& k = FZ_ENV_KNOB("FZ_GEMM_RESMAXK"); if (k.set) res_maxk = k.val; }
   if (d->epilogue == EPI_LNBWD) res_maxk = 64;
   // ... except one 32-row block without a residual or gate: with the ring refills pinned the streaming
   // kernel overlaps its MFMAs with the loads still in flight, which the LayerNorm prologue of the
@@ -2781,7 +2775,7 @@ static int gemm_launch(const fz_gemm_desc* d, fz_stream_t stream) {
   // plain 278 -> 248 us; with a residual (357 vs 362 us) or two row blocks (391 vs 439 us) the resident
   // kernel stays ahead (round-1/2 probe `gemm_probe9`)
   const bool stream_small = mblocks == 1 && d->K >= 16 && d->K <= 32 && !d->res && !d->bmul && !d->emul &&
-                            d->epilogue == EPI_PLAIN && d->bact == 0 && !FZ_ENV_KNOB("FZ_GEMM_RESMAXK").set;
+                            d->epilogue == EPI_PLAIN && d->bact == 0;
   if (d->loader == LOAD_PLAIN && d->K <= res_maxk && !stream_small) {
     const int nA = (d->K + 1) / 2;
     int RB = mblocks < 8 ? mblocks : 8;
@@ -2840,7 +2834,7 @@ static int gemm_launch(const fz_gemm_desc* d, fz_stream_t stream) {
       // (when even 32-voxel tiles cannot give one workgroup per CU — the 8^3 bottleneck — stay with 64-voxel tiles and
       // let the K-split below fill the chip: 8-byte lane loads; 512->1024 at 2 x 8^3: 33 against 43 us, round-1/2 probe `gemm_deep`)
       if (wgs(nacc, MBsel) < 256 && !(wgs(1, MBsel) < 256 && d->K >= 256)) nacc = 1;
-      const char* e = FZ_ENV_KNOB("FZ_GEMM_CFG").str;  // diagnostics: "<nacc><mb>", e.g. 42
+      const char* e = FZ_KNOB("FZ_GEMM_CFG").str;  // probe builds: "<nacc><mb>", e.g. 42
       if (e && e[0] && e[1]) { nacc = e[0] - '0'; MBsel = e[1] - '0'; if (MBsel == 2 && (nacc != 4 || mblocks < 2)) MBsel = 1; }
     }
   }
@@ -2853,14 +2847,11 @@ static int gemm_launch(const fz_gemm_desc* d, fz_stream_t stream) {
     const bool shape_ok = MBsel == 1 && ((d->loader == LOAD_PLAIN && d->epilogue == EPI_PLAIN && nacc <= 2) ||
                                          d->loader == LOAD_S2D);
     if (shape_ok && wg1 < 256 && d->K >= 256) ks = 4;
-    const auto& kk = FZ_ENV_KNOB("FZ_GEMM_KS");
-    if (kk.set) ks = (kk.val == 4 && shape_ok) ? 4 : 1;
   }
   const int WT = ks > 1 ? 1 : 4;
   const int64_t tiles = (d->Ncol + TN * WT - 1) / (TN * WT);
   const int ygr = (mblocks + MBsel - 1) / MBsel;
   int xcd_grid = 1;
-  { const auto& k = FZ_ENV_KNOB("FZ_GEMM_XCDGRID"); if (k.set) xcd_grid = k.val; }
   // (only where the COLUMN operand dominates the traffic: few row-block groups, many column tiles;
   // with e.g. 32 groups x 16 tiles — the deep transposed convs — the weights dominate and the
   // x-fastest order, which runs equal-weight workgroups together, is the better one: 61 vs 105 us)
@@ -3010,7 +3001,7 @@ static int mlp_launch(const fz_mlp_desc* d, fz_stream_t stream) {
     FZ_LAUNCH_CHECK();
     return FZ_OK;
   }
-  c.stagger = knob_chain_stagger(0);
+  c.stagger = 0;
   const int wgs = knob_mlp_wgs(d->H == 128 ? 512 : 768);  // resident workgroups (2 or 3 per CU), each walking tiles with a stride of the grid
   dim3 grid((unsigned)(ntiles < wgs ? ntiles : wgs)), block(256);
   if (d->mode == 0) {
@@ -3018,7 +3009,7 @@ static int mlp_launch(const fz_mlp_desc* d, fz_stream_t stream) {
     a.bias = d->b1; a.ln = 1; a.ln_g = d->ln_g; a.ln_b = d->ln_b; a.ln_eps = d->ln_eps; a.stats_out = d->stats;
     a.res = (const AT*)d->in; a.y = (AT*)d->out;
     c.wB = d->w2; c.wB_t = 0; c.ldwB = d->H;         // A2[m][k] = W2[m][k]
-    c.biasB = d->b2; c.side = FZ_ENV_KNOB("FZ_CHAIN_NOZ1").val ? nullptr : (AT*)d->z1;   // (knob: timing probe, z1 not written)
+    c.biasB = d->b2; c.side = (AT*)d->z1;
     if (d->H == 128) hipLaunchKernelGGL((gemm_chain_kernel<false, 2, 4>), grid, block, 0, st, a, c, ntiles);
     else if (products_split(d->products) && knob_chain_fwd_bx()) {   // split-bf16 form: two workgroups per CU
       const int wgs2 = knob_mlp_wgs(512);

@@ -348,8 +348,6 @@ int gemm_bx_launch(const GemmArgsT<AT>& a0, int loader, int epilogue, int pro, f
     auto wgs = [&](int na, int mbb) { return ((a.Ncol + 32 * na - 1) / (32 * na)) * a.B * ((mblocks + mbb - 1) / mbb); };
     if (wgs(kn, km) < 512 && km == 2) km = 1;
     if (wgs(kn, km) < 512 && loader != LOAD_S2D) kn = 1;
-    const char* e = FZ_ENV_KNOB("FZ_BX_KS").str;  // diagnostics (read once): "0" | "1" | "1<nacc><mb>"
-    if (e && e[0]) { ks = e[0] - '0'; if (e[1] && e[2]) { kn = e[1] - '0'; km = e[2] - '0'; if (km > mblocks) km = 1; if (loader == LOAD_S2D) kn = 2; } }
     if (a.tune >= 100) {   // per-call form of the same diagnostics (fz_gemm_desc.tune)
       ks = a.tune / 100 == 2;
       if (ks) { kn = (a.tune / 10) % 10; km = a.tune % 10; if (km > mblocks) km = 1; if (loader == LOAD_S2D) kn = 2; if (kn < 1 || kn > 2) kn = 2; if (km < 1 || km > 2) km = 1; }
@@ -368,8 +366,6 @@ int gemm_bx_launch(const GemmArgsT<AT>& a0, int loader, int epilogue, int pro, f
     auto wgs = [&](int na, int mbb) { return ((a.Ncol + 128 * na - 1) / (128 * na)) * a.B * ((mblocks + mbb - 1) / mbb); };
     if (wgs(nacc, mb) < 512) nacc = 2;
     if (wgs(nacc, mb) < 512 && mb == 2) mb = 1;
-    const char* e = FZ_ENV_KNOB("FZ_BX_CFG").str;  // diagnostics (read once): "<nacc><mb>"
-    if (e && e[0] && e[1]) { nacc = e[0] - '0'; mb = e[1] - '0'; if (mb > mblocks) mb = 1; }
     if (a.tune / 100 == 1) { nacc = (a.tune / 10) % 10; mb = a.tune % 10; if (mb > mblocks || mb < 1) mb = 1; }
     if (nacc != 2 && nacc != 4) nacc = 2;
     // the LayerNorm prologue (row sums, statistics) and the gated operand (second ring) do not fit beside 128-voxel wave

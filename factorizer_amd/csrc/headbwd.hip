@@ -181,7 +181,7 @@ extern "C" int fz_head_bwd(const void* gy, const void* x, const float* w, void* 
 
 template <typename AT>
 static int head_fwd_launch(const void* x, const float* w, const float* bias, void* y, int B, int M, int64_t V, hipStream_t st) {
-  static const unsigned grid = FZ_ENV_KNOB("FZ_HEAD_FWD_WGS").set ? (unsigned)FZ_ENV_KNOB("FZ_HEAD_FWD_WGS").val : 512u;   // persistent workgroups
+  const unsigned grid = 512u;   // persistent workgroups: two per CU
 #define FZ_HEADF(MM) hipLaunchKernelGGL((head_fwd_kernel<MM, AT>), dim3(grid), dim3(256), 0, st, (const AT*)x, w, bias, (AT*)y, B, V, M)
   if (M <= 2) FZ_HEADF(2); else FZ_HEADF(4);
 #undef FZ_HEADF

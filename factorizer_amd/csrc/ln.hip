@@ -447,8 +447,7 @@ static int ln_bwd_launch(const void* gl_, const void* x_, const float* stats, co
   hipStream_t st = (hipStream_t)stream;
   unsigned grid = ln_grid(V / 4 * B);
   {
-    int slice = 1;
-    { const auto& k = FZ_ENV_KNOB("FZ_LN_SLICE"); if (k.set) slice = k.val; }
+    const int slice = 1;
     if (slice && (C == 64 || C == 128 || C == 256 || C == 512)) {
       const int64_t quads = (V / 4) * B;
       const bool sub4 = ln_slice_sub4(quads);   // fewer than 512 workgroups of 64 quads: 16 quads x 4 channel sub-slices each

@@ -279,14 +279,11 @@ static int cf_fwd_launch(const AT* t, const float* u0, const float* v0, AT* out,
   // measured on MI355X (round-1/2 probe `cf_probe`): a workgroup = one full row of patches along W
   // (up to 16 waves) consumes whole 128-B lines inside one CU: 0.856 -> 0.725 ms at stage 0
   int wpb = 16;
-  { const auto& k = FZ_ENV_KNOB("FZ_CF_WPB"); if (k.set) wpb = k.val; }
   if (wpb > q.G2) wpb = q.G2;
   if (wpb < 1) wpb = 1;
-  int xr = 1;
-  { const auto& k = FZ_ENV_KNOB("FZ_CF_XCD"); if (k.set) xr = k.val; }
+  const int xr = 1;
   hipStream_t st = (hipStream_t)stream;
-  int tile = 1;
-  { const auto& k = FZ_ENV_KNOB("FZ_CF_TILE"); if (k.set) tile = k.val; }
+  const int tile = FZ_KNOB("FZ_CF_TILE").set ? FZ_KNOB("FZ_CF_TILE").val : 1;   // probe builds: 0 = the direct-gather kernels
   const bool half = (q.s2 % 4) != 0;  // W-axis shift ≡ 2 (mod 4): only the line-coalesced kernels handle it
   if (half || (tile && (q.G2 % 8) == 0)) {
     // line-coalesced kernel: WPB patches along W per workgroup.  8 patches per workgroup, two
@@ -348,20 +345,17 @@ static int cf_bwd_launch(const AT* t, const float* u0, const float* v0, const AT
   if (per_wave > 160 * 1024) return fail(FZ_E_UNSUPPORTED, "fz_nmf_cf_bwd: history exceeds LDS");
   int wpb = 65536 / per_wave;
   if (wpb > 4) wpb = 4;
-  { const auto& k = FZ_ENV_KNOB("FZ_CF_WPB_BWD"); if (k.set) { wpb = k.val; if (wpb * per_wave > 160 * 1024) wpb = 160 * 1024 / per_wave; } }
   if (wpb > 8) wpb = 8;
   if (wpb < 1) wpb = 1;
   // patch neighbours on the same XCD share its L2 (shifted windows straddle lines): 1.31 -> 1.17 ms
-  int xr = 1;
-  { const auto& k = FZ_ENV_KNOB("FZ_CF_XCD"); if (k.set) xr = k.val; }
+  const int xr = 1;
   hipStream_t st = (hipStream_t)stream;
-  int tile = 1;
-  { const auto& k = FZ_ENV_KNOB("FZ_CF_TILE_BWD"); if (k.set) tile = k.val; }
+  const int tile = FZ_KNOB("FZ_CF_TILE_BWD").set ? FZ_KNOB("FZ_CF_TILE_BWD").val : 1;
   const bool half = (q.s2 % 4) != 0;
   if (half || (tile && (q.G2 % 4) == 0)) {
     const int twpb = (q.G2 % 4) == 0 ? 4 : 1;
     // HALS rank 1 behind a ReLU (t >= 0 by the relu_gate contract): the row-space reverse mode, no per-column history
-    static const bool gram_on = !(FZ_ENV_KNOB("FZ_CF_GRAM").set && FZ_ENV_KNOB("FZ_CF_GRAM").val == 0);
+    const bool gram_on = !(FZ_KNOB("FZ_CF_GRAM").set && FZ_KNOB("FZ_CF_GRAM").val == 0);   // probe builds: 0 = the general kernel
     // (measured, tools/probes/gram_floor.sh: both kernels sit on the tile's memory skeleton; the row-space one is 6-11 % faster
     //  everywhere except fp32 windows w > 0 of >= 2^15 matrices, where the general kernel's single late burst of
     //  running-sum reads is 3-5 % ahead: 461-464 against 478-487 us at the README's stage 0)

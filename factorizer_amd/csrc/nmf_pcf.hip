@@ -19,6 +19,10 @@
 
 namespace fz {
 
+// two matrices per wave for 129..160-voxel patches (probe builds: FZ_PCF_HALF=0 restores the one-matrix kernels)
+static inline bool pcf_half_on() { return !(FZ_KNOB("FZ_PCF_HALF").set && FZ_KNOB("FZ_PCF_HALF").val == 0); }
+
+
 struct PcfGeom {
   int B, C, D, H, W;
   int h;                // heads (C / 8)
@@ -373,7 +377,7 @@ static int pcf_fwd_launch(const AT* t, const float* u0, const float* v0, AT* out
   if (nmat >= (int64_t)1 << 31) return fail(FZ_E_UNSUPPORTED, "fz_nmf_pcf: more than 2^31 matrices");
   dim3 grid((unsigned)((nmat + 3) / 4)), block(256);
   // 129..160 voxels per patch: two matrices per wave, five columns per lane (FZ_PCF_HALF=0: the one-matrix form, diagnostics)
-  static const bool half_on = !(FZ_ENV_KNOB("FZ_PCF_HALF").set && FZ_ENV_KNOB("FZ_PCF_HALF").val == 0);
+  const bool half_on = pcf_half_on();
   if (half_on && q.P > 128 && q.P <= 160) {
     dim3 grid2((unsigned)(((nmat + 1) / 2 + 3) / 4));
 #define FZ_PCF_FWD2(RR, SS) hipLaunchKernelGGL((nmf_pcf_fwd2_kernel<5, RR, SS, AT>), grid2, block, 0, st, t, u0, v0, out, q, nmat, T, eps)
@@ -404,7 +408,7 @@ static int pcf_bwd_launch(const AT* t, const float* u0, const float* v0, const A
                           int G, int solver, float eps, int relu_gate, hipStream_t st) {
   const int64_t nmat = (int64_t)q.B * q.h * q.G0 * q.G1 * q.G2;
   if (nmat >= (int64_t)1 << 31) return fail(FZ_E_UNSUPPORTED, "fz_nmf_pcf: more than 2^31 matrices");
-  static const bool half_on = !(FZ_ENV_KNOB("FZ_PCF_HALF").set && FZ_ENV_KNOB("FZ_PCF_HALF").val == 0);
+  const bool half_on = pcf_half_on();
   // (windows w > 0 — read-modify-write of the running gradient — keep the one-matrix form: at the two-matrix form's 5 waves per
   // CU the extra scattered read costs more than the form saves, 9.5 against 8.9 ms at the cfg-5 stage-0 launch; window 0: 6.3 / 7.1)
   if (half_on && !q.accumulate && q.P > 128 && q.P <= 160 && 2 * pcf_half_hist_floats(5, R, G) * (int)sizeof(float) <= 160 * 1024) {
@@ -429,7 +433,6 @@ static int pcf_bwd_launch(const AT* t, const float* u0, const float* v0, const A
   const int per_wave = pcf_per_wave(q.P, R, G);
   if (per_wave > 160 * 1024) return fail(FZ_E_UNSUPPORTED, "fz_nmf_pcf_bwd: history exceeds LDS");
   int wpb = fz_hist_waves_per_block(per_wave);
-  { const auto& k = FZ_ENV_KNOB("FZ_PCF_WPB"); if (k.set && k.val >= 1 && k.val <= 4) wpb = k.val; }   // diagnostics
   const int lds = per_wave * wpb;
   dim3 grid((unsigned)((nmat + wpb - 1) / wpb)), block(64 * wpb);
 #define FZ_PCF_BWD(NN, RR, SS)                                                                                \
@@ -526,8 +529,8 @@ extern "C" int fz_nmf_pcf_bwd(const void* t, const float* u0, const float* v0, c
  * as the read-modify-write of accumulate = 1: the two-matrices-per-wave shapes (129..160 voxels per patch) in bf16 storage
  * (cfg-5 step, B = 4: 100.3 -> 96.2 ms; fp32 storage, where the add moves twice the bytes: 116.9 -> 120.9, so not there). */
 extern "C" int fz_nmf_pcf_bwd_prefers_separate(int pd, int ph, int pw, int act_dtype) {
-  static const bool half_on = !(FZ_ENV_KNOB("FZ_PCF_HALF").set && FZ_ENV_KNOB("FZ_PCF_HALF").val == 0);
-  static const bool sep_on = !(FZ_ENV_KNOB("FZ_PCF_SEPARATE").set && FZ_ENV_KNOB("FZ_PCF_SEPARATE").val == 0);
+  const bool half_on = pcf_half_on();
+  const bool sep_on = !(FZ_KNOB("FZ_PCF_SEPARATE").set && FZ_KNOB("FZ_PCF_SEPARATE").val == 0);   // probe builds: 0 = read-modify-write
   const int64_t P = (int64_t)pd * ph * pw;
   return (half_on && sep_on && act_dtype == FZ_STORE_BF16 && P > 128 && P <= 160) ? 1 : 0;
 }

@@ -611,7 +611,7 @@ static bool use_fast(const fz_wgrad_desc* d) {
   bool fast = PR == 64 && QR == 64 && d->loader == QL_PLAIN && !d->pmul && (d->M % PR) == 0 && (d->K % QR) == 0 &&
               (d->N % kTile) == 0 && d->N == d->Vq && (c0 % 8) == 0 && d->src_mode == 0 && !(d->stats && d->qact) &&
               (int64_t)8 * d->N < ((int64_t)1 << 30);
-  { const auto& k = FZ_ENV_KNOB("FZ_WGRAD_FAST"); if (k.set && k.val == 0) fast = false; }
+  { const auto& k = FZ_KNOB("FZ_WGRAD_FAST"); if (k.set && k.val == 0) fast = false; }   // probe builds only
   return fast;
 }
 
@@ -623,7 +623,6 @@ static int pick_chunks(int64_t total_tiles, int out_blocks, bool fast, int* tile
   // optimum for the register-operand kernel (64x64 at 64^3: 83 us against 107 with 4 per CU), two per CU
   // for the HBM-bound generic kernel (32x64 at 128^3: 370 against 400 us); 1.5 per CU loses to both.
   int64_t total_units = fast ? 1024 : 2048;
-  { const auto& k = FZ_ENV_KNOB("FZ_WGRAD_UNITS"); if (k.set && k.val > 0) total_units = k.val; }
   int64_t units_target = total_units / (out_blocks > 0 ? out_blocks : 1);
   if (units_target < 16) units_target = 16;
   int64_t tpc = (total_tiles + units_target - 1) / units_target;
@@ -646,7 +645,7 @@ extern "C" int64_t fz_wgrad_workspace_bytes(const fz_wgrad_desc* d) {
 }
 
 static bool fz_wgrad_group_enabled() {   // FZ_WGRAD_GROUP=0: diagnostics (the single launches)
-  static const bool v = [] { const char* e = getenv("FZ_WGRAD_GROUP"); return !(e && atoi(e) == 0 && e[0] == '0'); }();
+  const bool v = !(FZ_KNOB("FZ_WGRAD_GROUP").set && FZ_KNOB("FZ_WGRAD_GROUP").val == 0);   // probe builds: 0 = one launch per layer
   return v;
 }
 

@@ -412,6 +412,7 @@ def _native_ok(*ts):
 # ---- LayerNorm → Linear → [ReLU] -----------------------------------------------------------
 class LNLinearFn(torch.autograd.Function):
     @staticmethod
+    @N.capture_products
     def forward(ctx, x, ln_w, ln_b, eps, w, b, act):
         x = x.contiguous()
         B, C = x.shape[:2]
@@ -427,6 +428,7 @@ class LNLinearFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @N.with_products
     def backward(ctx, gy):
         x, stats, ln_w, ln_b, w2, y = ctx.saved_tensors
         gy = gy.contiguous()
@@ -450,6 +452,7 @@ class LNLinearFn(torch.autograd.Function):
 # ---- res + Linear(act(z)) + bias -------------------------------------------------------------
 class ActLinearResFn(torch.autograd.Function):
     @staticmethod
+    @N.capture_products
     def forward(ctx, z, w, b, res, bact):
         z = z.contiguous()
         B, C = z.shape[:2]
@@ -466,6 +469,7 @@ class ActLinearResFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @N.with_products
     def backward(ctx, gy):
         z, w2 = ctx.saved_tensors
         gy = gy.contiguous()
@@ -501,6 +505,7 @@ class ActLinearResFn(torch.autograd.Function):
 # ---- Linear over a virtual channel concat -------------------------------------------------------
 class CatLinearFn(torch.autograd.Function):
     @staticmethod
+    @N.capture_products
     def forward(ctx, x1, x2, w, b):
         x1, x2 = x1.contiguous(), x2.contiguous()
         B, C1 = x1.shape[:2]
@@ -515,6 +520,7 @@ class CatLinearFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @N.with_products
     def backward(ctx, gy):
         x1, x2, w2 = ctx.saved_tensors
         gy = gy.contiguous()
@@ -542,10 +548,12 @@ class CatLinearFn(torch.autograd.Function):
 
 class LinearFn(torch.autograd.Function):
     @staticmethod
+    @N.capture_products
     def forward(ctx, x, w, b):
         return ActLinearResFn.forward(ctx, x, w, b, None, "none")
 
     @staticmethod
+    @N.with_products
     def backward(ctx, gy):
         return ActLinearResFn.backward(ctx, gy)[:3]
 
@@ -553,6 +561,7 @@ class LinearFn(torch.autograd.Function):
 # ---- standalone LayerNorm -------------------------------------------------------------------------
 class LayerNormFn(torch.autograd.Function):
     @staticmethod
+    @N.capture_products
     def forward(ctx, x, w, b, eps):
         x = x.contiguous()
         B, C = x.shape[:2]
@@ -568,6 +577,7 @@ class LayerNormFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @N.with_products
     def backward(ctx, gy):
         x, stats, w = ctx.saved_tensors
         gy = gy.contiguous()
@@ -582,6 +592,7 @@ class ConvK2S2Fn(torch.autograd.Function):
     """Conv3d(kernel 2, stride 2): space-to-depth gather fused into the GEMM's operand loads."""
 
     @staticmethod
+    @N.capture_products
     def forward(ctx, x, w, b):
         x = x.contiguous()
         B, C, D, H, W = x.shape
@@ -595,6 +606,7 @@ class ConvK2S2Fn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @N.with_products
     def backward(ctx, gy, g_skip=None):
         x, w = ctx.saved_tensors
         gy = gy.contiguous()
@@ -624,11 +636,13 @@ class SkipConvK2S2Fn(torch.autograd.Function):
     depth-to-space epilogue of the convolution's input-gradient kernel."""
 
     @staticmethod
+    @N.capture_products
     def forward(ctx, x, w, b):
         y = ConvK2S2Fn.forward(ctx, x, w, b)
         return x.view_as(x), y
 
     @staticmethod
+    @N.with_products
     def backward(ctx, g_skip, gy):
         if gy is None:  # the down path took no part in the loss
             return g_skip, None, None
@@ -639,6 +653,7 @@ class TConvK2S2Fn(torch.autograd.Function):
     """ConvTranspose3d(kernel 2, stride 2): GEMM with (o, tap) rows + depth-to-space epilogue."""
 
     @staticmethod
+    @N.capture_products
     def forward(ctx, x, w, b):
         x = x.contiguous()
         B, C, D, H, W = x.shape
@@ -652,6 +667,7 @@ class TConvK2S2Fn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @N.with_products
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         gy = gy.contiguous()
@@ -685,6 +701,7 @@ class ConvK3Fn(torch.autograd.Function):
     (csrc/conv3.hip); shapes outside them use the generic tap loaders of the GEMM family."""
 
     @staticmethod
+    @N.capture_products
     def forward(ctx, x, w, b):
         x = x.contiguous()
         B, C, D, H, W = x.shape
@@ -705,6 +722,7 @@ class ConvK3Fn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @N.with_products
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         gy = gy.contiguous()
@@ -823,6 +841,7 @@ class UpCatLinearFn(torch.autograd.Function):
     level instead of 10 U (U = one full-resolution activation tensor of the level)."""
 
     @staticmethod
+    @N.capture_products
     def forward(ctx, skip, deep, w_t, b_t, w_ad, b_ad):
         skip, deep = skip.contiguous(), deep.contiguous()
         B, Cd, D, H, W = deep.shape
@@ -858,6 +877,7 @@ class UpCatLinearFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @N.with_products
     def backward(ctx, g):
         skip, deep, w_t, w2, b_t = ctx.saved_tensors
         g = g.contiguous()
@@ -930,6 +950,7 @@ class FactorizerBlockFn(torch.autograd.Function):
     `cfg["core"]`, else the native modular chain swm_fwd → nmf → swm_inv."""
 
     @staticmethod
+    @N.capture_products
     def forward(ctx, x, n1w, n1b, win, u0, v0, wout, bout, n2w, n2b, w1, b1, w2, b2, cfg):
         x = x.contiguous()
         B, C = x.shape[:2]
@@ -976,6 +997,7 @@ class FactorizerBlockFn(torch.autograd.Function):
         return x2
 
     @staticmethod
+    @N.with_products
     def backward(ctx, g2):
         x, st1, t, a, x1, st2, z1, m, n1w, n1b, win2, u0c, v0c, wout2, n2w, n2b, w12, w22 = ctx.saved_tensors
         cfg = ctx.cfg

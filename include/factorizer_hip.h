@@ -44,6 +44,14 @@ typedef void* fz_stream_t; /* hipStream_t */
 
 /* Library version (major*10000 + minor*100 + patch). */
 int fz_version(void);
+/* ABI revision: bumped whenever an entry point's signature or a descriptor's layout changes (a caller built against another
+ * revision would pass a stream where an int is expected, or leave new trailing descriptor fields uninitialised).  A binding
+ * compares fz_abi_version() with the FZ_ABI_VERSION of the header it was written against BEFORE the first call and refuses
+ * to run on a mismatch (factorizer_amd/_native.py does).  History: 3 = round 3; 4 = round 4 (`products` / `tune` descriptor
+ * fields, `products` argument of fz_conv3_*); 5 = round 5 (the two-window entry points fz_nmf_cf_fwd2 / _bwd2 removed, this
+ * function added). */
+#define FZ_ABI_VERSION 5
+int fz_abi_version(void);
 /* Message for the last error returned on this thread ("" if none). */
 const char* fz_last_error_string(void);
 /* Number of kernel launches issued through this library by this process (test hook that

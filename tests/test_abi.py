@@ -34,6 +34,7 @@ def test_python_binding_matches_header(built_lib):
     assert set(_native.declared_symbols()) <= set(header_functions())
     lib = _native.lib()
     assert lib.fz_version() >= 100
+    assert lib.fz_abi_version() == _native.ABI_VERSION   # the loader refuses a library of another revision
     assert lib.fz_last_error_string() is not None
 
 

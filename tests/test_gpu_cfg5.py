@@ -134,3 +134,37 @@ def test_cfg5_reduced_extent_whole_model_vs_oracle():
                 why="ten rank-2 HALS sweeps per block amplify fp32 rounding: the reference's own fp32 arithmetic is this far "
                     "from its float64 evaluation; the device must be as close to float64 as the fp32 oracle (x2)")
     P.note("cfg5_reduced_model_worst_device_over_fp32oracle_distance_to_fp64", value=worst)
+
+
+def test_cfg5_per_gpu_batch_of_four_bf16_step():
+    """BASELINE configs[4] at ITS per-GPU batch: B = 4, 160 x 192 x 160, bf16 autocast (29.9 GB peak): one training step —
+    forward, DiceCE, backward — with no composed-ATen branch, finite loss and gradients (all fp32), replayed bit for bit.
+    (The B = 1 test above pins the arithmetic; this one pins that the launch geometries of the full batch — 4x the matrices
+    per launch: 2 359 296 at stage 0, grid sizes beyond 2^21 threads — run and reproduce.)"""
+    torch.manual_seed(0)
+    S = (160, 192, 160)
+    model = _model(S, (32, 64, 128, 256, 512), (1, 2, 2, 2, 2)).to(DEV)
+    x = torch.rand(4, 4, *S, device=DEV)
+    t = (torch.rand(4, 3, *S, device=DEV) > 0.5).float()
+
+    def run():
+        model.zero_grad(set_to_none=True)
+        with warnings.catch_warnings():
+            warnings.simplefilter("error", RuntimeWarning)
+            with torch.autocast("cuda", dtype=BF):
+                y = model(x)
+                loss = ft.dice_ce_loss(y, t)
+            loss.backward()
+        return loss.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+
+    torch.cuda.reset_peak_memory_stats()
+    n0 = _native.launch_count()
+    loss, g = run()
+    assert _native.launch_count() > n0 and torch.isfinite(loss)
+    for n, v in g.items():
+        assert v.dtype == torch.float32 and torch.isfinite(v).all(), n
+    loss2, g2 = run()
+    assert torch.equal(loss, loss2)
+    differs = [n for n in g if not torch.equal(g[n], g2[n])]
+    assert not differs, differs[:8]
+    P.note("cfg5_batch4_bf16_step", loss=float(loss), peak_mem_GB=round(torch.cuda.max_memory_allocated() / 1e9, 1))

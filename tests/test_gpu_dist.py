@@ -96,3 +96,47 @@ def test_overlapped_allreduce_gradients_equal_unattached_run(rccl_world1, S, wid
     opt.step(grad_scale=scale)
     moved = sum(1 for n, p in model.named_parameters() if not torch.equal(p.detach(), before[n]))
     assert moved >= len(before) - 2
+
+
+def test_bucket_allreduce_is_ordered_after_the_queued_weight_gradient_kernels(rccl_world1, monkeypatch):
+    """A bucket's all-reduce is launched from the post-accumulate hook of its last parameter — on the HOST, while the
+    weight-gradient kernels that write INTO that bucket may still be queued on the compute stream (the host runs milliseconds
+    ahead of the device).  Correct only if RCCL's stream waits for the compute stream's queue as of the call.  One rank cannot
+    show a violation in the DATA (an in-place all-reduce over one rank leaves whatever the later kernel writes), so the test
+    makes the ordering observable in TIME: right before every all-reduce of the backward it queues a long spin kernel on the
+    compute stream and then asks the returned work handle, from the host, whether the collective has completed while that spin
+    is provably still running (its end event has not fired).  A collective that did not wait for the compute stream completes
+    within microseconds and would be seen completed.  Also poisons the flat buffer before the backward: no NaN may survive.
+    Replaces what DistributedDataParallel guarantees for model_zoo/factorizer_brats23/configs/train_multigpu.yaml:3-6."""
+    import time
+    torch.manual_seed(0)
+    S, widths, strides = (32, 32, 32), (32, 64, 128), (1, 2, 2)
+    model = _model(S, widths, strides, 4).to(DEV)
+    x = torch.rand(2, 4, *S, device=DEV)
+    t = (torch.rand(2, 3, *S, device=DEV) > 0.5).float()
+    sync = FlatGradSync(model, num_buckets=4, overlap=True, force_collectives=True)
+    real = dist.all_reduce
+    seen = []
+
+    def spying_all_reduce(tensor, *a, **kw):
+        torch.cuda._sleep(400_000_000)                     # ~0.2 s of spinning on the compute stream, queued BEFORE the collective
+        done = torch.cuda.Event()
+        done.record()
+        work = real(tensor, *a, **kw)
+        time.sleep(0.02)                                    # two orders of magnitude more than an unordered collective needs
+        still_spinning = not done.query()
+        seen.append((still_spinning, bool(work.is_completed())))
+        return work
+
+    monkeypatch.setattr(dist, "all_reduce", spying_all_reduce)
+    sync.zero_grad()
+    sync.flat.fill_(float("nan"))                           # every element must be overwritten by a kernel or the packing copy
+    ft.dice_ce_loss(model(x), t).backward()
+    assert all(sync._launched) and len(seen) == 4
+    sync.finish(average=False)
+    torch.cuda.synchronize()
+    for spinning, completed in seen:
+        assert spinning, "the spin kernel had already ended: the probe measured nothing (raise the cycle count)"
+        assert not completed, "an all-reduce completed while earlier compute-stream work was still running: not ordered after it"
+    for n, p in model.named_parameters():                   # (the alignment padding between slices belongs to no gradient)
+        assert torch.isfinite(sync.views[p]).all(), ("poison survived: reduced before (or without) being produced", n)

@@ -71,3 +71,35 @@ def test_decoder_knobs_are_read_once_and_validated(monkeypatch):
     assert blocks._env_int("FZ_UP_FUSED_MIN", 1) == 256
     # the module-level values were fixed at import: changing the environment later does not reach forward_up_pair
     assert isinstance(blocks._UP_FUSED_MIN, int) and isinstance(blocks._UP_FUSED, bool)
+
+
+def test_products_setting_is_per_thread_and_travels_with_the_autograd_node():
+    """the setting a forward ran under must be the one its backward uses — also when the backward runs after the
+    `with` block has exited, or on another thread (autograd's workers) — and two threads must not see each other's."""
+    import threading
+    seen = {}
+
+    class Fn(torch.autograd.Function):
+        @staticmethod
+        @N.capture_products
+        def forward(ctx, x):
+            seen["fwd"] = N.products()
+            return x * 2
+
+        @staticmethod
+        @N.with_products
+        def backward(ctx, g):
+            seen["bwd"] = N.products()
+            return g * 2
+
+    x = torch.ones(3, requires_grad=True)
+    with N.use_products(N.PRODUCTS_FP32_MFMA):
+        y = Fn.apply(x).sum()
+        other = []
+        th = threading.Thread(target=lambda: other.append(N.products()))
+        th.start(); th.join()
+        assert other == [N.PRODUCTS_DEFAULT]          # another thread keeps its own setting
+    assert N.products() == N.PRODUCTS_DEFAULT
+    y.backward()                                       # after the block: the node re-establishes what its forward saw
+    assert seen == {"fwd": N.PRODUCTS_FP32_MFMA, "bwd": N.PRODUCTS_FP32_MFMA}
+    assert N.products() == N.PRODUCTS_DEFAULT

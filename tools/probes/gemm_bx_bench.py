@@ -1,5 +1,5 @@
 """Isolated timing of fz_gemm at the stage 1-4 shapes of the README model: split-bf16 family (per tile config,
-FZ_BX_CFG) against the fp32-MFMA family.  Prints one JSON line per (shape, variant): us per launch, TB/s of
+fz_gemm_desc.tune) against the fp32-MFMA family.  Prints one JSON line per (shape, variant): us per launch, TB/s of
 algorithmic bytes, TFLOP/s (fp32-equivalent).
 usage: python tools/probes/gemm_bx_bench.py [out.jsonl] [--cfgs 42,41,22,21,12,11]"""
 import json
