@@ -47,6 +47,17 @@ class use_products:
         _products.value = self.prev
 
 
+# Walking order of the fused core's window launches (fz_set_tile_order, include/factorizer_hip.h): window w walks the patch
+# tiles ascending for even w, descending for odd w — consecutive windows read the SAME tensors, so a window then starts where
+# the previous one ended, in the part the 256 MiB Infinity Cache still holds.  FZ_TILE_ORDER=0 (read once): always ascending.
+TILE_ORDER = os.environ.get("FZ_TILE_ORDER", "1") != "0"
+
+
+def set_tile_order(descending: int):
+    if TILE_ORDER:
+        lib().fz_set_tile_order(int(descending) & 1)
+
+
 def capture_products(fwd):
     """decorator of an autograd Function's forward(ctx, ...): remember the thread's products setting in the ctx"""
     import functools
@@ -87,6 +98,7 @@ _vp, _i, _i64, _f = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float
 _SIGS = {
     "fz_version": ([], _i),
     "fz_abi_version": ([], _i),
+    "fz_set_tile_order": ([_i], _i),
     "fz_last_error_string": ([], _c.c_char_p),
     "fz_launch_count": ([], _i64),
     "fz_swm_fwd": ([_vp, _vp] + [_i] * 10 + [_c.POINTER(_i), _i, _i, _i, _vp], _i),

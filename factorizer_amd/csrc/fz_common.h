@@ -15,6 +15,11 @@ namespace fz {
 // ---- error plumbing (thread-local message, integer status) ------------------------------
 std::string& last_error();
 std::atomic<int64_t>& launch_counter();
+// Walking order of the NEXT launches of this thread's streaming kernels over their column / patch tiles: 0 ascending, 1
+// descending (fz_set_tile_order, include/factorizer_hip.h).  A launch that walks a tensor in the direction opposite to the
+// launch that produced it starts where the 256 MiB Infinity Cache still holds that tensor.
+int& tile_order_ref();
+inline int tile_order() { return tile_order_ref() ? 1 : 0; }
 
 inline int fail(int code, const char* msg) {
   last_error() = msg;

@@ -139,9 +139,12 @@ __device__ __forceinline__ float4 cf_divide4(float4 o, float dv, bool pow2) {
 
 // logical workgroup id: optionally remapped so that consecutive workgroups (patch neighbours
 // along W, then H) run on the same XCD and share its L2 (blocks are dealt round-robin over 8 XCDs)
+// (bit 1 of xcd_remap: walk the tiles in DESCENDING order — the tail of a tensor the previous launch wrote in ascending order
+//  is what the 256 MiB Infinity Cache still holds when this launch starts)
 __device__ __forceinline__ int64_t cf_logical_block(int xcd_remap) {
-  const int64_t bid = blockIdx.x, nb = gridDim.x;
-  if (!xcd_remap || nb < 16) return bid;
+  const int64_t nb = gridDim.x;
+  const int64_t bid = (xcd_remap & 2) ? nb - 1 - (int64_t)blockIdx.x : (int64_t)blockIdx.x;
+  if (!(xcd_remap & 1) || nb < 16) return bid;
   const int64_t q = nb / 8, r = nb % 8, xcd = bid % 8, i = bid / 8;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
 }

@@ -281,7 +281,7 @@ static int cf_fwd_launch(const AT* t, const float* u0, const float* v0, AT* out,
   int wpb = 16;
   if (wpb > q.G2) wpb = q.G2;
   if (wpb < 1) wpb = 1;
-  const int xr = 1;
+  const int xr = 1 | (tile_order() << 1);
   hipStream_t st = (hipStream_t)stream;
   const int tile = FZ_KNOB("FZ_CF_TILE").set ? FZ_KNOB("FZ_CF_TILE").val : 1;   // probe builds: 0 = the direct-gather kernels
   const bool half = (q.s2 % 4) != 0;  // W-axis shift ≡ 2 (mod 4): only the line-coalesced kernels handle it
@@ -348,7 +348,7 @@ static int cf_bwd_launch(const AT* t, const float* u0, const float* v0, const AT
   if (wpb > 8) wpb = 8;
   if (wpb < 1) wpb = 1;
   // patch neighbours on the same XCD share its L2 (shifted windows straddle lines): 1.31 -> 1.17 ms
-  const int xr = 1;
+  const int xr = 1 | (tile_order() << 1);
   hipStream_t st = (hipStream_t)stream;
   const int tile = FZ_KNOB("FZ_CF_TILE_BWD").set ? FZ_KNOB("FZ_CF_TILE_BWD").val : 1;
   const bool half = (q.s2 % 4) != 0;

@@ -407,6 +407,7 @@ class FactCoreFn(torch.autograd.Function):
             for w, s in enumerate(geo.shifts):
                 arr = (N._i * 3)(*s)
                 last = geo.nshift if w == geo.nshift - 1 else 1
+                N.set_tile_order(w & 1)       # odd windows walk the tiles backwards (_native.py: set_tile_order)
                 if hot:
                     rc = _timed(f"nmf_cf_fwd_{geo.C}x" + "x".join(str(v) for v in geo.spatial), nb + (es * t.numel() if w else 0), cols=t.numel() // geo.C, fn=lambda: N.lib().fz_nmf_cf_fwd(
                         t.data_ptr(), u0.data_ptr(), v0.data_ptr(), out.data_ptr(), B, geo.C, *geo.spatial, arr,
@@ -416,6 +417,7 @@ class FactCoreFn(torch.autograd.Function):
                         t.data_ptr(), u0.data_ptr(), v0.data_ptr(), out.data_ptr(), B, geo.C, *geo.spatial, *geo.patch, arr,
                         int(w > 0), last, R, T, N.SOLVER_ID[solver], eps, ad, N.stream_ptr(t)))
                 N.check(rc, "fz_nmf_cf_fwd" if hot else "fz_nmf_pcf_fwd")
+            N.set_tile_order(0)
         ctx.save_for_backward(t, u0, v0)
         ctx.cfg = (geo, T, G, solver, eps, relu_gate)
         return out
@@ -439,6 +441,7 @@ class FactCoreFn(torch.autograd.Function):
         with _dev_guard(t):
             for w, s in enumerate(geo.shifts):
                 arr = (N._i * 3)(*s)
+                N.set_tile_order(w & 1)
                 if hot:
                     rc = _timed(f"nmf_cf_bwd_{geo.C}x" + "x".join(str(v) for v in geo.spatial), nb + (es * t.numel() if w else 0), cols=t.numel() // geo.C, fn=lambda: N.lib().fz_nmf_cf_bwd(
                         t.data_ptr(), u0.data_ptr(), v0.data_ptr(), ga.data_ptr(), gt.data_ptr(), B, geo.C,
@@ -462,6 +465,7 @@ class FactCoreFn(torch.autograd.Function):
                         *geo.spatial, *geo.patch, arr, int(w > 0), geo.nshift, int(relu_gate), R, T, G, N.SOLVER_ID[solver], eps,
                         ad, N.stream_ptr(t)))
                 N.check(rc, "fz_nmf_cf_bwd" if hot else "fz_nmf_pcf_bwd")
+            N.set_tile_order(0)
         return (gt,) + (None,) * 8
 
 

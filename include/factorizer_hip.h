@@ -52,6 +52,14 @@ int fz_version(void);
  * function added). */
 #define FZ_ABI_VERSION 5
 int fz_abi_version(void);
+/* Walking order of the fused-core launches (fz_nmf_cf_fwd / fz_nmf_cf_bwd) this THREAD issues from now on: 0 = ascending over
+ * the patch tiles (the default), 1 = descending; < 0 only queries.  Returns the previous setting.  Results do not depend on it.
+ * Why it exists: the windows of one SWMatricize are separate launches that read the SAME tensors; a window that walks them in
+ * the direction opposite to the previous window starts at the part the 256 MiB Infinity Cache still holds — measured on
+ * fz_nmf_cf_bwd: 3 % less time at the README model's stage 0 (537 MB tensors), 10 % at stage 1 (134 MB),
+ * profiles/r05_tile_order.md.  (Reading a tensor backwards right after the launch that WROTE it gains nothing measurable: the
+ * whole-step A/B with every streaming kernel alternating was -0.13 ms of 17.4, all of it from the window pairs.) */
+int fz_set_tile_order(int descending);
 /* Message for the last error returned on this thread ("" if none). */
 const char* fz_last_error_string(void);
 /* Number of kernel launches issued through this library by this process (test hook that
