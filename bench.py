@@ -77,8 +77,8 @@ MFMA_FLOP_PER_BYTE = {"mlp_chain_bwd_wgrad_": 16384 / 640}
 # read from inside the benchmark: the committed summary of the profiled run is quoted, and
 # `traffic_source` says which file (with its content hash and the commit it was measured at), so a stale
 # number is visible as such.
-PMC_TRAFFIC = os.path.join(ROOT, "profiles", os.environ.get("FZ_PMC_TRAFFIC", "r04_pmc_traffic.json"))
-PMC_TRAFFIC_BF16 = os.path.join(ROOT, "profiles", os.environ.get("FZ_PMC_TRAFFIC_BF16", "r04_pmc_traffic_bf16.json"))   # the --dtype bf16 command
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", os.environ.get("FZ_PMC_TRAFFIC", "r05_pmc_traffic.json"))
+PMC_TRAFFIC_BF16 = os.path.join(ROOT, "profiles", os.environ.get("FZ_PMC_TRAFFIC_BF16", "r05_pmc_traffic_bf16.json"))   # the --dtype bf16 command
 # What a hand-written streaming kernel of the same read : write mix reaches on MI355X (tools/probes/mem_ceilings.hip, 16 B per
 # lane, best over 4 / 8 / 16 waves per CU: profiles/r04_memory_ceilings.json).  `roofline.peak` stays the 8 TB/s of the
 # spec sheet; `stream_ceiling_GBps` is the number a memory-bound kernel can actually be held against.
@@ -97,7 +97,9 @@ def stream_ceiling(timer_name):
         return None, None
 # timer key of a BASELINE-size (stage-0) launch -> kernel-name prefix in the PMC summary; the summary averages
 # the launches with the largest grid of each kernel, i.e. the same stage-0 launches the key times
-PMC_KERNEL = {"nmf_cf_bwd_32x128x128x128": "fz::nmf_cf_bwd_tile_kernel<",
+# (a tuple: the timer's launches are one launch of each named kernel — round 5: window 0 of the fused core's backward runs the
+#  row-space kernel, window 1 the general one; the figure is then the mean over the kernels, like the timer's average launch)
+PMC_KERNEL = {"nmf_cf_bwd_32x128x128x128": ("fz::nmf_cf_bwd_gram_kernel<", "fz::nmf_cf_bwd_tile_kernel<"),
               "nmf_cf_fwd_32x128x128x128": "fz::nmf_cf_fwd_tile_kernel<",
               "mlp_chain_bwd_32": "fz::gemm_chain_kernel<true",
               "mlp_chain_bwd_wgrad_32": "fz::gemm_chain_bwd_wg_kernel<",
@@ -120,12 +122,14 @@ def pmc_traffic(timer_name, path=None):
     src = (f"{os.path.relpath(PMC_TRAFFIC, ROOT)} sha256:{hashlib.sha256(raw).hexdigest()[:12]} "
            f"measured_at_commit:{d.get('_meta', {}).get('commit', 'unknown')}")
     pre = PMC_KERNEL.get(timer_name)
-    hits = [v for k, v in d.items() if pre and k.startswith(pre) and isinstance(v, dict) and "traffic_bytes" in v]
-    if not hits:
+    pres = pre if isinstance(pre, tuple) else ((pre,) if pre else ())
+    per = [[v["traffic_bytes"] for k, v in d.items() if k.startswith(q) and isinstance(v, dict) and "traffic_bytes" in v] for q in pres]
+    hits = [max(h) for h in per if h]
+    if not hits or len(hits) != len(pres):
         print(f"[bench] NO PMC traffic entry for kernel {timer_name!r} (prefix {pre!r}) in {PMC_TRAFFIC}: "
               "roofline.traffic is null — re-run tools/pmc_traffic.py", file=sys.stderr, flush=True)
         return None, src + " (no entry for this kernel)"
-    return max(h["traffic_bytes"] for h in hits), src
+    return int(sum(hits) / len(hits)), src
 
 
 MODEL_KW = dict(in_channels=4, out_channels=3, spatial_size=(128, 128, 128),

@@ -17,7 +17,7 @@ def main():
     agg = collections.defaultdict(list)
     for r in rows:
         n = r["Kernel_Name"]
-        if any(s in n for s in ("nmf_cf_bwd_tile", "nmf_cf_fwd_tile", "gemm_chain", "gn_fwd", "gemm_resident", "gemm_dw_kernel")):
+        if any(s in n for s in ("nmf_cf_bwd_tile", "nmf_cf_bwd_gram", "nmf_cf_fwd_tile", "gemm_chain", "gn_fwd", "gemm_resident", "gemm_dw_kernel")):
             key = (n.split("(")[0].replace("void ", ""), int(r["Grid_Size_X"]))
             agg[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     pmc = json.load(open(pmc_path))
@@ -41,7 +41,9 @@ def main():
     out.append("## HBM traffic per launch from PMC counters (separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes, "
                "FETCH_SIZE x2 per the gfx950 correction; `tools/pmc_traffic.py` -> `profiles/" + tag.split("_")[0] + "_pmc_traffic.json`; stage-0 launches)\n")
     out.append("| kernel | fetch (corrected) MB | write MB | traffic MB | algorithmic MB |\n|---|---|---|---|---|")
-    alg = {"fz::nmf_cf_bwd_tile_kernel<1, 1, 4, false, float>": (3.5 * 536.87, " (avg over the 2 windows)"),
+    r5 = tag.startswith(("r05", "r06"))   # round 5 on: window 0 of the backward runs the row-space kernel, window 1 the general one
+    alg = {"fz::nmf_cf_bwd_gram_kernel<4, false, float, 0>": (3 * 536.87, " (window 0: t, dL/da in; dL/dt out)"),
+           "fz::nmf_cf_bwd_tile_kernel<1, 1, 4, false, float>": ((4 if r5 else 3.5) * 536.87, " (window 1: + the running sum)" if r5 else " (avg over the 2 windows)"),
            "fz::nmf_cf_fwd_tile_kernel<1, 1, 8, false, float>": (2.5 * 536.87, " (avg over the 2 windows)"),
            "fz::gemm_chain_kernel<true, 2, 2, float>": (7 * 536.87, ""), "fz::gemm_chain_kernel<false, 2, 2, float>": (4 * 536.87, ""),
            "fz::gemm_chain_bwd_wg_kernel<float>": (5 * 536.87, " (round 4: the residual rows g2 come from LDS; rounds 2-3 read them a second time, +537)"),

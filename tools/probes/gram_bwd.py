@@ -51,6 +51,16 @@ def run(B, C, S, dt):
     u0, v0 = torch.rand(8, 1, device=DEV), torch.rand(512, 1, device=DEV)
     gt = torch.empty_like(t)
     U = t.numel() * t.element_size()
+    out = torch.empty_like(t)
+
+    def fwd(sh, w):
+        arr = (N._i * 3)(*sh)
+        rc = lib.fz_nmf_cf_fwd(t.data_ptr(), u0.data_ptr(), v0.data_ptr(), out.data_ptr(), B, C, *S, arr, int(w > 0), 2 if w else 1, 1, 5, 1,
+                               1e-16, N.act_dtype(t), N.stream_ptr(t))
+        assert rc == 0
+    f0, f1 = timeit(lambda: fwd((0, 0, 0), 0)), timeit(lambda: fwd((4, 4, 4), 1))
+    print(json.dumps({"B": B, "C": C, "S": list(S), "dtype": str(dt), "kernel": "forward", "w0_us": round(f0 * 1e3, 1), "w1_us": round(f1 * 1e3, 1),
+                      "w0_TBps_alg": round(2 * U / f0 / 1e9, 3), "w1_TBps_alg": round(3 * U / f1 / 1e9, 3)}), flush=True)
     for gate in (1, 0):
         t0 = timeit(lambda: bwd(lib, t, u0, v0, ga, gt, B, C, S, (0, 0, 0), 0, 2, gate, 5, 5))
         t1 = timeit(lambda: bwd(lib, t, u0, v0, ga, gt, B, C, S, (4, 4, 4), 1, 2, gate, 5, 5))

@@ -8,8 +8,8 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 EXTRA=${2:-}
-CMD="python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline $EXTRA"
-python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline $EXTRA > $OUT/bench.json 2> $OUT/bench.err
+CMD="python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-other-configs $EXTRA"
+python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs $EXTRA > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $CMD > $OUT/trace.log 2>&1
 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/sq1 -o p -- $CMD > $OUT/sq1.log 2>&1
 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_VALU_MFMA_COEXEC_CYCLES --output-format csv -d $OUT/sq2 -o p -- $CMD > $OUT/sq2.log 2>&1
