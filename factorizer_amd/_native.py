@@ -186,7 +186,8 @@ class MlpDesc(_c.Structure):
     _fields_ = [("mode", _i), ("inp", _vp), ("w1", _vp), ("w2", _vp), ("b1", _vp), ("b2", _vp), ("ln_g", _vp),
                 ("ln_b", _vp), ("ln_eps", _f), ("stats", _vp), ("z1", _vp), ("gz1", _vp), ("x1", _vp), ("out", _vp),
                 ("part", _vp), ("B", _i), ("C", _i), ("H", _i), ("V", _i64), ("act_dtype", _i), ("wpart", _vp),
-                ("gw1", _vp), ("gb1", _vp), ("gw2", _vp), ("gb2", _vp), ("gln", _vp), ("glp", _vp), ("products", _i)]
+                ("gw1", _vp), ("gb1", _vp), ("gw2", _vp), ("gb2", _vp), ("gln", _vp), ("glp", _vp), ("products", _i),
+                ("pre_in", _vp), ("pre_w", _vp), ("pre_b", _vp), ("pre_res", _vp), ("pre_out", _vp)]
 
 
 class GemmDwDesc(_c.Structure):
@@ -221,6 +222,7 @@ _SIGS.update({
     "fz_nmf_pcf_bwd": ([_vp] * 5 + [_i] * 8 + [_c.POINTER(_i)] + [_i] * 7 + [_f, _i, _vp], _i),
     "fz_nmf_pcf_bwd_prefers_separate": ([_i] * 4, _i),
     "fz_act_add": ([_vp, _vp, _i64, _i, _vp], _i),
+    "fz_mlp_pre_supported": ([_i, _i, _i64, _i], _i),
     "fz_gemm": ([_c.POINTER(GemmDesc), _vp], _i),
     "fz_gemm_bx_enable": ([_i], _i),
     "fz_gemm_lnbwd_partials": ([_c.POINTER(GemmDesc)], _i64),

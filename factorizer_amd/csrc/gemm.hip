@@ -492,6 +492,13 @@ struct ChainArgsT {
   int wB_t, ldwB;
   const float* biasB;  // forward: [32] or null
   AT* side;            // (B, 64, V)
+  // PRE (forward, round 5): the block's out-projection in front of the chain — x1 = preW · preA + preB + preRes is formed on
+  // the accumulators, written to preOut (the backward needs it) and normalised in place: x1 is never read back
+  const AT* preA;      // (B, 32, V) the core's output a
+  const float* preW;   // (32, 32) out_proj weight W[m][k]
+  const float* preB;   // (32) or null
+  const AT* preRes;    // (B, 32, V) the block input x (residual)
+  AT* preOut;          // (B, 32, V) x1
   int stagger;         // start delay of the workgroups beyond the first 256, in units of 8 192 cycles per 256 workgroups (timing only)
 };
 
@@ -513,15 +520,18 @@ __device__ __forceinline__ void chain_stagger(int stagger) {
 // kernel's time with nothing running beside them — a bf16 MFMA for a quarter of its own.
 // (Six-wave workgroups — 73 KB, two per CU, three waves per SIMD again — were tried and are slower than these four-wave ones at two
 // waves per SIMD: 1.06 against 0.97 ms per step for the two launches, fp32 form 1.09; profiles/r04_chain_fwd_bx_ab.log.)
-template <bool BWD, int NACC, int HB, typename AT = float, bool BX = false>
+template <bool BWD, int NACC, int HB, typename AT = float, bool BX = false, bool PRE = false>
 __global__ __launch_bounds__(256, (NACC == 2 && HB == 2 && !BWD && !BX) ? 3 : 2) void gemm_chain_kernel(GemmArgsT<AT> p, ChainArgsT<AT> c, int ntiles) {
   constexpr int NW = 4;
   constexpr int HID = 32 * HB, N1 = BX ? 1536 * HB : 16 * HB * 64;  // hidden rows; floats of each staged weight block
   static_assert(!BX || (!BWD && NACC == 2), "the split-bf16 form is the forward chain");
+  static_assert(!PRE || (BX && HB == 2), "the out-projection in front of the chain: split-bf16 forward, hidden 64");
   __shared__ __attribute__((aligned(16))) float As1[N1];
   __shared__ __attribute__((aligned(16))) float As2[N1];
+  __shared__ __attribute__((aligned(16))) float As0[PRE ? 1536 : 4];   // (PRE) out_proj weights, pre-split: [g (2)][level][lane] x 16 B
   __shared__ float tW[HID];
   __shared__ float tB[32];
+  __shared__ float tB0[32];                                              // (PRE) out_proj bias
   __shared__ float red[256];
   // raw operand tile of each wave (32 channels x 32*NACC columns): the epilogue needs the SAME tensor
   // again in the accumulator layout (residual x1 / added gradient g2) — served from LDS instead of a
@@ -534,15 +544,23 @@ __global__ __launch_bounds__(256, (NACC == 2 && HB == 2 && !BWD && !BX) ? 3 : 2)
 
   if constexpr (BX) {
     // operand items of 8 steps each: As1x[g (2)][rb (HB)][level][lane], As2x[g (2 HB)][level][lane]
-    for (int it = threadIdx.x; it < 4 * HB * 64; it += 64 * NW) {
+    for (int it = threadIdx.x; it < (PRE ? 4 * HB + 2 : 4 * HB) * 64; it += 64 * NW) {
       float wv[8];
       const int l = it & 63;
       __bf16* dst;
-      if (it < 2 * HB * 64) {
+      if (PRE && it >= 4 * HB * 64) {   // GEMM 0: element e of lane half h = channel 2 (8g + e) + h of a (the operand tile's order)
+        const int g = (it - 4 * HB * 64) >> 6;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wv[e] = c.preW[(l & 31) * 32 + 2 * (8 * g + e) + (l >> 5)];
+        dst = reinterpret_cast<__bf16*>(As0) + (g * 3 * 64 + l) * 8;
+      } else if (it < 2 * HB * 64) {
         const int rb = (it >> 6) % HB, g = it / (64 * HB);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const int kk = 2 * (8 * g + e) + (l >> 5);
+          // (PRE: the column operand of GEMM 1 is x̂ in the ACCUMULATOR layout of GEMM 0 — register r = 8g + e of lane half h is
+          //  channel (r & 3) + 8 (r >> 2) + 4h, the order GEMM 2 uses for the hidden tensor)
+          const int r = 8 * g + e;
+          const int kk = PRE ? (r & 3) + 8 * (r >> 2) + 4 * (l >> 5) : 2 * r + (l >> 5);
           wv[e] = weight_at(p, rb * 32 + (l & 31), kk) * p.ln_g[kk];
         }
         dst = reinterpret_cast<__bf16*>(As1) + ((g * HB + rb) * 3 * 64 + l) * 8;
@@ -597,6 +615,7 @@ __global__ __launch_bounds__(256, (NACC == 2 && HB == 2 && !BWD && !BX) ? 3 : 2)
       for (int k = 0; k < 32; ++k) t += weight_at(p, r, k) * p.ln_b[k];
       tW[r] = t + (p.bias ? p.bias[r] : 0.f);
       if (r < 32) tB[r] = c.biasB ? c.biasB[r] : 0.f;
+      if (PRE && r < 32) tB0[r] = c.preB ? c.preB[r] : 0.f;
     }
   }
 
@@ -604,14 +623,21 @@ __global__ __launch_bounds__(256, (NACC == 2 && HB == 2 && !BWD && !BX) ? 3 : 2)
   // consumed the current one, so its latency hides behind the transform, GEMM 2 and the epilogue
   int tile = blockIdx.x;
   float bv[16][NACC];
+  float xr[PRE ? 16 : 1][NACC];   // (PRE) residual rows of the NEXT / current tile
   // operand loads: channel 2s + h → uniform part (b*32 + 2s)*V in scalar registers + ONE lane offset
   auto fetch_tile = [&](int t) {
     const int bt = t / tiles_per_sample;
     const int64_t ct = ((int64_t)(t % tiles_per_sample) * NW + wave) * (32 * NACC) + NACC * j;
     const unsigned lo = (unsigned)h * (unsigned)p.Ncol + (unsigned)(ct < p.Ncol ? ct : 0);
-    const AT* xb = p.x[0] + (int64_t)bt * 32 * p.Ncol;
+    const AT* xb = (PRE ? c.preA : p.x[0]) + (int64_t)bt * 32 * p.Ncol;
 #pragma unroll
     for (int s = 0; s < 16; ++s) vload<NACC>(xb + (int64_t)(2 * s) * p.Ncol + lo, bv[s]);
+    if constexpr (PRE) {   // the residual rows of x in the accumulator layout (row (r & 3) + 8 (r >> 2) + 4h)
+      const unsigned lr = (unsigned)(4 * h) * (unsigned)p.Ncol + (unsigned)(ct < p.Ncol ? ct : 0);
+      const AT* rb0 = c.preRes + (int64_t)bt * 32 * p.Ncol;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) vload<NACC>(rb0 + (int64_t)((r & 3) + 8 * (r >> 2)) * p.Ncol + lr, xr[PRE ? r : 0]);
+    }
   };
   fetch_tile(tile);
   __syncthreads();
@@ -625,11 +651,54 @@ __global__ __launch_bounds__(256, (NACC == 2 && HB == 2 && !BWD && !BX) ? 3 : 2)
     const bool col_ok = col_off < p.Ncol;
     const int64_t nc = col_ok ? col_off : 0;
     const unsigned lane_row = (unsigned)(4 * h) * (unsigned)p.Ncol + (unsigned)nc;
+    if constexpr (PRE) {
+      // ---- GEMM 0: x1 = W_o a + b_o + x on the accumulators; x1 -> HBM (for the backward) and -> stash (the chain's residual);
+      //      bv becomes x̂ in the ACCUMULATOR layout (register r = row (r & 3) + 8 (r >> 2) + 4h) — GEMM 1's weights are staged
+      //      in that order ----
+      f32x16 acc0[NACC];
+#pragma unroll
+      for (int q = 0; q < NACC; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[q][r] = 0.f;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        bx8 aop[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          aop[i] = *reinterpret_cast<const bx8*>(reinterpret_cast<const __bf16*>(As0) + ((g * 3 + i) * 64 + lane) * 8);
+#pragma unroll
+        for (int q = 0; q < NACC; ++q) {
+          float x8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x8[e] = bv[8 * g + e][q];
+          bx8 bop[3];
+          bx_split<3>(x8, bop);
+          bx_mfma<3, 3>(acc0[q], aop, bop);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rbase = (r & 3) + 8 * (r >> 2);
+        const int row = rbase + 4 * h;
+        const float add = tB0[row];
+#pragma unroll
+        for (int q = 0; q < NACC; ++q) {
+          float v = acc0[q][r] + add + xr[PRE ? r : 0][q];
+          // bf16 storage: everything downstream (LayerNorm, the chain's residual, the backward) sees the STORED x1, as in the
+          // two-launch form where the chain reads it back
+          if constexpr (sizeof(AT) == 2) v = (float)(AT)v;
+          bv[r][q] = v;
+        }
+        vstore<NACC>(&stash[wave][row][NACC * j], bv[r]);
+        if (col_ok) vstore<NACC>(c.preOut + ((int64_t)b * 32 + rbase) * p.Ncol + lane_row, bv[r]);
+      }
+    } else {
 #pragma unroll
     for (int s = 0; s < 16; ++s) vstore<NACC>(&stash[wave][2 * s + h][NACC * j], bv[s]);
+    }
 
     if (!BWD) {
-      // exact two-pass LayerNorm statistics (this lane holds the parity-h half of the channels)
+      // exact two-pass LayerNorm statistics (this lane holds the parity-h half of the channels; PRE: rows 4h + ...: also half)
       float mu[NACC], rs[NACC];
 #pragma unroll
       for (int e = 0; e < NACC; ++e) {
@@ -2921,6 +2990,10 @@ extern "C" int64_t fz_mlp_wgrad_workspace_bytes(int B, int64_t V) {
   return 2 * (int64_t)fz_mlp_wgrad_rows(B, V) * kWgRow * (int64_t)sizeof(float);   // two row blocks (hidden 128 runs in two halves)
 }
 
+extern "C" int fz_mlp_pre_supported(int C, int H, int64_t V, int products) {
+  return (C == 32 && H == 64 && V > 0 && (V % 4) == 0 && V <= ((int64_t)1 << 27) && products_split(products) && knob_chain_fwd_bx()) ? 1 : 0;
+}
+
 extern "C" int fz_mlp_supported(int C, int H, int64_t V) {
   const bool shape = (C == 32 && (H == 64 || H == 128)) || (C == 64 && H == 128);
   return (shape && V > 0 && (V % 4) == 0 && V <= ((int64_t)1 << 27)) ? 1 : 0;
@@ -2931,7 +3004,12 @@ static int mlp_launch(const fz_mlp_desc* d, fz_stream_t stream) {
   if (!fz_mlp_supported(d->C, d->H, d->V)) return fail(FZ_E_UNSUPPORTED, "fz_mlp_chain: needs (C, H) in {(32, 64), (32, 128), (64, 128)}, V % 4 == 0");
   if (d->C == 64 && d->mode == 2) return fail(FZ_E_UNSUPPORTED, "fz_mlp_chain: the fused weight gradients need C == 32, H == 64");
   if (d->B < 0) return fail(FZ_E_SHAPE, "fz_mlp_chain: negative batch");
-  if (!d->in || !d->w1 || !d->w2 || !d->out || !d->z1 || !d->stats)
+  const bool pre = d->pre_in != nullptr;   // the block's out-projection in front of the forward chain (x1 is then an OUTPUT)
+  if (pre && (d->mode != 0 || d->C != 32 || d->H != 64 || !d->pre_w || !d->pre_res || !d->pre_out))
+    return fail(FZ_E_ARG, "fz_mlp_chain: pre_in needs mode 0, C == 32, H == 64, pre_w, pre_res, pre_out (see fz_mlp_pre_supported)");
+  if (pre && !fz_mlp_pre_supported(d->C, d->H, d->V, d->products))
+    return fail(FZ_E_UNSUPPORTED, "fz_mlp_chain: the fused out-projection runs on split-bf16 products only (fz_mlp_pre_supported)");
+  if ((!d->in && !pre) || !d->w1 || !d->w2 || !d->out || !d->z1 || !d->stats)
     return fail(FZ_E_ARG, "fz_mlp_chain: null pointer");
   if (d->mode == 0 && (!d->ln_g || !d->ln_b)) return fail(FZ_E_ARG, "fz_mlp_chain: forward needs the LayerNorm affine");
   if (d->mode == 1 && (!d->gz1 || !d->x1 || !d->ln_g || !d->part)) return fail(FZ_E_ARG, "fz_mlp_chain: backward needs gz1, x1, gamma, part");
@@ -3013,6 +3091,10 @@ static int mlp_launch(const fz_mlp_desc* d, fz_stream_t stream) {
     if (d->H == 128) hipLaunchKernelGGL((gemm_chain_kernel<false, 2, 4>), grid, block, 0, st, a, c, ntiles);
     else if (products_split(d->products) && knob_chain_fwd_bx()) {   // split-bf16 form: two workgroups per CU
       const int wgs2 = knob_mlp_wgs(512);
+      if (pre) {
+        c.preA = (const AT*)d->pre_in; c.preW = d->pre_w; c.preB = d->pre_b; c.preRes = (const AT*)d->pre_res; c.preOut = (AT*)d->pre_out;
+        hipLaunchKernelGGL((gemm_chain_kernel<false, 2, 2, AT, true, true>), dim3((unsigned)(ntiles < wgs2 ? ntiles : wgs2)), block, 0, st, a, c, ntiles);
+      } else
       hipLaunchKernelGGL((gemm_chain_kernel<false, 2, 2, AT, true>), dim3((unsigned)(ntiles < wgs2 ? ntiles : wgs2)), block, 0, st, a, c, ntiles);
     } else hipLaunchKernelGGL((gemm_chain_kernel<false, 2, 2>), grid, block, 0, st, a, c, ntiles);
   } else if (d->mode == 2) {

@@ -234,6 +234,39 @@ def _mlp_fwd_chain(x1, ln_w, ln_b, eps, w12, b1, w22, b2):
     return x2, z1, st
 
 
+_OUTPROJ_MLP = os.environ.get("FZ_OUTPROJ_MLP", "1") != "0"   # diagnostics: 0 = out_proj and the MLP chain as two launches
+
+
+def _outproj_mlp_ok(C, Hd, V):
+    return _OUTPROJ_MLP and _mlp_chain_ok(C, Hd, V) and bool(N.lib().fz_mlp_pre_supported(C, Hd, V, N.products()))
+
+
+def _outproj_mlp_fwd_chain(a, wout2, bout, x, ln_w, ln_b, eps, w12, b1, w22, b2):
+    """x1 = x + out_proj(a) (factorizer.py:53,75) and x2 = x1 + fc2(gelu(fc1(LN(x1)))) (factorizer.py:76; mlp.py:54-63) in ONE
+    launch: the out-projection runs on the accumulators in front of the chained MLP GEMMs, x1 is written once (the backward
+    needs it) and never read back — 6 instead of 7 tensor passes.  Returns (x1, x2, z1, stats)."""
+    B, C = a.shape[:2]
+    V = _vox(a)
+    Hd = w12.shape[0]
+    z1 = torch.empty((B, Hd, *a.shape[2:]), dtype=a.dtype, device=a.device)
+    st = torch.empty((B, 2, V), dtype=torch.float32, device=a.device)
+    x1 = torch.empty_like(a)
+    x2 = torch.empty_like(a)
+    d = N.MlpDesc()
+    d.products = N.products()
+    d.mode, d.inp, d.w1, d.w2, d.b1, d.b2 = 0, None, w12.data_ptr(), w22.data_ptr(), _p(b1), _p(b2)
+    d.ln_g, d.ln_b, d.ln_eps = ln_w.data_ptr(), ln_b.data_ptr(), float(eps)
+    d.stats, d.z1, d.out = st.data_ptr(), z1.data_ptr(), x2.data_ptr()
+    d.B, d.C, d.H, d.V = B, C, Hd, V
+    d.act_dtype = N.act_dtype(a)
+    d.pre_in, d.pre_w, d.pre_b, d.pre_res, d.pre_out = a.data_ptr(), wout2.data_ptr(), _p(bout), x.data_ptr(), x1.data_ptr()
+    with torch.cuda.device(a.device):
+        rc = Fn._timed(f"outproj_mlp_chain_fwd_{C}", a.element_size() * (4 * a.numel() + z1.numel()),
+                       lambda: N.lib().fz_mlp_chain(ctypes.byref(d), N.stream_ptr(a)), cols=B * V, flops=4 * B * V * C * Hd + 2 * B * V * C * C)
+    N.check(rc, "fz_mlp_chain")
+    return x1, x2, z1, st
+
+
 def _mlp_bwd_chain(g2, z1, w12, w22, x1, st, ln_w):
     """(gz1, gx1, gγ, gβ): gz1 = (W2ᵀ g2) ∘ gelu'(z1); gx1 = LNbwd(W1ᵀ gz1) + g2, one kernel."""
     B, C = x1.shape[:2]
@@ -976,20 +1009,22 @@ class FactorizerBlockFn(torch.autograd.Function):
             ym, _, _ = Fn._nmf_fwd_raw(m, u0c, v0c, T, solver, neps)
             a = Fn._swm_inv_raw(ym, geo, average=True)
             del ym
-        # 3. x1 = x + out_proj(a)
-        x1 = new(C)
-        _gemm([a], wout2, x1, B=B, Cin=C, Vin=V, M=C, K=C, Ncol=V, bias=bout, res=x, name="act_linear_res")
-        # 4. z1 = fc1(LN2(x1)) ; x2 = x1 + fc2(gelu(z1))
-        if _mlp_chain_ok(C, Hd, V):
-            x2, z1, st2 = _mlp_fwd_chain(x1, n2w, n2b, cfg["eps2"], w12, b1, w22, b2)
+        # 3. x1 = x + out_proj(a)   4. z1 = fc1(LN2(x1)) ; x2 = x1 + fc2(gelu(z1))
+        if _outproj_mlp_ok(C, Hd, V) and a.is_contiguous() and x.is_contiguous():
+            x1, x2, z1, st2 = _outproj_mlp_fwd_chain(a, wout2, bout, x, n2w, n2b, cfg["eps2"], w12, b1, w22, b2)   # both in one launch
         else:
-            z1 = new(Hd)
-            st2 = torch.empty((B, 2, V), dtype=torch.float32, device=x.device)
-            _gemm([x1], w12, z1, B=B, Cin=C, Vin=V, M=Hd, K=C, Ncol=V, bias=b1, ln=(n2w, n2b, cfg["eps2"]),
-                  stats_out=st2, name="ln_linear")
-            x2 = new(C)
-            _gemm([z1], w22, x2, B=B, Cin=Hd, Vin=V, M=C, K=Hd, Ncol=V, bias=b2, bact=ACT["gelu"], res=x1,
-                  name="act_linear_res")
+            x1 = new(C)
+            _gemm([a], wout2, x1, B=B, Cin=C, Vin=V, M=C, K=C, Ncol=V, bias=bout, res=x, name="act_linear_res")
+            if _mlp_chain_ok(C, Hd, V):
+                x2, z1, st2 = _mlp_fwd_chain(x1, n2w, n2b, cfg["eps2"], w12, b1, w22, b2)
+            else:
+                z1 = new(Hd)
+                st2 = torch.empty((B, 2, V), dtype=torch.float32, device=x.device)
+                _gemm([x1], w12, z1, B=B, Cin=C, Vin=V, M=Hd, K=C, Ncol=V, bias=b1, ln=(n2w, n2b, cfg["eps2"]),
+                      stats_out=st2, name="ln_linear")
+                x2 = new(C)
+                _gemm([z1], w22, x2, B=B, Cin=Hd, Vin=V, M=C, K=Hd, Ncol=V, bias=b2, bact=ACT["gelu"], res=x1,
+                      name="act_linear_res")
         ctx.save_for_backward(x, st1, t, a, x1, st2, z1, m, n1w, n1b, win2, u0c, v0c, wout2, n2w, n2b, w12, w22)
         ctx.cfg = cfg
         ctx.shapes = (win.shape, wout.shape, w1.shape, w2.shape)

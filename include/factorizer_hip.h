@@ -312,6 +312,15 @@ typedef struct fz_mlp_desc {
   float* gln;         /* mode 2: (2*C) dgamma | dbeta of the LayerNorm (part is not used)    */
   float* glp;         /* mode 2, H = 128: (B, C, V) fp32 scratch (the first half's part of W1^T gz1) */
   int products;       /* FZ_PRODUCTS_* */
+  /* [r5] mode 0, C = 32, H = 64, split-bf16 products (fz_mlp_pre_supported): the block's out-projection in front of the chain,
+   * x1 = pre_w . pre_in + pre_b + pre_res (factorizer.py:53,75) formed on the accumulators, written to pre_out and
+   * normalised in registers — `in` is ignored, x1 is never read back (6 instead of 7 tensor passes for steps 3 + 4 of the
+   * block).  pre_in == NULL: the plain chain on `in`. */
+  const void* pre_in;   /* activation (B, C, V): the core's output a, or NULL                 */
+  const float* pre_w;   /* (C, C) out_proj weight                                              */
+  const float* pre_b;   /* (C) or NULL                                                         */
+  const void* pre_res;  /* activation (B, C, V): the block input x                             */
+  void* pre_out;        /* activation (B, C, V): x1                                            */
 } fz_mlp_desc;
 
 /* ---- input gradient AND weight gradient of a 32 -> 32 1x1 layer in one pass (in_proj behind LayerNorm, out_proj;
@@ -374,6 +383,7 @@ int fz_upcat(const void* skip, const void* deep, const float* wa, int lda, const
              int B, int C, int Cd, int D, int H, int W, int act_dtype, fz_stream_t stream);
 
 int fz_mlp_supported(int C, int H, int64_t V);
+int fz_mlp_pre_supported(int C, int H, int64_t V, int products);
 int64_t fz_mlp_partials(int B, int64_t V);
 int fz_mlp_wgrad_rows(int B, int64_t V);
 int64_t fz_mlp_wgrad_workspace_bytes(int B, int64_t V);

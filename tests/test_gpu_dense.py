@@ -350,6 +350,66 @@ def test_mlp_chain_kernel(B, S, C, Hd):
     _cmp(gb, lb.grad, "dbeta")
 
 
+@pytest.mark.parametrize("bf", [False, True])
+@pytest.mark.parametrize("B,S", [(2, (8, 8, 8)), (1, (6, 4, 5)), (2, (16, 16, 12)), (3, (32, 32, 40))])
+def test_outproj_and_mlp_chain_in_one_launch(B, S, bf):
+    """Steps 3 + 4 of FactorizerBlock.forward — x1 = x + out_proj(a) (factorizer.py:53,75) and x2 = x1 + mlp(LN(x1))
+    (factorizer.py:76; mlp.py:54-63; norm.py:29-34) — as ONE launch (fz_mlp_chain with pre_in: the out-projection on the
+    accumulators in front of the chained GEMMs, x1 written once and never read back) against the float64 composition on
+    the CPU and against the two-launch form it replaces.  V = 120 covers a ragged tile, (3, 32·32·40) several tiles per
+    workgroup.  bf16 storage: everything downstream of x1 must see the STORED (rounded) x1, as the two-launch form does."""
+    torch.manual_seed(17)
+    C, Hd = 32, 64
+    rnd = (lambda t: t.bfloat16().float()) if bf else (lambda t: t)
+    a = rnd(torch.relu(torch.randn(B, C, *S)) * 1.5)
+    x = rnd(torch.randn(B, C, *S) * 2 + 0.5)
+    wo, bo = torch.randn(C, C) * 0.2, torch.randn(C) * 0.1
+    ln_w, ln_b = torch.rand(C) + 0.5, torch.randn(C) * 0.1
+    w1, b1 = torch.randn(Hd, C) * 0.2, torch.randn(Hd) * 0.1
+    w2, b2 = torch.randn(C, Hd) * 0.2, torch.randn(C) * 0.1
+    dt = torch.bfloat16 if bf else torch.float32
+    d = lambda t: t.to(DEV).contiguous()  # noqa: E731
+    ad, xd = d(a).to(dt), d(x).to(dt)
+    V = a[0, 0].numel()
+    assert PW._outproj_mlp_ok(C, Hd, V)
+    n0 = _native.launch_count()
+    x1, x2, z1, st = PW._outproj_mlp_fwd_chain(ad, d(wo), d(bo), xd, d(ln_w), d(ln_b), 1e-5, d(w1), d(b1), d(w2), d(b2))
+    assert _native.launch_count() - n0 == 1
+    # float64 composition (bf16: with the storage rounding of x1, the one tensor between the two steps that reaches HBM)
+    D = torch.float64
+    x1c = x.to(D) + _lin_cpu(a.to(D), wo.to(D).unsqueeze(-1), bo.to(D))
+    if bf:
+        x1c = x1c.float().bfloat16().to(D)
+    xn = F.layer_norm(x1c.movedim(1, -1), (C,), ln_w.to(D), ln_b.to(D), 1e-5).movedim(-1, 1)
+    z1c = _lin_cpu(xn, w1.to(D).unsqueeze(-1), b1.to(D))
+    x2c = x1c + _lin_cpu(F.gelu(z1c), w2.to(D).unsqueeze(-1), b2.to(D))
+    _cmp(x1.float(), x1c.float(), "x1", **(dict(rtol=2.0 ** -8, why="bf16 storage: one rounding of the stored tensor") if bf else {}))
+    if not bf:
+        _cmp(z1, z1c.float(), "z1")
+        _cmp(x2, x2c.float(), "x2")
+        _cmp(st[:, 0], x1c.mean(1).reshape(B, -1).float(), "mean")
+        _cmp(st[:, 1], (1.0 / torch.sqrt(x1c.var(1, unbiased=False) + 1e-5)).reshape(B, -1).float(), "rstd")
+    # the two launches it replaces, same inputs
+    x1b = torch.empty_like(ad)
+    PW._gemm([ad], d(wo), x1b, B=B, Cin=C, Vin=V, M=C, K=C, Ncol=V, bias=d(bo), res=xd, name="act_linear_res")
+    x2b, z1b, stb = PW._mlp_fwd_chain(x1b, d(ln_w), d(ln_b), 1e-5, d(w1), d(b1), d(w2), d(b2))
+    if bf:
+        # one unit in the last place of bf16 where the two product paths round a tie differently; everything else identical
+        assert (x1.float() - x1b.float()).abs().max().item() <= 2.0 ** -7 * x1b.float().abs().max().item()
+        same = x1 == x1b
+        assert same.float().mean().item() > 0.995
+        _cmp(x2.float(), x2b.float(), "x2 one launch vs two (bf16)", rtol=4 * 2.0 ** -8,
+             why="bf16 storage: a handful of x1 elements rounded the other way by the two product paths, then one more stored rounding")
+    else:
+        _cmp(x1, x1b, "x1 one launch vs two", rtol=1e-5)
+        _cmp(z1, z1b, "z1 one launch vs two", rtol=1e-5)
+        _cmp(x2, x2b, "x2 one launch vs two", rtol=1e-5)
+        _cmp(st, stb, "stats one launch vs two", rtol=1e-5)
+    # replay: bit-identical
+    x1r, x2r, z1r, str_ = PW._outproj_mlp_fwd_chain(ad, d(wo), d(bo), xd, d(ln_w), d(ln_b), 1e-5, d(w1), d(b1), d(w2), d(b2))
+    assert torch.equal(x1, x1r) and torch.equal(x2, x2r) and torch.equal(z1, z1r) and torch.equal(st, str_)
+
+
 @pytest.mark.parametrize("Hd", [64, 128])
 @pytest.mark.parametrize("bf", [False, True])
 @pytest.mark.parametrize("B,S", [(2, (8, 8, 8)), (1, (6, 4, 5)), (2, (16, 16, 12)), (3, (32, 32, 40))])
