@@ -187,7 +187,8 @@ class MlpDesc(_c.Structure):
                 ("ln_b", _vp), ("ln_eps", _f), ("stats", _vp), ("z1", _vp), ("gz1", _vp), ("x1", _vp), ("out", _vp),
                 ("part", _vp), ("B", _i), ("C", _i), ("H", _i), ("V", _i64), ("act_dtype", _i), ("wpart", _vp),
                 ("gw1", _vp), ("gb1", _vp), ("gw2", _vp), ("gb2", _vp), ("gln", _vp), ("glp", _vp), ("products", _i),
-                ("pre_in", _vp), ("pre_w", _vp), ("pre_b", _vp), ("pre_res", _vp), ("pre_out", _vp)]
+                ("pre_in", _vp), ("pre_w", _vp), ("pre_b", _vp), ("pre_res", _vp), ("pre_out", _vp),
+                ("post_w", _vp), ("post_b", _vp), ("post_out", _vp), ("post_m", _i)]
 
 
 class GemmDwDesc(_c.Structure):

@@ -137,10 +137,20 @@ class FactorizerBlock(nn.Module):
                     G, sid = min(max(mf.num_grad_steps, 0), mf.num_iters), mf.solver.native_id
                 cfg = dict(geo=f.reshape.geometry, T=mf.num_iters, G=G, solver=sid, nmf_eps=mf.solver.eps,
                            eps1=n1.eps, eps2=n2.eps, core=core is not None)
-                return PW.FactorizerBlockFn.apply(
-                    x, n1.weight, n1.bias, f.in_proj.linear.weight, mf.init.u0, mf.init.v0,
-                    f.out_proj.linear.weight, f.out_proj.linear.bias, n2.weight, n2.bias,
-                    blk[0].linear.weight, blk[0].linear.bias, blk[3].linear.weight, blk[3].linear.bias, cfg)
+                args = (x, n1.weight, n1.bias, f.in_proj.linear.weight, mf.init.u0, mf.init.v0,
+                        f.out_proj.linear.weight, f.out_proj.linear.bias, n2.weight, n2.bias,
+                        blk[0].linear.weight, blk[0].linear.bias, blk[3].linear.weight, blk[3].linear.bias, cfg)
+                slot = PW.head_fusion_slot()
+                if slot is not None and slot.block is self and core is not None:
+                    # this block's output feeds ONLY the network's head (ushape.UNet.forward): the head runs inside the
+                    # block's last launch, HeadOfBlockFn carries its gradient
+                    hw, hb = slot.head_params
+                    C, Hd = x.shape[1], blk[0].linear.weight.shape[0]
+                    if PW.block_head_fusable(C, Hd, x[0, 0].numel(), hw, x):
+                        y, raw = PW.FactorizerBlockFn.apply(*args, hw, hb)
+                        slot.logits = PW.HeadOfBlockFn.apply(y, hw, hb, raw)
+                        return y
+                return PW.FactorizerBlockFn.apply(*args)
             # per-layer fused path (composed NMF, unusual bias layout, ...)
             t = PW.ln_linear(x, n1.weight, n1.bias, n1.eps, f.in_proj.linear.weight, f.in_proj.linear.bias, "relu")
             a = f.reshape.inverse_forward(f.factorize(f.reshape(t)))  # ReLU already applied (commutes)

@@ -499,6 +499,11 @@ struct ChainArgsT {
   const float* preB;   // (32) or null
   const AT* preRes;    // (B, 32, V) the block input x (residual)
   AT* preOut;          // (B, 32, V) x1
+  // POST (forward, with PRE): the network's head Linear(32 -> postM <= 4) on the chain's output while it is in registers
+  const float* postW;  // (postM, 32)
+  const float* postB;  // (postM) or null
+  AT* postOut;         // (B, postM, V) or null
+  int postM;
   int stagger;         // start delay of the workgroups beyond the first 256, in units of 8 192 cycles per 256 workgroups (timing only)
 };
 
@@ -532,6 +537,7 @@ __global__ __launch_bounds__(256, (NACC == 2 && HB == 2 && !BWD && !BX) ? 3 : 2)
   __shared__ float tW[HID];
   __shared__ float tB[32];
   __shared__ float tB0[32];                                              // (PRE) out_proj bias
+  __shared__ float tP[PRE ? 4 * 32 + 4 : 1];                             // (PRE + head) head weights, rows >= postM zero | bias
   __shared__ float red[256];
   // raw operand tile of each wave (32 channels x 32*NACC columns): the epilogue needs the SAME tensor
   // again in the accumulator layout (residual x1 / added gradient g2) — served from LDS instead of a
@@ -616,6 +622,13 @@ __global__ __launch_bounds__(256, (NACC == 2 && HB == 2 && !BWD && !BX) ? 3 : 2)
       tW[r] = t + (p.bias ? p.bias[r] : 0.f);
       if (r < 32) tB[r] = c.biasB ? c.biasB[r] : 0.f;
       if (PRE && r < 32) tB0[r] = c.preB ? c.preB[r] : 0.f;
+    }
+    if constexpr (PRE) {
+      if (c.postOut != nullptr && threadIdx.x < 4 * 32 + 4) {
+        const int i = threadIdx.x;
+        if (i < 128) tP[i] = (i >> 5) < c.postM ? c.postW[i] : 0.f;
+        else tP[i] = ((i - 128) < c.postM && c.postB) ? c.postB[i - 128] : 0.f;
+      }
     }
   }
 
@@ -861,6 +874,8 @@ __global__ __launch_bounds__(256, (NACC == 2 && HB == 2 && !BWD && !BX) ? 3 : 2)
       lnbwd_block<NACC, true, true>(p, acc2, b, col_off, col_ok, lane, wave, red, tile, tB, &stash[wave][0][0]);
       __syncthreads();  // red is reused by the next tile
     } else if (col_ok) {
+      const bool post = PRE && c.postOut != nullptr;   // uniform
+      float pl[4][NACC] = {};
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int rbase = (r & 3) + 8 * (r >> 2);
@@ -872,6 +887,23 @@ __global__ __launch_bounds__(256, (NACC == 2 && HB == 2 && !BWD && !BX) ? 3 : 2)
 #pragma unroll
         for (int q = 0; q < NACC; ++q) v[q] = acc2[q][r] + add + e[q];
         vstore<NACC>(p.y + ob + lane_row, v);
+        if (PRE && post) {   // the head sees what a separate launch would read back: the STORED value (bf16 storage: rounded)
+#pragma unroll
+          for (int q = 0; q < NACC; ++q) {
+            const float vs = sizeof(AT) == 2 ? (float)(AT)v[q] : v[q];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) pl[o][q] += tP[o * 32 + row] * vs;
+          }
+        }
+      }
+      if (PRE && post) {   // rows 4h + ... of this lane + the other half's (same column: both lanes are active together)
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+          float v[NACC];
+#pragma unroll
+          for (int q = 0; q < NACC; ++q) v[q] = pl[o][q] + __shfl_xor(pl[o][q], 32, 64) + tP[128 + o];
+          if (h == 0 && o < c.postM) vstore<NACC>(c.postOut + ((int64_t)b * c.postM + o) * p.Ncol + nc, v);
+        }
       }
     }
   }
@@ -3009,6 +3041,8 @@ static int mlp_launch(const fz_mlp_desc* d, fz_stream_t stream) {
     return fail(FZ_E_ARG, "fz_mlp_chain: pre_in needs mode 0, C == 32, H == 64, pre_w, pre_res, pre_out (see fz_mlp_pre_supported)");
   if (pre && !fz_mlp_pre_supported(d->C, d->H, d->V, d->products))
     return fail(FZ_E_UNSUPPORTED, "fz_mlp_chain: the fused out-projection runs on split-bf16 products only (fz_mlp_pre_supported)");
+  if (d->post_out && (!pre || !d->post_w || d->post_m < 1 || d->post_m > 4))
+    return fail(FZ_E_ARG, "fz_mlp_chain: post_out needs pre_in, post_w and 1 <= post_m <= 4");
   if ((!d->in && !pre) || !d->w1 || !d->w2 || !d->out || !d->z1 || !d->stats)
     return fail(FZ_E_ARG, "fz_mlp_chain: null pointer");
   if (d->mode == 0 && (!d->ln_g || !d->ln_b)) return fail(FZ_E_ARG, "fz_mlp_chain: forward needs the LayerNorm affine");
@@ -3093,6 +3127,7 @@ static int mlp_launch(const fz_mlp_desc* d, fz_stream_t stream) {
       const int wgs2 = knob_mlp_wgs(512);
       if (pre) {
         c.preA = (const AT*)d->pre_in; c.preW = d->pre_w; c.preB = d->pre_b; c.preRes = (const AT*)d->pre_res; c.preOut = (AT*)d->pre_out;
+        c.postW = d->post_w; c.postB = d->post_b; c.postOut = (AT*)d->post_out; c.postM = d->post_m;
         hipLaunchKernelGGL((gemm_chain_kernel<false, 2, 2, AT, true, true>), dim3((unsigned)(ntiles < wgs2 ? ntiles : wgs2)), block, 0, st, a, c, ntiles);
       } else
       hipLaunchKernelGGL((gemm_chain_kernel<false, 2, 2, AT, true>), dim3((unsigned)(ntiles < wgs2 ? ntiles : wgs2)), block, 0, st, a, c, ntiles);

@@ -241,10 +241,11 @@ def _outproj_mlp_ok(C, Hd, V):
     return _OUTPROJ_MLP and _mlp_chain_ok(C, Hd, V) and bool(N.lib().fz_mlp_pre_supported(C, Hd, V, N.products()))
 
 
-def _outproj_mlp_fwd_chain(a, wout2, bout, x, ln_w, ln_b, eps, w12, b1, w22, b2):
+def _outproj_mlp_fwd_chain(a, wout2, bout, x, ln_w, ln_b, eps, w12, b1, w22, b2, head=None):
     """x1 = x + out_proj(a) (factorizer.py:53,75) and x2 = x1 + fc2(gelu(fc1(LN(x1)))) (factorizer.py:76; mlp.py:54-63) in ONE
     launch: the out-projection runs on the accumulators in front of the chained MLP GEMMs, x1 is written once (the backward
-    needs it) and never read back — 6 instead of 7 tensor passes.  Returns (x1, x2, z1, stats)."""
+    needs it) and never read back — 6 instead of 7 tensor passes.  Returns (x1, x2, z1, stats), plus the logits when `head` =
+    (weight (M, C), bias or None) of the network's head Linear(C -> M <= 4) is given: it is applied to x2 in the same launch."""
     B, C = a.shape[:2]
     V = _vox(a)
     Hd = w12.shape[0]
@@ -260,10 +261,18 @@ def _outproj_mlp_fwd_chain(a, wout2, bout, x, ln_w, ln_b, eps, w12, b1, w22, b2)
     d.B, d.C, d.H, d.V = B, C, Hd, V
     d.act_dtype = N.act_dtype(a)
     d.pre_in, d.pre_w, d.pre_b, d.pre_res, d.pre_out = a.data_ptr(), wout2.data_ptr(), _p(bout), x.data_ptr(), x1.data_ptr()
+    logits = None
+    if head is not None:
+        hw, hb = head
+        Mh = hw.shape[0]
+        logits = torch.empty((B, Mh, *a.shape[2:]), dtype=a.dtype, device=a.device)
+        d.post_w, d.post_b, d.post_out, d.post_m = hw.data_ptr(), _p(hb), logits.data_ptr(), Mh
     with torch.cuda.device(a.device):
-        rc = Fn._timed(f"outproj_mlp_chain_fwd_{C}", a.element_size() * (4 * a.numel() + z1.numel()),
+        rc = Fn._timed(f"outproj_mlp_chain_fwd_{C}", a.element_size() * (4 * a.numel() + z1.numel() + (logits.numel() if head is not None else 0)),
                        lambda: N.lib().fz_mlp_chain(ctypes.byref(d), N.stream_ptr(a)), cols=B * V, flops=4 * B * V * C * Hd + 2 * B * V * C * C)
     N.check(rc, "fz_mlp_chain")
+    if head is not None:
+        return x1, x2, z1, st, logits
     return x1, x2, z1, st
 
 
@@ -984,7 +993,9 @@ class FactorizerBlockFn(torch.autograd.Function):
 
     @staticmethod
     @N.capture_products
-    def forward(ctx, x, n1w, n1b, win, u0, v0, wout, bout, n2w, n2b, w1, b1, w2, b2, cfg):
+    def forward(ctx, x, n1w, n1b, win, u0, v0, wout, bout, n2w, n2b, w1, b1, w2, b2, cfg, head_w=None, head_b=None):
+        # head_w (M <= 4, 32[, 1...]) / head_b: the network's head, applied to the block output inside the block's last launch;
+        # the node then returns (x2, logits) with the logits NOT differentiable here — HeadOfBlockFn carries their graph
         x = x.contiguous()
         B, C = x.shape[:2]
         V = _vox(x)
@@ -1010,8 +1021,13 @@ class FactorizerBlockFn(torch.autograd.Function):
             a = Fn._swm_inv_raw(ym, geo, average=True)
             del ym
         # 3. x1 = x + out_proj(a)   4. z1 = fc1(LN2(x1)) ; x2 = x1 + fc2(gelu(z1))
+        logits = None
         if _outproj_mlp_ok(C, Hd, V) and a.is_contiguous() and x.is_contiguous():
-            x1, x2, z1, st2 = _outproj_mlp_fwd_chain(a, wout2, bout, x, n2w, n2b, cfg["eps2"], w12, b1, w22, b2)   # both in one launch
+            if head_w is not None:
+                x1, x2, z1, st2, logits = _outproj_mlp_fwd_chain(a, wout2, bout, x, n2w, n2b, cfg["eps2"], w12, b1, w22, b2,
+                                                                 head=(head_w.reshape(head_w.shape[0], C), head_b))
+            else:
+                x1, x2, z1, st2 = _outproj_mlp_fwd_chain(a, wout2, bout, x, n2w, n2b, cfg["eps2"], w12, b1, w22, b2)   # both in one launch
         else:
             x1 = new(C)
             _gemm([a], wout2, x1, B=B, Cin=C, Vin=V, M=C, K=C, Ncol=V, bias=bout, res=x, name="act_linear_res")
@@ -1029,11 +1045,18 @@ class FactorizerBlockFn(torch.autograd.Function):
         ctx.cfg = cfg
         ctx.shapes = (win.shape, wout.shape, w1.shape, w2.shape)
         ctx.prm = tuple(weakref.ref(t) for t in (win, wout, bout, w1, b1, w2, b2))
+        ctx.nhead = 0 if head_w is None else 2
+        if head_w is not None:
+            if logits is None:
+                raise RuntimeError("FactorizerBlockFn: head fusion asked for a configuration outside fz_mlp_pre_supported "
+                                   "(callers check block_head_fusable first)")
+            ctx.mark_non_differentiable(logits)
+            return x2, logits
         return x2
 
     @staticmethod
     @N.with_products
-    def backward(ctx, g2):
+    def backward(ctx, g2, _g_logits=None):
         x, st1, t, a, x1, st2, z1, m, n1w, n1b, win2, u0c, v0c, wout2, n2w, n2b, w12, w22 = ctx.saved_tensors
         cfg = ctx.cfg
         g2 = g2.contiguous()
@@ -1132,7 +1155,79 @@ class FactorizerBlockFn(torch.autograd.Function):
             keep.clear()
         s_in, s_out, s_1, s_2 = ctx.shapes
         return (gx, gg1, gbt1, gwi.reshape(s_in), None, None, gwo.reshape(s_out), gbo, gg2, gbt2,
-                gw1.reshape(s_1), gb1, gw2.reshape(s_2), gb2, None)
+                gw1.reshape(s_1), gb1, gw2.reshape(s_2), gb2, None) + (None,) * ctx.nhead
+
+
+import threading as _threading
+
+_head_fusion = _threading.local()
+
+
+class HeadFusion:
+    """with HeadFusion(block, (w, b)) as slot: run the network; `block` (the module whose output feeds only the head) leaves
+    the logits in slot.logits if it applied the head itself, else None (the caller then runs the head module)."""
+
+    def __init__(self, block, head_params):
+        self.block, self.head_params, self.logits = block, head_params, None
+
+    def __enter__(self):
+        self.prev = getattr(_head_fusion, "slot", None)
+        _head_fusion.slot = self
+        return self
+
+    def __exit__(self, *exc):
+        _head_fusion.slot = self.prev
+
+
+def head_fusion_slot():
+    return getattr(_head_fusion, "slot", None)
+
+
+def block_head_fusable(C, Hd, V, head_w, x):
+    """may FactorizerBlockFn apply the head Linear(C -> M <= 4) inside its last launch? (csrc/gemm.hip: fz_mlp_chain post_*)"""
+    return (_outproj_mlp_ok(C, Hd, V) and head_w is not None and head_w.dtype == torch.float32 and head_w.numel() == head_w.shape[0] * C
+            and 1 <= head_w.shape[0] <= 4 and x.is_cuda and _HEAD_BWD)
+
+
+class HeadOfBlockFn(torch.autograd.Function):
+    """logits = head(y) (unet.py:253,274) where the logits were ALREADY produced by the launch that produced y
+    (FactorizerBlockFn with head_w): forward hands them out, backward is the head's own one-pass gradient kernel
+    (csrc/headbwd.hip: input, weight and bias gradient)."""
+
+    @staticmethod
+    @N.capture_products
+    def forward(ctx, y, w, b, logits):
+        ctx.save_for_backward(y, w)
+        ctx.has_bias, ctx.wshape = b is not None, w.shape
+        return logits.view_as(logits)
+
+    @staticmethod
+    @N.with_products
+    def backward(ctx, gl):
+        y, w = ctx.saved_tensors
+        B, C = y.shape[:2]
+        V = _vox(y)
+        M = w.shape[0]
+        w2 = w.reshape(M, C)
+        gl = gl.contiguous()
+        if gl.dtype != y.dtype:
+            gl = gl.to(y.dtype)
+        gy = torch.empty_like(y)
+        lib = N.lib()
+        rows = lib.fz_head_bwd_rows()
+        part = torch.empty(lib.fz_head_bwd_workspace_bytes() // 4, dtype=torch.float32, device=y.device)
+        out = torch.empty(132, dtype=torch.float32, device=y.device)
+        es = y.element_size()
+        with torch.cuda.device(y.device):
+            rc = Fn._timed(f"head_bwd_{C}->{M}", es * (gl.numel() + 2 * y.numel()),
+                           lambda: lib.fz_head_bwd(gl.data_ptr(), y.data_ptr(), w2.data_ptr(), gy.data_ptr(), part.data_ptr(),
+                                                   B, M, C, V, N.act_dtype(y), N.stream_ptr(y)), cols=B * V)
+            N.check(rc, "fz_head_bwd")
+            N.check(lib.fz_chunk_reduce(part.data_ptr(), rows, 132, out.data_ptr(), 0, N.stream_ptr(y)), "fz_chunk_reduce")
+        gw = _GB.out_like(w2)
+        gw.copy_(out[:M * 32].view(M, 32))
+        gb = out[128:128 + M]
+        return gy, gw.reshape(ctx.wshape), (gb if ctx.has_bias else None), None
 
 
 class _Ctx:

@@ -230,7 +230,37 @@ class UNet(nn.Module):
     def forward_features(self, x):
         return self.decoder(self.encoder(self.stem(self._mixed_precision_input(x))))
 
+    def _head_fusion_target(self):
+        """(block module, (head weight, head bias)) when the full-resolution decoder output feeds ONLY a k1 head of <= 4
+        channels and is produced by a FactorizerBlock: that block can apply the head inside its last launch
+        (pointwise.HeadFusion; unet.py:253,274), else None."""
+        from . import convs as _convs
+        from . import pointwise as _PW
+        h = getattr(self, "head", None)
+        if self.num_deep_supr or type(h) is not _convs.Conv3d or len(self.decoder.blocks) == 0:
+            return None
+        one = lambda t, v: all(int(e) == v for e in t)  # noqa: E731
+        if not (one(h.kernel_size, 1) and one(h.stride, 1) and one(h.padding, 0) and h.groups == 1 and h.out_channels <= 4
+                and h.weight.dtype == torch.float32) or h._forward_hooks or h._forward_pre_hooks:
+            return None
+        stage = getattr(self.decoder.blocks[-1], "block", None)
+        blocks = getattr(stage, "blocks", None)
+        if not blocks:
+            return None
+        blk = blocks[-1]
+        if type(blk).__name__ != "FactorizerBlock" or blk._forward_hooks or blk._forward_pre_hooks or stage._forward_hooks:
+            return None
+        return blk, (h.weight, h.bias), _PW
+
     def forward(self, x):
+        tgt = self._head_fusion_target() if x.is_cuda else None
+        if tgt is not None:
+            blk, params, _PW = tgt
+            with _PW.HeadFusion(blk, params) as slot:
+                feats = self.forward_features(x)
+            if slot.logits is not None:
+                return slot.logits
+            return self.head(feats[0])
         feats = self.forward_features(x)
         if self.num_deep_supr:
             return [h(feats[j]) for j, h in enumerate(self.heads)]

@@ -321,6 +321,12 @@ typedef struct fz_mlp_desc {
   const float* pre_b;   /* (C) or NULL                                                         */
   const void* pre_res;  /* activation (B, C, V): the block input x                             */
   void* pre_out;        /* activation (B, C, V): x1                                            */
+  /* [r5] with pre_in: the network's head Linear(C -> post_m <= 4, k1) (unet.py:253,274) applied to `out` while it is in
+   * registers — the launch that would read the block output back (fz_head_fwd) disappears.  post_out == NULL: no head. */
+  const float* post_w;  /* (post_m, C)                                                         */
+  const float* post_b;  /* (post_m) or NULL                                                    */
+  void* post_out;       /* activation (B, post_m, V) or NULL                                   */
+  int post_m;
 } fz_mlp_desc;
 
 /* ---- input gradient AND weight gradient of a 32 -> 32 1x1 layer in one pass (in_proj behind LayerNorm, out_proj;
