@@ -191,6 +191,11 @@ class MlpDesc(_c.Structure):
                 ("post_w", _vp), ("post_b", _vp), ("post_out", _vp), ("post_m", _i)]
 
 
+class BlockPrologue(_c.Structure):
+    """fz_block_prologue (include/factorizer_hip.h)"""
+    _fields_ = [("ln_g", _vp), ("ln_b", _vp), ("ln_eps", _f), ("w", _vp), ("t", _vp), ("stats", _vp)]
+
+
 class GemmDwDesc(_c.Structure):
     _fields_ = [("g", _vp), ("q", _vp), ("w", _vp), ("ln", _i), ("stats", _vp), ("ln_g", _vp), ("ln_b", _vp), ("gadd", _vp),
                 ("y", _vp), ("gln", _vp), ("wpart", _vp), ("gw", _vp), ("gb", _vp), ("B", _i), ("C", _i), ("V", _i64),
@@ -224,6 +229,9 @@ _SIGS.update({
     "fz_nmf_pcf_bwd_prefers_separate": ([_i] * 4, _i),
     "fz_act_add": ([_vp, _vp, _i64, _i, _vp], _i),
     "fz_mlp_pre_supported": ([_i, _i, _i64, _i], _i),
+    "fz_conv3_prologue_supported": ([_i] * 4, _i),
+    "fz_conv3_fwd2": ([_vp] * 4 + [_i] * 8 + [_c.POINTER(BlockPrologue), _vp], _i),
+    "fz_upcat2": ([_vp, _vp, _vp, _i, _vp, _vp, _vp] + [_i] * 7 + [_c.POINTER(BlockPrologue), _vp], _i),
     "fz_gemm": ([_c.POINTER(GemmDesc), _vp], _i),
     "fz_gemm_bx_enable": ([_i], _i),
     "fz_gemm_lnbwd_partials": ([_c.POINTER(GemmDesc)], _i64),

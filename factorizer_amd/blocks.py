@@ -122,6 +122,19 @@ class FactorizerBlock(nn.Module):
             return None
         return G, sid
 
+    def prologue_params(self, like):
+        """what a producer of this block's input needs to apply the block's first layer itself (pointwise.BlockPrologue), or
+        None when this block would not take the one-node native path with the fused core for a tensor like `like`"""
+        f, blk = self.fact, self.mlp.block
+        n1 = self.norm1.norm
+        if not (like.is_cuda and like.shape[1] == 32 and self._fusable(like) and self._core_cfg() is not None
+                and f.in_proj.linear.bias is None and blk[0].linear.bias is not None and blk[3].linear.bias is not None
+                and f.out_proj.linear.bias is not None and f.in_proj.linear.weight.dtype == torch.float32
+                and n1.weight is not None and n1.bias is not None
+                and not (self.norm1._forward_hooks or f.in_proj._forward_hooks or f._forward_hooks)):
+            return None
+        return n1.weight, n1.bias, n1.eps, f.in_proj.linear.weight
+
     def forward(self, x):
         if self._fusable(x):
             f, blk = self.fact, self.mlp.block
@@ -140,6 +153,8 @@ class FactorizerBlock(nn.Module):
                 args = (x, n1.weight, n1.bias, f.in_proj.linear.weight, mf.init.u0, mf.init.v0,
                         f.out_proj.linear.weight, f.out_proj.linear.bias, n2.weight, n2.bias,
                         blk[0].linear.weight, blk[0].linear.bias, blk[3].linear.weight, blk[3].linear.bias, cfg)
+                pre = PW.BlockPrologue.take(x) if core is not None else None   # t, statistics already formed by x's producer
+                t_pre, st_pre = pre if pre is not None else (None, None)
                 slot = PW.head_fusion_slot()
                 if slot is not None and slot.block is self and core is not None:
                     # this block's output feeds ONLY the network's head (ushape.UNet.forward): the head runs inside the
@@ -147,10 +162,10 @@ class FactorizerBlock(nn.Module):
                     hw, hb = slot.head_params
                     C, Hd = x.shape[1], blk[0].linear.weight.shape[0]
                     if PW.block_head_fusable(C, Hd, x[0, 0].numel(), hw, x):
-                        y, raw = PW.FactorizerBlockFn.apply(*args, hw, hb)
+                        y, raw = PW.FactorizerBlockFn.apply(*args, hw, hb, t_pre, st_pre)
                         slot.logits = PW.HeadOfBlockFn.apply(y, hw, hb, raw)
                         return y
-                return PW.FactorizerBlockFn.apply(*args)
+                return PW.FactorizerBlockFn.apply(*args, None, None, t_pre, st_pre)
             # per-layer fused path (composed NMF, unusual bias layout, ...)
             t = PW.ln_linear(x, n1.weight, n1.bias, n1.eps, f.in_proj.linear.weight, f.in_proj.linear.bias, "relu")
             a = f.reshape.inverse_forward(f.factorize(f.reshape(t)))  # ReLU already applied (commutes)
@@ -206,8 +221,25 @@ class FactorizerStage(nn.Module):
                        or self.adapter.linear._forward_hooks or self.adapter.linear._forward_pre_hooks))
         if not ok:
             return None
+        pro = self._first_block_prologue(skip) if PW.upcat_prologue_ok(skip, deep, upsample.weight, self.adapter.linear.weight) else None
+        if pro is not None:
+            # the first block's LayerNorm 1 + in_proj + ReLU in the launch that produces its input (csrc/upcat.hip PRO)
+            out, t, st = PW.up_cat_linear(skip, deep, upsample.weight, upsample.bias, self.adapter.linear.weight, self.adapter.linear.bias, pro)
+            with PW.BlockPrologue(out, t, st):
+                return self._after_adapter(out)
         out = PW.up_cat_linear(skip, deep, upsample.weight, upsample.bias, self.adapter.linear.weight, self.adapter.linear.bias)
         return self._after_adapter(out)
+
+    def _first_block_prologue(self, like):
+        """(ln1 weight, ln1 bias, eps, in_proj weight) of the first block when the stage hands its adapter output straight to a
+        FactorizerBlock of 32 channels that runs as the one-node native block with the fused core (no position embedding or
+        dropout in between, no hooks that expect the separate launch), else None."""
+        if not isinstance(self.pos_embed, nn.Identity) or (hasattr(self, "pos_drop") and self.pos_drop.p > 0) or len(self.blocks) == 0:
+            return None
+        blk = self.blocks[0]
+        if type(blk).__name__ != "FactorizerBlock" or blk._forward_hooks or blk._forward_pre_hooks:
+            return None
+        return blk.prologue_params(like)
 
     def forward(self, x):
         out = self.adapter(x) if hasattr(self, "adapter") else x

@@ -43,12 +43,12 @@ class Conv3d(nn.Conv3d):
                 # pairs, so run them on one extra all-zero channel (input 1/C larger, weights padded to match)
                 xp = torch.nn.functional.pad(x, (0, 0, 0, 0, 0, 0, 0, 1))
                 wp = torch.nn.functional.pad(self.weight, (0, 0, 0, 0, 0, 0, 0, 1))
-                return PW.ConvK3Fn.apply(xp, wp, self.bias)
+                return PW.ConvK3Fn.apply(xp, wp, self.bias, None)
             if self._k2s2_native(x):
                 return PW.ConvK2S2Fn.apply(x, self.weight, self.bias)
             if _all(self.kernel_size, 3) and _all(self.stride, 1) and _all(self.padding, 1) \
                     and x.shape[-1] % 4 == 0 and C % 2 == 0:
-                return PW.ConvK3Fn.apply(x, self.weight, self.bias)
+                return PW.ConvK3Fn.apply(x, self.weight, self.bias, None)
             if _all(self.kernel_size, 1) and _all(self.stride, 1) and _all(self.padding, 0) and C % 2 == 0 \
                     and (x.shape[2] * x.shape[3] * x.shape[4]) % 4 == 0:
                 return PW.LinearFn.apply(x, self.weight.reshape(self.out_channels, C, 1), self.bias)

@@ -26,6 +26,7 @@ struct Conv3ArgsT {
   const float* bias;  // (M) or null
   AT* y;              // (B, M, D, H, W)
   int B, Cin, M, D, H, W;
+  BlockPrologueArgs pro;   // (PRO, M == 32) the consuming FactorizerBlock's LayerNorm 1 + in_proj + ReLU on the output tile (gemm_bx.h)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -132,13 +133,17 @@ __global__ __launch_bounds__(256, 2) void conv3_fwd_kernel(Conv3ArgsT<AT> p) {
 // the same one, so the operand registers of the fp32 form are simply packed eight at a time.  CP = C_in / 2 is a
 // compile-time constant (the whole tap loop is unrolled: groups straddle channel pairs).  Weights are split once per
 // workgroup into LDS: As[group][row block][term][lane] x 16 B; the tail group is zero-padded.
-template <int MB, int CP, typename AT>
+template <int MB, int CP, typename AT, bool PRO = false>
 __global__ __launch_bounds__(256, 2) void conv3_fwd_bx_kernel(Conv3ArgsT<AT> p) {
+  static_assert(!PRO || MB == 1, "the block prologue needs all 32 output channels in one row block");
   constexpr int NTA = BxTerms<AT>::A, NTB = bx_terms_b<AT>(BXPRO_NONE);
   constexpr int NS = CP * 27;                 // K-steps of two
   constexpr int NG = (NS + 7) / 8;            // groups of eight steps
   __shared__ __attribute__((aligned(16))) __bf16 As[NG * MB * NTA * 64 * 8];
   __shared__ float sBias[32 * MB];
+  __shared__ __attribute__((aligned(16))) __bf16 Apro[PRO ? 2 * 3 * 64 * 8 : 8];
+  __shared__ float twp[PRO ? 32 : 1];
+  if constexpr (PRO) ln_inproj_stage(Apro, twp, p.pro, (int)threadIdx.x, 256);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, h = lane >> 5;
   const int64_t V = (int64_t)p.D * p.H * p.W;
@@ -238,6 +243,7 @@ __global__ __launch_bounds__(256, 2) void conv3_fwd_bx_kernel(Conv3ArgsT<AT> p) 
     }
   }
   if (!col_ok) return;
+  float yv[PRO ? 4 : 1][16];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -245,10 +251,32 @@ __global__ __launch_bounds__(256, 2) void conv3_fwd_bx_kernel(Conv3ArgsT<AT> p) 
       const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
       const int m = m0 + mb * 32 + rl;
       const float bs = sBias[mb * 32 + rl];
-      if (m < p.M)
-        st4(p.y + ((int64_t)b * p.M + m) * V + col,
-            make_float4(acc[mb][0][r] + bs, acc[mb][1][r] + bs, acc[mb][2][r] + bs, acc[mb][3][r] + bs));
+      const float4 o = make_float4(acc[mb][0][r] + bs, acc[mb][1][r] + bs, acc[mb][2][r] + bs, acc[mb][3][r] + bs);
+      if (m < p.M) st4(p.y + ((int64_t)b * p.M + m) * V + col, o);
+      if constexpr (PRO) {   // bf16 storage: the block's first layer sees the STORED values
+        constexpr bool R = sizeof(AT) == 2;
+        yv[0][r] = R ? (float)(AT)o.x : o.x; yv[1][r] = R ? (float)(AT)o.y : o.y;
+        yv[2][r] = R ? (float)(AT)o.z : o.z; yv[3][r] = R ? (float)(AT)o.w : o.w;
+      }
     }
+  if constexpr (PRO) {
+    float mu[4], rs[4];
+    f32x16 tacc[4];
+    ln_inproj_tile<4>(yv, Apro, p.pro.ln_eps, lane, mu, rs, tacc);
+    AT* tb = reinterpret_cast<AT*>(p.pro.t) + (int64_t)b * 32 * V + col;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
+      const float add = twp[rl];
+      st4(tb + (int64_t)rl * V, make_float4(fmaxf(tacc[0][r] + add, 0.f), fmaxf(tacc[1][r] + add, 0.f), fmaxf(tacc[2][r] + add, 0.f),
+                                            fmaxf(tacc[3][r] + add, 0.f)));
+    }
+    if (h == 0) {
+      float* so = p.pro.stats + (int64_t)b * 2 * V + col;
+      *reinterpret_cast<float4*>(so) = make_float4(mu[0], mu[1], mu[2], mu[3]);
+      *reinterpret_cast<float4*>(so + V) = make_float4(rs[0], rs[1], rs[2], rs[3]);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -494,8 +522,13 @@ using namespace fz;
 
 template <typename AT>
 static int conv3_fwd_launch(const void* x, const float* w, const float* bias, void* y, int B, int Cin, int M, int D,
-                            int H, int W, int products, fz_stream_t stream) {
-  Conv3ArgsT<AT> p{(const AT*)x, w, bias, (AT*)y, B, Cin, M, D, H, W};
+                            int H, int W, int products, const fz_block_prologue* pro, fz_stream_t stream) {
+  Conv3ArgsT<AT> p{(const AT*)x, w, bias, (AT*)y, B, Cin, M, D, H, W, BlockPrologueArgs{}};
+  if (pro) {
+    if (!(Cin == 4 && M == 32 && products_split(products)))
+      return fail(FZ_E_UNSUPPORTED, "fz_conv3_fwd2: the block prologue needs C_in = 4, 32 output channels, split-bf16 products (fz_conv3_prologue_supported)");
+    p.pro = BlockPrologueArgs{pro->ln_g, pro->ln_b, pro->ln_eps, pro->w, pro->t, pro->stats};
+  }
   const int64_t V = (int64_t)D * H * W;
   const int mblocks = (M + 31) / 32;
   const int MB = mblocks >= 2 ? 2 : 1;
@@ -505,6 +538,7 @@ static int conv3_fwd_launch(const void* x, const float* w, const float* bias, vo
   hipStream_t st = (hipStream_t)stream;
   if (Cin == 4 && products_split(products)) {   // the stem of the README model: split-bf16 form (FZ_PRODUCTS_FP32_MFMA: fp32 MFMAs)
     if (MB == 2) hipLaunchKernelGGL((conv3_fwd_bx_kernel<2, 2, AT>), grid, block, 0, st, p);
+    else if (pro) hipLaunchKernelGGL((conv3_fwd_bx_kernel<1, 2, AT, true>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((conv3_fwd_bx_kernel<1, 2, AT>), grid, block, 0, st, p);
     FZ_LAUNCH_CHECK();
     return FZ_OK;
@@ -515,15 +549,25 @@ static int conv3_fwd_launch(const void* x, const float* w, const float* bias, vo
   return FZ_OK;
 }
 
-extern "C" int fz_conv3_fwd(const void* x, const float* w, const float* bias, void* y, int B, int Cin, int M, int D,
-                            int H, int W, int act_dtype, int products, fz_stream_t stream) {
+extern "C" int fz_conv3_prologue_supported(int Cin, int M, int W, int products) {
+  return (Cin == 4 && M == 32 && W >= 4 && (W & 3) == 0 && products_split(products)) ? 1 : 0;
+}
+
+extern "C" int fz_conv3_fwd2(const void* x, const float* w, const float* bias, void* y, int B, int Cin, int M, int D,
+                             int H, int W, int act_dtype, int products, const fz_block_prologue* pro, fz_stream_t stream) {
   if (!x || !w || !y) return fail(FZ_E_ARG, "fz_conv3_fwd: null pointer");
+  if (pro && (!pro->ln_g || !pro->ln_b || !pro->w || !pro->t || !pro->stats)) return fail(FZ_E_ARG, "fz_conv3_fwd2: incomplete block prologue");
   if (B < 0 || Cin < 2 || (Cin & 1) || M < 1 || D < 1 || H < 1 || W < 4 || (W & 3))
     return fail(FZ_E_UNSUPPORTED, "fz_conv3_fwd: needs even C_in and W % 4 == 0");
   if (B == 0) return FZ_OK;
-  if (act_dtype == FZ_STORE_F32) return conv3_fwd_launch<float>(x, w, bias, y, B, Cin, M, D, H, W, products, stream);
-  if (act_dtype == FZ_STORE_BF16) return conv3_fwd_launch<bf16>(x, w, bias, y, B, Cin, M, D, H, W, products, stream);
+  if (act_dtype == FZ_STORE_F32) return conv3_fwd_launch<float>(x, w, bias, y, B, Cin, M, D, H, W, products, pro, stream);
+  if (act_dtype == FZ_STORE_BF16) return conv3_fwd_launch<bf16>(x, w, bias, y, B, Cin, M, D, H, W, products, pro, stream);
   return fail(FZ_E_ARG, "fz_conv3_fwd: bad act_dtype");
+}
+
+extern "C" int fz_conv3_fwd(const void* x, const float* w, const float* bias, void* y, int B, int Cin, int M, int D,
+                            int H, int W, int act_dtype, int products, fz_stream_t stream) {
+  return fz_conv3_fwd2(x, w, bias, y, B, Cin, M, D, H, W, act_dtype, products, nullptr, stream);
 }
 
 static int conv3_units(int64_t total_tiles, int* tiles_per_unit) {

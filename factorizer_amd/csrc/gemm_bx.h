@@ -44,6 +44,85 @@ __device__ __forceinline__ void bx_mfma(f32x16& acc, const bx8 (&a)[NTA], const 
     }
 }
 
+// ---- "LayerNorm + Linear(32 -> 32, no bias) + ReLU" on a 32-channel tile that sits in MFMA ACCUMULATOR layout ------------------
+// The first layer of a FactorizerBlock, t = relu(in_proj(LN1(x))) (factorizer.py:38,44,75; norm.py:29-34), applied by the kernel
+// that PRODUCES the block input x while the tile is in registers: the launch that would read x back (fz_gemm: LayerNorm + in_proj)
+// disappears.  Layout: register r of lane (j, h) = channel (r & 3) + 8 (r >> 2) + 4 h of the lane's NQ voxels.
+//   Aw: LDS image of W·diag(γ) pre-split for that operand order, [g (2)][level (3)][lane (64)] x 16 B (ln_inproj_stage)
+//   y : the tile (bias added; bf16 storage: ALREADY rounded to the stored value — what a separate launch would read)
+//   out: mu, rs (exact two-pass statistics of each voxel) and tacc = W·(γ ∘ x̂) — the caller adds tw[row] = (W β)[row], applies
+//   the ReLU and stores.
+struct BlockPrologueArgs {
+  const float* ln_g;   // (32)
+  const float* ln_b;   // (32)
+  float ln_eps;
+  const float* w;      // (32, 32) in_proj weight W[m][k]
+  void* t;             // (B, 32, V) activation storage type of the launch
+  float* stats;        // (B, 2, V): mean | rstd
+};
+
+__device__ __forceinline__ void ln_inproj_stage(__bf16* Aw, float* tw, const BlockPrologueArgs& a, int tid, int nthreads) {
+  for (int it = tid; it < 128; it += nthreads) {
+    const int l = it & 63, g = it >> 6;
+    float wv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int r = 8 * g + e;
+      const int kk = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+      wv[e] = a.w[(l & 31) * 32 + kk] * a.ln_g[kk];
+    }
+    bx8 t3[3];
+    bx_split<3>(wv, t3);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) *reinterpret_cast<bx8*>(Aw + ((g * 3 + i) * 64 + l) * 8) = t3[i];
+  }
+  for (int r = tid; r < 32; r += nthreads) {
+    float s = 0.f;
+    for (int k = 0; k < 32; ++k) s += a.w[r * 32 + k] * a.ln_b[k];
+    tw[r] = s;
+  }
+}
+
+template <int NQ>
+__device__ __forceinline__ void ln_inproj_tile(float (&y)[NQ][16], const __bf16* Aw, float eps, int lane, float (&mu)[NQ],
+                                               float (&rs)[NQ], f32x16 (&tacc)[NQ]) {
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += y[q][r];
+    s += __shfl_xor(s, 32, 64);
+    mu[q] = s / 32.0f;
+    float v = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float d = y[q][r] - mu[q];
+      v += d * d;
+    }
+    v += __shfl_xor(v, 32, 64);
+    rs[q] = 1.0f / sqrtf(v / 32.0f + eps);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) y[q][r] = (y[q][r] - mu[q]) * rs[q];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tacc[q][r] = 0.f;
+  }
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    bx8 aop[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) aop[i] = *reinterpret_cast<const bx8*>(Aw + ((g * 3 + i) * 64 + lane) * 8);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      float x8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x8[e] = y[q][8 * g + e];
+      bx8 bop[3];
+      bx_split<3>(x8, bop);
+      bx_mfma<3, 3>(tacc[q], aop, bop);
+    }
+  }
+}
+
 // Terms per operand.  fp32 storage: three bf16 levels each (six products).  bf16 storage (mixed-precision mode): the
 // column operand IS bf16 — one term, exact — unless a prologue has produced new fp32 values from it (LayerNorm's
 // x - pivot, GELU): those are split in three levels like any fp32 value; the fp32 weights always are.  So the mode differs

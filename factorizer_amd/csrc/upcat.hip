@@ -28,6 +28,7 @@ struct UpcatArgsT {
   AT* out;            // (B, 32, 2D, 2H, 2W)
   int lda;
   int B, D, H, W;     // coarse extent
+  BlockPrologueArgs pro;   // (PRO) the consuming FactorizerBlock's LayerNorm 1 + in_proj + ReLU, applied to `out` in registers
 };
 
 // One PERSISTENT workgroup of 256 threads per CU (one wave per SIMD): W_a and all eight taps of Wbt are split into bf16
@@ -41,7 +42,7 @@ struct UpcatArgsT {
 #define UPCAT_WAVES 4
 #endif
 #define UPCAT_THREADS (UPCAT_WAVES * 64)
-template <typename AT>
+template <typename AT, bool PRO = false>
 __global__ __launch_bounds__(UPCAT_THREADS, 1) void upcat_bx_kernel(UpcatArgsT<AT> p, unsigned ntiles) {
   constexpr int C = 32, CD = 64;
   constexpr int GS = C / 16, GD = CD / 16;          // K16-groups of the two segments
@@ -74,6 +75,10 @@ __global__ __launch_bounds__(UPCAT_THREADS, 1) void upcat_bx_kernel(UpcatArgsT<A
     bx8* dst = reinterpret_cast<bx8*>(As) + (slot * 3) * 64 + l;
     dst[0] = t3[0]; dst[64] = t3[1]; dst[128] = t3[2];
   }
+  // (PRO) behind the 34 weight slots: the in_proj image (2 groups x 3 levels x 64 lanes x 16 B = 6 KB) and (W β)[32]
+  __bf16* Apro = reinterpret_cast<__bf16*>(As + (GS + 8 * GD) * 3 * 256);
+  float* twp = As + (GS + 8 * GD) * 3 * 256 + 2 * 3 * 256;
+  if constexpr (PRO) ln_inproj_stage(Apro, twp, p.pro, (int)threadIdx.x, UPCAT_THREADS);
   __syncthreads();
   float badd[16];   // the bias' entries of this lane's 16 output rows
 #pragma unroll
@@ -193,12 +198,35 @@ __global__ __launch_bounds__(UPCAT_THREADS, 1) void upcat_bx_kernel(UpcatArgsT<A
     // ---- epilogue: rows (r & 3) + 8 (r >> 2) + 4 hk, the lane's two voxels as one 8-byte (4-byte) store ----
     const unsigned yoff = (unsigned)((((int64_t)4 * hk) * Vf + n0 + 2 * j) * (int64_t)sizeof(AT));
     AT* yb = p.out + (int64_t)b * C * Vf;
+    float yv[2][16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int rb = (r & 3) + 8 * (r >> 2);
       const float add = badd[r];
-      const float v[2] = {acc[0][r] + add, acc[1][r] + add};
+      float v[2] = {acc[0][r] + add, acc[1][r] + add};
       vstore<2>(reinterpret_cast<AT*>(reinterpret_cast<char*>(yb + (int64_t)rb * Vf) + yoff), v);
+      if constexpr (PRO) {   // bf16 storage: the block's first layer sees the STORED value, as a separate launch would
+        yv[0][r] = sizeof(AT) == 2 ? (float)(AT)v[0] : v[0];
+        yv[1][r] = sizeof(AT) == 2 ? (float)(AT)v[1] : v[1];
+      }
+    }
+    if constexpr (PRO) {
+      float mu[2], rs[2];
+      f32x16 tacc[2];
+      ln_inproj_tile<2>(yv, Apro, p.pro.ln_eps, lane, mu, rs, tacc);
+      AT* tb = reinterpret_cast<AT*>(p.pro.t) + (int64_t)b * C * Vf;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rb = (r & 3) + 8 * (r >> 2);
+        const float add = twp[rb + 4 * hk];
+        const float v[2] = {fmaxf(tacc[0][r] + add, 0.f), fmaxf(tacc[1][r] + add, 0.f)};
+        vstore<2>(reinterpret_cast<AT*>(reinterpret_cast<char*>(tb + (int64_t)rb * Vf) + yoff), v);
+      }
+      if (hk == 0) {
+        float* so = p.pro.stats + (int64_t)b * 2 * Vf + n0 + 2 * j;
+        *reinterpret_cast<float2*>(so) = make_float2(mu[0], mu[1]);
+        *reinterpret_cast<float2*>(so + Vf) = make_float2(rs[0], rs[1]);
+      }
     }
   };
 
@@ -311,27 +339,42 @@ extern "C" int fz_upcat_supported(int C, int Cd, int D, int H, int W) {
 
 template <typename AT>
 static int upcat_launch(const void* skip, const void* deep, const float* wa, int lda, const float* wbt, const float* bias, void* out,
-                        int B, int D, int H, int W, fz_stream_t stream) {
+                        int B, int D, int H, int W, const fz_block_prologue* pro, fz_stream_t stream) {
   UpcatArgsT<AT> a;
+  a.pro = BlockPrologueArgs{};
+  if (pro) a.pro = BlockPrologueArgs{pro->ln_g, pro->ln_b, pro->ln_eps, pro->w, pro->t, pro->stats};
   a.skip = (const AT*)skip; a.deep = (const AT*)deep; a.wa = wa; a.wbt = wbt; a.bias = bias; a.out = (AT*)out;
   a.lda = lda; a.B = B; a.D = D; a.H = H; a.W = W;
   const int64_t ntiles = (int64_t)8 * D * H * W / 64 * B;   // 64-voxel wave tiles
   if (ntiles >= ((int64_t)1 << 30)) return fail(FZ_E_ARG, "fz_upcat: more than 2^30 wave tiles (32-bit tile arithmetic)");
-  constexpr int lds = (2 + 8 * 4) * 3 * 64 * 16;            // 34 slots x 3 levels x 64 lanes x 16 B = 102 KB
+  constexpr int lds = (2 + 8 * 4) * 3 * 64 * 16 + 2 * 3 * 64 * 16 + 32 * 4;   // 34 slots x 3 levels x 64 lanes x 16 B = 102 KB (+ the prologue's 6 KB)
+  const int64_t wgs = (ntiles + UPCAT_WAVES - 1) / UPCAT_WAVES;
+  if (pro) {
+    auto kern = upcat_bx_kernel<AT, true>;
+    FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)(wgs < 256 ? wgs : 256)), dim3(UPCAT_THREADS), lds, (hipStream_t)stream, a, (unsigned)ntiles);
+    FZ_LAUNCH_CHECK();
+    return FZ_OK;
+  }
   auto kern = upcat_bx_kernel<AT>;
   FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  const int64_t wgs = (ntiles + UPCAT_WAVES - 1) / UPCAT_WAVES;
   hipLaunchKernelGGL(kern, dim3((unsigned)(wgs < 256 ? wgs : 256)), dim3(UPCAT_THREADS), lds, (hipStream_t)stream, a, (unsigned)ntiles);
   FZ_LAUNCH_CHECK();
   return FZ_OK;
 }
 
-extern "C" int fz_upcat(const void* skip, const void* deep, const float* wa, int lda, const float* wbt, const float* bias, void* out,
-                        int B, int C, int Cd, int D, int H, int W, int act_dtype, fz_stream_t stream) {
+extern "C" int fz_upcat2(const void* skip, const void* deep, const float* wa, int lda, const float* wbt, const float* bias, void* out,
+                         int B, int C, int Cd, int D, int H, int W, int act_dtype, const fz_block_prologue* pro, fz_stream_t stream) {
   if (!skip || !deep || !wa || !wbt || !out) return fail(FZ_E_ARG, "fz_upcat: null pointer");
+  if (pro && (!pro->ln_g || !pro->ln_b || !pro->w || !pro->t || !pro->stats)) return fail(FZ_E_ARG, "fz_upcat2: incomplete block prologue");
   if (!fz_upcat_supported(C, Cd, D, H, W) || lda < C) return fail(FZ_E_UNSUPPORTED, "fz_upcat: needs C = 32, 64 deep channels, 2W % 64 == 0, 4HW % 256 == 0");
   if (B <= 0) return B == 0 ? FZ_OK : fail(FZ_E_SHAPE, "fz_upcat: negative batch");
-  if (act_dtype == FZ_STORE_F32) return upcat_launch<float>(skip, deep, wa, lda, wbt, bias, out, B, D, H, W, stream);
-  if (act_dtype == FZ_STORE_BF16) return upcat_launch<bf16>(skip, deep, wa, lda, wbt, bias, out, B, D, H, W, stream);
+  if (act_dtype == FZ_STORE_F32) return upcat_launch<float>(skip, deep, wa, lda, wbt, bias, out, B, D, H, W, pro, stream);
+  if (act_dtype == FZ_STORE_BF16) return upcat_launch<bf16>(skip, deep, wa, lda, wbt, bias, out, B, D, H, W, pro, stream);
   return fail(FZ_E_ARG, "fz_upcat: act_dtype must be FZ_STORE_F32 or FZ_STORE_BF16");
+}
+
+extern "C" int fz_upcat(const void* skip, const void* deep, const float* wa, int lda, const float* wbt, const float* bias, void* out,
+                        int B, int C, int Cd, int D, int H, int W, int act_dtype, fz_stream_t stream) {
+  return fz_upcat2(skip, deep, wa, lda, wbt, bias, out, B, C, Cd, D, H, W, act_dtype, nullptr, stream);
 }

