@@ -745,7 +745,7 @@ class ConvK3Fn(torch.autograd.Function):
 
     @staticmethod
     @N.capture_products
-    def forward(ctx, x, w, b, pro):   # (callers pass `pro` explicitly, None included: backward returns one gradient per argument)
+    def forward(ctx, x, w, b, pro=None):
         # pro: as UpCatLinearFn.forward — the consuming block's (ln1 weight, ln1 bias, eps, in_proj weight); the node then returns
         # (y, t, statistics), the last two formed in the same launch and not differentiable here
         x = x.contiguous()
@@ -829,7 +829,7 @@ class ConvK3Fn(torch.autograd.Function):
         else:
             _wgrad(gy, [x], gw, B=B, M=O, Cin=C, K=27 * C, Vq=V, Ncols=V, gbias=gb, loader=LOAD_K3, D=D, H=H, W=W,
                    name="wgrad_conv_k3")
-        return gx, gw, (gb if ctx.has_bias else None), None
+        return (gx, gw, (gb if ctx.has_bias else None), None)[:len(ctx.needs_input_grad)]   # (one per argument actually passed)
 
 
 # ---- public dispatchers (device → native, CPU → composed ATen) ---------------------------------------
@@ -1001,7 +1001,7 @@ class UpCatLinearFn(torch.autograd.Function):
             N.check(N.lib().fz_upcat_wgrads(gt.data_ptr(), w_t.data_ptr(), w_b.data_ptr(), C1 + O, gb_ad.data_ptr(), _p(b_t),
                                             gw_t.data_ptr(), gw_ad[:, C1:].data_ptr(), C1 + O, _p(gb_t), Cd, O, M,
                                             N.stream_ptr(g)), "fz_upcat_wgrads")
-        return (g_skip, g_deep, gw_t, gb_t, gw_ad.reshape(ctx.wshape), gb_ad if ctx.has_bad else None, None)
+        return (g_skip, g_deep, gw_t, gb_t, gw_ad.reshape(ctx.wshape), gb_ad if ctx.has_bad else None, None)[:len(ctx.needs_input_grad)]
 
 
 _UPCAT_FWD = os.environ.get("FZ_UPCAT_FWD", "1") != "0"   # diagnostics: 0 = the two forward launches
@@ -1132,7 +1132,6 @@ class FactorizerBlockFn(torch.autograd.Function):
         ctx.cfg = cfg
         ctx.shapes = (win.shape, wout.shape, w1.shape, w2.shape)
         ctx.prm = tuple(weakref.ref(t) for t in (win, wout, bout, w1, b1, w2, b2))
-        ctx.nhead = 4
         if head_w is not None:
             if logits is None:
                 raise RuntimeError("FactorizerBlockFn: head fusion asked for a configuration outside fz_mlp_pre_supported "
@@ -1245,7 +1244,7 @@ class FactorizerBlockFn(torch.autograd.Function):
             keep.clear()
         s_in, s_out, s_1, s_2 = ctx.shapes
         return (gx, gg1, gbt1, gwi.reshape(s_in), None, None, gwo.reshape(s_out), gbo, gg2, gbt2,
-                gw1.reshape(s_1), gb1, gw2.reshape(s_2), gb2, None) + (None,) * ctx.nhead
+                gw1.reshape(s_1), gb1, gw2.reshape(s_2), gb2, None, None, None, None, None)[:len(ctx.needs_input_grad)]
 
 
 _head_fusion = _threading.local()

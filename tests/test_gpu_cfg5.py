@@ -83,7 +83,7 @@ def test_cfg5_whole_model_full_size_fp32_and_bf16():
                 small_worst, small_name = cos, n
     whole = F.cosine_similarity(torch.cat([g16[n].flatten() for n in g32]), torch.cat([g32[n].flatten() for n in g32]), dim=0).item()
     P.note("cfg5_full_size_bf16_vs_fp32_gradient_cosine", whole_gradient=whole, per_tensor_min=worst, tensor=worst_name,
-           per_tensor_min_below_1e-3_of_the_gradient_norm=small_worst, that_tensor=small_name,
+           per_tensor_min_among_small_tensors=small_worst, small_tensor=small_name, small_means="below 1e-3 of the gradient norm",
            loss_fp32=float(loss.detach()), loss_bf16=float(lossb.detach()))
     assert abs(float(lossb.detach()) - float(loss.detach())) <= 2e-2 * abs(float(loss.detach()))
     # The whole gradient must point the same way.  Per tensor the bar is lower: the gradients behind ten rank-2 HALS sweeps
