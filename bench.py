@@ -50,7 +50,8 @@ def split_products(name, dtype):
         return 0
     m = re.search(r"_(\d+)(?:->|x)", name)
     k = int(m.group(1)) if m else 0
-    if name.startswith(("wgrad_", "conv_k3", "mlp_chain_bwd_wgrad_", "dgrad_lnbwd_64", "conv_k2s2", "tconv_k2s2")):
+    if name.startswith(("wgrad_", "conv_k3", "mlp_chain_bwd_wgrad_", "dgrad_lnbwd_64", "conv_k2s2", "tconv_k2s2", "outproj_mlp_chain_fwd_",
+                        "mlp_chain_fwd_32", "upcat_")):
         bx = True
     elif name.startswith(("ln_linear_", "act_linear_res_", "cat_linear_", "linear_dgrad_", "linear_")):
         bx = k >= 64
@@ -83,7 +84,8 @@ PMC_TRAFFIC_BF16 = os.path.join(ROOT, "profiles", os.environ.get("FZ_PMC_TRAFFIC
 # lane, best over 4 / 8 / 16 waves per CU: profiles/r04_memory_ceilings.json).  `roofline.peak` stays the 8 TB/s of the
 # spec sheet; `stream_ceiling_GBps` is the number a memory-bound kernel can actually be held against.
 STREAM_CEILINGS = os.path.join(ROOT, "profiles", "r04_memory_ceilings.json")
-STREAM_MIX = {"nmf_cf_bwd_": "2:1", "nmf_cf_fwd_": "2:1", "mlp_chain_bwd_wgrad_": "3:1", "mlp_chain_fwd_": "1:1", "dgrad_": "3:1"}
+STREAM_MIX = {"nmf_cf_bwd_": "2:1", "nmf_cf_fwd_": "2:1", "mlp_chain_bwd_wgrad_": "3:1", "mlp_chain_fwd_": "1:1", "dgrad_": "3:1",
+              "outproj_mlp_chain_fwd_": "1:1"}   # (2 tensors read, 4 written: the closest measured mix)
 
 
 def stream_ceiling(timer_name):
@@ -105,7 +107,8 @@ PMC_KERNEL = {"nmf_cf_bwd_32x128x128x128": ("fz::nmf_cf_bwd_gram_kernel<", "fz::
               "mlp_chain_bwd_wgrad_32": "fz::gemm_chain_bwd_wg_kernel<",
               "dgrad_lnbwd_wgrad_32": "fz::gemm_dw_kernel<true",
               "dgrad_wgrad_32": "fz::gemm_dw_kernel<false",
-              "mlp_chain_fwd_32": "fz::gemm_chain_kernel<false"}
+              "mlp_chain_fwd_32": "fz::gemm_chain_kernel<false, 2, 2, float, true, false>",
+              "outproj_mlp_chain_fwd_32": "fz::gemm_chain_kernel<false, 2, 2, float, true, true>"}
 
 
 def pmc_traffic(timer_name, path=None):
@@ -212,7 +215,7 @@ def by_stage(table, nsteps, B, stage0_cols, dtype="f32"):
         while cols and cols * 8 ** s < stage0_cols and s < 8:
             s += 1
         key = "unattributed" if not cols else ("stage0" if s == 0 else "stage1" if s == 1 else "stage2-4")
-        for k2, dst in ((key, out), ("gemm_family" if a.get("flops", 0) and not name.startswith(("wgrad", "mlp_chain", "dgrad_", "conv_k3")) else None, fam)):
+        for k2, dst in ((key, out), ("gemm_family" if a.get("flops", 0) and not name.startswith(("wgrad", "mlp_chain", "outproj_mlp_chain", "dgrad_", "conv_k3", "upcat_")) else None, fam)):
             if k2 is None:
                 continue
             d = dst.setdefault(k2, {"kernel_ms": 0.0, "GB": 0.0, "GFLOP": 0.0, "GFLOP_split_bf16": 0.0, "mfma_min_ms": 0.0, "launches": 0})

@@ -17,7 +17,7 @@ def main():
     agg = collections.defaultdict(list)
     for r in rows:
         n = r["Kernel_Name"]
-        if any(s in n for s in ("nmf_cf_bwd_tile", "nmf_cf_bwd_gram", "nmf_cf_fwd_tile", "gemm_chain", "gn_fwd", "gemm_resident", "gemm_dw_kernel")):
+        if any(s in n for s in ("nmf_cf_bwd_tile", "nmf_cf_bwd_gram", "nmf_cf_fwd_tile", "gemm_chain", "upcat_bx", "conv3_fwd_bx", "gemm_p32", "gn_fwd", "gemm_resident", "gemm_dw_kernel")):
             key = (n.split("(")[0].replace("void ", ""), int(r["Grid_Size_X"]))
             agg[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     pmc = json.load(open(pmc_path))
@@ -46,6 +46,9 @@ def main():
            "fz::nmf_cf_bwd_tile_kernel<1, 1, 4, false, float>": ((4 if r5 else 3.5) * 536.87, " (window 1: + the running sum)" if r5 else " (avg over the 2 windows)"),
            "fz::nmf_cf_fwd_tile_kernel<1, 1, 8, false, float>": (2.5 * 536.87, " (avg over the 2 windows)"),
            "fz::gemm_chain_kernel<true, 2, 2, float>": (7 * 536.87, ""), "fz::gemm_chain_kernel<false, 2, 2, float>": (4 * 536.87, ""),
+           "fz::gemm_chain_kernel<false, 2, 2, float, true, true>": (6 * 536.87 + 25.2, " (round 5: out_proj + residual + MLP chain, a, x in; x1, z1 (2), y out; + the head's logits on one of the two launches)"),
+           "fz::upcat_bx_kernel<float, true>": (3.5 * 536.87 + 16.8, " (round 5: skip, deep in; out, t, statistics out)"),
+           "fz::conv3_fwd_bx_kernel<1, 2, float, true>": (2 * 536.87 + 67.1 + 16.8, " (round 5: image in; x, t, statistics out)"),
            "fz::gemm_chain_bwd_wg_kernel<float>": (5 * 536.87, " (round 4: the residual rows g2 come from LDS; rounds 2-3 read them a second time, +537)"),
            "fz::gemm_chain_bwd_wg_kernel<float, 1, 0, true>": (5 * 536.87, " (round 4: the residual rows g2 come from LDS; rounds 2-3 read them a second time, +537)"),
            "fz::gemm_dw_kernel<true, float>": (4 * 536.87, ""), "fz::gemm_dw_kernel<false, float>": (3 * 536.87, "")}
