@@ -21,10 +21,13 @@ def test_products_setting_nests_and_reaches_the_descriptors():
             assert N.products() == N.PRODUCTS_SPLIT_BF16
         assert N.products() == N.PRODUCTS_FP32_MFMA
     assert N.products() == N.PRODUCTS_DEFAULT
-    # the field is the LAST-but-one int of fz_gemm_desc (then `tune`), the last of fz_mlp_desc / fz_wgrad_desc: a descriptor that
-    # leaves them zero follows the process default, and the process default itself is untouched by the context manager
+    # the field is the LAST-but-one int of fz_gemm_desc (then `tune`), the last of fz_wgrad_desc, and in fz_mlp_desc the last field
+    # before round 5's pre_* / post_* block: a descriptor that leaves them zero follows the process default, and the process default
+    # itself is untouched by the context manager
     assert [f[0] for f in N.GemmDesc._fields_][-2:] == ["products", "tune"]
-    assert N.MlpDesc._fields_[-1][0] == "products" and N.WgradDesc._fields_[-1][0] == "products"
+    assert N.WgradDesc._fields_[-1][0] == "products"
+    mlp = [f[0] for f in N.MlpDesc._fields_]
+    assert mlp[mlp.index("products") + 1:] == ["pre_in", "pre_w", "pre_b", "pre_res", "pre_out", "post_w", "post_b", "post_out", "post_m"]
     assert N.lib().fz_gemm_bx_enable(-1) == 1
     d = N.GemmDesc()
     assert d.products == 0 and d.tune == 0
