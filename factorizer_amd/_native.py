@@ -263,6 +263,10 @@ _SIGS.update({
     "fz_conv3_wgrad_chunks": ([_i] * 4, _i),
     "fz_conv3_wgrad_partials": ([_vp] * 4 + [_i] * 8 + [_vp], _i),
     "fz_chunk_reduce": ([_vp, _i, _i64, _vp, _i, _vp], _i),
+    "fz_chunk_reduce_ld": ([_vp, _i, _i64, _i64, _vp, _i, _vp], _i),
+    "fz_finish_defer": ([_i], _i),
+    "fz_finish_pending": ([], _i),
+    "fz_finish_flush": ([_vp], _i),
     "fz_dice_bce_chunks": ([_i64], _i),
     "fz_dice_bce_sums": ([_vp, _vp, _vp, _i, _i64, _vp], _i),
     "fz_dice_bce_grad": ([_vp, _vp, _vp, _vp, _i, _i64, _f, _f, _vp, _vp], _i),

@@ -20,6 +20,7 @@
 // The accumulator tile has its row in (register, h) and its column in j, so the epilogue
 // stores 16-byte vectors (4 voxels) per register: 512 B contiguous per output row.
 #include "gemm_bx.h"   // split-bf16 operand helpers for the fused kernels (brings gemm_common.h)
+#include "finish.h"    // kWgRow / kDwRow and the jobs that add the weight-gradient rows
 
 namespace fz {
 
@@ -1429,12 +1430,12 @@ __global__ __launch_bounds__(P512 ? 512 : 256, 2) void gemm_chain64_kernel(GemmA
 //   T   16 x 64: one 16-channel block of gelu(z1) (pass A) resp. gz1 (pass B) at a time.
 // The (dW2 | dW1 | db2 | db1) sums stay in registers across the tiles of the persistent workgroup, are added
 // over its four waves through LDS at the end and leave as one row of `wpart` per workgroup;
-// chain_wg_finish_kernel adds the rows in index order (no float atomics) and applies the LayerNorm affine to dW1.
+// the FK_CHAIN_WG job of the finish kernel (finish.h) adds the rows in index order (no float atomics) and applies the LayerNorm affine to dW1.
 // 13 KB of LDS per wave + 64 accumulator registers: two workgroups per CU (the plain chain runs three).
 // =================================================================================================
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kTS = 66;                       // LDS row stride of the transposable tiles (floats): ≡ 2 (mod 32), even
-constexpr int kWgRow = 2048 + 2048 + 32 + 64 + 64; // floats of one wpart row: dW2 [32][64] | S1 [64][32] | db2 | db1 | dγ | dβ
+// (kWgRow — floats of one wpart row: dW2 [32][64] | S1 [64][32] | db2 | db1 | dγ | dβ — lives in finish.h with the job that adds the rows)
 
 // gelu(x) and gelu'(x) with ONE exponential: erf(x/√2) by Abramowitz-Stegun 7.1.26 (fast_erf, fz_common.h) needs
 // exp(−x²/2), which is also the Gaussian density of gelu'
@@ -1937,57 +1938,7 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
   if (threadIdx.x < 64) row[4096 + 96 + threadIdx.x] = gln;
 }
 
-// gw2 = Σ rows dW2;  gb2, gb1 likewise;  gw1[c][k] = γ[k]·Σ S1[c][k] + β[k]·gb1[c]   (z1 = W1·(γ x̂ + β) + b1).
-// 256 threads = 16 elements x 16 row slices; slices walk the rows with stride 16 and are added in slice order.
-// (hidden 128: called once per half with gw2 advanced by 64·half columns and ldw2 = 128, gw1 / gb1 by 64·half rows;
-// gb2 from the first half, gln from the second — null where not wanted)
-__global__ __launch_bounds__(256) void chain_wg_finish_kernel(const float* wpart, int rows, const float* ln_g, const float* ln_b,
-                                                              float* gw1, float* gb1, float* gw2, int ldw2, float* gb2, float* gln) {
-  __shared__ float s[16][17];
-  __shared__ float sb1[64];
-  const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  auto total = [&](int e) {
-    float t = 0.f;
-    // 8 row loads in flight per thread (the adds stay in row order: same result, a fraction of the round trips)
-    int r = sl;
-    for (; r + 7 * 16 < rows; r += 8 * 16) {
-      float v[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = wpart[(int64_t)(r + 16 * i) * kWgRow + e];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) t += v[i];
-    }
-    for (; r < rows; r += 16) t += wpart[(int64_t)r * kWgRow + e];
-    return t;
-  };
-  // every block also needs db1 of the rows it scales: blocks over S1 recompute the 16-row slice sums of their db1 entry
-  const int e = blockIdx.x * 16 + el;
-  s[sl][el] = e < kWgRow ? total(e) : 0.f;
-  __syncthreads();
-  float v = 0.f;
-  if (sl == 0) {
-    for (int q = 0; q < 16; ++q) v += s[q][el];
-  }
-  const bool is_s1 = e >= 2048 && e < 4096;
-  if (is_s1) {   // uniform per block: 16 consecutive elements of one S1 row c
-    __syncthreads();
-    const int cidx = (blockIdx.x * 16 - 2048) / 32;
-    if (el == 0) s[sl][0] = total(4096 + 32 + cidx);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      float t = 0.f;
-      for (int q = 0; q < 16; ++q) t += s[q][0];
-      sb1[0] = t;
-    }
-    __syncthreads();
-  }
-  if (sl != 0 || e >= kWgRow) return;
-  if (e < 2048) gw2[(e >> 6) * ldw2 + (e & 63)] = v;
-  else if (e < 4096) { const int k = (e - 2048) & 31; gw1[e - 2048] = ln_g[k] * v + ln_b[k] * sb1[0]; }
-  else if (e < 4096 + 32) { if (gb2 != nullptr) gb2[e - 4096] = v; }
-  else if (e < 4096 + 96) gb1[e - 4096 - 32] = v;
-  else if (gln != nullptr) gln[e - 4096 - 96] = v;          // dγ (32) | dβ (32)
-}
+// (the rows are added, and the LayerNorm affine applied to dW1, by the FK_CHAIN_WG job of the finish kernel: finish.h)
 
 // =================================================================================================
 // Input gradient AND weight gradient of a 32 -> 32 layer in one pass (C = 32: in_proj behind LayerNorm, out_proj):
@@ -1998,7 +1949,7 @@ __global__ __launch_bounds__(256) void chain_wg_finish_kernel(const float* wpart
 // tile in LDS (stride kTS) and reads them back with the channel on the lane axis — no register transposes.
 // Persistent workgroups (two per CU), sums carried in registers across tiles, one wpart row per workgroup.
 // =================================================================================================
-constexpr int kDwRow = 1024 + 32 + 64;   // floats of one wpart row: dW [32][32] | db [32] | dγ [32] | dβ [32] (LNB)
+// (kDwRow — floats of one wpart row: dW [32][32] | db [32] | dγ [32] | dβ [32] (LNB) — lives in finish.h)
 
 template <typename AT>
 struct DwArgsT {
@@ -2306,55 +2257,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_kernel(DwArgsT<AT> p, int ntil
   if (threadIdx.x < 64) row[1024 + 32 + threadIdx.x] = gln;
 }
 
-// gw[m][k] = (ln ? γ[k]·S[m][k] + β[k]·sg[m] : S[m][k]),  gb[m] = sg[m] (when wanted); rows added in slice order
-__global__ __launch_bounds__(256) void dw_finish_kernel(const float* wpart, int rows, const float* ln_g, const float* ln_b,
-                                                        float* gw, float* gb, float* gln, int ldgw) {
-  __shared__ float s[16][17];
-  __shared__ float sm;
-  const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  auto total = [&](int e) {
-    float t = 0.f;
-    // 8 row loads in flight per thread (the adds stay in row order: same result, a fraction of the round trips)
-    int r = sl;
-    for (; r + 7 * 16 < rows; r += 8 * 16) {
-      float v[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = wpart[(int64_t)(r + 16 * i) * kDwRow + e];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) t += v[i];
-    }
-    for (; r < rows; r += 16) t += wpart[(int64_t)r * kDwRow + e];
-    return t;
-  };
-  const int e = blockIdx.x * 16 + el;      // kDwRow = 70 x 16
-  s[sl][el] = total(e);
-  __syncthreads();
-  float v = 0.f;
-  if (sl == 0)
-    for (int q = 0; q < 16; ++q) v += s[q][el];
-  const bool is_w = e < 1024;              // uniform per block
-  if (is_w && ln_g != nullptr) {
-    __syncthreads();
-    const int m = (blockIdx.x * 16) / 32;
-    if (el == 0) s[sl][0] = total(1024 + m);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      float t = 0.f;
-      for (int q = 0; q < 16; ++q) t += s[q][0];
-      sm = t;
-    }
-    __syncthreads();
-  }
-  if (sl != 0) return;
-  if (is_w) {
-    const int k = e & 31;
-    gw[(e >> 5) * ldgw + k] = ln_g != nullptr ? ln_g[k] * v + ln_b[k] * sm : v;
-  } else if (e < 1024 + 32) {
-    if (gb != nullptr) gb[e - 1024] = v;
-  } else if (gln != nullptr) {
-    gln[e - 1024 - 32] = v;
-  }
-}
+// (rows added in slice order, LayerNorm affine applied, by the FK_DW job of the finish kernel: finish.h)
 
 // =================================================================================================
 // Kernel B — streaming operand with a PF-deep register prefetch ring, any K, all loaders.
@@ -3145,9 +3048,9 @@ static int mlp_launch(const fz_mlp_desc* d, fz_stream_t stream) {
       FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
       hipLaunchKernelGGL(kern, dim3((unsigned)rows), block, lds, st, a, c, ntiles, (float*)d->wpart, (float*)nullptr);
       FZ_LAUNCH_CHECK();
-      hipLaunchKernelGGL(chain_wg_finish_kernel, dim3(kWgRow / 16), dim3(256), 0, st, (const float*)d->wpart, rows, d->ln_g, d->ln_b,
-                         d->gw1, d->gb1, d->gw2, 64, d->gb2, d->gln);
-      FZ_LAUNCH_CHECK();
+      FinishJob fj = finish_job(FK_CHAIN_WG, kWgRow / 16);
+      fj.u.cw = FinChainWg{(const float*)d->wpart, d->ln_g, d->ln_b, d->gw1, d->gb1, d->gw2, d->gb2, d->gln, rows, 64};
+      return finish_run(&fj, 1, st);
     } else {   // hidden 128: one launch per 64-row half (wpart holds two row blocks)
       auto kern0 = bxon ? gemm_chain_bwd_wg_kernel<AT, 2, 0, true> : gemm_chain_bwd_wg_kernel<AT, 2, 0, false>;
       auto kern1 = bxon ? gemm_chain_bwd_wg_kernel<AT, 2, 1, true> : gemm_chain_bwd_wg_kernel<AT, 2, 1, false>;
@@ -3158,10 +3061,11 @@ static int mlp_launch(const fz_mlp_desc* d, fz_stream_t stream) {
         if (half == 0) hipLaunchKernelGGL(kern0, dim3((unsigned)rows), block, lds, st, a, c, ntiles, wp, d->glp);
         else hipLaunchKernelGGL(kern1, dim3((unsigned)rows), block, lds, st, a, c, ntiles, wp, d->glp);
         FZ_LAUNCH_CHECK();
-        hipLaunchKernelGGL(chain_wg_finish_kernel, dim3(kWgRow / 16), dim3(256), 0, st, (const float*)wp, rows, d->ln_g, d->ln_b,
-                           d->gw1 + half * 64 * 32, d->gb1 + half * 64, d->gw2 + half * 64, 128,
-                           half == 0 ? d->gb2 : (float*)nullptr, half == 1 ? d->gln : (float*)nullptr);
-        FZ_LAUNCH_CHECK();
+        FinishJob fj = finish_job(FK_CHAIN_WG, kWgRow / 16);
+        fj.u.cw = FinChainWg{(const float*)wp, d->ln_g, d->ln_b, d->gw1 + half * 64 * 32, d->gb1 + half * 64, d->gw2 + half * 64,
+                             half == 0 ? d->gb2 : (float*)nullptr, half == 1 ? d->gln : (float*)nullptr, rows, 128};
+        const int frc = finish_run(&fj, 1, st);
+        if (frc != FZ_OK) return frc;
       }
     }
     return FZ_OK;
@@ -3198,11 +3102,10 @@ static int gemm_dw_launch(const fz_gemm_dw_desc* d, fz_stream_t stream) {
     hipLaunchKernelGGL(kern, dim3((unsigned)rows), dim3(256), lds, st, a, ntiles);
   }
   FZ_LAUNCH_CHECK();
-  hipLaunchKernelGGL(dw_finish_kernel, dim3(kDwRow / 16), dim3(256), 0, st, (const float*)d->wpart, rows,
-                     d->ln ? d->ln_g : (const float*)nullptr, d->ln_b, d->gw, d->gb, d->ln ? d->gln : (float*)nullptr,
-                     d->ldgw > 0 ? d->ldgw : 32);
-  FZ_LAUNCH_CHECK();
-  return FZ_OK;
+  FinishJob fj = finish_job(FK_DW, kDwRow / 16);
+  fj.u.dw = FinDw{(const float*)d->wpart, d->ln ? d->ln_g : (const float*)nullptr, d->ln_b, d->gw, d->gb, d->ln ? d->gln : (float*)nullptr,
+                  rows, d->ldgw > 0 ? d->ldgw : 32};
+  return finish_run(&fj, 1, st);
 }
 
 extern "C" int fz_gemm_dw_rows(int B, int64_t V) {

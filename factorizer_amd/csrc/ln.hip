@@ -8,6 +8,7 @@
 #include <cstdlib>
 
 #include "fz_common.h"
+#include "finish.h"
 
 namespace fz {
 
@@ -350,24 +351,7 @@ __global__ __launch_bounds__(512) void ln_bwd_slice_kernel(const AT* __restrict_
   }
 }
 
-// out[grp][e] = Σ_{row in group grp} part[row][e], fixed order.  Rows are split into `groups`
-// contiguous slices (blockIdx.y); 32 outputs per block, 8 strided partial sums per output.
-__global__ __launch_bounds__(256) void ln_part_reduce_kernel(const float* __restrict__ part, int nrows, int n,
-                                                             int rows_per_group, float* __restrict__ out) {
-  __shared__ float red[8][33];
-  const int el = threadIdx.x & 31, gq = threadIdx.x >> 5;
-  const int e = blockIdx.x * 32 + el;
-  const int r0 = blockIdx.y * rows_per_group;
-  const int r1 = min(nrows, r0 + rows_per_group);
-  float s = 0.f;
-  if (e < n)
-    for (int ch = r0 + gq; ch < r1; ch += 8) s += part[(int64_t)ch * n + e];
-  red[gq][el] = s;
-  __syncthreads();
-  if (gq == 0 && e < n)
-    out[(int64_t)blockIdx.y * n + e] = ((red[0][el] + red[1][el]) + (red[2][el] + red[3][el])) +
-                                       ((red[4][el] + red[5][el]) + (red[6][el] + red[7][el]));
-}
+// (the fixed-order row reductions behind these kernels are jobs of the finish kernel: finish.h, FK_ROWS)
 
 // per-channel sums over batch and voxels (bias gradient of the transposed conv, unet.py:123):
 // part[(b*nchunk + chunk)][c] = Σ_{v in chunk} x[b, c, v]
@@ -480,10 +464,7 @@ static int ln_bwd_launch(const void* gl_, const void* x_, const float* stats, co
     else
       hipLaunchKernelGGL((ln_bwd_kernel<64, AT>), dim3(grid), dim3(256), 0, st, gl, x, stats, gamma, gadd, gx, part, B, C, V);
     FZ_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ln_part_reduce_kernel, dim3((2 * C + 31) / 32, 1), dim3(256), 0, st, part, (int)grid, 2 * C,
-                       (int)grid, gparams);
-    FZ_LAUNCH_CHECK();
-    return FZ_OK;
+    return finish_rows(part, (int)grid, 2 * C, (int)grid, 1, gparams, 0, st);
   }
   if (C > 64) {
     const int64_t quads = (V / 4) * B;
@@ -526,19 +507,13 @@ extern "C" int fz_ln_bwd(const void* gl, const void* x, const float* stats, cons
 extern "C" int fz_reduce_rows(const float* part, int64_t rows, int n, float* out, float* tmp, fz_stream_t stream) {
   if (!part || !out || rows < 1 || n < 1 || rows > 0x7fffffff) return fail(FZ_E_ARG, "fz_reduce_rows: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  if (rows <= 512 || tmp == nullptr) {
-    hipLaunchKernelGGL(ln_part_reduce_kernel, dim3((n + 31) / 32, 1), dim3(256), 0, st, part, (int)rows, n, (int)rows,
-                       out);
-    FZ_LAUNCH_CHECK();
-    return FZ_OK;
-  }
+  if (rows <= 512 || tmp == nullptr) return finish_rows(part, (int)rows, n, (int)rows, 1, out, 0, st);
   const int groups = 64;
   const int rpg = (int)((rows + groups - 1) / groups);
-  hipLaunchKernelGGL(ln_part_reduce_kernel, dim3((n + 31) / 32, groups), dim3(256), 0, st, part, (int)rows, n, rpg, tmp);
-  FZ_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ln_part_reduce_kernel, dim3((n + 31) / 32, 1), dim3(256), 0, st, tmp, groups, n, groups, out);
-  FZ_LAUNCH_CHECK();
-  return FZ_OK;
+  FinishJob j[2] = {finish_job(FK_ROWS, ((n + 31) / 32) * groups, 0), finish_job(FK_ROWS, (n + 31) / 32, 1)};
+  j[0].u.rows = FinRows{part, tmp, (int)rows, n, rpg, (n + 31) / 32};
+  j[1].u.rows = FinRows{tmp, out, groups, n, groups, (n + 31) / 32};
+  return finish_run(j, 2, st);
 }
 
 // out[c] = Σ_{b,v} x[b,c,v]; part: workspace of B*nchunk*C floats with nchunk = fz_rowsum_chunks(V)
@@ -562,8 +537,5 @@ extern "C" int fz_rowsum(const void* x, float* part, float* out, int B, int C, i
   else
     return fail(FZ_E_ARG, "fz_rowsum: bad act_dtype");
   FZ_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ln_part_reduce_kernel, dim3((C + 31) / 32, 1), dim3(256), 0, st, part, B * nchunk, C, B * nchunk,
-                     out);
-  FZ_LAUNCH_CHECK();
-  return FZ_OK;
+  return finish_rows(part, B * nchunk, C, B * nchunk, 1, out, 0, st);
 }

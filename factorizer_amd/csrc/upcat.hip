@@ -15,6 +15,7 @@
 // pre-split in LDS (gemm_bx.h: six exact bf16 products per fp32 product; bf16 storage: the activations are exact single
 // terms); operand reads from LDS through one opaque per-lane base per image (see gemm_chain64).
 #include "gemm_bx.h"
+#include "finish.h"
 
 namespace fz {
 
@@ -270,43 +271,8 @@ __global__ __launch_bounds__(256) void upcat_compose_kernel(const float* __restr
   }
 }
 
-// gw_t[k][c][t] = Σ_m w_b[m][c]·gt[k][m][t]  (blocks 0 .. Cd-1);  gw_b[m][c] = Σ_{k,t} gt[k][m][t]·w_t[k][c][t] + gb_ad[m]·b_t[c]
-// (blocks Cd .. Cd+M-1, written with row stride ldg into the adapter's weight gradient);  gb_t[c] = Σ_m gb_ad[m]·w_b[m][c] (last block)
-__global__ __launch_bounds__(256) void upcat_wgrads_kernel(const float* __restrict__ gt, const float* __restrict__ w_t,
-                                                           const float* __restrict__ w_b, int ldb, const float* __restrict__ gb_ad,
-                                                           const float* __restrict__ b_t, float* __restrict__ gw_t,
-                                                           float* __restrict__ gw_b, int ldg, float* __restrict__ gb_t, int Cd, int O,
-                                                           int M) {
-  const int blk = blockIdx.x;
-  if (blk < Cd) {
-    const float* gk = gt + (int64_t)blk * M * 8;
-    for (int i = threadIdx.x; i < O * 8; i += 256) {
-      const int c = i >> 3, t = i & 7;
-      float acc = 0.f;
-      for (int m = 0; m < M; ++m) acc += w_b[(int64_t)m * ldb + c] * gk[m * 8 + t];
-      gw_t[((int64_t)blk * O + c) * 8 + t] = acc;
-    }
-  } else if (blk < Cd + M) {
-    const int m = blk - Cd;
-    for (int c = threadIdx.x; c < O; c += 256) {
-      float acc = 0.f;
-      for (int k = 0; k < Cd; ++k) {
-        const float* g8 = gt + ((int64_t)k * M + m) * 8;
-        const float* w8 = w_t + ((int64_t)k * O + c) * 8;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) acc += g8[t] * w8[t];
-      }
-      if (b_t != nullptr) acc += gb_ad[m] * b_t[c];
-      gw_b[(int64_t)m * ldg + c] = acc;
-    }
-  } else if (gb_t != nullptr) {
-    for (int c = threadIdx.x; c < O; c += 256) {
-      float acc = 0.f;
-      for (int m = 0; m < M; ++m) acc += gb_ad[m] * w_b[(int64_t)m * ldb + c];
-      gb_t[c] = acc;
-    }
-  }
-}
+// (dW_t, dW_b, db_t from the (deep x g) correlation: the FK_UPCAT job of the finish kernel, finish.h — phase 1: it reads the
+// correlation and the adapter bias gradient, both outputs of phase-0 finish jobs)
 
 }  // namespace fz
 
@@ -325,10 +291,9 @@ extern "C" int fz_upcat_wgrads(const float* gt, const float* w_t, const float* w
                                float* gw_t, float* gw_b, int ldg, float* gb_t, int Cd, int O, int M, fz_stream_t stream) {
   if (!gt || !w_t || !w_b || !gb_ad || !gw_t || !gw_b || Cd < 1 || O < 1 || M < 1 || ldb < O || ldg < O)
     return fail(FZ_E_ARG, "fz_upcat_wgrads: bad arguments");
-  hipLaunchKernelGGL(upcat_wgrads_kernel, dim3((unsigned)(Cd + M + 1)), dim3(256), 0, (hipStream_t)stream, gt, w_t, w_b, ldb, gb_ad, b_t,
-                     gw_t, gw_b, ldg, gb_t, Cd, O, M);
-  FZ_LAUNCH_CHECK();
-  return FZ_OK;
+  FinishJob fj = finish_job(FK_UPCAT, Cd + M + 1, 1);
+  fj.u.up = FinUpcat{gt, w_t, w_b, gb_ad, b_t, gw_t, gw_b, gb_t, ldb, ldg, Cd, O, M};
+  return finish_run(&fj, 1, (hipStream_t)stream);
 }
 
 extern "C" int fz_upcat_supported(int C, int Cd, int D, int H, int W) {

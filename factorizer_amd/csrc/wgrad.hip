@@ -17,6 +17,7 @@
 #include <type_traits>
 
 #include "fz_common.h"
+#include "finish.h"
 
 namespace fz {
 
@@ -415,177 +416,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_group_kernel(WgradGroupT<AT
   }
 }
 
-// out[e] = Σ_chunks part[chunk][e] in a fixed order: 32 strided partial sums per element (8
-// elements per 256-thread block), combined by a fixed tree through LDS — bitwise reproducible.
-__global__ __launch_bounds__(256) void chunk_reduce_kernel(const float* __restrict__ part, int nchunk, int64_t n,
-                                                           float* __restrict__ out, int accumulate) {
-  __shared__ float red[32][9];
-  const int el = threadIdx.x & 7, g = threadIdx.x >> 3;
-  const int64_t e = (int64_t)blockIdx.x * 8 + el;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (e < n) {
-    int ch = g;
-    for (; ch + 96 < nchunk; ch += 128) {  // 4 independent loads in flight
-      s0 += part[(int64_t)ch * n + e];
-      s1 += part[(int64_t)(ch + 32) * n + e];
-      s2 += part[(int64_t)(ch + 64) * n + e];
-      s3 += part[(int64_t)(ch + 96) * n + e];
-    }
-    for (; ch < nchunk; ch += 32) s0 += part[(int64_t)ch * n + e];
-  }
-  red[g][el] = (s0 + s1) + (s2 + s3);
-  __syncthreads();
-  if (g == 0 && e < n) {
-    float t = 0.f;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) t += red[i][el];
-    out[e] = accumulate ? out[e] + t : t;
-  }
-}
-
-// One launch that finishes a weight gradient: workgroups [0, nbw) reduce the M·K partial blocks
-// (8 elements each, 32 strided partial sums per element, fixed tree — bitwise reproducible),
-// optionally folding the LayerNorm affine  gw[m][k] = Σ_ch (γ_k·part[ch][m][k] + β_k·pb[ch][m]);
-// workgroups [nbw, nbw + nbb) reduce the M bias sums.  Replaces 2-4 tiny dependent launches.
-__device__ __forceinline__ void wgrad_finish_body(const float* __restrict__ part, const float* __restrict__ part_bias,
-                                                  int nchunk, int M, int K, float* __restrict__ gw,
-                                                  float* __restrict__ gbias, const float* __restrict__ ln_g,
-                                                  const float* __restrict__ ln_b, int accumulate, int nbw,
-                                                  float (*red)[9], const int bid) {
-  const int el = threadIdx.x & 7, g = threadIdx.x >> 3;
-  const bool bias_blk = bid >= nbw;
-  const int64_t n = bias_blk ? (int64_t)M : (int64_t)M * K;
-  const int64_t e = (int64_t)(bias_blk ? bid - nbw : bid) * 8 + el;
-  const float* src = bias_blk ? part_bias : part;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (e < n) {
-    const bool fold = !bias_blk && ln_g != nullptr;
-    const int m = fold ? (int)(e / K) : 0, k = fold ? (int)(e % K) : 0;
-    const float gk = fold ? ln_g[k] : 1.f, bk = fold ? ln_b[k] : 0.f;
-    int ch = g;
-    if (fold) {
-      for (; ch + 96 < nchunk; ch += 128) {
-        s0 += gk * src[(int64_t)ch * n + e] + bk * part_bias[(int64_t)ch * M + m];
-        s1 += gk * src[(int64_t)(ch + 32) * n + e] + bk * part_bias[(int64_t)(ch + 32) * M + m];
-        s2 += gk * src[(int64_t)(ch + 64) * n + e] + bk * part_bias[(int64_t)(ch + 64) * M + m];
-        s3 += gk * src[(int64_t)(ch + 96) * n + e] + bk * part_bias[(int64_t)(ch + 96) * M + m];
-      }
-      for (; ch < nchunk; ch += 32) s0 += gk * src[(int64_t)ch * n + e] + bk * part_bias[(int64_t)ch * M + m];
-    } else {
-      // 8 independent loads in flight: the kernel is pure dependent-load latency (1024 partial blocks
-      // = 32 per thread at stage 0)
-      for (; ch + 224 < nchunk; ch += 256) {
-        const float a0 = src[(int64_t)ch * n + e], a1 = src[(int64_t)(ch + 32) * n + e];
-        const float a2 = src[(int64_t)(ch + 64) * n + e], a3 = src[(int64_t)(ch + 96) * n + e];
-        const float a4 = src[(int64_t)(ch + 128) * n + e], a5 = src[(int64_t)(ch + 160) * n + e];
-        const float a6 = src[(int64_t)(ch + 192) * n + e], a7 = src[(int64_t)(ch + 224) * n + e];
-        s0 += a0; s1 += a1; s2 += a2; s3 += a3;
-        s0 += a4; s1 += a5; s2 += a6; s3 += a7;
-      }
-      for (; ch + 96 < nchunk; ch += 128) {
-        s0 += src[(int64_t)ch * n + e];
-        s1 += src[(int64_t)(ch + 32) * n + e];
-        s2 += src[(int64_t)(ch + 64) * n + e];
-        s3 += src[(int64_t)(ch + 96) * n + e];
-      }
-      for (; ch < nchunk; ch += 32) s0 += src[(int64_t)ch * n + e];
-    }
-  }
-  red[g][el] = (s0 + s1) + (s2 + s3);
-  __syncthreads();
-  if (g == 0 && e < n) {
-    float t = 0.f;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) t += red[i][el];
-    float* out = bias_blk ? gbias : gw;
-    out[e] = accumulate ? out[e] + t : t;
-  }
-}
-__global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restrict__ part,
-                                                           const float* __restrict__ part_bias, int nchunk, int M,
-                                                           int K, float* __restrict__ gw, float* __restrict__ gbias,
-                                                           const float* __restrict__ ln_g,
-                                                           const float* __restrict__ ln_b, int accumulate, int nbw) {
-  __shared__ float red[32][9];
-  wgrad_finish_body(part, part_bias, nchunk, M, K, gw, gbias, ln_g, ln_b, accumulate, nbw, red, (int)blockIdx.x);
-}
-
-// Same result layout as wgrad_finish_kernel for FEW partial blocks of a LARGE weight (the deep stages:
-// 512x2048 weights x 4 chunks): one thread per element walks the chunks in a fixed order (bitwise
-// reproducible) with 256-byte coalesced reads, instead of 32 threads per element reading 32-byte
-// segments — 131 136 workgroups / 52 us become 4 100 / a few us.
-__device__ __forceinline__ void wgrad_finish_wide_body(const float* __restrict__ part, const float* __restrict__ part_bias,
-                                                       int nchunk, int M, int K, float* __restrict__ gw,
-                                                       float* __restrict__ gbias, const float* __restrict__ ln_g,
-                                                       const float* __restrict__ ln_b, int accumulate, int nbw,
-                                                       const int bid) {
-  const bool bias_blk = bid >= nbw;
-  const int64_t n = bias_blk ? (int64_t)M : (int64_t)M * K;
-  const int64_t e = (int64_t)(bias_blk ? bid - nbw : bid) * 256 + threadIdx.x;
-  if (e >= n) return;
-  const float* src = bias_blk ? part_bias : part;
-  const bool fold = !bias_blk && ln_g != nullptr;
-  const int m = fold ? (int)(e / K) : 0, k = fold ? (int)(e % K) : 0;
-  const float gk = fold ? ln_g[k] : 1.f, bk = fold ? ln_b[k] : 0.f;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int ch = 0;
-  for (; ch + 3 < nchunk; ch += 4) {
-    float a0 = src[(int64_t)ch * n + e], a1 = src[(int64_t)(ch + 1) * n + e];
-    float a2 = src[(int64_t)(ch + 2) * n + e], a3 = src[(int64_t)(ch + 3) * n + e];
-    if (fold) {
-      a0 = gk * a0 + bk * part_bias[(int64_t)ch * M + m];
-      a1 = gk * a1 + bk * part_bias[(int64_t)(ch + 1) * M + m];
-      a2 = gk * a2 + bk * part_bias[(int64_t)(ch + 2) * M + m];
-      a3 = gk * a3 + bk * part_bias[(int64_t)(ch + 3) * M + m];
-    }
-    s0 += a0; s1 += a1; s2 += a2; s3 += a3;
-  }
-  for (; ch < nchunk; ++ch) {
-    float a0 = src[(int64_t)ch * n + e];
-    if (fold) a0 = gk * a0 + bk * part_bias[(int64_t)ch * M + m];
-    s0 += a0;
-  }
-  const float t = (s0 + s1) + (s2 + s3);
-  float* out = bias_blk ? gbias : gw;
-  out[e] = accumulate ? out[e] + t : t;
-}
-__global__ __launch_bounds__(256) void wgrad_finish_wide_kernel(const float* __restrict__ part,
-                                                                const float* __restrict__ part_bias, int nchunk,
-                                                                int M, int K, float* __restrict__ gw,
-                                                                float* __restrict__ gbias,
-                                                                const float* __restrict__ ln_g,
-                                                                const float* __restrict__ ln_b, int accumulate,
-                                                                int nbw) {
-  wgrad_finish_wide_body(part, part_bias, nchunk, M, K, gw, gbias, ln_g, ln_b, accumulate, nbw, (int)blockIdx.x);
-}
-
-// The finish launches of a grouped weight-gradient call as ONE grid (same bodies, same order of every sum).
-struct WgradFinishOne {
-  const float* part;
-  const float* part_bias;
-  float* gw;
-  float* gbias;
-  const float* ln_g;
-  const float* ln_b;
-  int nchunk, M, K, accumulate, nbw, wide;
-};
-struct WgradFinishGroup {
-  WgradFinishOne f[4];
-  int start[5];
-  int n;
-};
-__global__ __launch_bounds__(256) void wgrad_finish_group_kernel(WgradFinishGroup g) {
-  __shared__ float red[32][9];
-  int i = 0;
-#pragma unroll
-  for (int t = 1; t < 4; ++t)
-    if (t < g.n && (int)blockIdx.x >= g.start[t]) i = t;
-  const WgradFinishOne& f = g.f[i];
-  const int bid = (int)blockIdx.x - g.start[i];
-  if (f.wide) wgrad_finish_wide_body(f.part, f.part_bias, f.nchunk, f.M, f.K, f.gw, f.gbias, f.ln_g, f.ln_b, f.accumulate, f.nbw, bid);
-  else wgrad_finish_body(f.part, f.part_bias, f.nchunk, f.M, f.K, f.gw, f.gbias, f.ln_g, f.ln_b, f.accumulate, f.nbw, red, bid);
-}
-
+// (the fixed-order reductions of the partial blocks — chunk sums, one weight gradient with its bias sums and LayerNorm
+// fold — are jobs of the finish kernel: finish.h, FK_CHUNK / FK_WGRAD)
 
 // LayerNorm affine folded into the weight gradient: gw[m][k] = γ_k · acc[m][k] + β_k · gb[m]
 __global__ __launch_bounds__(256) void ln_fold_kernel(float* __restrict__ gw, const float* __restrict__ acc,
@@ -742,26 +574,23 @@ static int wgrad_main_launch(const fz_wgrad_desc* d, const WgradPlan<AT>& pl, hi
 }
 
 // the fixed-order reduction of one problem's partial blocks into gw / gbias
+// the fixed-order reduction of one problem's partial blocks into gw / gbias, as a finish job
+template <typename AT>
+static FinishJob wgrad_finish_job(const fz_wgrad_desc* d, const WgradPlan<AT>& pl) {
+  const int64_t MK = (int64_t)d->M * d->K;
+  const bool wide = pl.nchunk <= 64 && MK >= 16384;   // few partial blocks of a large weight: one thread per element
+  const int per = wide ? 256 : 8;
+  const int nbw = (int)((MK + per - 1) / per);
+  const int nbb = d->gbias != nullptr ? (d->M + per - 1) / per : 0;
+  FinishJob j = finish_job(FK_WGRAD, nbw + nbb);
+  j.u.wg = WgradFinishOne{pl.a.part, pl.a.part_bias, d->gw, d->gbias, d->ln_g != nullptr ? d->ln_g : (const float*)nullptr, d->ln_b,
+                          pl.nchunk, d->M, d->K, d->accumulate, nbw, wide ? 1 : 0};
+  return j;
+}
 template <typename AT>
 static int wgrad_finish_launch(const fz_wgrad_desc* d, const WgradPlan<AT>& pl, hipStream_t st) {
-  const WgradArgsT<AT>& a = pl.a;
-  const int nchunk = pl.nchunk;
-  const int64_t MK = (int64_t)d->M * d->K;
-  const bool fold = d->ln_g != nullptr;
-  const int nbw = (int)((MK + 7) / 8);
-  const int nbb = d->gbias != nullptr ? (d->M + 7) / 8 : 0;
-  if (nchunk <= 64 && MK >= 16384) {
-    const int wbw = (int)((MK + 255) / 256);
-    const int wbb = d->gbias != nullptr ? (d->M + 255) / 256 : 0;
-    hipLaunchKernelGGL(wgrad_finish_wide_kernel, dim3((unsigned)(wbw + wbb)), dim3(256), 0, st, a.part, a.part_bias,
-                       nchunk, d->M, d->K, d->gw, d->gbias, fold ? d->ln_g : (const float*)nullptr, d->ln_b,
-                       d->accumulate, wbw);
-  } else {
-    hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)(nbw + nbb)), dim3(256), 0, st, a.part, a.part_bias, nchunk,
-                       d->M, d->K, d->gw, d->gbias, fold ? d->ln_g : (const float*)nullptr, d->ln_b, d->accumulate, nbw);
-  }
-  FZ_LAUNCH_CHECK();
-  return FZ_OK;
+  const FinishJob j = wgrad_finish_job<AT>(d, pl);
+  return finish_run(&j, 1, st);
 }
 
 template <typename AT>
@@ -816,26 +645,9 @@ static int wgrad_group_launch(const fz_wgrad_desc* const* ds, void* const* ws, i
   else if (bf3) hipLaunchKernelGGL((wgrad_fast_group_kernel<2, 2, 6, AT>), dim3(total), dim3(256), ldsz, st, g);
   else hipLaunchKernelGGL((wgrad_fast_group_kernel<2, 2, 0, AT>), dim3(total), dim3(256), ldsz, st, g);
   FZ_LAUNCH_CHECK();
-  WgradFinishGroup fg;
-  int ftotal = 0;
-  for (int i = 0; i < 4; ++i) {
-    const int j = i < n ? i : n - 1;
-    const fz_wgrad_desc* d = ds[j];
-    const int64_t MK = (int64_t)d->M * d->K;
-    const bool wide = pl[j].nchunk <= 64 && MK >= 16384;   // (the choice of wgrad_finish_launch)
-    const int per = wide ? 256 : 8;
-    const int nbw = (int)((MK + per - 1) / per);
-    const int nbb = d->gbias != nullptr ? (d->M + per - 1) / per : 0;
-    fg.f[i] = {pl[j].a.part, pl[j].a.part_bias, d->gw, d->gbias, d->ln_g != nullptr ? d->ln_g : (const float*)nullptr, d->ln_b,
-               pl[j].nchunk, d->M, d->K, d->accumulate, nbw, wide ? 1 : 0};
-    fg.start[i] = ftotal;
-    if (i < n) ftotal += nbw + nbb;
-  }
-  fg.start[4] = ftotal;
-  fg.n = n;
-  hipLaunchKernelGGL(wgrad_finish_group_kernel, dim3((unsigned)ftotal), dim3(256), 0, st, fg);
-  FZ_LAUNCH_CHECK();
-  return FZ_OK;
+  FinishJob fj[kWgGroupMax];
+  for (int i = 0; i < n; ++i) fj[i] = wgrad_finish_job<AT>(ds[i], pl[i]);
+  return finish_run(fj, n, st);
 }
 
 extern "C" int fz_wgrad(const fz_wgrad_desc* d, void* workspace, fz_stream_t stream) {
@@ -858,11 +670,15 @@ extern "C" int fz_wgrad_group(const fz_wgrad_desc* const* descs, void* const* wo
 
 // out[e] (+)= Σ_chunks part[chunk][e], fixed order — exposed for kernels that produce their own
 // per-workgroup partial sums (conv3.hip).
+extern "C" int fz_chunk_reduce_ld(const float* part, int nchunk, int64_t n, int64_t ld, float* out, int accumulate,
+                                  fz_stream_t stream) {
+  if (!part || !out || nchunk < 1 || n < 1 || ld < n) return fail(FZ_E_ARG, "fz_chunk_reduce: bad arguments");
+  FinishJob j = finish_job(FK_CHUNK, (int)((n + 7) / 8));
+  j.u.chunk = FinChunk{part, out, (long long)n, (long long)ld, nchunk, accumulate};
+  return finish_run(&j, 1, (hipStream_t)stream);
+}
+
 extern "C" int fz_chunk_reduce(const float* part, int nchunk, int64_t n, float* out, int accumulate,
                                fz_stream_t stream) {
-  if (!part || !out || nchunk < 1 || n < 1) return fail(FZ_E_ARG, "fz_chunk_reduce: bad arguments");
-  hipLaunchKernelGGL(chunk_reduce_kernel, dim3((unsigned)((n + 7) / 8)), dim3(256), 0, (hipStream_t)stream, part,
-                     nchunk, n, out, accumulate);
-  FZ_LAUNCH_CHECK();
-  return FZ_OK;
+  return fz_chunk_reduce_ld(part, nchunk, n, n, out, accumulate, stream);
 }

@@ -19,7 +19,8 @@ import torch.distributed as dist
 
 class FlatGradSync:
     def __init__(self, module: torch.nn.Module, process_group=None, num_buckets: int = 4,
-                 overlap: bool = True, late_wgrad_join: bool = False, force_collectives: bool = False):
+                 overlap: bool = True, late_wgrad_join: bool = False, force_collectives: bool = False,
+                 deferred_finishes: bool = True):
         # force_collectives: run the hook-launched all-reduces and finish() even in a one-rank group
         # (bench.py --force-dist: the N = 1 line then executes the same RCCL path as N > 1)
         # late_wgrad_join: the side-stream weight-gradient kernels of the deep blocks are awaited once,
@@ -29,6 +30,9 @@ class FlatGradSync:
         if self.late_join:
             from . import pointwise as _PW
             _PW.late_wgrad_join(True)
+        if deferred_finishes:   # the finish reductions of the weight-gradient launches: queued, run in front of each bucket's
+            from . import pointwise as _PW   # collective and at the end of the backward (pointwise._Defer)
+            _PW.defer_finishes(True)
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -88,9 +92,10 @@ class FlatGradSync:
     def _launch(self, bi):
         b = self.buckets[bi]
         self._launched[bi] = True
+        from . import pointwise as _PW
         if self.late_join:
-            from . import pointwise as _PW
             _PW.wait_wgrad_streams()  # (ownership is checked in finish(), once every gradient is assigned)
+        _PW.flush_finishes()          # the bucket's gradients must be complete before they are packed and reduced
         # pack the bucket's gradients into the flat buffer with one multi-tensor copy (autograd
         # produced them as separate tensors: assigning, not accumulating, costs no kernel)
         ps = [p for p in b["params"] if p.grad is not None and p.grad.data_ptr() != self.views[p].data_ptr()]
@@ -112,6 +117,7 @@ class FlatGradSync:
             p.grad = None
         from . import gradbuf as _GB
         _GB.release(self.flat)
+        _PW.arm_deferred_finishes()
         self._ready = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
 
@@ -126,9 +132,10 @@ class FlatGradSync:
         it): freeze such parameters (`requires_grad_(False)`) instead of leaving them unused.
         `average=False` leaves the SUM in the buffer and returns the factor
         1/world for the optimizer to apply (`FlatAdamW.step(grad_scale=...)`: no extra pass)."""
+        from . import pointwise as _PW
         if self.late_join:
-            from . import pointwise as _PW
             _PW.join_wgrad_streams()
+        _PW.flush_finishes(disarm=True)
         if not self.active:
             return 1.0
         for bi in range(len(self.buckets)):

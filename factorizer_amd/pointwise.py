@@ -95,7 +95,7 @@ def _wgrad_desc(p, qs, gw, *, B, M, Cin, K, Vq, Ncols, gbias=None, pmul=None, pm
 
 def _wgrad(p, qs, gw, **kw):
     d, ws, key, nbytes, cols, flops = _wgrad_desc(p, qs, gw, **kw)
-    with torch.cuda.device(p.device):
+    with torch.cuda.device(p.device), _finish_scope(ws, gw, kw.get("gbias")):
         rc = Fn._timed(key, nbytes, lambda: N.lib().fz_wgrad(ctypes.byref(d), ws.data_ptr(), N.stream_ptr(p)),
                        cols=cols, flops=flops)
     N.check(rc, "fz_wgrad")
@@ -113,7 +113,8 @@ def _wgrad_group(problems, name):
     descs = (ctypes.POINTER(N.WgradDesc) * n)(*[ctypes.pointer(pl[0]) for pl in plans])
     wss = (ctypes.c_void_p * n)(*[pl[1].data_ptr() for pl in plans])
     t0 = problems[0][0]
-    with torch.cuda.device(t0.device):
+    held = [pl[1] for pl in plans] + [pr[2] for pr in problems] + [pr[3].get("gbias") for pr in problems]
+    with torch.cuda.device(t0.device), _finish_scope(*held):
         rc = Fn._timed(name, sum(pl[3] for pl in plans),
                        lambda: N.lib().fz_wgrad_group(descs, wss, n, N.stream_ptr(t0)),
                        cols=max(pl[4] for pl in plans), flops=sum(pl[5] for pl in plans))
@@ -128,7 +129,7 @@ def _ln_backward(gl, x, stats, ln_w, gadd=None):
     gx = torch.empty_like(x)
     gpar = torch.empty(2 * C, dtype=torch.float32, device=x.device)
     ws = torch.empty(max(N.lib().fz_ln_bwd_workspace_bytes2(B, C, V) // 4, 1), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with torch.cuda.device(x.device), _finish_scope(ws, gpar):
         rc = Fn._timed(f"ln_bwd_{C}", 3 * x.element_size() * x.numel(), lambda: N.lib().fz_ln_bwd(
             gl.data_ptr(), x.data_ptr(), stats.data_ptr(), ln_w.data_ptr(), _p(gadd), gx.data_ptr(), _p(gpar), _p(ws),
             B, C, V, N.act_dtype(x), N.stream_ptr(x)), cols=B * V)
@@ -167,7 +168,8 @@ def _dgrad_lnbwd(gz, w2, x, stats, ln_w, gadd):
         rc = Fn._timed(f"dgrad_lnbwd_{Mz}->{C}", nbytes, lambda: N.lib().fz_gemm(ctypes.byref(d), N.stream_ptr(x)),
                        cols=B * V, flops=2 * B * V * C * Mz)
         N.check(rc, "fz_gemm")
-        rc = N.lib().fz_reduce_rows(part.data_ptr(), rows, 2 * C, gpar.data_ptr(), tmp.data_ptr(), N.stream_ptr(x))
+        with _finish_scope(part, gpar, tmp):
+            rc = N.lib().fz_reduce_rows(part.data_ptr(), rows, 2 * C, gpar.data_ptr(), tmp.data_ptr(), N.stream_ptr(x))
         N.check(rc, "fz_reduce_rows")
     return gx, gpar[:C], gpar[C:]
 
@@ -198,7 +200,7 @@ def _gemm_dw(g, w2, q, ln=None, stats=None, gadd=None, want_bias=False, name="dg
         gpar = torch.empty(64, dtype=torch.float32, device=dev)
         d.ln, d.stats, d.ln_g, d.ln_b, d.gadd, d.gln = 1, stats.data_ptr(), ln[0].data_ptr(), ln[1].data_ptr(), _p(gadd), gpar.data_ptr()
     nbytes = q.element_size() * (3 * q.numel() + (gadd.numel() if gadd is not None else 0))
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _finish_scope(wpart, gw, gb, gpar):
         rc = Fn._timed(f"{name}_{C}", nbytes, lambda: N.lib().fz_gemm_dw(ctypes.byref(d), N.stream_ptr(q)),
                        cols=B * V, flops=4 * B * V * C * C)
         N.check(rc, "fz_gemm_dw")
@@ -299,7 +301,8 @@ def _mlp_bwd_chain(g2, z1, w12, w22, x1, st, ln_w):
         rc = Fn._timed(f"mlp_chain_bwd_{C}", x1.element_size() * (3 * x1.numel() + 2 * z1.numel()),
                        lambda: N.lib().fz_mlp_chain(ctypes.byref(d), N.stream_ptr(x1)), cols=B * V, flops=4 * B * V * C * Hd)
         N.check(rc, "fz_mlp_chain")
-        rc = N.lib().fz_reduce_rows(part.data_ptr(), rows, 2 * C, gpar.data_ptr(), tmp.data_ptr(), N.stream_ptr(x1))
+        with _finish_scope(part, gpar, tmp):
+            rc = N.lib().fz_reduce_rows(part.data_ptr(), rows, 2 * C, gpar.data_ptr(), tmp.data_ptr(), N.stream_ptr(x1))
         N.check(rc, "fz_reduce_rows")
     return gz1, gx1, gpar[:C], gpar[C:]
 
@@ -335,7 +338,7 @@ def _mlp_bwd_chain_wgrad(g2, z1, w12, w22, x1, st, ln_w, ln_b):
     d.act_dtype = N.act_dtype(x1)
     # algorithmic bytes: H = 64: g2, z1, x1 in, gx1 out; H = 128: both halves read g2 and x1, + the fp32 partial out and in
     nbytes = x1.element_size() * (3 * x1.numel() + z1.numel()) + (0 if Hd == 64 else x1.element_size() * 2 * x1.numel() + 8 * x1.numel())
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _finish_scope(wpart, gpar, gw1, gb1, gw2, gb2):
         rc = Fn._timed(f"mlp_chain_bwd_wgrad_{C}" + ("" if Hd == 64 else f"x{Hd}"), nbytes,
                        lambda: N.lib().fz_mlp_chain(ctypes.byref(d), N.stream_ptr(x1)), cols=B * V, flops=8 * B * V * C * Hd)
         N.check(rc, "fz_mlp_chain")
@@ -435,6 +438,106 @@ def join_wgrad_streams():
                                "factorizer_amd.pointwise.late_wgrad_join(False) for this training loop")
 
 
+class _Defer:
+    """Deferred finishes (csrc/finish.h; include/factorizer_hip.h: fz_finish_defer / fz_finish_flush).  Every weight-gradient
+    launch ends with a tiny fixed-order reduction of per-workgroup partial rows whose output is a PARAMETER gradient; a README
+    training step has 54 of them, each a 5-10 us serial slot of the stream.  A caller that owns the step — `FlatAdamW`,
+    `FlatGradSync`: gradients are None at zero_grad, nothing reads them before the owner does — lets the library queue them and
+    run them as one grid at the end of the backward (and in front of every gradient bucket's collective).
+    Armed by the owner's zero_grad, disarmed by the end-of-backward flush: a second backward without zero_grad (gradient
+    accumulation: autograd then ADDS to .grad while the backward runs) is never deferred.  Sites whose results feed a torch
+    op inside the backward stay immediate (`_no_defer`).  The arithmetic is the same either way (bitwise)."""
+    enabled = False
+    armed = False
+    suppress = 0
+    keep = []       # workspaces and gradient outputs of queued finishes: alive until the flush
+    dev = None
+    queued = False  # an end-of-backward engine callback is pending
+    flushed = 0     # finishes run through flushes so far (tests)
+    flushes = 0
+
+
+def defer_finishes(flag: bool = True):
+    """Owner-level switch (FlatAdamW / FlatGradSync constructors); FZ_DEFER_FINISH=0 in the environment keeps it off."""
+    if not flag:
+        flush_finishes(disarm=True)
+    _Defer.enabled = bool(flag) and os.environ.get("FZ_DEFER_FINISH", "1") != "0"
+
+
+def arm_deferred_finishes():
+    """The owner's zero_grad: gradients are None from here to the end of the next backward."""
+    flush_finishes(disarm=True)
+    _Defer.queued = False
+    _Defer.armed = _Defer.enabled
+
+
+def flush_finishes(disarm: bool = False):
+    """Run what is queued (current stream of the device the finishes were issued on) and release the buffers held for it."""
+    d = _Defer
+    if disarm:
+        d.armed = False
+    if d.dev is not None:
+        with torch.cuda.device(d.dev):
+            n = N.lib().fz_finish_pending()
+            if n:
+                cols = 0
+                rc = Fn._timed("finish_batch", 0, lambda: N.lib().fz_finish_flush(torch.cuda.current_stream(d.dev).cuda_stream), cols=cols)
+                if rc < 0:
+                    N.check(rc, "fz_finish_flush")
+                d.flushed += n
+                d.flushes += 1
+    d.keep.clear()
+
+
+def _end_of_backward_finishes():
+    _Defer.queued = False
+    flush_finishes(disarm=True)
+
+
+class _finish_scope:
+    """with _finish_scope(ws, gw, gb, ...): the finish launches of the calls inside may be deferred; the tensors named —
+    EVERY buffer those finishes read or write that autograd does not own — are held until the flush."""
+
+    def __init__(self, *tensors):
+        self.tensors = tensors
+        self.on = False
+
+    def __enter__(self):
+        d = _Defer
+        if d.armed and d.suppress == 0:
+            t0 = next((t for t in self.tensors if t is not None), None)
+            if t0 is not None and t0.is_cuda:
+                if not d.queued:
+                    try:   # only while the autograd engine runs a backward: otherwise the finishes stay immediate
+                        torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward_finishes)
+                        d.queued = True
+                    except RuntimeError:
+                        return self
+                if d.dev is not None and d.dev != t0.device:
+                    flush_finishes()
+                d.dev = t0.device
+                # (aliases, not the tensors themselves: autograd adopts a returned gradient as p.grad without a copy only while
+                # nothing else references the tensor object — holding the object would make it CLONE the not-yet-written buffer)
+                d.keep.extend(t.detach() for t in self.tensors if t is not None)
+                N.lib().fz_finish_defer(1)
+                self.on = True
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            N.lib().fz_finish_defer(0)
+        return False
+
+
+class _no_defer:
+    def __enter__(self):
+        _Defer.suppress += 1
+
+    def __exit__(self, *exc):
+        _Defer.suppress -= 1
+        return False
+
+
 def _native_ok(*ts):
     """Device tensors the GEMM family takes: activations (5-D, first) fp32 or — mixed precision — bf16, all of
     one type; parameters (<= 3-D) fp32; voxel count divisible by 4."""
@@ -450,6 +553,19 @@ def _native_ok(*ts):
         elif t.dtype != torch.float32:
             return False
     return True
+
+
+def _head_rows_reduce(part, rows, w2, M, like):
+    """The head backward's partial rows (132 floats: gW[m][c] at m*32 + c, gb[m] at 128 + m) -> (gw, gb): two column blocks of the
+    rows, each reduced straight into its gradient tensor (the weight's slice of a flat gradient buffer when one is attached)."""
+    lib = N.lib()
+    gw = _GB.out_like(w2, (M, 32), torch.float32)
+    gb = torch.empty(M, dtype=torch.float32, device=like.device)
+    st = N.stream_ptr(like)
+    with _finish_scope(part, gw, gb):
+        N.check(lib.fz_chunk_reduce_ld(part.data_ptr(), rows, M * 32, 132, gw.data_ptr(), 0, st), "fz_chunk_reduce_ld")
+        N.check(lib.fz_chunk_reduce_ld(part.data_ptr() + 128 * 4, rows, M, 132, gb.data_ptr(), 0, st), "fz_chunk_reduce_ld")
+    return gw, gb
 
 
 # ---- LayerNorm → Linear → [ReLU] -----------------------------------------------------------
@@ -525,17 +641,13 @@ class ActLinearResFn(torch.autograd.Function):
             lib = N.lib()
             rows = lib.fz_head_bwd_rows()
             part = torch.empty(lib.fz_head_bwd_workspace_bytes() // 4, dtype=torch.float32, device=z.device)
-            out = torch.empty(132, dtype=torch.float32, device=z.device)
             es = z.element_size()
             with torch.cuda.device(z.device):
                 rc = Fn._timed(f"head_bwd_{C}->{M}", es * (gy.numel() + 2 * z.numel()),
                                lambda: lib.fz_head_bwd(gy.data_ptr(), z.data_ptr(), w2.data_ptr(), gz.data_ptr(), part.data_ptr(),
                                                        B, M, C, V, N.act_dtype(z), N.stream_ptr(z)), cols=B * V)
                 N.check(rc, "fz_head_bwd")
-                N.check(lib.fz_chunk_reduce(part.data_ptr(), rows, 132, out.data_ptr(), 0, N.stream_ptr(z)), "fz_chunk_reduce")
-            gw = _GB.out_like(w2)
-            gw.copy_(out[:M * 32].view(M, 32))
-            gb = out[128:128 + M]
+                gw, gb = _head_rows_reduce(part, rows, w2, M, z)
             return gz, gw.reshape(ctx.wshape), (gb if ctx.has_bias else None), (gy if ctx.has_res else None), None
         _gemm([gy], w2, gz, B=B, Cin=M, Vin=V, M=C, K=M, Ncol=V, w_t=True, ldw=C,
               emul=(z if ctx.bact != "none" else None), emul_kind=ACT[ctx.bact], name="linear_dgrad")
@@ -732,7 +844,7 @@ class TConvK2S2Fn(torch.autograd.Function):
             Vf = 8 * V
             gb = torch.empty(O, dtype=torch.float32, device=x.device)
             part = torch.empty(B * N.lib().fz_rowsum_chunks(Vf) * O, dtype=torch.float32, device=x.device)
-            with torch.cuda.device(x.device):
+            with torch.cuda.device(x.device), _finish_scope(part, gb):
                 rc = N.lib().fz_rowsum(gy.data_ptr(), part.data_ptr(), gb.data_ptr(), B, O, Vf, N.act_dtype(gy),
                                        N.stream_ptr(x))
             N.check(rc, "fz_rowsum")
@@ -811,7 +923,7 @@ class ConvK3Fn(torch.autograd.Function):
             K = 27 * C
             part = torch.empty(nchunk * O * K, dtype=torch.float32, device=x.device)
             pbias = torch.empty(nchunk * O, dtype=torch.float32, device=x.device)
-            with torch.cuda.device(x.device):
+            with torch.cuda.device(x.device), _finish_scope(part, pbias, gw, gb):
                 st = N.stream_ptr(x)
                 prod = N.products()
 
@@ -979,7 +1091,8 @@ class UpCatLinearFn(torch.autograd.Function):
             g_skip = torch.empty_like(skip)
             _gemm([g], w2, g_skip, B=B, Cin=M, Vin=Vf, M=C1, K=M, Ncol=Vf, w_t=True, ldw=C1 + O, name="linear_dgrad")
             gwa = torch.empty((M, C1), dtype=torch.float32, device=dev)
-            _wgrad(g, [skip], gwa, B=B, M=M, Cin=C1, K=C1, Vq=Vf, Ncols=Vf, gbias=gb_ad, name="wgrad_linear")
+            with _no_defer():   # (the copy below reads the result inside this backward)
+                _wgrad(g, [skip], gwa, B=B, M=M, Cin=C1, K=C1, Vq=Vf, Ncols=Vf, gbias=gb_ad, name="wgrad_linear")
             gw_ad[:, :C1].copy_(gwa)
         w_b = w2[:, C1:]                                       # (M, O), row stride C1 + O
         wc = torch.empty((Cd, M, 2, 2, 2), dtype=torch.float32, device=dev)
@@ -997,7 +1110,7 @@ class UpCatLinearFn(torch.autograd.Function):
                W=2 * W, Ho=H, Wo=W, name="wgrad_tconv_k2s2")
         gw_t = _GB.out_like(w_t)       # (its slice of the flat gradient buffer when one is attached)
         gb_t = torch.empty(O, dtype=torch.float32, device=dev) if ctx.has_bt else None
-        with torch.cuda.device(dev):   # up = T(deep) + b_t: the constant part of up meets Σ_v g in dW_b
+        with torch.cuda.device(dev), _finish_scope(gt, gb_ad, gw_t, gw_ad, gb_t):   # up = T(deep) + b_t: the constant part of up meets Σ_v g in dW_b
             N.check(N.lib().fz_upcat_wgrads(gt.data_ptr(), w_t.data_ptr(), w_b.data_ptr(), C1 + O, gb_ad.data_ptr(), _p(b_t),
                                             gw_t.data_ptr(), gw_ad[:, C1:].data_ptr(), C1 + O, _p(gb_t), Cd, O, M,
                                             N.stream_ptr(g)), "fz_upcat_wgrads")
@@ -1169,7 +1282,7 @@ class FactorizerBlockFn(torch.autograd.Function):
                 return _wgrad(*args, **kw)
             side.wait_stream(cur)
             keep.extend(t for t in (args[0], *args[1], kw.get("stats")) if t is not None)
-            with torch.cuda.stream(side):
+            with torch.cuda.stream(side), _no_defer():   # (a queue of deferred finishes belongs to ONE stream)
                 return _wgrad(*args, **kw)
 
         # --- MLP ---
@@ -1303,17 +1416,13 @@ class HeadOfBlockFn(torch.autograd.Function):
         lib = N.lib()
         rows = lib.fz_head_bwd_rows()
         part = torch.empty(lib.fz_head_bwd_workspace_bytes() // 4, dtype=torch.float32, device=y.device)
-        out = torch.empty(132, dtype=torch.float32, device=y.device)
         es = y.element_size()
         with torch.cuda.device(y.device):
             rc = Fn._timed(f"head_bwd_{C}->{M}", es * (gl.numel() + 2 * y.numel()),
                            lambda: lib.fz_head_bwd(gl.data_ptr(), y.data_ptr(), w2.data_ptr(), gy.data_ptr(), part.data_ptr(),
                                                    B, M, C, V, N.act_dtype(y), N.stream_ptr(y)), cols=B * V)
             N.check(rc, "fz_head_bwd")
-            N.check(lib.fz_chunk_reduce(part.data_ptr(), rows, 132, out.data_ptr(), 0, N.stream_ptr(y)), "fz_chunk_reduce")
-        gw = _GB.out_like(w2)
-        gw.copy_(out[:M * 32].view(M, 32))
-        gb = out[128:128 + M]
+            gw, gb = _head_rows_reduce(part, rows, w2, M, y)
         return gy, gw.reshape(ctx.wshape), (gb if ctx.has_bias else None), None
 
 

@@ -41,7 +41,13 @@ class FlatAdamW:
     checkpoints interchange with the reference recipe's (train.yaml:354-358)."""
 
     def __init__(self, module_or_params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, flat_grad=None,
-                 grad_views=None):
+                 grad_views=None, deferred_finishes: bool = True):
+        # deferred_finishes: this optimizer owns the step (gradients are None from zero_grad() to the backward, nothing reads
+        # them before step()), so the tiny fixed-order reductions that end every weight-gradient launch may be queued during
+        # the backward and run as one grid at its end (pointwise._Defer; csrc/finish.h) — same sums, same order
+        if deferred_finishes:
+            from . import pointwise as _PW
+            _PW.defer_finishes(True)
         params = module_or_params.parameters() if isinstance(module_or_params, torch.nn.Module) else module_or_params
         self.all_params = list(params)               # torch's param_groups[0]["params"] order
         self.params = [p for p in self.all_params if p.requires_grad]
@@ -118,6 +124,7 @@ class FlatAdamW:
         for p in self.params:
             p.grad = None
         _GB.release(self.flat_grad)
+        _PW.arm_deferred_finishes()
 
     def _update(self, lo, hi, t, grad_scale):
         b1, b2 = self.betas
@@ -141,6 +148,7 @@ class FlatAdamW:
     def step(self, grad_scale: float = 1.0):
         from . import pointwise as _PW
         _PW.join_wgrad_streams()  # no-op unless late_wgrad_join is on (pointwise._LateJoin)
+        _PW.flush_finishes(disarm=True)   # (the end of the backward already did: nothing is queued unless backward() raised)
         src = [p for p in self.params if p.grad is not None and p.grad.data_ptr() != self.grad_views[p].data_ptr()]
         if src:
             torch._foreach_copy_([self.grad_views[p] for p in src], [p.grad for p in src])

@@ -60,6 +60,20 @@ int fz_abi_version(void);
  * profiles/r05_tile_order.md.  (Reading a tensor backwards right after the launch that WROTE it gains nothing measurable: the
  * whole-step A/B with every streaming kernel alternating was -0.13 ms of 17.4, all of it from the window pairs.) */
 int fz_set_tile_order(int descending);
+/* Deferred finishes.  Every weight-gradient entry point (fz_wgrad, fz_wgrad_group, fz_gemm_dw, fz_mlp_chain mode 2, fz_ln_bwd with
+ * affine gradients, fz_reduce_rows, fz_rowsum, fz_chunk_reduce, fz_upcat_wgrads) ends with a tiny launch that adds per-workgroup
+ * partial rows in a fixed order.  Those launches produce PARAMETER gradients — nothing in a backward pass reads them — but each
+ * one is a 5-10 us serial slot of the stream (54 per README training step: 0.33 ms).  fz_finish_defer(1) makes the calls that
+ * follow in this process QUEUE them instead (the descriptors only; nothing is copied), fz_finish_defer(0) stops queueing;
+ * fz_finish_flush(stream) runs everything queued as one or two grids and returns how many were queued (< 0: an error code).
+ * While finishes are queued the caller keeps alive, and does not touch, every buffer handed to those calls (workspaces,
+ * gradient outputs); a flush must go to the stream the deferred calls were given (FZ_E_ARG otherwise); a call that ACCUMULATES
+ * into its output drains the queue and runs at once.  The sums and their order are the same deferred or not: bit-identical.
+ * fz_finish_defer(-1) / fz_finish_pending() only query.  Reference counterpart: none — autograd launches one reduction kernel
+ * per gradient as it goes. */
+int fz_finish_defer(int on);
+int fz_finish_pending(void);
+int fz_finish_flush(fz_stream_t stream);
 /* Message for the last error returned on this thread ("" if none). */
 const char* fz_last_error_string(void);
 /* Number of kernel launches issued through this library by this process (test hook that
@@ -486,6 +500,9 @@ int fz_conv3_wgrad_chunks(int B, int D, int H, int W);
 int fz_conv3_wgrad_partials(const void* gy, const void* x /* activations */, float* part, float* part_bias, int B,
                             int Cin, int M, int D, int H, int W, int act_dtype, int products, fz_stream_t stream);
 int fz_chunk_reduce(const float* part, int nchunk, int64_t n, float* out, int accumulate, fz_stream_t stream);
+/* the same over rows `ld` floats apart (ld >= n): a column block of wider partial rows (the head's 132-float rows: weight block
+ * and bias block into their own gradient tensors) */
+int fz_chunk_reduce_ld(const float* part, int nchunk, int64_t n, int64_t ld, float* out, int accumulate, fz_stream_t stream);
 
 /* out[c] = sum over batch and voxels of x[b,c,v] (bias gradient of ConvTranspose3d, unet.py:123);
  * part: workspace of B * fz_rowsum_chunks(V) * C floats. */
