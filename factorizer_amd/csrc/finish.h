@@ -38,7 +38,7 @@ struct WgradFinishOne {
   float* gbias;
   const float* ln_g;
   const float* ln_b;
-  int nchunk, M, K, accumulate, nbw, wide;
+  int nchunk, M, K, accumulate, nbw, wide;   // wide: 0 = 8 elements per block, 1 = 256 (one thread each), 2 = 64 x 4 slices
 };
 // gemm_dw rows -> gw (ld ldgw), gb, (dγ | dβ)
 struct FinDw {
@@ -246,6 +246,52 @@ __device__ __forceinline__ void wgrad_finish_wide_body(const float* __restrict__
   out[e] = accumulate ? out[e] + t : t;
 }
 
+// The form between the two (65-256 partial blocks of a weight of >= 4 096 elements: the C = 64 and C = 128 stages): 64
+// consecutive elements per block (256-byte coalesced rows), the chunks in 4 interleaved slices, 4 loads in flight per thread,
+// the slices added in a fixed tree.  The 8-element form spends 8x the blocks on these problems and each block touches a quarter
+// of every 128-byte line it reads: two grids of 15-21 thousand blocks took 110 us of a deferred flush.
+__device__ __forceinline__ void wgrad_finish_mid_body(const float* __restrict__ part, const float* __restrict__ part_bias,
+                                                      int nchunk, int M, int K, float* __restrict__ gw,
+                                                      float* __restrict__ gbias, const float* __restrict__ ln_g,
+                                                      const float* __restrict__ ln_b, int accumulate, int nbw,
+                                                      float* red /* [4][64] */, const int bid) {
+  const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const bool bias_blk = bid >= nbw;
+  const int64_t n = bias_blk ? (int64_t)M : (int64_t)M * K;
+  const int64_t e = (int64_t)(bias_blk ? bid - nbw : bid) * 64 + el;
+  const float* src = bias_blk ? part_bias : part;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (e < n) {
+    const bool fold = !bias_blk && ln_g != nullptr;
+    const int m = fold ? (int)(e / K) : 0, k = fold ? (int)(e % K) : 0;
+    const float gk = fold ? ln_g[k] : 1.f, bk = fold ? ln_b[k] : 0.f;
+    int ch = sl;
+    for (; ch + 12 < nchunk; ch += 16) {
+      float a0 = src[(int64_t)ch * n + e], a1 = src[(int64_t)(ch + 4) * n + e];
+      float a2 = src[(int64_t)(ch + 8) * n + e], a3 = src[(int64_t)(ch + 12) * n + e];
+      if (fold) {
+        a0 = gk * a0 + bk * part_bias[(int64_t)ch * M + m];
+        a1 = gk * a1 + bk * part_bias[(int64_t)(ch + 4) * M + m];
+        a2 = gk * a2 + bk * part_bias[(int64_t)(ch + 8) * M + m];
+        a3 = gk * a3 + bk * part_bias[(int64_t)(ch + 12) * M + m];
+      }
+      s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+    }
+    for (; ch < nchunk; ch += 4) {
+      float a0 = src[(int64_t)ch * n + e];
+      if (fold) a0 = gk * a0 + bk * part_bias[(int64_t)ch * M + m];
+      s0 += a0;
+    }
+  }
+  red[sl * 64 + el] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (sl == 0 && e < n) {
+    const float t = (red[el] + red[64 + el]) + (red[128 + el] + red[192 + el]);
+    float* out = bias_blk ? gbias : gw;
+    out[e] = accumulate ? out[e] + t : t;
+  }
+}
+
 // gw[m][k] = (ln ? γ[k]·S[m][k] + β[k]·sg[m] : S[m][k]),  gb[m] = sg[m] (when wanted); rows added in slice order.
 // kDwRow = 70 x 16: 256 threads = 16 elements x 16 row slices.
 __device__ __forceinline__ void fin_dw_body(const FinDw& a, int vb, float (*s)[17], float* sm) {
@@ -346,33 +392,46 @@ __device__ __forceinline__ void fin_chain_wg_body(const FinChainWg& a, int vb, f
   else if (a.gln != nullptr) a.gln[e - 4096 - 96] = v;          // dγ (32) | dβ (32)
 }
 
-// gw_t[k][c][t] = Σ_m w_b[m][c]·gt[k][m][t]  (blocks 0 .. Cd-1);  gw_b[m][c] = Σ_{k,t} gt[k][m][t]·w_t[k][c][t] + gb_ad[m]·b_t[c]
-// (blocks Cd .. Cd+M-1, written with row stride ldg into the adapter's weight gradient);  gb_t[c] = Σ_m gb_ad[m]·w_b[m][c] (last block)
-__device__ __forceinline__ void fin_upcat_body(const FinUpcat& a, int blk) {
+// With ncb = ceil(O/32) column blocks:  gw_t[k][c][t] = Σ_m w_b[m][c]·gt[k][m][t]  (blocks (k, cb): 32 columns x 8 taps, one
+// output per thread);  gw_b[m][c] = Σ_{k,t} gt[k][m][t]·w_t[k][c][t] + gb_ad[m]·b_t[c]  (blocks (m, cb): the k range in 8 interleaved
+// slices whose sums meet in a fixed tree; written with row stride ldg into the adapter's weight gradient);
+// gb_t[c] = Σ_m gb_ad[m]·w_b[m][c] (last block).  (One block per k resp. per m, as rounds 3-4 had it, left a thread with up to
+// 2 048 resp. 4 096 dependent products at the 512 -> 256 level: 30-60 us for a few kiloflops.)
+__host__ __device__ inline int fin_upcat_blocks(int Cd, int O, int M) { return (Cd + M) * ((O + 31) / 32) + 1; }
+__device__ __forceinline__ void fin_upcat_body(const FinUpcat& a, int blk, float (*red)[33]) {
   const int Cd = a.Cd, O = a.O, M = a.M, ldb = a.ldb;
+  const int ncb = (O + 31) / 32;
   const float* __restrict__ gt = a.gt;
   const float* __restrict__ w_t = a.w_t;
   const float* __restrict__ w_b = a.w_b;
-  if (blk < Cd) {
-    const float* gk = gt + (int64_t)blk * M * 8;
-    for (int i = threadIdx.x; i < O * 8; i += 256) {
-      const int c = i >> 3, t = i & 7;
+  if (blk < Cd * ncb) {
+    const int k = blk / ncb, cb = blk % ncb;
+    const float* gk = gt + (int64_t)k * M * 8;
+    const int c = cb * 32 + (threadIdx.x >> 3), t = threadIdx.x & 7;
+    if (c < O) {
       float acc = 0.f;
       for (int m = 0; m < M; ++m) acc += w_b[(int64_t)m * ldb + c] * gk[m * 8 + t];
-      a.gw_t[((int64_t)blk * O + c) * 8 + t] = acc;
+      a.gw_t[((int64_t)k * O + c) * 8 + t] = acc;
     }
-  } else if (blk < Cd + M) {
-    const int m = blk - Cd;
-    for (int c = threadIdx.x; c < O; c += 256) {
-      float acc = 0.f;
-      for (int k = 0; k < Cd; ++k) {
+  } else if (blk < (Cd + M) * ncb) {
+    const int m = (blk - Cd * ncb) / ncb, cb = (blk - Cd * ncb) % ncb;
+    const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = cb * 32 + el;
+    float acc = 0.f;
+    if (c < O) {
+      for (int k = sl; k < Cd; k += 8) {
         const float* g8 = gt + ((int64_t)k * M + m) * 8;
         const float* w8 = w_t + ((int64_t)k * O + c) * 8;
 #pragma unroll
         for (int t = 0; t < 8; ++t) acc += g8[t] * w8[t];
       }
-      if (a.b_t != nullptr) acc += a.gb_ad[m] * a.b_t[c];
-      a.gw_b[(int64_t)m * a.ldg + c] = acc;
+    }
+    red[sl][el] = acc;
+    __syncthreads();
+    if (sl == 0 && c < O) {
+      float v = ((red[0][el] + red[1][el]) + (red[2][el] + red[3][el])) + ((red[4][el] + red[5][el]) + (red[6][el] + red[7][el]));
+      if (a.b_t != nullptr) v += a.gb_ad[m] * a.b_t[c];
+      a.gw_b[(int64_t)m * a.ldg + c] = v;
     }
   } else if (a.gb_t != nullptr) {
     for (int c = threadIdx.x; c < O; c += 256) {

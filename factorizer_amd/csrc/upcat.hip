@@ -291,7 +291,7 @@ extern "C" int fz_upcat_wgrads(const float* gt, const float* w_t, const float* w
                                float* gw_t, float* gw_b, int ldg, float* gb_t, int Cd, int O, int M, fz_stream_t stream) {
   if (!gt || !w_t || !w_b || !gb_ad || !gw_t || !gw_b || Cd < 1 || O < 1 || M < 1 || ldb < O || ldg < O)
     return fail(FZ_E_ARG, "fz_upcat_wgrads: bad arguments");
-  FinishJob fj = finish_job(FK_UPCAT, Cd + M + 1, 1);
+  FinishJob fj = finish_job(FK_UPCAT, fin_upcat_blocks(Cd, O, M), 1);
   fj.u.up = FinUpcat{gt, w_t, w_b, gb_ad, b_t, gw_t, gw_b, gb_t, ldb, ldg, Cd, O, M};
   return finish_run(&fj, 1, (hipStream_t)stream);
 }

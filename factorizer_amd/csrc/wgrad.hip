@@ -578,13 +578,14 @@ static int wgrad_main_launch(const fz_wgrad_desc* d, const WgradPlan<AT>& pl, hi
 template <typename AT>
 static FinishJob wgrad_finish_job(const fz_wgrad_desc* d, const WgradPlan<AT>& pl) {
   const int64_t MK = (int64_t)d->M * d->K;
-  const bool wide = pl.nchunk <= 64 && MK >= 16384;   // few partial blocks of a large weight: one thread per element
-  const int per = wide ? 256 : 8;
+  // few partial blocks of a large weight: one thread per element; up to 256 of a mid-sized one: 64 elements x 4 chunk slices
+  const int wide = (pl.nchunk <= 64 && MK >= 16384) ? 1 : ((pl.nchunk <= 256 && MK >= 4096) ? 2 : 0);
+  const int per = wide == 1 ? 256 : (wide == 2 ? 64 : 8);
   const int nbw = (int)((MK + per - 1) / per);
   const int nbb = d->gbias != nullptr ? (d->M + per - 1) / per : 0;
   FinishJob j = finish_job(FK_WGRAD, nbw + nbb);
   j.u.wg = WgradFinishOne{pl.a.part, pl.a.part_bias, d->gw, d->gbias, d->ln_g != nullptr ? d->ln_g : (const float*)nullptr, d->ln_b,
-                          pl.nchunk, d->M, d->K, d->accumulate, nbw, wide ? 1 : 0};
+                          pl.nchunk, d->M, d->K, d->accumulate, nbw, wide};
   return j;
 }
 template <typename AT>
