@@ -1002,20 +1002,28 @@ __device__ __forceinline__ void bx_group_ps(f32x16 (&acc)[NRB][NQ], FA load_term
 // added (6 / 23 spilled), so the split-bf16 chain runs as ONE workgroup of 512 threads per CU — two independent 4-wave
 // halves, each walking its own tiles — sharing a PRE-SPLIT weight image (bf16x8 triples in operand order: 2 x 48 KB):
 // same two waves per SIMD, no weight splits on the VALU, 3 ds_read_b128 per row operand instead of 8 ds_read_b32.
-template <bool BWD, typename AT, bool SINGLE = false, bool BX = false, bool P512 = false>
+// PRE (forward, P512) [r5]: the block's out-projection in front of the chain, as gemm_chain_kernel<.., PRE> does at C = 32 —
+// the tile loaded is a, GEMM 0 forms x1 = W_o·a + b_o + x on 64 accumulator registers (rounded to the stored value under bf16
+// storage), x1 goes to preOut, is normalised in place and feeds GEMM 1 as the column operand in the ACCUMULATOR layout (the W1
+// image is staged in that k order: the order the W2 image always had); the residual of the epilogue re-reads the lane's own x1.
+// A third pre-split image (W_o: 24 KB) joins the two: 121 KB of LDS.
+template <bool BWD, typename AT, bool SINGLE = false, bool BX = false, bool P512 = false, bool PRE = false>
 __global__ __launch_bounds__(P512 ? 512 : 256, 2) void gemm_chain64_kernel(GemmArgsT<AT> p, ChainArgsT<AT> c, int ntiles) {
   constexpr int NACC = 2, C = 64, HID = 128;
   constexpr int NTA = BxTerms<AT>::A, NTB = bx_terms_b<AT>(BXPRO_GELU);
   constexpr bool HOIST = SINGLE || sizeof(AT) == 2;
   static_assert(!P512 || (BX && !SINGLE), "P512: the split-bf16 chain around a pre-split weight image");
+  static_assert(!PRE || (P512 && !BWD), "PRE: the forward chain around the pre-split images");
   constexpr int NA = P512 ? 12288 : 8192;   // floats of one weight image (P512: [16 (group, row block)][3 terms][64 lanes] x 16 B)
+  constexpr int NA0 = PRE ? 6144 : 0;       // the W_o image: [8 (group, row block)][3 terms][64 lanes] x 16 B
   extern __shared__ __attribute__((aligned(16))) float fz_lds_c64[];
   float* As1 = fz_lds_c64;            // [32 steps][4 row blocks][64]
   float* As2 = As1 + NA;              // [4 x 16 (rb, r) steps][2 row blocks][64]
-  float* tW = As2 + NA;               // [128]
+  float* tW = As2 + NA + NA0;         // [128]
   float* tB = tW + 128;               // [64]
+  float* tB0 = tB + 64;               // [64] (PRE: the out-projection's bias)
   const int half = P512 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;   // P512: which 4-wave half of the workgroup (wave-uniform)
-  float* red = tB + 64 + half * 512;  // [4][128] per half
+  float* red = tB + 64 + (PRE ? 64 : 0) + half * 512;  // [4][128] per half
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6) & 3);
   const int j = lane & 31, h = lane >> 5;
   const int tiles_per_sample = (int)((p.Ncol + 128 * NACC - 1) / (128 * NACC));
@@ -1024,27 +1032,36 @@ __global__ __launch_bounds__(P512 ? 512 : 256, 2) void gemm_chain64_kernel(GemmA
   // P512 operand reads: one OPAQUE per-lane float index per image + compile-time slot offsets (ds_read_b128 immediates are
   // 16 bits: the second image starts at 48 KB, and left to itself the optimiser keeps one loop-invariant VGPR address for
   // every slot beyond 64 KB — 32 of them — and spills)
-  int lane4 = lane * 4, lane4b = lane * 4 + NA;
+  int lane4 = lane * 4, lane4b = lane * 4 + NA, lane4c = lane * 4 + 2 * NA;
   if constexpr (P512) {
     asm volatile("" : "+v"(lane4));
     asm volatile("" : "+v"(lane4b));
+    if constexpr (PRE) asm volatile("" : "+v"(lane4c));
   }
   auto ld_a1 = [&](int slot3) { return *reinterpret_cast<const bx8*>(As1 + slot3 * 256 + lane4); };
   auto ld_a2 = [&](int slot3) { return *reinterpret_cast<const bx8*>(As1 + slot3 * 256 + lane4b); };
+  auto ld_a0 = [&](int slot3) { return *reinterpret_cast<const bx8*>(As1 + slot3 * 256 + lane4c); };
+  (void)ld_a0; (void)lane4c; (void)tB0;
 
   if constexpr (P512) {
     // item = (image, slot [16], lane): eight weights -> three bf16 levels -> three 16-byte stores
-    for (int item = threadIdx.x; item < 2048; item += 512) {
+    for (int item = threadIdx.x; item < (PRE ? 2560 : 2048); item += 512) {
       const int l = item & 63, slot = (item >> 6) & 15, img = item >> 10;
       float a8[8];
       if (img == 0) {        // slot = g*4 + rb: A1[m = rb*32 + (l & 31)][k = 2 (8g + e) + (l >> 5)]
         const int g = slot >> 2, rb = slot & 3;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const int k = 2 * (8 * g + e) + (l >> 5);
+          // PRE: the column operand of GEMM 1 is the accumulator tile of GEMM 0 — k = row (mb = g >> 1, r = 8 (g & 1) + e, lane half)
+          const int rr = 8 * (g & 1) + e;
+          const int k = PRE ? (g >> 1) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * (l >> 5) : 2 * (8 * g + e) + (l >> 5);
           a8[e] = weight_at(p, rb * 32 + (l & 31), k);
           if (!BWD) a8[e] *= p.ln_g[k];
         }
+      } else if (PRE && img == 2) {   // slot = g*2 + mb: A0[m = mb*32 + (l & 31)][k = 2 (8g + e) + (l >> 5)] = W_o[m][k]
+        const int g = slot >> 1, mb = slot & 1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a8[e] = c.preW[(int64_t)(mb * 32 + (l & 31)) * 64 + 2 * (8 * g + e) + (l >> 5)];
       } else {               // slot = (rb4*2 + g8)*2 + mb: A2[m = mb*32 + (l & 31)][k = rb4*32 + row(r = 8 g8 + e) + 4 (l >> 5)]
         const int mb = slot & 1, g8 = (slot >> 1) & 1, rb4 = slot >> 2;
 #pragma unroll
@@ -1056,7 +1073,7 @@ __global__ __launch_bounds__(P512 ? 512 : 256, 2) void gemm_chain64_kernel(GemmA
       }
       bx8 t3[3];
       bx_split<3>(a8, t3);
-      bx8* dst = reinterpret_cast<bx8*>(img == 0 ? As1 : As2) + (slot * 3) * 64 + l;
+      bx8* dst = reinterpret_cast<bx8*>(img == 0 ? As1 : (img == 1 ? As2 : As2 + NA)) + (slot * 3) * 64 + l;
       dst[0] = t3[0]; dst[64] = t3[1]; dst[128] = t3[2];
     }
   }
@@ -1094,6 +1111,7 @@ __global__ __launch_bounds__(P512 ? 512 : 256, 2) void gemm_chain64_kernel(GemmA
       for (int k = 0; k < C; ++k) t += weight_at(p, r, k) * p.ln_b[k];
       tW[r] = t + (p.bias ? p.bias[r] : 0.f);
       if (r < C) tB[r] = c.biasB ? c.biasB[r] : 0.f;
+      if (PRE && r < C) tB0[r] = c.preB ? c.preB[r] : 0.f;
     }
   }
 
@@ -1106,7 +1124,7 @@ __global__ __launch_bounds__(P512 ? 512 : 256, 2) void gemm_chain64_kernel(GemmA
     const int bt = t / tiles_per_sample;
     const int64_t ct = ((int64_t)(t % tiles_per_sample) * 4 + wave) * (32 * NACC) + NACC * j;
     const unsigned lo = (unsigned)h * (unsigned)p.Ncol + (unsigned)(ct < p.Ncol ? ct : 0);
-    const AT* xb = p.x[0] + (int64_t)bt * C * p.Ncol;
+    const AT* xb = (PRE ? c.preA : p.x[0]) + (int64_t)bt * C * p.Ncol;
 #pragma unroll
     for (int s = 0; s < 32; ++s) vload<NACC>(xb + (int64_t)(2 * s) * p.Ncol + lo, bv[s]);
   };
@@ -1121,7 +1139,80 @@ __global__ __launch_bounds__(P512 ? 512 : 256, 2) void gemm_chain64_kernel(GemmA
     const int64_t nc = col_ok ? col_off : 0;
     const unsigned lane_row = (unsigned)(4 * h) * (unsigned)p.Ncol + (unsigned)nc;
 
-    if (!BWD) {
+    f32x16 acc0[PRE ? 2 : 1][NACC];   // PRE: x1, then LN(x1), rows (mb, r, lane half) x the lane's two voxels
+    if constexpr (PRE) {
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int q = 0; q < NACC; ++q)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc0[mb][q][r] = 0.f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bx_group_ps<2, NACC, NTB>(acc0,
+            [&](int mb, int t) { return ld_a0((g * 2 + mb) * 3 + t); },
+            [&](int q, float (&x8)[8]) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) x8[e] = bv[8 * g + e][q];
+            });
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const int64_t smp = (int64_t)b * C * p.Ncol;
+      float s1[NACC] = {0.f, 0.f};
+#pragma unroll
+      for (int g8 = 0; g8 < 4; ++g8) {
+        float e[8][NACC];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int rr = g8 * 8 + i, mb = rr >> 4, r = rr & 15;
+          vload<NACC>(c.preRes + smp + (int64_t)(mb * 32 + (r & 3) + 8 * (r >> 2)) * p.Ncol + lane_row, e[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int rr = g8 * 8 + i, mb = rr >> 4, r = rr & 15;
+          const int rbase = mb * 32 + (r & 3) + 8 * (r >> 2);
+          const float add = tB0[rbase + 4 * h];
+          float v[NACC];
+#pragma unroll
+          for (int q = 0; q < NACC; ++q) v[q] = acc0[mb][q][r] + add + e[i][q];
+          if (col_ok) vstore<NACC>(c.preOut + smp + (int64_t)rbase * p.Ncol + lane_row, v);
+#pragma unroll
+          for (int q = 0; q < NACC; ++q) {
+            if constexpr (sizeof(AT) == 2) v[q] = (float)(AT)v[q];   // the MLP sees the STORED x1, as the two-launch form does
+            acc0[mb][q][r] = v[q];
+            s1[q] += v[q];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      float mu[NACC], rs[NACC];
+#pragma unroll
+      for (int q = 0; q < NACC; ++q) {
+        s1[q] += __shfl_xor(s1[q], 32, 64);
+        mu[q] = s1[q] / 64.0f;
+        float t = 0.f;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float dd = acc0[mb][q][r] - mu[q];
+            t += dd * dd;
+          }
+        t += __shfl_xor(t, 32, 64);
+        rs[q] = 1.0f / sqrtf(t / 64.0f + p.ln_eps);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc0[mb][q][r] = (acc0[mb][q][r] - mu[q]) * rs[q];
+      }
+      if (p.stats_out != nullptr && h == 0 && col_ok) {
+        float* so = p.stats_out + (int64_t)b * 2 * p.Vin;
+        vstore<NACC>(so + col_off, mu);
+        vstore<NACC>(so + p.Vin + col_off, rs);
+      }
+    }
+
+    if (!BWD && !PRE) {
       float mu[NACC], rs[NACC];
 #pragma unroll
       for (int e = 0; e < NACC; ++e) {
@@ -1208,7 +1299,7 @@ __global__ __launch_bounds__(P512 ? 512 : 256, 2) void gemm_chain64_kernel(GemmA
                 [&](int rbl, int t) { return ld_a1((g * 4 + 2 * p2 + rbl) * 3 + t); },
                 [&](int q, float (&x8)[8]) {
 #pragma unroll
-                  for (int e = 0; e < 8; ++e) x8[e] = bv[8 * g + e][q];
+                  for (int e = 0; e < 8; ++e) x8[e] = PRE ? acc0[PRE ? (g >> 1) : 0][q][8 * (g & 1) + e] : bv[8 * g + e][q];
                 });
           else
           bx_group<HOIST, 2, NACC, NTA, NTB>(acc1,
@@ -2926,7 +3017,11 @@ extern "C" int64_t fz_mlp_wgrad_workspace_bytes(int B, int64_t V) {
 }
 
 extern "C" int fz_mlp_pre_supported(int C, int H, int64_t V, int products) {
-  return (C == 32 && H == 64 && V > 0 && (V % 4) == 0 && V <= ((int64_t)1 << 27) && products_split(products) && knob_chain_fwd_bx()) ? 1 : 0;
+  if (!(V > 0 && (V % 4) == 0 && V <= ((int64_t)1 << 27) && products_split(products))) return 0;
+  if (C == 32 && H == 64) return knob_chain_fwd_bx() ? 1 : 0;
+  // C = 64: the 512-thread form around the pre-split images, which walks the tiles in pairs (an even number per sample)
+  if (C == 64 && H == 128) return (((V + 255) / 256) % 2 == 0 && knob_chain64_p512()) ? 1 : 0;
+  return 0;
 }
 
 extern "C" int fz_mlp_supported(int C, int H, int64_t V) {
@@ -2940,12 +3035,12 @@ static int mlp_launch(const fz_mlp_desc* d, fz_stream_t stream) {
   if (d->C == 64 && d->mode == 2) return fail(FZ_E_UNSUPPORTED, "fz_mlp_chain: the fused weight gradients need C == 32, H == 64");
   if (d->B < 0) return fail(FZ_E_SHAPE, "fz_mlp_chain: negative batch");
   const bool pre = d->pre_in != nullptr;   // the block's out-projection in front of the forward chain (x1 is then an OUTPUT)
-  if (pre && (d->mode != 0 || d->C != 32 || d->H != 64 || !d->pre_w || !d->pre_res || !d->pre_out))
-    return fail(FZ_E_ARG, "fz_mlp_chain: pre_in needs mode 0, C == 32, H == 64, pre_w, pre_res, pre_out (see fz_mlp_pre_supported)");
+  if (pre && (d->mode != 0 || !d->pre_w || !d->pre_res || !d->pre_out))
+    return fail(FZ_E_ARG, "fz_mlp_chain: pre_in needs mode 0, pre_w, pre_res, pre_out (see fz_mlp_pre_supported)");
   if (pre && !fz_mlp_pre_supported(d->C, d->H, d->V, d->products))
     return fail(FZ_E_UNSUPPORTED, "fz_mlp_chain: the fused out-projection runs on split-bf16 products only (fz_mlp_pre_supported)");
-  if (d->post_out && (!pre || !d->post_w || d->post_m < 1 || d->post_m > 4))
-    return fail(FZ_E_ARG, "fz_mlp_chain: post_out needs pre_in, post_w and 1 <= post_m <= 4");
+  if (d->post_out && (!pre || d->C != 32 || !d->post_w || d->post_m < 1 || d->post_m > 4))
+    return fail(FZ_E_ARG, "fz_mlp_chain: post_out needs pre_in, C == 32, post_w and 1 <= post_m <= 4");
   if ((!d->in && !pre) || !d->w1 || !d->w2 || !d->out || !d->z1 || !d->stats)
     return fail(FZ_E_ARG, "fz_mlp_chain: null pointer");
   if (d->mode == 0 && (!d->ln_g || !d->ln_b)) return fail(FZ_E_ARG, "fz_mlp_chain: forward needs the LayerNorm affine");
@@ -2986,6 +3081,17 @@ static int mlp_launch(const fz_mlp_desc* d, fz_stream_t stream) {
       a.res = (const AT*)d->in; a.y = (AT*)d->out;
       c.wB = d->w2; c.wB_t = 0; c.ldwB = 128; c.biasB = d->b2; c.side = (AT*)d->z1;
       // split-bf16 products only where the kernel stays inside 256 registers without scratch (fp32 storage: 6 / 23 spilled)
+      if (pre) {   // (fz_mlp_pre_supported: split-bf16 products, an even tile count)
+        if (!p512) return fail(FZ_E_UNSUPPORTED, "fz_mlp_chain: the fused out-projection at C == 64 needs an even number of tiles");
+        c.preA = (const AT*)d->pre_in; c.preW = d->pre_w; c.preB = d->pre_b; c.preRes = (const AT*)d->pre_res; c.preOut = (AT*)d->pre_out;
+        a.res = (const AT*)d->pre_out;   // the epilogue's residual: the lane's own x1, written a moment earlier
+        constexpr int lds_pre = lds512 + (6144 + 64) * (int)sizeof(float);
+        auto kern = gemm_chain64_kernel<false, AT, false, true, true, true>;
+        FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_pre));
+        hipLaunchKernelGGL(kern, grid512, dim3(512), lds_pre, st, a, c, ntiles);
+        FZ_LAUNCH_CHECK();
+        return FZ_OK;
+      }
       if (p512) {
         auto kern = gemm_chain64_kernel<false, AT, false, true, true>;
         FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds512));

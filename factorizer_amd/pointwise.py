@@ -1385,7 +1385,7 @@ def head_fusion_slot():
 
 def block_head_fusable(C, Hd, V, head_w, x):
     """may FactorizerBlockFn apply the head Linear(C -> M <= 4) inside its last launch? (csrc/gemm.hip: fz_mlp_chain post_*)"""
-    return (_outproj_mlp_ok(C, Hd, V) and head_w is not None and head_w.dtype == torch.float32 and head_w.numel() == head_w.shape[0] * C
+    return (C == 32 and _outproj_mlp_ok(C, Hd, V) and head_w is not None and head_w.dtype == torch.float32 and head_w.numel() == head_w.shape[0] * C
             and 1 <= head_w.shape[0] <= 4 and x.is_cuda and _HEAD_BWD)
 
 

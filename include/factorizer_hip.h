@@ -326,16 +326,18 @@ typedef struct fz_mlp_desc {
   float* gln;         /* mode 2: (2*C) dgamma | dbeta of the LayerNorm (part is not used)    */
   float* glp;         /* mode 2, H = 128: (B, C, V) fp32 scratch (the first half's part of W1^T gz1) */
   int products;       /* FZ_PRODUCTS_* */
-  /* [r5] mode 0, C = 32, H = 64, split-bf16 products (fz_mlp_pre_supported): the block's out-projection in front of the chain,
+  /* [r5] mode 0, (C, H) = (32, 64) or (64, 128: an even number of 256-voxel tiles per sample), split-bf16 products
+   * (fz_mlp_pre_supported answers for a shape): the block's out-projection in front of the chain,
    * x1 = pre_w . pre_in + pre_b + pre_res (factorizer.py:53,75) formed on the accumulators, written to pre_out and
-   * normalised in registers — `in` is ignored, x1 is never read back (6 instead of 7 tensor passes for steps 3 + 4 of the
-   * block).  pre_in == NULL: the plain chain on `in`. */
+   * normalised in registers — `in` is ignored, x1 is never read back by another launch (6 instead of 7 tensor passes for
+   * steps 3 + 4 of the block at C = 32; at C = 64 the epilogue re-reads the lane's own x1 from L2).  pre_in == NULL: the
+   * plain chain on `in`. */
   const void* pre_in;   /* activation (B, C, V): the core's output a, or NULL                 */
   const float* pre_w;   /* (C, C) out_proj weight                                              */
   const float* pre_b;   /* (C) or NULL                                                         */
   const void* pre_res;  /* activation (B, C, V): the block input x                             */
   void* pre_out;        /* activation (B, C, V): x1                                            */
-  /* [r5] with pre_in: the network's head Linear(C -> post_m <= 4, k1) (unet.py:253,274) applied to `out` while it is in
+  /* [r5] with pre_in and C = 32: the network's head Linear(C -> post_m <= 4, k1) (unet.py:253,274) applied to `out` while it is in
    * registers — the launch that would read the block output back (fz_head_fwd) disappears.  post_out == NULL: no head. */
   const float* post_w;  /* (post_m, C)                                                         */
   const float* post_b;  /* (post_m) or NULL                                                    */

@@ -351,15 +351,20 @@ def test_mlp_chain_kernel(B, S, C, Hd):
 
 
 @pytest.mark.parametrize("bf", [False, True])
-@pytest.mark.parametrize("B,S", [(2, (8, 8, 8)), (1, (6, 4, 5)), (2, (16, 16, 12)), (3, (32, 32, 40))])
-def test_outproj_and_mlp_chain_in_one_launch(B, S, bf):
+@pytest.mark.parametrize("C,Hd", [(32, 64), (64, 128)])
+@pytest.mark.parametrize("B,S", [(2, (8, 8, 8)), (1, (6, 4, 5)), (1, (8, 8, 6)), (2, (16, 16, 12)), (3, (32, 32, 40))])
+def test_outproj_and_mlp_chain_in_one_launch(B, S, bf, C, Hd):
     """Steps 3 + 4 of FactorizerBlock.forward — x1 = x + out_proj(a) (factorizer.py:53,75) and x2 = x1 + mlp(LN(x1))
     (factorizer.py:76; mlp.py:54-63; norm.py:29-34) — as ONE launch (fz_mlp_chain with pre_in: the out-projection on the
     accumulators in front of the chained GEMMs, x1 written once and never read back) against the float64 composition on
     the CPU and against the two-launch form it replaces.  V = 120 covers a ragged tile, (3, 32·32·40) several tiles per
-    workgroup.  bf16 storage: everything downstream of x1 must see the STORED (rounded) x1, as the two-launch form does."""
+    workgroup.  bf16 storage: everything downstream of x1 must see the STORED (rounded) x1, as the two-launch form does.
+    [r5] also at C = 64, hidden 128 (stage 1 of the README model: the 512-thread chain around three pre-split weight images),
+    which takes an even number of 256-voxel tiles per sample — V = 384: a ragged second tile; V = 120 is refused."""
     torch.manual_seed(17)
-    C, Hd = 32, 64
+    if C == 64 and ((S[0] * S[1] * S[2] + 255) // 256) % 2:
+        assert not PW._outproj_mlp_ok(C, Hd, S[0] * S[1] * S[2])
+        return
     rnd = (lambda t: t.bfloat16().float()) if bf else (lambda t: t)
     a = rnd(torch.relu(torch.randn(B, C, *S)) * 1.5)
     x = rnd(torch.randn(B, C, *S) * 2 + 0.5)
