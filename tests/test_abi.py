@@ -29,6 +29,13 @@ def test_header_symbols_exported(built_lib):
         assert hasattr(lib, n), f"{n} declared in include/factorizer_hip.h but not exported"
 
 
+def test_integration_md_names_every_entry_point():
+    """INTEGRATION.md maps each entry point to the reference call site it replaces: none may be missing from it."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [n for n in header_functions() if n not in text]
+    assert not missing, missing
+
+
 def test_python_binding_matches_header(built_lib):
     from factorizer_amd import _native
     assert set(_native.declared_symbols()) <= set(header_functions())
