@@ -71,6 +71,35 @@ def test_host_side_argument_checks(built_lib):
     assert rc == -4 and b"act_dtype" in lib.fz_last_error_string()
 
 
+def test_fused_chain_and_finish_queue_argument_checks(built_lib):
+    """Round-5 entry points: which shapes take the out-projection in front of the MLP chain, what the descriptor must carry, and
+    the finish queue's host-side state — all decided before anything touches the device."""
+    from factorizer_amd import _native
+    lib = _native.lib()
+    S = _native.PRODUCTS_SPLIT_BF16
+    assert lib.fz_mlp_pre_supported(32, 64, 128 ** 3, S) == 1 and lib.fz_mlp_pre_supported(32, 64, 120, S) == 1
+    assert lib.fz_mlp_pre_supported(64, 128, 64 ** 3, S) == 1          # 1024 tiles of 256 voxels per sample: even
+    assert lib.fz_mlp_pre_supported(64, 128, 120, S) == 0              # one tile: the 512-thread form walks tiles in pairs
+    assert lib.fz_mlp_pre_supported(64, 128, 64 ** 3, _native.PRODUCTS_FP32_MFMA) == 0
+    assert lib.fz_mlp_pre_supported(32, 128, 128 ** 3, S) == 0 and lib.fz_mlp_pre_supported(128, 256, 32 ** 3, S) == 0
+    p8 = 8   # (a non-null pointer value the host code never dereferences)
+    d = _native.MlpDesc()
+    d.mode, d.B, d.C, d.H, d.V, d.act_dtype, d.products = 0, 1, 64, 128, 64 ** 3, _native.STORE_F32, S
+    d.w1 = d.w2 = d.out = d.z1 = d.stats = d.ln_g = d.ln_b = p8
+    d.pre_in = p8                                                          # ... without pre_w / pre_res / pre_out
+    assert lib.fz_mlp_chain(ctypes.byref(d), None) == -4 and b"pre_in" in lib.fz_last_error_string()
+    d.pre_w = d.pre_res = d.pre_out = p8
+    d.post_out, d.post_w, d.post_m = p8, p8, 3                             # the head rides only in the C = 32 chain
+    assert lib.fz_mlp_chain(ctypes.byref(d), None) == -4 and b"post_out" in lib.fz_last_error_string()
+    d.post_out = None
+    d.V = 120
+    assert lib.fz_mlp_chain(ctypes.byref(d), None) == -2                   # FZ_E_UNSUPPORTED (fz_mlp_pre_supported says no)
+    # finish queue: state only
+    assert lib.fz_finish_defer(-1) == 0 and lib.fz_finish_pending() == 0 and lib.fz_finish_flush(None) == 0
+    assert lib.fz_finish_defer(1) == 0 and lib.fz_finish_defer(-1) == 1 and lib.fz_finish_defer(0) == 1
+    assert lib.fz_chunk_reduce_ld(ctypes.c_void_p(8), 4, 96, 64, ctypes.c_void_p(8), 0, None) == -4   # ld < n
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from factorizer_amd import _native
     monkeypatch.setattr(_native, "_lib", None)
