@@ -38,7 +38,7 @@ struct WgradFinishOne {
   float* gbias;
   const float* ln_g;
   const float* ln_b;
-  int nchunk, M, K, accumulate, nbw, wide;   // wide: 0 = 8 elements per block, 1 = 256 (one thread each), 2 = 64 x 4 slices
+  int nchunk, M, K, accumulate, nbw, wide;   // wide: 0 = 8 elements per block, 1 = 256 (one thread each), 2 = 64 x 4 slices, 3 = 1 024 (four per thread)
 };
 // gemm_dw rows -> gw (ld ldgw), gb, (dγ | dβ)
 struct FinDw {
@@ -244,6 +244,53 @@ __device__ __forceinline__ void wgrad_finish_wide_body(const float* __restrict__
   const float t = (s0 + s1) + (s2 + s3);
   float* out = bias_blk ? gbias : gw;
   out[e] = accumulate ? out[e] + t : t;
+}
+
+// The one-thread-per-element form with FOUR consecutive elements per thread (16-byte loads, 1 024 elements per block): the same
+// sums in the same order as wgrad_finish_wide_body, a quarter of the blocks — the deep stages' weights (0.4-1.5 M elements, 4-8
+// partial blocks) made two grids of 10-17 thousand near-empty blocks out of a deferred flush.  Needs M·K % 4 == 0, M % 4 == 0,
+// K % 4 == 0 (the four elements then share their row m).
+__device__ __forceinline__ void wgrad_finish_wide4_body(const float* __restrict__ part, const float* __restrict__ part_bias,
+                                                        int nchunk, int M, int K, float* __restrict__ gw,
+                                                        float* __restrict__ gbias, const float* __restrict__ ln_g,
+                                                        const float* __restrict__ ln_b, int accumulate, int nbw,
+                                                        const int bid) {
+  const bool bias_blk = bid >= nbw;
+  const int64_t n = bias_blk ? (int64_t)M : (int64_t)M * K;
+  const int64_t e = ((int64_t)(bias_blk ? bid - nbw : bid) * 256 + threadIdx.x) * 4;
+  if (e >= n) return;
+  const float* src = bias_blk ? part_bias : part;
+  const bool fold = !bias_blk && ln_g != nullptr;
+  const int m = fold ? (int)(e / K) : 0, k = fold ? (int)(e % K) : 0;
+  float4 gk = make_float4(1.f, 1.f, 1.f, 1.f), bk = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (fold) {
+    gk = *reinterpret_cast<const float4*>(ln_g + k);
+    bk = *reinterpret_cast<const float4*>(ln_b + k);
+  }
+  auto ld = [&](int ch) {
+    float4 a = *reinterpret_cast<const float4*>(src + (int64_t)ch * n + e);
+    if (fold) {
+      const float pb = part_bias[(int64_t)ch * M + m];
+      a.x = gk.x * a.x + bk.x * pb; a.y = gk.y * a.y + bk.y * pb; a.z = gk.z * a.z + bk.z * pb; a.w = gk.w * a.w + bk.w * pb;
+    }
+    return a;
+  };
+  auto add = [](float4& s, const float4& a) { s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w; };
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+  int ch = 0;
+  for (; ch + 3 < nchunk; ch += 4) {
+    const float4 a0 = ld(ch), a1 = ld(ch + 1), a2 = ld(ch + 2), a3 = ld(ch + 3);
+    add(s0, a0); add(s1, a1); add(s2, a2); add(s3, a3);
+  }
+  for (; ch < nchunk; ++ch) add(s0, ld(ch));
+  float4 t = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z),
+                         (s0.w + s1.w) + (s2.w + s3.w));
+  float* out = (bias_blk ? gbias : gw) + e;
+  if (accumulate) {
+    const float4 o = *reinterpret_cast<const float4*>(out);
+    t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+  }
+  *reinterpret_cast<float4*>(out) = t;
 }
 
 // The form between the two (65-256 partial blocks of a weight of >= 4 096 elements: the C = 64 and C = 128 stages): 64

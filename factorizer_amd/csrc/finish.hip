@@ -31,7 +31,8 @@ __global__ __launch_bounds__(256) void finish_batch_kernel(FinishTable<N> t) {
     case FK_CHUNK: fin_chunk_body(J.u.chunk, vb, red9); break;
     case FK_WGRAD: {
       const WgradFinishOne& f = J.u.wg;
-      if (f.wide == 2) wgrad_finish_mid_body(f.part, f.part_bias, f.nchunk, f.M, f.K, f.gw, f.gbias, f.ln_g, f.ln_b, f.accumulate, f.nbw, &red33[0][0], vb);
+      if (f.wide == 3) wgrad_finish_wide4_body(f.part, f.part_bias, f.nchunk, f.M, f.K, f.gw, f.gbias, f.ln_g, f.ln_b, f.accumulate, f.nbw, vb);
+      else if (f.wide == 2) wgrad_finish_mid_body(f.part, f.part_bias, f.nchunk, f.M, f.K, f.gw, f.gbias, f.ln_g, f.ln_b, f.accumulate, f.nbw, &red33[0][0], vb);
       else if (f.wide) wgrad_finish_wide_body(f.part, f.part_bias, f.nchunk, f.M, f.K, f.gw, f.gbias, f.ln_g, f.ln_b, f.accumulate, f.nbw, vb);
       else wgrad_finish_body(f.part, f.part_bias, f.nchunk, f.M, f.K, f.gw, f.gbias, f.ln_g, f.ln_b, f.accumulate, f.nbw, red9, vb);
       break;

@@ -579,8 +579,13 @@ template <typename AT>
 static FinishJob wgrad_finish_job(const fz_wgrad_desc* d, const WgradPlan<AT>& pl) {
   const int64_t MK = (int64_t)d->M * d->K;
   // few partial blocks of a large weight: one thread per element; up to 256 of a mid-sized one: 64 elements x 4 chunk slices
-  const int wide = (pl.nchunk <= 64 && MK >= 16384) ? 1 : ((pl.nchunk <= 256 && MK >= 4096) ? 2 : 0);
-  const int per = wide == 1 ? 256 : (wide == 2 ? 64 : 8);
+  int wide = (pl.nchunk <= 64 && MK >= 16384) ? 1 : ((pl.nchunk <= 256 && MK >= 4096) ? 2 : 0);
+  // ... four elements per thread where the 16-byte accesses are aligned (partial rows, outputs, LayerNorm vectors)
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  if (wide == 1 && MK >= 65536 && (d->M % 4) == 0 && (d->K % 4) == 0 && al16(pl.a.part) && al16(d->gw) &&
+      (d->gbias == nullptr || (al16(pl.a.part_bias) && al16(d->gbias))) && (d->ln_g == nullptr || (al16(d->ln_g) && al16(d->ln_b))))
+    wide = 3;
+  const int per = wide == 3 ? 1024 : (wide == 1 ? 256 : (wide == 2 ? 64 : 8));
   const int nbw = (int)((MK + per - 1) / per);
   const int nbb = d->gbias != nullptr ? (d->M + per - 1) / per : 0;
   FinishJob j = finish_job(FK_WGRAD, nbw + nbb);
