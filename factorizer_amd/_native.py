@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("FZ_LIB_PATH") or os.path.join(_HERE, "libfactorizer_h
 
 FZ_OK = 0
 FZ_E_UNSUPPORTED = -2
-ABI_VERSION = 5   # include/factorizer_hip.h: FZ_ABI_VERSION this binding's argument lists / descriptor layouts are written against
+ABI_VERSION = 6   # include/factorizer_hip.h: FZ_ABI_VERSION this binding's argument lists / descriptor layouts are written against
 SOLVER_ID = {"mu": 0, "hals": 1}
 STORE_F32, STORE_BF16 = 0, 1   # include/factorizer_hip.h: FZ_STORE_*
 PRODUCTS_DEFAULT, PRODUCTS_SPLIT_BF16, PRODUCTS_FP32_MFMA = 0, 1, 2   # FZ_PRODUCTS_*: the `products` field of the descriptors
@@ -199,7 +199,7 @@ class BlockPrologue(_c.Structure):
 class GemmDwDesc(_c.Structure):
     _fields_ = [("g", _vp), ("q", _vp), ("w", _vp), ("ln", _i), ("stats", _vp), ("ln_g", _vp), ("ln_b", _vp), ("gadd", _vp),
                 ("y", _vp), ("gln", _vp), ("wpart", _vp), ("gw", _vp), ("gb", _vp), ("B", _i), ("C", _i), ("V", _i64),
-                ("act_dtype", _i), ("ldgw", _i)]
+                ("act_dtype", _i), ("ldgw", _i), ("ldw", _i)]
 
 
 class WgradDesc(_c.Structure):
@@ -267,6 +267,7 @@ _SIGS.update({
     "fz_finish_defer": ([_i], _i),
     "fz_finish_pending": ([], _i),
     "fz_finish_flush": ([_vp], _i),
+    "fz_finish_flush_all": ([_vp], _i),
     "fz_dice_bce_chunks": ([_i64], _i),
     "fz_dice_bce_sums": ([_vp, _vp, _vp, _i, _i64, _vp], _i),
     "fz_dice_bce_grad": ([_vp, _vp, _vp, _vp, _i, _i64, _f, _f, _vp, _vp], _i),

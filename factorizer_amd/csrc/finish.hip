@@ -44,10 +44,18 @@ __global__ __launch_bounds__(256) void finish_batch_kernel(FinishTable<N> t) {
 }
 
 namespace {
+// One queue per stream (a stream belongs to one device): the jobs of a queue read what kernels on THAT stream produced.  The
+// table is process-wide and mutex-guarded; WHETHER a call queues is a per-thread flag (the thread that sets it — an autograd
+// device thread running one backward — is the thread that issues the weight-gradient calls it covers; another thread's calls
+// in the same process stay immediate).
+struct FinishQueue {
+  hipStream_t stream;
+  int device;   // the device that was current when the queue was opened: the stream's device
+  std::vector<FinishJob> jobs;
+};
 std::mutex g_mu;
-std::vector<FinishJob> g_queue;
-hipStream_t g_queue_stream = nullptr;
-std::atomic<int> g_defer{0};
+std::vector<FinishQueue> g_queues;
+thread_local int t_defer = 0;
 
 template <int N>
 int launch_table(const FinishJob* jobs, int n, hipStream_t st) {
@@ -82,48 +90,13 @@ bool accumulates(const FinishJob& j) {
   return (j.kind == FK_WGRAD && j.u.wg.accumulate) || (j.kind == FK_CHUNK && j.u.chunk.accumulate);
 }
 
-// everything queued, phase by phase, in queue order within a phase (caller holds g_mu)
-int flush_locked(hipStream_t st) {
-  if (g_queue.empty()) return 0;
-  const int n = (int)g_queue.size();
-  int maxph = 0;
-  for (const auto& j : g_queue) maxph = j.phase > maxph ? j.phase : maxph;
-  std::vector<FinishJob> sel;
-  sel.reserve(g_queue.size());
-  int rc = FZ_OK;
-  for (int ph = 0; ph <= maxph && rc == FZ_OK; ++ph) {
-    sel.clear();
-    for (const auto& j : g_queue)
-      if (j.phase == ph) sel.push_back(j);
-    if (!sel.empty()) rc = launch_jobs(sel.data(), (int)sel.size(), st);
-  }
-  g_queue.clear();
-  g_queue_stream = nullptr;
-  return rc == FZ_OK ? n : rc;
-}
-}  // namespace
-
-int finish_run(const FinishJob* jobs, int n, hipStream_t st) {
-  if (n < 1) return FZ_OK;
-  bool acc = false;
-  for (int i = 0; i < n; ++i) acc = acc || accumulates(jobs[i]);
-  if (g_defer.load(std::memory_order_relaxed) > 0 || acc) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (!g_queue.empty() && (acc || g_queue_stream != st)) {   // (a queue that belongs to another stream, or a job that adds to earlier results)
-      const int rc = flush_locked(g_queue_stream);
-      if (rc < 0) return rc;
-    }
-    if (!acc && g_defer.load(std::memory_order_relaxed) > 0) {
-      g_queue.insert(g_queue.end(), jobs, jobs + n);
-      g_queue_stream = st;
-      return FZ_OK;
-    }
-  }
-  // now: jobs of one call are independent of each other except through their phases
+// jobs phase by phase, in the given order within a phase
+int launch_phases(const FinishJob* jobs, int n, hipStream_t st) {
   int maxph = 0;
   for (int i = 0; i < n; ++i) maxph = jobs[i].phase > maxph ? jobs[i].phase : maxph;
   if (maxph == 0) return launch_jobs(jobs, n, st);
   std::vector<FinishJob> sel;
+  sel.reserve((size_t)n);
   for (int ph = 0; ph <= maxph; ++ph) {
     sel.clear();
     for (int i = 0; i < n; ++i)
@@ -136,24 +109,91 @@ int finish_run(const FinishJob* jobs, int n, hipStream_t st) {
   return FZ_OK;
 }
 
+FinishQueue* find_queue(hipStream_t st) {
+  for (auto& q : g_queues)
+    if (q.stream == st) return &q;
+  return nullptr;
+}
+
+// everything queued for one stream, on that stream (caller holds g_mu); returns the number of jobs or an error code
+int flush_queue_locked(FinishQueue& q) {
+  const int n = (int)q.jobs.size();
+  if (n == 0) return 0;
+  int cur = q.device;
+  (void)hipGetDevice(&cur);
+  if (cur != q.device) FZ_HIP_OK(hipSetDevice(q.device));
+  const int rc = launch_phases(q.jobs.data(), n, q.stream);
+  if (cur != q.device) (void)hipSetDevice(cur);
+  q.jobs.clear();
+  return rc == FZ_OK ? n : rc;
+}
+}  // namespace
+
+int finish_run(const FinishJob* jobs, int n, hipStream_t st) {
+  if (n < 1) return FZ_OK;
+  bool acc = false;
+  for (int i = 0; i < n; ++i) acc = acc || accumulates(jobs[i]);
+  const bool defer = t_defer > 0 && !acc;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    FinishQueue* q = find_queue(st);
+    if (acc && q != nullptr) {   // a job that ADDS to earlier results: those results must exist first
+      const int rc = flush_queue_locked(*q);
+      if (rc < 0) return rc;
+    }
+    if (defer) {
+      if (q == nullptr) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        g_queues.push_back(FinishQueue{st, dev, {}});
+        q = &g_queues.back();
+      }
+      q->jobs.insert(q->jobs.end(), jobs, jobs + n);
+      return FZ_OK;
+    }
+  }
+  return launch_phases(jobs, n, st);
+}
+
 }  // namespace fz
 
 using namespace fz;
 
 extern "C" int fz_finish_defer(int on) {
-  if (on < 0) return g_defer.load();
-  return g_defer.exchange(on ? 1 : 0);
+  const int was = t_defer;
+  if (on >= 0) t_defer = on ? 1 : 0;
+  return was;
 }
 
 extern "C" int fz_finish_pending(void) {
   std::lock_guard<std::mutex> lk(g_mu);
-  return (int)g_queue.size();
+  size_t n = 0;
+  for (const auto& q : g_queues) n += q.jobs.size();
+  return (int)n;
 }
 
 extern "C" int fz_finish_flush(fz_stream_t stream) {
   std::lock_guard<std::mutex> lk(g_mu);
-  if (g_queue.empty()) return 0;
-  // the jobs read what kernels on THEIR stream produced: a flush on another stream would race with them
-  if (g_queue_stream != (hipStream_t)stream) return fail(FZ_E_ARG, "fz_finish_flush: the queued finishes belong to another stream");
-  return flush_locked((hipStream_t)stream);
+  FinishQueue* q = find_queue((hipStream_t)stream);
+  return q == nullptr ? 0 : flush_queue_locked(*q);
+}
+
+extern "C" int fz_finish_flush_all(fz_stream_t waiter) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  int total = 0;
+  for (auto& q : g_queues) {
+    if (q.jobs.empty()) continue;
+    const int rc = flush_queue_locked(q);
+    if (rc < 0) return rc;
+    total += rc;
+    if (q.stream != (hipStream_t)waiter) {   // whoever reads the gradients on `waiter` is ordered behind the queue's own stream
+      hipEvent_t ev;
+      FZ_HIP_OK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      hipError_t e = hipEventRecord(ev, q.stream);
+      if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)waiter, ev, 0);
+      hipEventDestroy(ev);
+      if (e != hipSuccess) return fail(FZ_E_HIP, hipGetErrorString(e));
+    }
+  }
+  return total;
 }

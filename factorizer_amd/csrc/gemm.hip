@@ -2046,7 +2046,8 @@ template <typename AT>
 struct DwArgsT {
   const AT* g;        // (B, 32, V) gradient of the layer output
   const AT* q;        // (B, 32, V) layer input (LNB: the LayerNorm input)
-  const float* w;     // (32, 32) forward weight W[m][k]
+  const float* w;     // (32, 32) forward weight W[m][k], row stride ldw
+  int ldw;
   const float* stats; // LNB: (B, 2, V)
   const float* ln_g;  // LNB: gamma
   const AT* gadd;     // LNB: (B, 32, V) added to y, or null
@@ -2082,7 +2083,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_kernel(DwArgsT<AT> p, int ntil
       const int l = threadIdx.x & 63, g = threadIdx.x >> 6;
       float a8[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) a8[e] = p.w[(int64_t)(2 * (8 * g + e) + (l >> 5)) * 32 + (l & 31)];
+      for (int e = 0; e < 8; ++e) a8[e] = p.w[(int64_t)(2 * (8 * g + e) + (l >> 5)) * p.ldw + (l & 31)];
       bx8 t3[3];
       bx_split<3>(a8, t3);
       bx8* dst = reinterpret_cast<bx8*>(As) + (g * 3) * 64 + l;
@@ -2091,7 +2092,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_kernel(DwArgsT<AT> p, int ntil
   } else {
   for (int idx = threadIdx.x; idx < 1024; idx += 256) {
     const int l = idx & 63, a = idx >> 6;
-    As[idx] = p.w[(int64_t)(2 * a + (l >> 5)) * 32 + (l & 31)];   // A[m = l&31][k = 2a + h] = W[k][m]
+    As[idx] = p.w[(int64_t)(2 * a + (l >> 5)) * p.ldw + (l & 31)];   // A[m = l&31][k = 2a + h] = W[k][m]
   }
   }
   if (LNB && threadIdx.x < 32) tB[threadIdx.x] = p.ln_g[threadIdx.x];
@@ -3192,7 +3193,7 @@ extern "C" int fz_gemm_dw_rows(int B, int64_t V);
 template <typename AT>
 static int gemm_dw_launch(const fz_gemm_dw_desc* d, fz_stream_t stream) {
   DwArgsT<AT> a;
-  a.g = (const AT*)d->g; a.q = (const AT*)d->q; a.w = d->w; a.stats = d->stats; a.ln_g = d->ln_g; a.gadd = (const AT*)d->gadd;
+  a.g = (const AT*)d->g; a.q = (const AT*)d->q; a.w = d->w; a.ldw = d->ldw > 0 ? d->ldw : 32; a.stats = d->stats; a.ln_g = d->ln_g; a.gadd = (const AT*)d->gadd;
   a.y = (AT*)d->y; a.wpart = (float*)d->wpart; a.V = d->V; a.B = d->B;
   const int ntiles = (int)fz_mlp_partials(d->B, d->V);
   const int rows = fz_gemm_dw_rows(d->B, d->V);
@@ -3230,6 +3231,7 @@ extern "C" int fz_gemm_dw(const fz_gemm_dw_desc* d, fz_stream_t stream) {
   if (!d->ln && d->gadd) return fail(FZ_E_UNSUPPORTED, "fz_gemm_dw: gadd only with the LayerNorm backward");
   if (d->C != 32) return fail(FZ_E_UNSUPPORTED, "fz_gemm_dw: needs C == 32");
   if (d->ldgw != 0 && d->ldgw < 32) return fail(FZ_E_ARG, "fz_gemm_dw: ldgw must be 0 (= 32) or >= 32");
+  if (d->ldw != 0 && d->ldw < 32) return fail(FZ_E_ARG, "fz_gemm_dw: ldw must be 0 (= 32) or >= 32");
   if (d->B < 1 || d->V < 1 || d->V % 4 != 0 || d->V > ((int64_t)1 << 27)) return fail(FZ_E_UNSUPPORTED, "fz_gemm_dw: needs B >= 1, V % 4 == 0, V <= 2^27");
   if (d->act_dtype == FZ_STORE_F32) return gemm_dw_launch<float>(d, stream);
   if (d->act_dtype == FZ_STORE_BF16) return gemm_dw_launch<bf16>(d, stream);

@@ -39,6 +39,7 @@ class FlatGradSync:
         self.params = [p for p in module.parameters() if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
+        self._param_ids = frozenset(id(p) for p in self.params)   # deferred finishes are armed for these parameters only
         dev, dt = self.params[0].device, self.params[0].dtype
         from .training import flat_align   # same 16-byte-aligned layout as FlatAdamW's buffers (it aliases this one)
         total = sum(flat_align(p.numel()) for p in self.params)
@@ -117,7 +118,7 @@ class FlatGradSync:
             p.grad = None
         from . import gradbuf as _GB
         _GB.release(self.flat)
-        _PW.arm_deferred_finishes()
+        _PW.arm_deferred_finishes(self._param_ids)
         self._ready = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
 

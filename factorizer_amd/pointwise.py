@@ -195,6 +195,7 @@ def _gemm_dw(g, w2, q, ln=None, stats=None, gadd=None, want_bias=False, name="dg
     d.wpart, d.gw, d.gb = wpart.data_ptr(), gw.data_ptr(), _p(gb)
     d.B, d.C, d.V, d.act_dtype = B, C, V, N.act_dtype(q)
     d.ldgw = gw.stride(0)
+    d.ldw = w2.stride(0)          # (a 32-column block of a wider weight is read in place)
     gpar = None
     if ln is not None:
         gpar = torch.empty(64, dtype=torch.float32, device=dev)
@@ -439,22 +440,32 @@ def join_wgrad_streams():
 
 
 class _Defer:
-    """Deferred finishes (csrc/finish.h; include/factorizer_hip.h: fz_finish_defer / fz_finish_flush).  Every weight-gradient
+    """Deferred finishes (csrc/finish.h; include/factorizer_hip.h: fz_finish_defer / fz_finish_flush_all).  Every weight-gradient
     launch ends with a tiny fixed-order reduction of per-workgroup partial rows whose output is a PARAMETER gradient; a README
     training step has 54 of them, each a 5-10 us serial slot of the stream.  A caller that owns the step — `FlatAdamW`,
     `FlatGradSync`: gradients are None at zero_grad, nothing reads them before the owner does — lets the library queue them and
     run them as one grid at the end of the backward (and in front of every gradient bucket's collective).
-    Armed by the owner's zero_grad, disarmed by the end-of-backward flush: a second backward without zero_grad (gradient
-    accumulation: autograd then ADDS to .grad while the backward runs) is never deferred.  Sites whose results feed a torch
-    op inside the backward stay immediate (`_no_defer`).  The arithmetic is the same either way (bitwise)."""
+    Armed by the owner's zero_grad FOR THE OWNER'S PARAMETERS, disarmed by the end-of-backward flush: a second backward
+    without zero_grad (gradient accumulation: autograd then ADDS to .grad while the backward runs) is never deferred.
+    A returned gradient buffer stays unwritten until the flush, so a node defers only when nothing can read its parameter
+    gradients before the backward ends — `_param_sinks_ok` decides that per node from the autograd graph (each one must go,
+    through views at most, straight to the AccumulateGrad of an owned leaf that has no gradient yet, no tensor hooks, and is
+    used once in this backward; no double backward).  Everything else — a weight that is computed from a parameter (the
+    padded stem weight of odd channel counts), a parameter used twice, `p.register_hook`, `create_graph=True`, a model the
+    owner does not cover — runs its finishes at once, as do sites whose results feed a torch op inside the backward
+    (`_no_defer`).  Post-accumulate hooks other than the owner's must call `flush_finishes()` before they read `.grad`.
+    The arithmetic is the same either way (bitwise)."""
     enabled = False
     armed = False
     suppress = 0
-    keep = []       # workspaces and gradient outputs of queued finishes: alive until the flush
-    dev = None
+    owned = frozenset()   # id() of the parameters the arming owner covers
+    seen = set()          # id() of the parameters whose gradient a node of this backward has already produced
+    keep = {}             # device index -> workspaces and gradient outputs of queued finishes: alive until the flush
+    lock = _threading.Lock()
     queued = False  # an end-of-backward engine callback is pending
     flushed = 0     # finishes run through flushes so far (tests)
     flushes = 0
+    refused = 0     # backward nodes that ran their finishes at once because `_param_sinks_ok` said no (tests)
 
 
 def defer_finishes(flag: bool = True):
@@ -464,33 +475,40 @@ def defer_finishes(flag: bool = True):
     _Defer.enabled = bool(flag) and os.environ.get("FZ_DEFER_FINISH", "1") != "0"
 
 
-def arm_deferred_finishes():
-    """The owner's zero_grad: gradients are None from here to the end of the next backward."""
+def arm_deferred_finishes(params=()):
+    """The owner's zero_grad: the gradients of `params` are None from here to the end of the next backward."""
     flush_finishes(disarm=True)
-    _Defer.queued = False
-    _Defer.armed = _Defer.enabled
+    d = _Defer
+    d.queued = False
+    d.owned = params if isinstance(params, frozenset) else frozenset(id(p) for p in params)
+    d.seen = set()
+    d.armed = d.enabled and bool(d.owned)
 
 
 def flush_finishes(disarm: bool = False):
-    """Run what is queued (current stream of the device the finishes were issued on) and release the buffers held for it."""
+    """Run what is queued — every queue on the stream its jobs were issued on; the current stream of each device waits for
+    them (a forward under `torch.cuda.stream(s)` with `backward()` called outside it queues on `s`) — and release the buffers
+    held for it."""
     d = _Defer
     if disarm:
         d.armed = False
-    if d.dev is not None:
-        with torch.cuda.device(d.dev):
+    with d.lock:
+        devs, keep, d.keep = list(d.keep), d.keep, {}
+    for idx in devs:
+        with torch.cuda.device(idx):
             n = N.lib().fz_finish_pending()
             if n:
-                cols = 0
-                rc = Fn._timed("finish_batch", 0, lambda: N.lib().fz_finish_flush(torch.cuda.current_stream(d.dev).cuda_stream), cols=cols)
+                rc = Fn._timed("finish_batch", 0, lambda: N.lib().fz_finish_flush_all(torch.cuda.current_stream(idx).cuda_stream), cols=0)
                 if rc < 0:
-                    N.check(rc, "fz_finish_flush")
-                d.flushed += n
+                    N.check(rc, "fz_finish_flush_all")
+                d.flushed += rc
                 d.flushes += 1
-    d.keep.clear()
+    keep.clear()
 
 
 def _end_of_backward_finishes():
     _Defer.queued = False
+    _Defer.seen = set()
     flush_finishes(disarm=True)
 
 
@@ -513,19 +531,18 @@ class _finish_scope:
                         d.queued = True
                     except RuntimeError:
                         return self
-                if d.dev is not None and d.dev != t0.device:
-                    flush_finishes()
-                d.dev = t0.device
                 # (aliases, not the tensors themselves: autograd adopts a returned gradient as p.grad without a copy only while
                 # nothing else references the tensor object — holding the object would make it CLONE the not-yet-written buffer)
-                d.keep.extend(t.detach() for t in self.tensors if t is not None)
-                N.lib().fz_finish_defer(1)
+                held = [t.detach() for t in self.tensors if t is not None]
+                with d.lock:
+                    d.keep.setdefault(t0.device.index, []).extend(held)
+                self.was = N.lib().fz_finish_defer(1)   # (per thread: the launches inside this scope are issued by this thread)
                 self.on = True
         return self
 
     def __exit__(self, *exc):
         if self.on:
-            N.lib().fz_finish_defer(0)
+            N.lib().fz_finish_defer(self.was)
         return False
 
 
@@ -536,6 +553,59 @@ class _no_defer:
     def __exit__(self, *exc):
         _Defer.suppress -= 1
         return False
+
+
+# autograd nodes a gradient passes through WITHOUT being read (and without losing the dense layout AccumulateGrad adopts as is)
+_VIEW_NODES = frozenset(("ViewBackward0", "ReshapeAliasBackward0", "UnsafeViewBackward0", "UnsqueezeBackward0", "SqueezeBackward0",
+                         "SqueezeBackward1", "AliasBackward0", "DetachBackward0"))
+
+
+def _param_sinks_ok(ctx) -> bool:
+    """May this backward node leave its parameter gradients unwritten until the end of the backward?  Inputs listed in the
+    Function's `_fz_acts` (default: input 0) are activations — their gradients are complete when the node returns; every other
+    input that needs a gradient gets it from a finish job and must lead, through views at most, to the AccumulateGrad of an
+    owned, gradient-less, hook-less leaf that no earlier node of this backward has served."""
+    d = _Defer
+    if torch.is_grad_enabled():          # create_graph=True: the gradients are graph inputs of a double backward
+        return False
+    acts = getattr(ctx, "_fz_acts", (0,))
+    for i, need in enumerate(ctx.needs_input_grad):
+        if not need or i in acts:
+            continue
+        fn = ctx.next_functions[i][0]
+        while fn is not None and type(fn).__name__ in _VIEW_NODES:
+            fn = fn.next_functions[0][0]
+        if fn is None or type(fn).__name__ != "AccumulateGrad":
+            return False
+        v = fn.variable
+        vid = id(v)
+        if vid not in d.owned or v.grad is not None or v._backward_hooks:
+            return False
+        if vid in d.seen:
+            # second use of a parameter in one graph: the engine is about to ADD this node's gradient to the first one's —
+            # which must therefore be complete now
+            flush_finishes()
+            return False
+        d.seen.add(vid)
+    return True
+
+
+def _bwd(fn):
+    """decorator of every backward below: N.with_products + the deferral decision above (made once per node)"""
+    import functools
+    inner = N.with_products(fn)
+
+    @functools.wraps(fn)
+    def wrapper(ctx, *a, **kw):
+        d = _Defer
+        if d.armed and d.suppress == 0 and not getattr(ctx, "_fz_defer_checked", False):
+            ctx._fz_defer_checked = True
+            if not _param_sinks_ok(ctx):
+                d.refused += 1
+                with _no_defer():
+                    return inner(ctx, *a, **kw)
+        return inner(ctx, *a, **kw)
+    return wrapper
 
 
 def _native_ok(*ts):
@@ -587,7 +657,7 @@ class LNLinearFn(torch.autograd.Function):
         return y
 
     @staticmethod
-    @N.with_products
+    @_bwd
     def backward(ctx, gy):
         x, stats, ln_w, ln_b, w2, y = ctx.saved_tensors
         gy = gy.contiguous()
@@ -610,6 +680,8 @@ class LNLinearFn(torch.autograd.Function):
 
 # ---- res + Linear(act(z)) + bias -------------------------------------------------------------
 class ActLinearResFn(torch.autograd.Function):
+    _fz_acts = (0, 3)   # inputs that are activations (see _param_sinks_ok); every other input is a parameter
+
     @staticmethod
     @N.capture_products
     def forward(ctx, z, w, b, res, bact):
@@ -628,7 +700,7 @@ class ActLinearResFn(torch.autograd.Function):
         return y
 
     @staticmethod
-    @N.with_products
+    @_bwd
     def backward(ctx, gy):
         z, w2 = ctx.saved_tensors
         gy = gy.contiguous()
@@ -659,6 +731,8 @@ class ActLinearResFn(torch.autograd.Function):
 
 # ---- Linear over a virtual channel concat -------------------------------------------------------
 class CatLinearFn(torch.autograd.Function):
+    _fz_acts = (0, 1)   # inputs that are activations (see _param_sinks_ok); every other input is a parameter
+
     @staticmethod
     @N.capture_products
     def forward(ctx, x1, x2, w, b):
@@ -675,7 +749,7 @@ class CatLinearFn(torch.autograd.Function):
         return y
 
     @staticmethod
-    @N.with_products
+    @_bwd
     def backward(ctx, gy):
         x1, x2, w2 = ctx.saved_tensors
         gy = gy.contiguous()
@@ -688,8 +762,8 @@ class CatLinearFn(torch.autograd.Function):
             # full-resolution adapter (64 -> 32): each half is a 32 -> 32 layer — input gradient and weight gradient of a
             # half in one pass (gy is read twice instead of three times, x1 / x2 once instead of twice)
             gw = _GB.out_like(w2)
-            g1, _, gb, _, _ = _gemm_dw(gy, w2[:, :C1].contiguous(), x1, want_bias=ctx.has_bias, name="dgrad_wgrad", gw_out=gw[:, :C1])
-            g2, _, _, _, _ = _gemm_dw(gy, w2[:, C1:].contiguous(), x2, name="dgrad_wgrad", gw_out=gw[:, C1:])
+            g1, _, gb, _, _ = _gemm_dw(gy, w2[:, :C1], x1, want_bias=ctx.has_bias, name="dgrad_wgrad", gw_out=gw[:, :C1])
+            g2, _, _, _, _ = _gemm_dw(gy, w2[:, C1:], x2, name="dgrad_wgrad", gw_out=gw[:, C1:])
             return g1, g2, gw.reshape(ctx.wshape), gb
         g1 = torch.empty_like(x1)
         g2 = torch.empty_like(x2)
@@ -708,7 +782,7 @@ class LinearFn(torch.autograd.Function):
         return ActLinearResFn.forward(ctx, x, w, b, None, "none")
 
     @staticmethod
-    @N.with_products
+    @_bwd
     def backward(ctx, gy):
         return ActLinearResFn.backward(ctx, gy)[:3]
 
@@ -732,7 +806,7 @@ class LayerNormFn(torch.autograd.Function):
         return y
 
     @staticmethod
-    @N.with_products
+    @_bwd
     def backward(ctx, gy):
         x, stats, w = ctx.saved_tensors
         gy = gy.contiguous()
@@ -761,7 +835,7 @@ class ConvK2S2Fn(torch.autograd.Function):
         return y
 
     @staticmethod
-    @N.with_products
+    @_bwd
     def backward(ctx, gy, g_skip=None):
         x, w = ctx.saved_tensors
         gy = gy.contiguous()
@@ -797,7 +871,7 @@ class SkipConvK2S2Fn(torch.autograd.Function):
         return x.view_as(x), y
 
     @staticmethod
-    @N.with_products
+    @_bwd
     def backward(ctx, g_skip, gy):
         if gy is None:  # the down path took no part in the loss
             return g_skip, None, None
@@ -822,7 +896,7 @@ class TConvK2S2Fn(torch.autograd.Function):
         return y
 
     @staticmethod
-    @N.with_products
+    @_bwd
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         gy = gy.contiguous()
@@ -854,6 +928,8 @@ class TConvK2S2Fn(torch.autograd.Function):
 class ConvK3Fn(torch.autograd.Function):
     """Conv3d(kernel 3, padding 1) — the stem (C_in = 4): direct implicit-GEMM kernels
     (csrc/conv3.hip); shapes outside them use the generic tap loaders of the GEMM family."""
+
+    _fz_acts = (0, 3)   # inputs that are activations (see _param_sinks_ok); every other input is a parameter
 
     @staticmethod
     @N.capture_products
@@ -894,7 +970,7 @@ class ConvK3Fn(torch.autograd.Function):
         return y
 
     @staticmethod
-    @N.with_products
+    @_bwd
     def backward(ctx, gy, _gt=None, _gst=None):
         x, w = ctx.saved_tensors
         if gy is None:
@@ -1014,6 +1090,8 @@ class UpCatLinearFn(torch.autograd.Function):
     and the up-sampled tensor, its gradient and the row-sum pass over it never exist in the backward: 6 U of traffic per
     level instead of 10 U (U = one full-resolution activation tensor of the level)."""
 
+    _fz_acts = (0, 1, 6)   # inputs that are activations (see _param_sinks_ok); every other input is a parameter
+
     @staticmethod
     @N.capture_products
     def forward(ctx, skip, deep, w_t, b_t, w_ad, b_ad, pro=None):
@@ -1068,7 +1146,7 @@ class UpCatLinearFn(torch.autograd.Function):
         return y
 
     @staticmethod
-    @N.with_products
+    @_bwd
     def backward(ctx, g, _gt=None, _gst=None):
         skip, deep, w_t, w2, b_t = ctx.saved_tensors
         if g is None:   # (only with materialize_grads off and an unused output: a zero gradient, as autograd would have made)
@@ -1085,7 +1163,7 @@ class UpCatLinearFn(torch.autograd.Function):
         gb_ad = torch.empty(M, dtype=torch.float32, device=dev)
         # --- skip half: input gradient + W_a weight gradient (+ Σ_v g) ---
         if M == 32 and C1 == 32 and _dw_fused_ok(M, Vf):
-            g_skip, _, _, _, _ = _gemm_dw(g, w2[:, :C1].contiguous(), skip, want_bias=True, name="dgrad_wgrad",
+            g_skip, _, _, _, _ = _gemm_dw(g, w2[:, :C1], skip, want_bias=True, name="dgrad_wgrad",
                                           gw_out=gw_ad[:, :C1], gb_out=gb_ad)
         else:
             g_skip = torch.empty_like(skip)
@@ -1185,6 +1263,8 @@ class FactorizerBlockFn(torch.autograd.Function):
     core = matricize → NMF → inverse: the fused channels-first kernels (csrc/nmf_cf.hip) when
     `cfg["core"]`, else the native modular chain swm_fwd → nmf → swm_inv."""
 
+    _fz_acts = (0, 4, 5, 14, 15, 16, 17, 18)   # inputs that are activations (see _param_sinks_ok); every other input is a parameter
+
     @staticmethod
     @N.capture_products
     def forward(ctx, x, n1w, n1b, win, u0, v0, wout, bout, n2w, n2b, w1, b1, w2, b2, cfg, head_w=None, head_b=None,
@@ -1255,7 +1335,7 @@ class FactorizerBlockFn(torch.autograd.Function):
         return x2
 
     @staticmethod
-    @N.with_products
+    @_bwd
     def backward(ctx, g2, _g_logits=None):
         x, st1, t, a, x1, st2, z1, m, n1w, n1b, win2, u0c, v0c, wout2, n2w, n2b, w12, w22 = ctx.saved_tensors
         cfg = ctx.cfg
@@ -1394,6 +1474,8 @@ class HeadOfBlockFn(torch.autograd.Function):
     (FactorizerBlockFn with head_w): forward hands them out, backward is the head's own one-pass gradient kernel
     (csrc/headbwd.hip: input, weight and bias gradient)."""
 
+    _fz_acts = (0, 3)   # inputs that are activations (see _param_sinks_ok); every other input is a parameter
+
     @staticmethod
     @N.capture_products
     def forward(ctx, y, w, b, logits):
@@ -1402,7 +1484,7 @@ class HeadOfBlockFn(torch.autograd.Function):
         return logits.view_as(logits)
 
     @staticmethod
-    @N.with_products
+    @_bwd
     def backward(ctx, gl):
         y, w = ctx.saved_tensors
         B, C = y.shape[:2]

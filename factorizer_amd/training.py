@@ -53,6 +53,7 @@ class FlatAdamW:
         self.params = [p for p in self.all_params if p.requires_grad]
         if not self.params:
             raise ValueError("FlatAdamW: no trainable parameters")
+        self._param_ids = frozenset(id(p) for p in self.params)   # deferred finishes are armed for these parameters only
         dev, dt = self.params[0].device, self.params[0].dtype
         if dt != torch.float32 or any(p.dtype != dt or p.device != dev for p in self.params):
             raise ValueError("FlatAdamW: fp32 parameters on one device")
@@ -124,7 +125,7 @@ class FlatAdamW:
         for p in self.params:
             p.grad = None
         _GB.release(self.flat_grad)
-        _PW.arm_deferred_finishes()
+        _PW.arm_deferred_finishes(self._param_ids)
 
     def _update(self, lo, hi, t, grad_scale):
         b1, b2 = self.betas

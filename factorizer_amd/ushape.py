@@ -246,7 +246,10 @@ class UNet(nn.Module):
         if e0 is None or not isinstance(getattr(e0, "downsample", None), nn.Identity) or hasattr(stage, "adapter") or e0._forward_hooks:
             return None
         fn = getattr(stage, "_first_block_prologue", None)
-        return fn(x.new_empty((1, 32, *x.shape[2:]))) if fn is not None and not stage._forward_hooks else None
+        if fn is None or stage._forward_hooks:
+            return None
+        from .utils import TensorSpec   # (the stem's output as the block will see it: real batch, no allocation)
+        return fn(TensorSpec((x.shape[0], 32, *x.shape[2:]), x.dtype, x.device))
 
     def forward_features(self, x):
         x = self._mixed_precision_input(x)

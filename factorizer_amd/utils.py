@@ -51,3 +51,24 @@ def partialize(spec) -> Callable:
                 args.append(item)
         return functools.partial(spec[0], *args, **kwargs)
     raise TypeError(f"Expected a callable or valid tuple, got {type(spec).__name__}")
+
+
+class TensorSpec:
+    """Shape, dtype and device of a tensor that does not exist yet — what the dispatch predicates (`_fusable`, `prologue_params`,
+    ...) read of their argument.  A producer asks "would the consumer take the native path for my output?" without allocating it."""
+
+    def __init__(self, shape, dtype, device):
+        self.shape, self.dtype, self.device = tuple(int(s) for s in shape), dtype, device
+
+    @property
+    def is_cuda(self):
+        return self.device.type == "cuda"
+
+    def dim(self):
+        return len(self.shape)
+
+    def numel(self):
+        n = 1
+        for s in self.shape:
+            n *= s
+        return n

@@ -10,7 +10,10 @@
  *   - return 0 on success, <0 on error (FZ_E_*); never throw, never abort.
  *   - never allocate or free caller memory; workspaces are passed in.
  *   - asynchronous on the passed hipStream_t (void*); no host synchronisation inside.
- *   - re-entrant and thread-safe: no mutable globals besides a thread-local error string.
+ *   - re-entrant and thread-safe.  Process-wide state is exactly: the launch counter (atomic), the per-stream queues of
+ *     deferred finish jobs (mutex-guarded; fz_finish_* below), the FZ_GEMM_BX default read once.  Per-thread state: the last
+ *     error string, the `products` default (fz_set_products), the tile order (fz_set_tile_order), the defer flag
+ *     (fz_finish_defer).  Nothing else outlives a call.
  *   - tensors are dense, contiguous, row-major ("channels-first": B,C,D,H,W).
  */
 #ifndef FACTORIZER_HIP_H
@@ -49,8 +52,8 @@ int fz_version(void);
  * compares fz_abi_version() with the FZ_ABI_VERSION of the header it was written against BEFORE the first call and refuses
  * to run on a mismatch (factorizer_amd/_native.py does).  History: 3 = round 3; 4 = round 4 (`products` / `tune` descriptor
  * fields, `products` argument of fz_conv3_*); 5 = round 5 (the two-window entry points fz_nmf_cf_fwd2 / _bwd2 removed, this
- * function added). */
-#define FZ_ABI_VERSION 5
+ * function added); 6 = round 6 (fz_finish_defer is per THREAD, one finish queue per stream, fz_finish_flush_all added, fz_gemm_dw_desc.ldw). */
+#define FZ_ABI_VERSION 6
 int fz_abi_version(void);
 /* Walking order of the fused-core launches (fz_nmf_cf_fwd / fz_nmf_cf_bwd) this THREAD issues from now on: 0 = ascending over
  * the patch tiles (the default), 1 = descending; < 0 only queries.  Returns the previous setting.  Results do not depend on it.
@@ -64,16 +67,20 @@ int fz_set_tile_order(int descending);
  * affine gradients, fz_reduce_rows, fz_rowsum, fz_chunk_reduce, fz_upcat_wgrads) ends with a tiny launch that adds per-workgroup
  * partial rows in a fixed order.  Those launches produce PARAMETER gradients — nothing in a backward pass reads them — but each
  * one is a 5-10 us serial slot of the stream (54 per README training step: 0.33 ms).  fz_finish_defer(1) makes the calls that
- * follow in this process QUEUE them instead (the descriptors only; nothing is copied), fz_finish_defer(0) stops queueing;
- * fz_finish_flush(stream) runs everything queued as one or two grids and returns how many were queued (< 0: an error code).
- * While finishes are queued the caller keeps alive, and does not touch, every buffer handed to those calls (workspaces,
- * gradient outputs); a flush must go to the stream the deferred calls were given (FZ_E_ARG otherwise); a call that ACCUMULATES
- * into its output drains the queue and runs at once.  The sums and their order are the same deferred or not: bit-identical.
- * fz_finish_defer(-1) / fz_finish_pending() only query.  Reference counterpart: none — autograd launches one reduction kernel
- * per gradient as it goes. */
+ * follow ON THIS THREAD queue them instead (the descriptors only; nothing is copied), fz_finish_defer(0) stops queueing; both
+ * return the previous setting, fz_finish_defer(-1) only queries.  There is one queue per stream the deferred calls were given
+ * (a stream belongs to one device).  fz_finish_flush(stream) runs what is queued for THAT stream, on it, as one or two grids
+ * and returns how many jobs that was (0: nothing queued for it; < 0: an error code).  fz_finish_flush_all(waiter) runs every
+ * queue on its own stream and makes `waiter` wait (event) for each queue whose stream is another one: the caller that is about
+ * to read the gradients on `waiter` is ordered behind all of them; returns the total.  fz_finish_pending() counts queued jobs
+ * over all queues.  While finishes are queued the caller keeps alive, and does not touch, every buffer handed to those calls
+ * (workspaces, gradient outputs); a call that ACCUMULATES into its output drains its stream's queue and runs at once.  The
+ * sums and their order are the same deferred or not: bit-identical.  Reference counterpart: none — autograd launches one
+ * reduction kernel per gradient as it goes. */
 int fz_finish_defer(int on);
 int fz_finish_pending(void);
 int fz_finish_flush(fz_stream_t stream);
+int fz_finish_flush_all(fz_stream_t waiter);
 /* Message for the last error returned on this thread ("" if none). */
 const char* fz_last_error_string(void);
 /* Number of kernel launches issued through this library by this process (test hook that
@@ -370,6 +377,7 @@ typedef struct fz_gemm_dw_desc {
   int64_t V;
   int act_dtype;
   int ldgw;            /* floats between rows of gw; 0 = 32 (a column block of a wider weight gradient: its width) */
+  int ldw;             /* floats between rows of w;  0 = 32 (a column block of a wider weight, read in place)  [ABI 6] */
 } fz_gemm_dw_desc;
 int fz_gemm_dw_rows(int B, int64_t V);
 int64_t fz_gemm_dw_workspace_bytes(int B, int64_t V);

@@ -94,7 +94,7 @@ def test_queue_semantics_through_the_c_abi():
         assert lib.fz_finish_pending() == 2 and lib.fz_finish_defer(-1) == 1
         torch.cuda.synchronize()
         assert bool((out == -7.0).all())                                   # nothing ran yet
-        assert lib.fz_finish_flush(other.cuda_stream) == -4                # FZ_E_ARG: the queue belongs to the other stream
+        assert lib.fz_finish_flush(other.cuda_stream) == 0                 # nothing is queued for THAT stream
         assert lib.fz_finish_pending() == 2
         # a job that accumulates drains the queue first and runs at once
         acc = torch.ones(n, device=DEV)
@@ -108,6 +108,34 @@ def test_queue_semantics_through_the_c_abi():
         assert lib.fz_finish_flush(st) == 2 and lib.fz_finish_pending() == 0 and lib.fz_finish_flush(st) == 0
         torch.cuda.synchronize()
         assert torch.equal(out, ref)
+        # one queue per stream; fz_finish_flush_all runs each on its own stream and orders the waiter behind them
+        out.fill_(-7.0)
+        out2 = torch.full((n,), -7.0, device=DEV)
+        tmp2 = torch.empty(64, n, device=DEV)
+        other.wait_stream(torch.cuda.current_stream())
+        N.check(lib.fz_reduce_rows(part.data_ptr(), rows, n, out.data_ptr(), tmp.data_ptr(), st), "fz_reduce_rows")
+        N.check(lib.fz_reduce_rows(part.data_ptr(), rows, n, out2.data_ptr(), tmp2.data_ptr(), other.cuda_stream), "fz_reduce_rows")
+        assert lib.fz_finish_pending() == 4
+        assert lib.fz_finish_flush_all(st) == 4 and lib.fz_finish_pending() == 0
+        both = out + out2            # on the current stream: ordered behind `other` by the flush itself
+        torch.cuda.synchronize()
+        assert torch.equal(both, ref + ref)
+        # the flag is per thread: another thread's calls stay immediate while this one defers
+        import threading
+        seen = {}
+
+        def worker():
+            seen["flag"] = lib.fz_finish_defer(-1)
+            o3 = torch.full((n,), -7.0, device=DEV)
+            t3 = torch.empty(64, n, device=DEV)
+            N.check(lib.fz_reduce_rows(part.data_ptr(), rows, n, o3.data_ptr(), t3.data_ptr(), torch.cuda.current_stream().cuda_stream), "fz_reduce_rows")
+            seen["pending"] = lib.fz_finish_pending()
+            torch.cuda.synchronize()
+            seen["equal"] = torch.equal(o3, ref)
+        th = threading.Thread(target=worker)
+        th.start()
+        th.join()
+        assert seen == {"flag": 0, "pending": 0, "equal": True}, seen
     finally:
         assert lib.fz_finish_defer(0) == 1
     # column blocks of wider rows (the head's 132-float partial rows)
@@ -121,3 +149,130 @@ def test_queue_semantics_through_the_c_abi():
     assert torch.equal(gw, whole[:96]) and torch.equal(gb, whole[128:131])
     assert lib.fz_chunk_reduce_ld(wide.data_ptr(), 40, 96, 64, gw.data_ptr(), 0, st) == -4
     assert ctypes.c_int(lib.fz_finish_pending()).value == 0
+
+
+def _tiny(in_channels=4):
+    return ft.Factorizer(in_channels=in_channels, out_channels=3, spatial_size=(32, 32, 32), encoder_depth=(1, 1), encoder_width=(32, 64),
+                         strides=(1, 2), decoder_depth=(1,), norm=ft.LayerNorm,
+                         reshape=(ft.SWMatricize, {"head_dim": 8, "patch_size": 4}), act=nn.ReLU, factorize=ft.NMF, rank=1,
+                         num_iters=5, init="uniform", solver="hals", mlp_ratio=2, dropout=0.0)
+
+
+def _deferred_vs_immediate(model, opt, step):
+    """gradients of `step()` with deferral armed by opt.zero_grad() vs with deferral switched off: (deferred, immediate, #queued, #refused)"""
+    PW.defer_finishes(True)
+    f0, r0 = PW._Defer.flushed, PW._Defer.refused
+    opt.zero_grad()
+    step()
+    torch.cuda.synchronize()
+    g_def = [None if p.grad is None else p.grad.detach().clone() for p in model.parameters()]
+    queued, refused = PW._Defer.flushed - f0, PW._Defer.refused - r0
+    PW.defer_finishes(False)
+    opt.zero_grad()
+    step()
+    torch.cuda.synchronize()
+    g_imm = [None if p.grad is None else p.grad.detach().clone() for p in model.parameters()]
+    return g_def, g_imm, queued, refused
+
+
+@pytest.mark.parametrize("cin", [1, 3])
+def test_odd_input_channels_stem_weight_is_not_a_leaf(cin):
+    """Conv3d with an odd C_in hands ConvK3Fn a PADDED weight — a non-leaf whose gradient autograd slices
+    (and clones) inside the backward.  That node must run its finishes at once; every gradient equals the immediate form."""
+    torch.manual_seed(0)
+    model = _tiny(cin).to(DEV)
+    x = torch.rand(2, cin, 32, 32, 32, device=DEV)
+    t = (torch.rand(2, 3, 32, 32, 32, device=DEV) > 0.5).float()
+    opt = FlatAdamW(model, lr=1e-3, deferred_finishes=True)
+    try:
+        g_def, g_imm, queued, refused = _deferred_vs_immediate(model, opt, lambda: ft.dice_ce_loss(model(x), t).backward())
+        assert queued > 0 and refused >= 1, (queued, refused)      # the rest of the network still defers; the stem does not
+        for (name, _), a, b in zip(model.named_parameters(), g_def, g_imm):
+            assert torch.equal(a, b), name
+        # and the values are right, not merely equal: against ATen's own gradient of the same convolution
+        stem = model.stem if hasattr(model, "stem") else next(m for m in model.modules() if isinstance(m, nn.Conv3d) and m.kernel_size == (3, 3, 3))
+        xs = torch.rand(2, cin, 32, 32, 32, device=DEV)
+        gy = torch.rand(2, stem.out_channels, 32, 32, 32, device=DEV)
+        opt.zero_grad()
+        PW.defer_finishes(True)
+        opt.zero_grad()
+        stem(xs).backward(gy)
+        torch.cuda.synchronize()
+        ref_w = torch.nn.grad.conv3d_weight(xs, stem.weight.shape, gy, padding=1)
+        assert (stem.weight.grad - ref_w).abs().max() <= 1e-4 * ref_w.abs().max()
+    finally:
+        PW.defer_finishes(False)
+
+
+def test_deferral_is_refused_where_autograd_reads_the_gradient_early():
+    """a parameter used twice in one graph, a tensor hook on a parameter, a model the arming owner does not
+    cover, create_graph=True — each must fall back to immediate finishes for the nodes concerned and give the immediate
+    gradients bit for bit."""
+    torch.manual_seed(0)
+    model = _tiny().to(DEV)
+    x = torch.rand(2, 4, 32, 32, 32, device=DEV)
+    t = (torch.rand(2, 3, 32, 32, 32, device=DEV) > 0.5).float()
+    opt = FlatAdamW(model, lr=1e-3, deferred_finishes=True)
+    try:
+        # (1) every parameter used twice: two forwards in one graph
+        g_def, g_imm, queued, refused = _deferred_vs_immediate(
+            model, opt, lambda: (ft.dice_ce_loss(model(x), t) + ft.dice_ce_loss(model(x * 0.5), t)).backward())
+        assert refused >= 1
+        for (name, _), a, b in zip(model.named_parameters(), g_def, g_imm):
+            assert torch.equal(a, b), name
+        # (2) a tensor hook that reads the gradient inside the backward
+        p0 = next(p for n, p in model.named_parameters() if n.endswith("out_proj.weight") or n.endswith("fc2.weight"))
+        got = []
+        h = p0.register_hook(lambda g: got.append(g.detach().clone()))
+        g_def, g_imm, queued, refused = _deferred_vs_immediate(model, opt, lambda: ft.dice_ce_loss(model(x), t).backward())
+        h.remove()
+        assert refused >= 1 and len(got) == 2 and torch.equal(got[0], got[1]) and torch.equal(got[0], p0.grad)
+        for (name, _), a, b in zip(model.named_parameters(), g_def, g_imm):
+            assert torch.equal(a, b), name
+        # (3) a second model in the process that the arming owner does not cover: never deferred
+        other = _tiny().to(DEV)
+        PW.defer_finishes(True)
+        opt.zero_grad()                      # arms deferral — for `model`'s parameters
+        f0 = PW._Defer.flushed
+        ft.dice_ce_loss(other(x), t).backward()
+        torch.cuda.synchronize()
+        assert PW._Defer.flushed == f0 and N.lib().fz_finish_pending() == 0
+        g_other = [p.grad.detach().clone() for p in other.parameters()]
+        PW.defer_finishes(False)
+        for p in other.parameters():
+            p.grad = None
+        ft.dice_ce_loss(other(x), t).backward()
+        torch.cuda.synchronize()
+        for a, p in zip(g_other, other.parameters()):
+            assert torch.equal(a, p.grad)
+    finally:
+        PW.defer_finishes(False)
+
+
+def test_flush_follows_the_stream_the_backward_ran_on():
+    """forward under `with torch.cuda.stream(s)`, backward() called outside it — autograd runs the nodes on s,
+    the finishes queue on s, the end-of-backward flush runs them THERE and the caller's stream waits."""
+    torch.manual_seed(0)
+    model = _tiny().to(DEV)
+    x = torch.rand(2, 4, 32, 32, 32, device=DEV)
+    t = (torch.rand(2, 3, 32, 32, 32, device=DEV) > 0.5).float()
+    opt = FlatAdamW(model, lr=1e-3, deferred_finishes=True)
+    try:
+        s = torch.cuda.Stream()
+        opt.zero_grad()
+        s.wait_stream(torch.cuda.current_stream())
+        f0 = PW._Defer.flushed
+        with torch.cuda.stream(s):
+            loss = ft.dice_ce_loss(model(x), t)
+        loss.backward()
+        g_def = [p.grad.detach().clone() for p in model.parameters()]     # on the current stream: ordered behind s by the flush
+        torch.cuda.synchronize()
+        assert PW._Defer.flushed - f0 > 0 and N.lib().fz_finish_pending() == 0
+        PW.defer_finishes(False)
+        opt.zero_grad()
+        ft.dice_ce_loss(model(x), t).backward()
+        torch.cuda.synchronize()
+        for a, p in zip(g_def, model.parameters()):
+            assert torch.equal(a, p.grad)
+    finally:
+        PW.defer_finishes(False)
