@@ -143,15 +143,17 @@ MODEL_KW = dict(in_channels=4, out_channels=3, spatial_size=(128, 128, 128),
                 dropout=0.1)
 
 
-def cpu_baseline_sample():
-    """CPU oracle (a port of the reference's CPU path, pinned to goldens generated by the imported reference) on a
-    bounded sample of THIS workload: one whole training step of the README Swin Factorizer — forward, DiceCE loss,
-    backward, AdamW — on ONE 128^3 volume (the benchmark's per-GPU batch is 2), measured, not extrapolated:
-    one warm-up step + 2 timed steps (≈ 3 x 15 s on 32 threads).  The long form (cfg 1-4 at full batch, warm-up + repetitions) is
-    tools/cpu_baseline_full.py → profiles/rNN_cpu_baseline.json."""
+def cpu_baseline_sample(batch=2, timed=3):
+    """CPU oracle (a port of the reference's CPU path, pinned to goldens generated by the imported reference) on THIS workload
+    at THIS batch: whole training steps of the README Swin Factorizer — forward, DiceCE loss, backward, AdamW — on `batch` 128^3
+    volumes (the benchmark's per-GPU batch), measured, not extrapolated: one warm-up step + `timed` timed steps on 32 threads
+    (where ATen's CPU kernels run fastest at these sizes), then ONE more step with torch.set_num_threads(os.cpu_count()) so the
+    line itself shows what every host core gives (SURVEY.md §8d asks for that setting).  BASELINE configs[0]-[2] ride along:
+    the cfg-1 NMF forward, one FactorizerBlock forward+backward, one eval forward of the model (one warm-up + one timed each).
+    The long form is tools/cpu_baseline_full.py → profiles/rNN_cpu_baseline.json."""
     from oracle import cpu_ref as O
-    # ATen's CPU kernels stop scaling (and regress) beyond a few dozen threads on these sizes
-    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    ncpu = os.cpu_count() or 1
+    torch.set_num_threads(min(ncpu, 32))
     torch.manual_seed(0)
     model = ft.Factorizer(**{**MODEL_KW, "dropout": 0.0})
     sd = {k: v.clone() for k, v in model.state_dict().items()}
@@ -161,8 +163,8 @@ def cpu_baseline_sample():
     cfg = dict(widths=MODEL_KW["encoder_width"], strides=MODEL_KW["strides"], reshape=dict(head_dim=8, patch_size=8),
                num_iters=5, solver="hals")
     opt = torch.optim.AdamW(list(prm.values()), lr=1e-4, weight_decay=1e-5)
-    x = torch.rand(1, 4, 128, 128, 128)
-    tgt = (torch.rand(1, 3, 128, 128, 128) > 0.5).float()
+    x = torch.rand(batch, 4, 128, 128, 128)
+    tgt = (torch.rand(batch, 3, 128, 128, 128) > 0.5).float()
     # BASELINE cfg 1 (plumbing): ft.NMF((8,512), rank 2, 5 iterations, MU) forward on one matrix
     x1, u0, v0 = torch.rand(1, 8, 512), torch.rand(8, 2), torch.rand(512, 2)
     O.nmf_forward(x1, u0, v0, 5, "mu")
@@ -170,6 +172,7 @@ def cpu_baseline_sample():
     for _ in range(20):
         O.nmf_forward(x1, u0, v0, 5, "mu")
     t_cfg1 = (time.perf_counter() - t1) / 20
+
     def one_step():
         t0 = time.perf_counter()
         opt.zero_grad(set_to_none=True)
@@ -180,22 +183,57 @@ def cpu_baseline_sample():
         return time.perf_counter() - t0
 
     warm = one_step()                       # first touch of every buffer, thread-pool start-up
-    samples = sorted(one_step() for _ in range(2))
+    samples = [one_step() for _ in range(timed)]
     t = sum(samples) / len(samples)
+    threads = torch.get_num_threads()
+    # BASELINE configs[2] (eval forward of the same model) and configs[1] (one FactorizerBlock, forward + backward), same threads
+    with torch.no_grad():
+        O.factorizer_forward(x, full, cfg)
+        t0 = time.perf_counter()
+        O.factorizer_forward(x, full, cfg)
+        t_cfg3 = time.perf_counter() - t0
+    torch.manual_seed(0)
+    blk = ft.FactorizerBlock(channels=32, spatial_size=(128, 128, 128), norm=ft.LayerNorm,
+                             reshape=(ft.SWMatricize, {"head_dim": 8, "patch_size": 8}), act=nn.ReLU, factorize=ft.NMF, rank=1,
+                             num_iters=5, init="uniform", solver="hals", mlp_ratio=2, dropout=0.0)
+    bsd = {k: v.clone() for k, v in blk.state_dict().items()}
+    bprm = {k: v.requires_grad_(True) for k, v in bsd.items() if not k.endswith(("u0", "v0"))}
+    bfull = dict(bsd)
+    bfull.update(bprm)
+    bcfg = dict(reshape=dict(head_dim=8, patch_size=8), num_iters=5, solver="hals")
+    xb = torch.rand(batch, 32, 128, 128, 128, requires_grad=True)
+    gb = torch.rand(batch, 32, 128, 128, 128)
+
+    def block_fb():
+        t0 = time.perf_counter()
+        torch.autograd.grad(O.factorizer_block(xb, bfull, "", bcfg), [xb] + list(bprm.values()), gb)
+        return time.perf_counter() - t0
+    block_fb()
+    t_cfg2 = block_fb()
+    del xb, gb
+    # the same training step with every host core
+    t_all = None
+    if ncpu > threads:
+        torch.set_num_threads(ncpu)
+        one_step()
+        t_all = one_step()
+        torch.set_num_threads(threads)
     cpu_model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
             cpu_model = next(line.split(":", 1)[1].strip() for line in f if line.startswith("model name"))
     except Exception:
         pass
-    return {"value": 1.0 / t, "unit": "volumes/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": batch / t, "unit": "volumes/s", "cores": threads, "kind": "port",
             "sample": "oracle (port of the reference's CPU path): whole training steps (forward + DiceCE + backward + AdamW) of "
-                      "the README Swin Factorizer on one 128^3 volume (batch 1; the benchmark's per-GPU batch is 2): one "
-                      f"warm-up step ({warm:.1f} s) + 2 timed steps ({samples[0]:.1f}, {samples[1]:.1f} s), mean {t:.1f} s, on "
-                      f"{torch.get_num_threads()} threads of {os.cpu_count()} host CPUs ({cpu_model}); ATen's CPU kernels stop "
-                      "scaling beyond a few dozen threads at these sizes; full-batch runs: profiles/r02_cpu_baseline.json (round 2, unchanged oracle)",
-            "seconds_sample": t, "seconds_warmup": warm, "seconds_timed": samples, "cpu_model": cpu_model,
-            "cfg1_nmf_8x512_mu_r2_t5_fwd_us": round(t_cfg1 * 1e6, 1), "host_cpus": os.cpu_count()}
+                      f"the README Swin Factorizer at the benchmark's per-GPU batch ({batch} x 128^3): one warm-up step "
+                      f"({warm:.1f} s) + {timed} timed steps ({', '.join(f'{v:.1f}' for v in samples)} s), mean {t:.1f} s, on "
+                      f"{threads} threads of {ncpu} host CPUs ({cpu_model})"
+                      + (f"; the same step with torch.set_num_threads({ncpu}): {t_all:.1f} s" if t_all is not None else ""),
+            "batch": batch, "seconds_sample": t, "seconds_warmup": warm, "seconds_timed": samples, "cpu_model": cpu_model,
+            "seconds_step_all_host_threads": t_all, "host_cpus": ncpu,
+            "cfg1_nmf_8x512_mu_r2_t5_fwd_us": round(t_cfg1 * 1e6, 1),
+            "cfg2_block_fwd_bwd_seconds": round(t_cfg2, 2), "cfg3_model_eval_forward_seconds": round(t_cfg3, 2)}
 
 
 def by_stage(table, nsteps, B, stage0_cols, dtype="f32"):
@@ -514,6 +552,13 @@ def main():
                     "native_kernels_GBps": {k: round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 0) for k, v in (wagg or agg).items()},
                     "native_kernels_table_from": "warm-up steps" if wagg else "timed steps",
                     "by_stage": by_stage(wagg or agg, wsteps if wagg else max(args.steps, 1), B, B * 128 ** 3, args.dtype)}
+            # what the per-kernel table does NOT see: framework kernels (loss glue, gradient packing), copies, idle gaps of the
+            # stream — the timed step minus the summed device time of the library's launches in the instrumented steps
+            lib_ms = sum(roof["native_kernels_ms_per_step"].values())
+            roof["by_stage"]["library_kernels_ms_per_step"] = round(lib_ms, 3)
+            roof["by_stage"]["other_device_time_ms"] = round(elapsed / args.steps * 1e3 - lib_ms, 3)
+            roof["by_stage"]["other_device_time_note"] = ("ms_per_step minus the library's summed launch time: framework kernels (9 launches, "
+                                                          "0.06 ms per step; no device-to-device copy runs inside a step: profiles/r06_step_copies*.md) + gaps between launches")
         out = {
             "metric": "volumes/sec fwd+bwd, Swin Factorizer 128^3",
             "value": round(world * B * args.steps / elapsed, 4),

@@ -345,3 +345,4 @@ if __name__ == "__main__":
     g6()
     g7()
     g8()
+    g9()
