@@ -370,16 +370,18 @@ def gnmf_decompose(x, u0, v0, T, G, solver, eps=1e-16):
 # ---- fused FactMixer core on channels-first tensors ------------------------------------------
 def nmf_cf_supported(geo: Geometry, R, T, G) -> bool:
     """the 8x8x8 hot-shape kernels (csrc/nmf_cf.hip)"""
-    if len(geo.spatial) != 3 or any(s[2] % 2 for s in geo.shifts):  # odd W-axis shifts: the generic-patch kernels
+    if len(geo.spatial) != 3 or any(s[2] % 2 for s in geo.shifts):  # odd W-axis shifts, 1-D / 2-D: the generic-patch kernels
         return False
     return bool(N.lib().fz_nmf_cf_supported(geo.C, *geo.spatial, geo.d, *geo.patch, int(R), int(T), int(G)))
 
 
 def nmf_pcf_supported(geo: Geometry, R, T, G) -> bool:
-    """the generic-patch fused core (csrc/nmf_pcf.hip): head_dim 8, <= 256 voxels per patch, any shift"""
-    if len(geo.spatial) != 3 or os.environ.get("FZ_NMF_PCF", "1") == "0":
+    """the generic-patch fused core (csrc/nmf_pcf.hip): head_dim 8, <= 256 voxels per patch, any shift.  1-D and 2-D tensors
+    (operations.py:318-325 is N-D generic; the reference's own test models are 2-D) run as depth-1 (and height-1) volumes:
+    the matricized order '(b h) (g..) d (p..)' of a (1, H, W) volume with (1, ph, pw) patches is that of the 2-D tensor."""
+    if os.environ.get("FZ_NMF_PCF", "1") == "0":
         return False
-    return bool(N.lib().fz_nmf_pcf_supported(geo.C, *geo.spatial, geo.d, *geo.patch, int(R), int(T), int(G)))
+    return bool(N.lib().fz_nmf_pcf_supported(geo.C, *geo.s3, geo.d, *geo.p3, int(R), int(T), int(G)))
 
 
 def nmf_core_supported(geo: Geometry, R, T, G) -> bool:
@@ -404,7 +406,7 @@ class FactCoreFn(torch.autograd.Function):
         ad = N.act_dtype(t)
         hot = nmf_cf_supported(geo, R, T, G)      # 8x8x8 patches: csrc/nmf_cf.hip; any other patch: csrc/nmf_pcf.hip
         with _dev_guard(t):
-            for w, s in enumerate(geo.shifts):
+            for w, s in enumerate(geo.shifts3):
                 arr = (N._i * 3)(*s)
                 last = geo.nshift if w == geo.nshift - 1 else 1
                 N.set_tile_order(w & 1)       # odd windows walk the tiles backwards (_native.py: set_tile_order)
@@ -414,7 +416,7 @@ class FactCoreFn(torch.autograd.Function):
                         int(w > 0), last, R, T, N.SOLVER_ID[solver], eps, ad, N.stream_ptr(t)))
                 else:
                     rc = _timed(f"nmf_pcf_fwd_{geo.C}x" + "x".join(str(v) for v in geo.spatial), nb + (es * t.numel() if w else 0), cols=t.numel() // geo.C, fn=lambda: N.lib().fz_nmf_pcf_fwd(
-                        t.data_ptr(), u0.data_ptr(), v0.data_ptr(), out.data_ptr(), B, geo.C, *geo.spatial, *geo.patch, arr,
+                        t.data_ptr(), u0.data_ptr(), v0.data_ptr(), out.data_ptr(), B, geo.C, *geo.s3, *geo.p3, arr,
                         int(w > 0), last, R, T, N.SOLVER_ID[solver], eps, ad, N.stream_ptr(t)))
                 N.check(rc, "fz_nmf_cf_fwd" if hot else "fz_nmf_pcf_fwd")
             N.set_tile_order(0)
@@ -439,7 +441,7 @@ class FactCoreFn(torch.autograd.Function):
         ad = N.act_dtype(t)
         hot = nmf_cf_supported(geo, R, T, G)
         with _dev_guard(t):
-            for w, s in enumerate(geo.shifts):
+            for w, s in enumerate(geo.shifts3):
                 arr = (N._i * 3)(*s)
                 N.set_tile_order(w & 1)
                 if hot:
@@ -447,12 +449,12 @@ class FactCoreFn(torch.autograd.Function):
                         t.data_ptr(), u0.data_ptr(), v0.data_ptr(), ga.data_ptr(), gt.data_ptr(), B, geo.C,
                         *geo.spatial, arr, int(w > 0), geo.nshift, int(relu_gate), R, T, G, N.SOLVER_ID[solver], eps,
                         ad, N.stream_ptr(t)))
-                elif w > 0 and N.lib().fz_nmf_pcf_bwd_prefers_separate(*geo.patch, ad):
+                elif w > 0 and N.lib().fz_nmf_pcf_bwd_prefers_separate(*geo.p3, ad):
                     # the window's gradient into its own buffer, then one coalesced add (include/factorizer_hip.h)
                     tmp = torch.empty_like(gt)
                     rc = _timed(f"nmf_pcf_bwd_{geo.C}x" + "x".join(str(v) for v in geo.spatial), nb, cols=t.numel() // geo.C, fn=lambda: N.lib().fz_nmf_pcf_bwd(
                         t.data_ptr(), u0.data_ptr(), v0.data_ptr(), ga.data_ptr(), tmp.data_ptr(), B, geo.C,
-                        *geo.spatial, *geo.patch, arr, 0, geo.nshift, int(relu_gate), R, T, G, N.SOLVER_ID[solver], eps,
+                        *geo.s3, *geo.p3, arr, 0, geo.nshift, int(relu_gate), R, T, G, N.SOLVER_ID[solver], eps,
                         ad, N.stream_ptr(t)))
                     N.check(rc, "fz_nmf_pcf_bwd")
                     rc = _timed(f"window_add_{geo.C}x" + "x".join(str(v) for v in geo.spatial), nb, cols=t.numel() // geo.C, fn=lambda: N.lib().fz_act_add(
@@ -462,7 +464,7 @@ class FactCoreFn(torch.autograd.Function):
                 else:
                     rc = _timed(f"nmf_pcf_bwd_{geo.C}x" + "x".join(str(v) for v in geo.spatial), nb + (es * t.numel() if w else 0), cols=t.numel() // geo.C, fn=lambda: N.lib().fz_nmf_pcf_bwd(
                         t.data_ptr(), u0.data_ptr(), v0.data_ptr(), ga.data_ptr(), gt.data_ptr(), B, geo.C,
-                        *geo.spatial, *geo.patch, arr, int(w > 0), geo.nshift, int(relu_gate), R, T, G, N.SOLVER_ID[solver], eps,
+                        *geo.s3, *geo.p3, arr, int(w > 0), geo.nshift, int(relu_gate), R, T, G, N.SOLVER_ID[solver], eps,
                         ad, N.stream_ptr(t)))
                 N.check(rc, "fz_nmf_cf_bwd" if hot else "fz_nmf_pcf_bwd")
             N.set_tile_order(0)

@@ -568,7 +568,7 @@ def _param_sinks_ok(ctx) -> bool:
     d = _Defer
     if torch.is_grad_enabled():          # create_graph=True: the gradients are graph inputs of a double backward
         return False
-    acts = getattr(ctx, "_fz_acts", (0,))
+    acts = getattr(getattr(ctx, "_forward_cls", None), "_fz_acts", (0,))   # (a backward ctx is not an instance of the Function class)
     for i, need in enumerate(ctx.needs_input_grad):
         if not need or i in acts:
             continue
@@ -576,12 +576,18 @@ def _param_sinks_ok(ctx) -> bool:
         while fn is not None and type(fn).__name__ in _VIEW_NODES:
             fn = fn.next_functions[0][0]
         if fn is None or type(fn).__name__ != "AccumulateGrad":
+            if os.environ.get("FZ_DEFER_DEBUG"):
+                print(f"[defer] {type(ctx).__name__}: input {i} sink {type(fn).__name__}", flush=True)
             return False
         v = fn.variable
         vid = id(v)
         if vid not in d.owned or v.grad is not None or v._backward_hooks:
+            if os.environ.get("FZ_DEFER_DEBUG"):
+                print(f"[defer] {type(ctx).__name__}: input {i} {tuple(v.shape)} owned={vid in d.owned} grad={v.grad is not None} hooks={bool(v._backward_hooks)}", flush=True)
             return False
         if vid in d.seen:
+            if os.environ.get("FZ_DEFER_DEBUG"):
+                print(f"[defer] {type(ctx).__name__}: input {i} {tuple(v.shape)} already served in this backward", flush=True)
             # second use of a parameter in one graph: the engine is about to ADD this node's gradient to the first one's —
             # which must therefore be complete now
             flush_finishes()

@@ -221,7 +221,7 @@ def test_deferral_is_refused_where_autograd_reads_the_gradient_early():
         for (name, _), a, b in zip(model.named_parameters(), g_def, g_imm):
             assert torch.equal(a, b), name
         # (2) a tensor hook that reads the gradient inside the backward
-        p0 = next(p for n, p in model.named_parameters() if n.endswith("out_proj.weight") or n.endswith("fc2.weight"))
+        p0 = next(p for n, p in model.named_parameters() if n.endswith("out_proj.linear.weight"))
         got = []
         h = p0.register_hook(lambda g: got.append(g.detach().clone()))
         g_def, g_imm, queued, refused = _deferred_vs_immediate(model, opt, lambda: ft.dice_ce_loss(model(x), t).backward())

@@ -522,3 +522,65 @@ def test_empty_batch_keeps_shapes():
     yb = blk(xb)
     yb.sum().backward()
     assert yb.shape == xb.shape and xb.grad.shape == xb.shape
+
+
+# ---- the N-D generic path on 2-D and 1-D tensors (operations.py:318-325; goldens g10 from the imported reference) ----
+G10_BLOCKS = {
+    "blk2d_hals_r1": (dict(rank=1, num_iters=5, solver="hals"), 16, (16, 16), 4),
+    "blk2d_mu_r2": (dict(rank=2, num_iters=3, solver="mu"), 16, (16, 24), (4, 8)),
+    "blk2d_c32_p8": (dict(rank=1, num_iters=5, solver="hals"), 32, (32, 32), 8),
+    "blk1d_hals_r1": (dict(rank=1, num_iters=5, solver="hals"), 16, (64,), 16),
+}
+
+
+def lower_d_block(name):
+    kw, C, S, patch = G10_BLOCKS[name]
+    return ft.FactorizerBlock(channels=C, spatial_size=S, norm=ft.LayerNorm, reshape=(ft.SWMatricize, {"head_dim": 8, "patch_size": patch}),
+                              act=nn.ReLU, factorize=ft.NMF, init="uniform", mlp_ratio=2, dropout=0.0, **kw)
+
+
+def lower_d_model():
+    return ft.Factorizer(in_channels=3, out_channels=2, spatial_size=(32, 32), encoder_depth=(1, 1), encoder_width=(16, 32), strides=(1, 2),
+                         decoder_depth=(1,), norm=ft.LayerNorm, reshape=(ft.SWMatricize, {"head_dim": 8, "patch_size": 4}), act=nn.ReLU,
+                         factorize=ft.NMF, rank=1, num_iters=5, init="uniform", solver="hals", mlp_ratio=2, dropout=0.1)
+
+
+@pytest.mark.parametrize("name", sorted(G10_BLOCKS))
+def test_lower_d_block_seed_state_dict_and_values(golden, name):
+    g = golden("g10_lower_d").case(name)
+    torch.manual_seed(0)
+    blk = lower_d_block(name)
+    sd = blk.state_dict()
+    ref = {k[3:]: v for k, v in g.items() if k.startswith("sd:")}
+    assert sorted(sd) == sorted(ref)
+    for k in sd:
+        assert torch.equal(sd[k], ref[k]), k
+    x = g["x"].clone().requires_grad_(True)
+    y = blk(x)
+    assert torch.allclose(y, g["y"], rtol=1e-4, atol=1e-5)
+    names = [k for k, _ in blk.named_parameters()]
+    grads = torch.autograd.grad(y, [x] + list(blk.parameters()), g["gy"])
+    assert torch.allclose(grads[0], g["gx"], rtol=1e-3, atol=2e-4)
+    for k, gr in zip(names, grads[1:]):
+        r = g["grad:" + k]
+        assert (gr - r).abs().max().item() <= 1e-3 * (r.abs().max().item() + 1e-6), k
+
+
+def test_lower_d_model_seed_state_dict_and_values(golden):
+    g = golden("g10_lower_d").case("model2d")
+    torch.manual_seed(0)
+    model = lower_d_model().eval()
+    ref = {k[3:]: v for k, v in g.items() if k.startswith("sd:")}
+    sd = model.state_dict()
+    assert sorted(sd) == sorted(ref)
+    for k in sd:
+        assert torch.equal(sd[k], ref[k]), k
+    x = g["x"].clone().requires_grad_(True)
+    y = model(x)
+    assert torch.allclose(y, g["y"], rtol=1e-4, atol=1e-5)
+    names = [k for k, _ in model.named_parameters()]
+    grads = torch.autograd.grad(y, [x] + list(model.parameters()), g["gy"])
+    assert torch.allclose(grads[0], g["gx"], rtol=1e-3, atol=2e-4)
+    for k, gr in zip(names, grads[1:]):
+        r = g["grad:" + k]
+        assert (gr - r).abs().max().item() <= 1e-3 * (r.abs().max().item() + 1e-6), k

@@ -338,6 +338,54 @@ def g9():
     npz("g9_deconver", **arrs)
 
 
+# ---- G10: the N-D generic path on 2-D and 1-D tensors (operations.py:318-325; the reference's own tests build 2-D models) ----
+G10_BLOCKS = {
+    "blk2d_hals_r1": (dict(rank=1, num_iters=5, solver="hals"), 16, (16, 16), 4),
+    "blk2d_mu_r2": (dict(rank=2, num_iters=3, solver="mu"), 16, (16, 24), (4, 8)),
+    "blk2d_c32_p8": (dict(rank=1, num_iters=5, solver="hals"), 32, (32, 32), 8),       # 64-voxel patches, both fused-GEMM widths
+    "blk1d_hals_r1": (dict(rank=1, num_iters=5, solver="hals"), 16, (64,), 16),
+}
+
+
+def g10():
+    arrs = {}
+    for name, (kw, C, S, patch) in G10_BLOCKS.items():
+        torch.manual_seed(0)
+        blk = ft.FactorizerBlock(
+            channels=C, spatial_size=S, norm=ft.LayerNorm,
+            reshape=(ft.SWMatricize, {"head_dim": 8, "patch_size": patch}), act=nn.ReLU,
+            factorize=ft.NMF, init="uniform", mlp_ratio=2, dropout=0.0, **kw)
+        x = torch.randn(2, C, *S).requires_grad_(True)
+        y = blk(x)
+        torch.manual_seed(1)
+        gy = torch.rand_like(y)
+        grads = torch.autograd.grad(y, [x] + list(blk.parameters()), gy)
+        arrs.update({f"{name}:x": x, f"{name}:y": y, f"{name}:gy": gy, f"{name}:gx": grads[0]})
+        arrs.update(sd_arrays(blk, f"{name}:sd:"))
+        for (k, _), g in zip(blk.named_parameters(), grads[1:]):
+            arrs[f"{name}:grad:{k}"] = g
+    # a 2-D Factorizer (Conv2d stem / down / up / head from the reference's N-D generic UNet)
+    torch.manual_seed(0)
+    model = ft.Factorizer(
+        in_channels=3, out_channels=2, spatial_size=(32, 32),
+        encoder_depth=(1, 1), encoder_width=(16, 32), strides=(1, 2),
+        decoder_depth=(1,), norm=ft.LayerNorm,
+        reshape=(ft.SWMatricize, {"head_dim": 8, "patch_size": 4}), act=nn.ReLU,
+        factorize=ft.NMF, rank=1, num_iters=5, init="uniform", solver="hals",
+        mlp_ratio=2, dropout=0.1).eval()
+    x = torch.rand(2, 3, 32, 32).requires_grad_(True)
+    y = model(x)
+    torch.manual_seed(1)
+    gy = torch.rand_like(y)
+    params = dict(model.named_parameters())
+    grads = torch.autograd.grad(y, [x] + list(params.values()), gy)
+    arrs.update({"model2d:x": x, "model2d:y": y, "model2d:gy": gy, "model2d:gx": grads[0]})
+    arrs.update(sd_arrays(model, "model2d:sd:"))
+    for k, g in zip(params.keys(), grads[1:]):
+        arrs[f"model2d:grad:{k}"] = g
+    npz("g10_lower_d", **arrs)
+
+
 if __name__ == "__main__":
     g1()
     g2_g4()
@@ -346,3 +394,4 @@ if __name__ == "__main__":
     g7()
     g8()
     g9()
+    g10()
