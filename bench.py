@@ -373,8 +373,41 @@ def other_configs(dev):
         loss.backward()
         return loss
     loss = fb()
+    ms5 = gpu_ms(fb, 5, 2)
+    # one more step with every native launch bracketed by HIP events: the per-kernel table and the roofline of the dominant kernel.
+    # These launches are VALU-bound, not HBM-bound (8 x 150, HALS rank 2, 10 iterations = 119 760 flop per 4.8 KB
+    # matrix forward, 3x that backward with the in-kernel recompute): priced against the fp32 VECTOR peak — 256 CUs x 4 SIMDs x
+    # 16 lanes x 2 (packed fp32) x 2 flop x 2.4 GHz = 157.3 TFLOP/s, the same number as the fp32 matrix peak.
+    tm = Fn.KernelTimer()
+    Fn.set_timer(tm)
+    fb()
+    Fn.set_timer(None)
+    agg = tm.summary()
+    tot = sum(a["ms"] for a in agg.values())
+    M5, N5, R5, T5 = 8, 150, 2, 10
+    f_iter = 4 * M5 * N5 * R5 + 2 * (M5 + N5) * R5 * R5 + 2 * (M5 + N5) * R5 * (R5 - 1)
+    f_fwd = T5 * f_iter + 2 * M5 * N5 * R5                       # 119 760
+    roof5 = None
+    nmf_rows = {k: a for k, a in agg.items() if k.startswith(("nmf_pcf_fwd", "nmf_pcf_bwd"))}
+    if nmf_rows:
+        name, a = max(nmf_rows.items(), key=lambda kv: kv[1]["ms"])
+        C5 = int(name.split("_")[3].split("x")[0])
+        nmat = a["cols"] * C5 // 8 // N5                          # matrices per launch: batch x heads x patches
+        flop = nmat * f_fwd * (3 if "_bwd_" in name else 1)
+        avg_ms = a["ms"] / a["calls"]
+        tfl = flop / (avg_ms * 1e-3) / 1e12
+        roof5 = {"bound": "valu", "kernel": name, "achieved": round(tfl, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                 "frac": round(tfl / FP32_MFMA_PEAK_TFLOPS, 4), "avg_launch_ms": round(avg_ms, 3), "launches": a["calls"],
+                 "matrices_per_launch": nmat, "flop_per_matrix": f_fwd * (3 if "_bwd_" in name else 1),
+                 "flop_formula": "SURVEY.md 8(d): F = T*F_iter(HALS) + F_recon = 119 760 at 8x150, R 2, T 10; backward 3F",
+                 "hbm_GBps": round(a["bytes"] / a["calls"] / (avg_ms * 1e-3) / 1e9, 1),
+                 "share_of_step": round(a["ms"] / ms5, 4),
+                 "nmf_launches_ms": {k: [v["calls"], round(v["ms"], 3)] for k, v in sorted(nmf_rows.items(), key=lambda kv: -kv[1]["ms"])},
+                 "instruction_mix": "profiles/r06_cfg5.md"}
+    table5 = {k: [v["calls"], round(v["ms"], 3)] for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:14]}
     record("configs[4] BraTS-shape stress 160x192x160, HALS R2 T10, patch (5,6,5), fwd+loss+bwd", "bf16 activations (autocast), fp32 "
-           "parameters / statistics / NMF internals", 4, gpu_ms(fb, 5, 2), loss_finite=bool(torch.isfinite(loss).item()))
+           "parameters / statistics / NMF internals", 4, ms5, loss_finite=bool(torch.isfinite(loss).item()), roofline=roof5,
+           native_kernels_ms_total=round(tot, 2), top_kernels_calls_ms=table5)
     del model, x, t
     torch.cuda.empty_cache()
     return out

@@ -1571,15 +1571,57 @@ __device__ __forceinline__ void gelu_both2(const float (&x)[2], float (&g)[2], f
 // of two of the fp32 form are packed eight at a time — element e of lane half h of a 32x32x16 bf16 MFMA = step 8g + e —
 // with the weights pre-split in LDS (As1 / As2 hold bf16x8 triples instead of floats: 12 KB each instead of 8).  The two
 // weight-gradient passes keep their transposed fp32 operands (v_mfma_f32_16x16x4_f32).
-template <typename AT, int HALVES = 1, int HALF = 0, bool BX = false>
+// WGB [r6]: the two weight-gradient passes on the bf16 matrix pipe as well.  Each value that enters a voxel reduction (g2, gelu(z1),
+// x̂, gz1) is split ONCE, by the lane that holds it, into two bf16 levels (hi = rne(x), lo = rne(x - hi): 16 significand bits) and
+// parked in wave-private LDS as a hi plane and a lo plane of [channel][64 voxels] bf16 — 2 x 2 bytes per value, the fp32 footprint —
+// with the 16-byte voxel chunks of a row XOR-swizzled by (row & 7): the pair stores of the voxel-owner lanes and the 16-byte operand
+// reads of the channel-owner lanes (lane (l16, k4) = channel l16, voxels 32 ks + 8 k4 .. + 7: one ds_read_b128 per level) are both
+// conflict-free.  a·b = a_lo·b_hi + a_hi·b_lo + a_hi·b_hi on v_mfma_f32_16x16x32_bf16: 96 MFMAs of 16 cycles per tile that overlap
+// the other wave's vector work, in place of 256 exclusive v_mfma_f32_16x16x4_f32 of 32 cycles.  The accumulator layout of the
+// 16x16 tile does not depend on K: dW2 / dW1 registers, the partial rows and the finish job are unchanged.  g2's two levels are the
+// ones GEMM 1 splits anyway; the bias sums Σ_v g2, Σ_v gz1 come from the same operand registers through v_dot2c_f32_bf16.
+// Error: each product carries 2^-16 relative (the dropped a_lo·b_lo and third levels), random in sign over the >= 10^5 voxels of a
+// sum (tests/test_gpu_dense.py: against float64 next to the fp32-MFMA form).
+typedef __bf16 wg2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void wg_split2(float x0, float x1, unsigned& hi, unsigned& lo) {
+  fx2 v = {x0, x1};
+  const wg2 a = __builtin_convertvector(v, wg2);
+  v = v - __builtin_convertvector(a, fx2);
+  const wg2 b = __builtin_convertvector(v, wg2);
+  hi = __builtin_bit_cast(unsigned, a);
+  lo = __builtin_bit_cast(unsigned, b);
+}
+__device__ __forceinline__ float2 wg_join2(unsigned hi, unsigned lo) {   // the two values a (hi, lo) dword pair stands for
+  return make_float2(__uint_as_float(hi << 16) + __uint_as_float(lo << 16),
+                     __uint_as_float(hi & 0xffff0000u) + __uint_as_float(lo & 0xffff0000u));
+}
+__device__ __forceinline__ float wg_sum8(const bx8& hi, const bx8& lo, float acc) {   // acc + Σ of the 8 values of a level pair
+  const wg2 one = {(__bf16)1.0f, (__bf16)1.0f};
+  struct Q { wg2 p[4]; };
+  const Q h = __builtin_bit_cast(Q, hi), l = __builtin_bit_cast(Q, lo);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    acc = __builtin_amdgcn_fdot2_f32_bf16(l.p[i], one, acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(h.p[i], one, acc, false);
+  }
+  return acc;
+}
+__device__ __forceinline__ void wg_mfma3(f32x4& acc, const bx8& ah, const bx8& al, const bx8& bh, const bx8& bl) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
+}
+
+template <typename AT, int HALVES = 1, int HALF = 0, bool BX = false, bool WGB = false>
 __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT> p, ChainArgsT<AT> c, int ntiles, float* wpart,
                                                                    float* glp) {
+  static_assert(!WGB || (BX && HALVES == 1), "WGB: the one-launch split-bf16 form");
   constexpr int NACC = 2, HB = 2, HID = 64 * HALVES, N1 = BX ? 3072 : 16 * HB * 64;   // floats of each staged weight block
   constexpr int NTA = BxTerms<AT>::A, NTB = bx_terms_b<AT>(BXPRO_GELU);
   constexpr int half = HALF;
   constexpr int hoff = 64 * HALF;             // first hidden row of this launch
   constexpr bool last = HALF == HALVES - 1;   // this launch ends with the LayerNorm backward
-  constexpr int kWave = 48 * kTS;             // floats of one wave's (Bf | T) region
+  constexpr int kWave = WGB ? 3072 : 48 * kTS;   // floats of one wave's (Bf | T) region (WGB: hi | lo planes of 32 + 16 rows x 128 B)
   extern __shared__ __attribute__((aligned(16))) float fz_lds_cw[];
   float* As1 = fz_lds_cw;
   float* As2 = As1 + N1;
@@ -1591,6 +1633,21 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
   const int l16 = lane & 15, k4 = lane >> 4;
   float* Bf = R + wave * kWave;
   float* T = Bf + 32 * kTS;
+  // WGB planes of this wave (bytes): GH [0, 4096) g2 / x̂ hi, GL [4096, 8192) lo, TH [8192, 10240) the 16-row group hi, TL lo.
+  // element (row, voxel v) of a plane: row * 128 + (((v >> 3) ^ (row & 7)) << 4) + (v & 7) * 2
+  char* const PL = reinterpret_cast<char*>(Bf);
+  constexpr int kGL = 4096, kTH = 8192, kTL = 10240;
+  // voxel-owner stores of the pair (2j, 2j+1): rows 2s + h (operand layout) at wop[s & 3] + s * 256; rows (i & 3) + 8 (i >> 2) + 4h
+  // (accumulator layout) at wac[i & 3] + (i & 3) * 128 + (i >> 2) * 1024; channel-owner reads of block b, k-step ks at rd[ks] + b * 2048
+  unsigned wop[4], wac[4], rd[2];
+  if constexpr (WGB) {
+    const unsigned ob = (unsigned)h * 128u + ((((unsigned)j >> 2) ^ (unsigned)h) << 4) + ((unsigned)j & 3u) * 4u;
+    const unsigned ab = (unsigned)h * 512u + ((((unsigned)j >> 2) ^ (4u * (unsigned)h)) << 4) + ((unsigned)j & 3u) * 4u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { wop[q] = ob ^ ((unsigned)q << 5); wac[q] = ab ^ ((unsigned)q << 4); }
+    rd[0] = (unsigned)l16 * 128u + ((((unsigned)k4) ^ ((unsigned)l16 & 7u)) << 4);
+    rd[1] = rd[0] ^ 64u;
+  }
   const int tiles_per_sample = (int)((p.Ncol + 128 * NACC - 1) / (128 * NACC));
   chain_stagger(c.stagger);
 
@@ -1693,10 +1750,12 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
 #pragma unroll
       for (int s = 0; s < 16; ++s) { bv[s][0] = col_ok ? bv[s][0] : 0.f; bv[s][1] = col_ok ? bv[s][1] : 0.f; }
     }
-    // ---- Bf <- g2 ----
+    // ---- Bf <- g2 (WGB: the hi / lo planes are written from GEMM 1's own operand split below) ----
+    if constexpr (!WGB) {
 #pragma unroll
     for (int s = 0; s < 16; ++s)
       *reinterpret_cast<float2*>(Bf + (2 * s + h) * kTS + 2 * j) = make_float2(zs(bv[s][0]), zs(bv[s][1]));
+    }
 
     // Every global operand of the tile is requested one phase AHEAD of its use (two waves per SIMD cannot hide a
     // memory round trip per phase): z1 block g+1 during block g, x1 during the last z1 block, the residual rows before
@@ -1739,6 +1798,17 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
 #pragma unroll
           for (int e = 0; e < 8; ++e) x8[e] = bv[8 * g + e][q];
           bx_split<NTB>(x8, bop[q]);
+        }
+        if constexpr (WGB) {   // levels 0 and 1 of g2, as (voxel 2j, voxel 2j+1) pairs of channel 2s + h, into the planes
+          static_assert(!WGB || NTB >= 2, "two levels of the column operand");
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int s = 8 * g + e;
+            const wg2 ph = {bop[0][0][e], bop[1][0][e]};
+            const wg2 pl = {bop[0][NTB >= 2 ? 1 : 0][e], bop[1][NTB >= 2 ? 1 : 0][e]};
+            *reinterpret_cast<wg2*>(PL + wop[s & 3] + s * 256) = ph;
+            *reinterpret_cast<wg2*>(PL + kGL + wop[s & 3] + s * 256) = pl;
+          }
         }
 #pragma unroll
         for (int rb = 0; rb < HB; ++rb) {
@@ -1787,9 +1857,35 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
           asm volatile("" : "+v"(gz));
           acc1[rb][q][r] = gz;
         }
+        if constexpr (WGB) {
+          unsigned ph, pl;
+          wg_split2(gl[0], gl[1], ph, pl);
+          *reinterpret_cast<unsigned*>(PL + kTH + wac[i & 3] + (i & 3) * 128 + (i >> 2) * 1024) = ph;
+          *reinterpret_cast<unsigned*>(PL + kTL + wac[i & 3] + (i & 3) * 128 + (i >> 2) * 1024) = pl;
+        } else {
         const int loc = (i & 3) + 8 * (i >> 2) + 4 * h;
         *reinterpret_cast<float2*>(T + loc * kTS + 2 * j) = make_float2(zs(gl[0]), zs(gl[1]));
+        }
       }
+      if constexpr (WGB) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {   // 32 voxels per MFMA: six 16-byte operands in flight, then 6 MFMAs
+          const bx8 bh = *reinterpret_cast<const bx8*>(PL + kTH + rd[ks]);
+          const bx8 bl = *reinterpret_cast<const bx8*>(PL + kTL + rd[ks]);
+          const bx8 a0h = *reinterpret_cast<const bx8*>(PL + rd[ks]);
+          const bx8 a0l = *reinterpret_cast<const bx8*>(PL + kGL + rd[ks]);
+          const bx8 a1h = *reinterpret_cast<const bx8*>(PL + 2048 + rd[ks]);
+          const bx8 a1l = *reinterpret_cast<const bx8*>(PL + kGL + 2048 + rd[ks]);
+          wg_mfma3(dW2[0][g8], a0h, a0l, bh, bl);
+          wg_mfma3(dW2[1][g8], a1h, a1l, bh, bl);
+          if (g8 == 0) {   // db2 = Σ_v g2 from the operands of the first group
+            db2[0] = wg_sum8(a0h, a0l, db2[0]);
+            db2[1] = wg_sum8(a1h, a1l, db2[1]);
+            asm volatile("" : "+v"(db2[0]), "+v"(db2[1]));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
 #pragma unroll
       for (int tc = 0; tc < 2; ++tc) {   // 8 voxel quads at a time: 24 LDS operands in flight, then 16 MFMAs
         float bq[8], a0[8], a1[8];
@@ -1813,6 +1909,7 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
 
@@ -1824,7 +1921,12 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
     if (last && BX) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float2 gv = *reinterpret_cast<const float2*>(Bf + ((r & 3) + 8 * (r >> 2) + 4 * h) * kTS + 2 * j);
+        float2 gv;
+        if constexpr (WGB)
+          gv = wg_join2(*reinterpret_cast<const unsigned*>(PL + wac[r & 3] + (r & 3) * 128 + (r >> 2) * 1024),
+                        *reinterpret_cast<const unsigned*>(PL + kGL + wac[r & 3] + (r & 3) * 128 + (r >> 2) * 1024));
+        else
+          gv = *reinterpret_cast<const float2*>(Bf + ((r & 3) + 8 * (r >> 2) + 4 * h) * kTS + 2 * j);
         ga[r >> 3][r & 7][0] = gv.x; ga[r >> 3][r & 7][1] = gv.y;
       }
       asm volatile("" ::: "memory");   // (the reads must stay ahead of the x̂ stores below: same addresses)
@@ -1834,9 +1936,17 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-      for (int s8 = 0; s8 < 8; ++s8)
+      for (int s8 = 0; s8 < 8; ++s8) {
+        if constexpr (WGB) {
+          const int s = hf * 8 + s8;
+          unsigned ph, pl;
+          wg_split2((xv[hf][s8][0] - mu[0]) * rs[0], (xv[hf][s8][1] - mu[1]) * rs[1], ph, pl);
+          *reinterpret_cast<unsigned*>(PL + wop[s & 3] + s * 256) = ph;
+          *reinterpret_cast<unsigned*>(PL + kGL + wop[s & 3] + s * 256) = pl;
+        } else
         *reinterpret_cast<float2*>(Bf + (2 * (hf * 8 + s8) + h) * kTS + 2 * j) =
             make_float2(zs((xv[hf][s8][0] - mu[0]) * rs[0]), zs((xv[hf][s8][1] - mu[1]) * rs[1]));
+      }
 
     // ---- pass B: gz1 block -> T; S1 += gz1 ⊗ x̂, db1 += Σ gz1 ----
 #pragma unroll
@@ -1845,9 +1955,32 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int rr = g8 * 8 + i, rb = rr >> 4, r = rr & 15;
+        if constexpr (WGB) {
+          unsigned ph, pl;
+          wg_split2(acc1[rb][0][r], acc1[rb][1][r], ph, pl);
+          *reinterpret_cast<unsigned*>(PL + kTH + wac[i & 3] + (i & 3) * 128 + (i >> 2) * 1024) = ph;
+          *reinterpret_cast<unsigned*>(PL + kTL + wac[i & 3] + (i & 3) * 128 + (i >> 2) * 1024) = pl;
+        } else {
         const int loc = (i & 3) + 8 * (i >> 2) + 4 * h;
         *reinterpret_cast<float2*>(T + loc * kTS + 2 * j) = make_float2(zs(acc1[rb][0][r]), zs(acc1[rb][1][r]));
+        }
       }
+      if constexpr (WGB) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const bx8 ah = *reinterpret_cast<const bx8*>(PL + kTH + rd[ks]);
+          const bx8 al = *reinterpret_cast<const bx8*>(PL + kTL + rd[ks]);
+          const bx8 b0h = *reinterpret_cast<const bx8*>(PL + rd[ks]);
+          const bx8 b0l = *reinterpret_cast<const bx8*>(PL + kGL + rd[ks]);
+          const bx8 b1h = *reinterpret_cast<const bx8*>(PL + 2048 + rd[ks]);
+          const bx8 b1l = *reinterpret_cast<const bx8*>(PL + kGL + 2048 + rd[ks]);
+          wg_mfma3(dW1[g8][0], ah, al, b0h, b0l);
+          wg_mfma3(dW1[g8][1], ah, al, b1h, b1l);
+          db1[g8] = wg_sum8(ah, al, db1[g8]);
+          asm volatile("" : "+v"(db1[g8]));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
 #pragma unroll
       for (int tc = 0; tc < 2; ++tc) {
         float aq[8], b0[8], b1[8];
@@ -1866,6 +1999,7 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
         db1[g8] += ((aq[0] + aq[1]) + (aq[2] + aq[3])) + ((aq[4] + aq[5]) + (aq[6] + aq[7]));
         asm volatile("" : "+v"(db1[g8]));
         __builtin_amdgcn_sched_barrier(0);
+      }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1939,7 +2073,12 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
       const float gc = tB[row];
-      const float2 xh = *reinterpret_cast<const float2*>(Bf + row * kTS + 2 * j);
+      float2 xh;
+      if constexpr (WGB)
+        xh = wg_join2(*reinterpret_cast<const unsigned*>(PL + wac[r & 3] + (r & 3) * 128 + (r >> 2) * 1024),
+                      *reinterpret_cast<const unsigned*>(PL + kGL + wac[r & 3] + (r & 3) * 128 + (r >> 2) * 1024));
+      else
+        xh = *reinterpret_cast<const float2*>(Bf + row * kTS + 2 * j);
       const float a0 = acc2[0][r] * gc, a1 = acc2[1][r] * gc;
       m1[0] += a0; m1[1] += a1;
       m2[0] += a0 * xh.x; m2[1] += a1 * xh.y;
@@ -1957,7 +2096,12 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
         const int rbase = (r & 3) + 8 * (r >> 2);
         const int row = rbase + 4 * h;
         const float gc = tB[row];
-        const float2 xh = *reinterpret_cast<const float2*>(Bf + row * kTS + 2 * j);
+        float2 xh;
+        if constexpr (WGB)
+          xh = wg_join2(*reinterpret_cast<const unsigned*>(PL + wac[r & 3] + (r & 3) * 128 + (r >> 2) * 1024),
+                        *reinterpret_cast<const unsigned*>(PL + kGL + wac[r & 3] + (r & 3) * 128 + (r >> 2) * 1024));
+        else
+          xh = *reinterpret_cast<const float2*>(Bf + row * kTS + 2 * j);
         float v[NACC];
         v[0] = rs[0] * (acc2[0][r] * gc - m1[0] - xh.x * m2[0]) + ga[r8][i][0];
         v[1] = rs[1] * (acc2[1][r] * gc - m1[1] - xh.y * m2[1]) + ga[r8][i][1];
@@ -2747,6 +2891,7 @@ static int knob_res_prefetch() { return knob_pos(FZ_KNOB("FZ_RES_PREFETCH"), 1) 
 static int knob_p32() { return knob_pos(FZ_KNOB("FZ_GEMM_P32"), 1) == 1; }                // 2 = off
 static int knob_p32_wgs() { return knob_pos(FZ_KNOB("FZ_GEMM_P32_WGS"), 512); }           // resident: 2 per CU
 static int knob_head_fwd() { const auto& k = FZ_KNOB("FZ_HEAD_FWD"); return k.set ? k.val : 1; }   // 0: the head through gemm_p32
+static int knob_chain_wgb() { const auto& k = FZ_KNOB("FZ_CHAIN_WGB"); return k.set ? k.val : 1; }   // 0: fp32-MFMA weight-gradient passes
 static int knob_chain_fwd_bx() { const auto& k = FZ_KNOB("FZ_CHAIN_FWD_BX"); return k.set ? k.val : 1; }   // 0: the fp32-MFMA forward chain
 static int knob_mlp_wgs(int dflt) { return knob_pos(FZ_KNOB("FZ_MLP_WGS"), dflt); }
 
@@ -3151,9 +3296,14 @@ static int mlp_launch(const fz_mlp_desc* d, fz_stream_t stream) {
     const bool bxon = products_split(d->products);
     const int lds = (2 * (bxon ? 3072 : 2048) + 32 + 256 + 4 * 48 * kTS) * (int)sizeof(float);
     if (d->H == 64) {
-      auto kern = bxon ? gemm_chain_bwd_wg_kernel<AT, 1, 0, true> : gemm_chain_bwd_wg_kernel<AT, 1, 0, false>;
-      FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-      hipLaunchKernelGGL(kern, dim3((unsigned)rows), block, lds, st, a, c, ntiles, (float*)d->wpart, (float*)nullptr);
+      // split products: the weight-gradient passes on the bf16 pipe too (WGB, two operand levels); FZ_CHAIN_WGB=0 in a probe
+      // build keeps them on v_mfma_f32_16x16x4_f32 (same-box A/B)
+      const bool wgb = bxon && knob_chain_wgb();
+      auto kern = bxon ? (wgb ? gemm_chain_bwd_wg_kernel<AT, 1, 0, true, true> : gemm_chain_bwd_wg_kernel<AT, 1, 0, true>)
+                       : gemm_chain_bwd_wg_kernel<AT, 1, 0, false>;
+      const int lds64 = wgb ? (2 * 3072 + 32 + 256 + 4 * 3072) * (int)sizeof(float) : lds;
+      FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds64));
+      hipLaunchKernelGGL(kern, dim3((unsigned)rows), block, lds64, st, a, c, ntiles, (float*)d->wpart, (float*)nullptr);
       FZ_LAUNCH_CHECK();
       FinishJob fj = finish_job(FK_CHAIN_WG, kWgRow / 16);
       fj.u.cw = FinChainWg{(const float*)d->wpart, d->ln_g, d->ln_b, d->gw1, d->gb1, d->gw2, d->gb2, d->gln, rows, 64};
