@@ -1618,6 +1618,9 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
   static_assert(!WGB || (BX && HALVES == 1), "WGB: the one-launch split-bf16 form");
   constexpr int NACC = 2, HB = 2, HID = 64 * HALVES, N1 = BX ? 3072 : 16 * HB * 64;   // floats of each staged weight block
   constexpr int NTA = BxTerms<AT>::A, NTB = bx_terms_b<AT>(BXPRO_GELU);
+  // WGF: GEMM 2's K-groups run inside pass B and its operand split also feeds the planes (fp32 storage; the bf16-storage
+  // instantiation has no 32 registers for acc2 across pass B — 2 spilled registers — and splits gz1 a second time instead)
+  constexpr bool WGF = WGB && sizeof(AT) == 4;
   constexpr int half = HALF;
   constexpr int hoff = 64 * HALF;             // first hidden row of this launch
   constexpr bool last = HALF == HALVES - 1;   // this launch ends with the LayerNorm backward
@@ -1948,14 +1951,23 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
             make_float2(zs((xv[hf][s8][0] - mu[0]) * rs[0]), zs((xv[hf][s8][1] - mu[1]) * rs[1]));
       }
 
-    // ---- pass B: gz1 block -> T; S1 += gz1 ⊗ x̂, db1 += Σ gz1 ----
+    f32x16 acc2[NACC];
+    if constexpr (WGF) {
+#pragma unroll
+      for (int q = 0; q < NACC; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[q][r] = 0.f;
+    }
+    // ---- pass B: gz1 block -> T; S1 += gz1 ⊗ x̂, db1 += Σ gz1 (WGB: and GEMM 2's K-group of the same channels) ----
 #pragma unroll
     for (int g8 = 0; g8 < 4; ++g8) {
       asm volatile("" ::: "memory");   // as in pass A: re-read the x̂ operands per group instead of holding 32 registers
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int rr = g8 * 8 + i, rb = rr >> 4, r = rr & 15;
-        if constexpr (WGB) {
+        if constexpr (WGF) {
+          // (the two levels come from GEMM 2's own three-level split of this group, below)
+        } else if constexpr (WGB) {
           unsigned ph, pl;
           wg_split2(acc1[rb][0][r], acc1[rb][1][r], ph, pl);
           *reinterpret_cast<unsigned*>(PL + kTH + wac[i & 3] + (i & 3) * 128 + (i >> 2) * 1024) = ph;
@@ -1966,6 +1978,29 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
         }
       }
       if constexpr (WGB) {
+        // K-group g8 of GEMM 2 (gl += W1ᵀ gz1) IS this group of hidden channels: split it once, multiply, and park levels 0 / 1
+        if constexpr (WGF) {
+          bx8 aop[NTA];
+#pragma unroll
+          for (int i = 0; i < NTA; ++i)
+            aop[i] = *reinterpret_cast<const bx8*>(reinterpret_cast<const __bf16*>(As2) + ((g8 * NTA + i) * 64 + lane) * 8);
+          bx8 bop[NACC][NTB];
+#pragma unroll
+          for (int q = 0; q < NACC; ++q) {
+            float x8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x8[e] = acc1[g8 >> 1][q][8 * (g8 & 1) + e];
+            bx_split<NTB>(x8, bop[q]);
+            bx_mfma<NTA, NTB>(acc2[q], aop, bop[q]);
+          }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const wg2 ph = {bop[0][0][i], bop[1][0][i]};
+            const wg2 pl = {bop[0][1][i], bop[1][1][i]};
+            *reinterpret_cast<wg2*>(PL + kTH + wac[i & 3] + (i & 3) * 128 + (i >> 2) * 1024) = ph;
+            *reinterpret_cast<wg2*>(PL + kTL + wac[i & 3] + (i & 3) * 128 + (i >> 2) * 1024) = pl;
+          }
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           const bx8 ah = *reinterpret_cast<const bx8*>(PL + kTH + rd[ks]);
@@ -2012,8 +2047,9 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
     }
 
     // ---- GEMM 2: gl = W1ᵀ gz1 straight from the accumulators (second half: on top of the first half's part) ----
-    f32x16 acc2[NACC];
-    if (HALVES == 2 && half == 1) {
+    if constexpr (WGF) {
+      // (done inside pass B)
+    } else if (HALVES == 2 && half == 1) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float v[NACC];
@@ -2026,7 +2062,8 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[q][r] = 0.f;
     }
-    if constexpr (BX) {
+    if constexpr (WGF) {
+    } else if constexpr (BX) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {   // steps (rb, r) = (g >> 1, 8 (g & 1) + e): accumulator registers as the column operand
         bx8 aop[NTA];
@@ -2069,15 +2106,17 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
     }
     // ---- LayerNorm backward + residual gradient (x̂ from Bf in the accumulator layout, g2 re-read: L2 / MALL) ----
     float m1[NACC] = {0.f, 0.f}, m2[NACC] = {0.f, 0.f};
+    float xkeep[WGB ? 16 : 1][2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
       const float gc = tB[row];
       float2 xh;
-      if constexpr (WGB)
+      if constexpr (WGB) {   // (rebuilt from its two levels once and kept: the registers of gz1 are free by now)
         xh = wg_join2(*reinterpret_cast<const unsigned*>(PL + wac[r & 3] + (r & 3) * 128 + (r >> 2) * 1024),
                       *reinterpret_cast<const unsigned*>(PL + kGL + wac[r & 3] + (r & 3) * 128 + (r >> 2) * 1024));
-      else
+        xkeep[r][0] = xh.x; xkeep[r][1] = xh.y;
+      } else
         xh = *reinterpret_cast<const float2*>(Bf + row * kTS + 2 * j);
       const float a0 = acc2[0][r] * gc, a1 = acc2[1][r] * gc;
       m1[0] += a0; m1[1] += a1;
@@ -2090,6 +2129,7 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
     }
 #pragma unroll
     for (int r8 = 0; r8 < 2; ++r8) {
+      float sgv[8], sbv[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int r = r8 * 8 + i;
@@ -2098,8 +2138,7 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
         const float gc = tB[row];
         float2 xh;
         if constexpr (WGB)
-          xh = wg_join2(*reinterpret_cast<const unsigned*>(PL + wac[r & 3] + (r & 3) * 128 + (r >> 2) * 1024),
-                        *reinterpret_cast<const unsigned*>(PL + kGL + wac[r & 3] + (r & 3) * 128 + (r >> 2) * 1024));
+          xh = make_float2(xkeep[r][0], xkeep[r][1]);
         else
           xh = *reinterpret_cast<const float2*>(Bf + row * kTS + 2 * j);
         float v[NACC];
@@ -2110,13 +2149,27 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bwd_wg_kernel(GemmArgsT<AT>
         float sb = acc2[0][r] + acc2[1][r];
         sg = zs(sg);
         sb = zs(sb);
+        if constexpr (WGF) {   // the eight rows of the block are reduced together below (multi-value butterfly: 19 operations for
+          sgv[i] = sg;         // sixteen half-wave sums instead of 5 per sum; fp32 storage: the bf16 instantiation spills with it)
+          sbv[i] = sb;
+        } else {
         sg = half_sum32(sg);
         sb = half_sum32(sb);
         if ((lane & 31) == 31) {
           red[wave * 64 + row] = sg;
           red[wave * 64 + 32 + row] = sb;
         }
+        }
         __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (WGF) {
+        const float tg = half_sum8_dist(sgv, lane), tb = half_sum8_dist(sbv, lane);   // 4-lane group i of a half holds row i's total
+        const int gi = (lane >> 2) & 7, rr = r8 * 8 + gi;
+        if ((lane & 3) == 0) {
+          const int rw = (rr & 3) + 8 * (rr >> 2) + 4 * h;
+          red[wave * 64 + rw] = tg;
+          red[wave * 64 + 32 + rw] = tb;
+        }
       }
     }
     __syncthreads();

@@ -182,15 +182,34 @@ template <typename AT>
 int cf_bwd_gram_launch(const AT* t, const float* v0, const AT* ga, AT* gt, const CfGeom& q, int64_t nmat, int T, int G,
                        float eps, int xcd_remap, hipStream_t st) {
   const bool half = (q.s2 % 4) != 0;
+#ifdef FZ_PROBE_GRAM_WPB   // timing probe (tools/probes/gram_tile.sh): FZ_PROBE_GRAM_WPB patches along W per workgroup instead of 4
+  const int twpb = (q.G2 % FZ_PROBE_GRAM_WPB) == 0 ? FZ_PROBE_GRAM_WPB : ((q.G2 % 4) == 0 ? 4 : 1);
+#else
   const int twpb = (q.G2 % 4) == 0 ? 4 : 1;
+#endif
   constexpr bool kF32 = sizeof(AT) == 4;
+#ifdef FZ_PROBE_GRAM_WPB
+  const int stage = twpb == FZ_PROBE_GRAM_WPB ? CfTile<FZ_PROBE_GRAM_WPB>::STAGE_FLOATS : (twpb == 4 ? CfTile<4>::STAGE_FLOATS : CfTile<1>::STAGE_FLOATS);
+#else
   const int stage = twpb == 4 ? CfTile<4>::STAGE_FLOATS : CfTile<1>::STAGE_FLOATS;
+#endif
   const int glds = (stage + twpb * gram_hist_floats(G - 1)) * (int)sizeof(float);
+#ifndef FZ_PROBE_GRAM_WPB
   if (glds > 64 * 1024) return FZ_E_UNSUPPORTED;
+#endif
   const unsigned nblk = (unsigned)(nmat / twpb);
 #define FZ_CF_BWD_GRAM(WW, HH, MM) \
   hipLaunchKernelGGL((nmf_cf_bwd_gram_kernel<WW, HH, AT, MM>), dim3(nblk), dim3(64 * WW), glds, st, t, v0, ga, gt, q, T, G, eps, xcd_remap)
   constexpr int kRegMode = kF32 ? CFG_HALVES : CFG_RAW;
+#ifdef FZ_PROBE_GRAM_WPB
+  if (!half && twpb == FZ_PROBE_GRAM_WPB) {
+    auto kern = nmf_cf_bwd_gram_kernel<FZ_PROBE_GRAM_WPB, false, AT, kRegMode>;
+    if (glds > 64 * 1024) FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, glds));
+    FZ_CF_BWD_GRAM(FZ_PROBE_GRAM_WPB, false, kRegMode);
+    FZ_LAUNCH_CHECK();
+    return FZ_OK;
+  }
+#endif
   if (half) { if (twpb == 4) FZ_CF_BWD_GRAM(4, true, kRegMode); else FZ_CF_BWD_GRAM(1, true, kRegMode); }
   else if (twpb == 4) FZ_CF_BWD_GRAM(4, false, kRegMode);
   else return FZ_E_UNSUPPORTED;
