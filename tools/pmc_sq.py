@@ -29,7 +29,12 @@ def main():
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for path in sys.argv[2:]:
         for r in csv.DictReader(open(path)):
-            name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").strip()
+            name = r["Kernel_Name"]
+            if name.startswith("_ZN2fz"):      # names with bf16 template arguments stay mangled in rocprofv3's output
+                m = re.match(r"_ZN2fz(\d+)", name)
+                name = "fz::" + name[m.end():m.end() + int(m.group(1))] + "<" + name[m.end() + int(m.group(1)):][:40] + ">"
+            else:
+                name = re.sub(r"\(.*", "", name).replace("void ", "").strip()
             if not name.startswith("fz::"):
                 continue
             agg[name][(int(r["Grid_Size"]), r["Counter_Name"])].append(float(r["Counter_Value"]))

@@ -12,10 +12,17 @@ def main():
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for path in sys.argv[1:]:
         for r in csv.DictReader(open(path)):
-            name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").strip()
+            name = r["Kernel_Name"]
+            if name.startswith("_ZN2fz"):      # rocprofv3 leaves names with bf16 template arguments mangled: _ZN2fz<len><name>I...
+                m = re.match(r"_ZN2fz(\d+)", name)
+                n = int(m.group(1))
+                name = "fz::" + name[m.end():m.end() + n] + ("<bf16 storage>" if "DF16b" in name else "")
+            else:
+                name = re.sub(r"\(.*", "", name).replace("void ", "").strip()
+                name = re.sub(r"<.*", "", name)
             if not name.startswith("fz::"):
                 continue
-            agg[re.sub(r"<.*", "", name)][(int(r["Grid_Size"]), r["Counter_Name"])].append(float(r["Counter_Value"]))
+            agg[name][(int(r["Grid_Size"]), r["Counter_Name"])].append(float(r["Counter_Value"]))
     print("| kernel (largest grid) | waves' VALU instr | FMA f32 | MUL f32 | ADD f32 | TRANS | INT32 | CVT | other (mov / select / cmp / bits / dpp) | FMA share |")
     print("|---|---|---|---|---|---|---|---|---|---|")
     rows = []
