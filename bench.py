@@ -143,13 +143,15 @@ MODEL_KW = dict(in_channels=4, out_channels=3, spatial_size=(128, 128, 128),
                 dropout=0.1)
 
 
-def cpu_baseline_sample(batch=2, timed=3):
+def cpu_baseline_sample(batch=2, timed=3, all_threads=False):
     """CPU oracle (a port of the reference's CPU path, pinned to goldens generated by the imported reference) on THIS workload
     at THIS batch: whole training steps of the README Swin Factorizer — forward, DiceCE loss, backward, AdamW — on `batch` 128^3
     volumes (the benchmark's per-GPU batch), measured, not extrapolated: one warm-up step + `timed` timed steps on 32 threads
-    (where ATen's CPU kernels run fastest at these sizes), then ONE more step with torch.set_num_threads(os.cpu_count()) so the
-    line itself shows what every host core gives (SURVEY.md §8d asks for that setting).  BASELINE configs[0]-[2] ride along:
-    the cfg-1 NMF forward, one FactorizerBlock forward+backward, one eval forward of the model (one warm-up + one timed each).
+    (where ATen's CPU kernels run fastest at these sizes).  SURVEY.md §8d asks for torch.set_num_threads(os.cpu_count()): measured
+    once in round 6 on the 256-thread host of the pool — 379.5 s per step against 34.4 s on 32 threads, 11 x SLOWER
+    (profiles/r06_bench_default_with_all_threads_cpu_step.json) — so the default run keeps 32 threads and `--cpu-all-threads` adds
+    that step (two more steps, ~13 minutes) for whoever wants it in the line.  BASELINE configs[0]-[2] ride along: the cfg-1 NMF
+    forward, one FactorizerBlock forward+backward, one eval forward of the model (one timed run each, after the steps above).
     The long form is tools/cpu_baseline_full.py → profiles/rNN_cpu_baseline.json."""
     from oracle import cpu_ref as O
     ncpu = os.cpu_count() or 1
@@ -188,7 +190,6 @@ def cpu_baseline_sample(batch=2, timed=3):
     threads = torch.get_num_threads()
     # BASELINE configs[2] (eval forward of the same model) and configs[1] (one FactorizerBlock, forward + backward), same threads
     with torch.no_grad():
-        O.factorizer_forward(x, full, cfg)
         t0 = time.perf_counter()
         O.factorizer_forward(x, full, cfg)
         t_cfg3 = time.perf_counter() - t0
@@ -208,12 +209,11 @@ def cpu_baseline_sample(batch=2, timed=3):
         t0 = time.perf_counter()
         torch.autograd.grad(O.factorizer_block(xb, bfull, "", bcfg), [xb] + list(bprm.values()), gb)
         return time.perf_counter() - t0
-    block_fb()
     t_cfg2 = block_fb()
     del xb, gb
     # the same training step with every host core
     t_all = None
-    if ncpu > threads:
+    if all_threads and ncpu > threads:
         torch.set_num_threads(ncpu)
         one_step()
         t_all = one_step()
@@ -229,7 +229,9 @@ def cpu_baseline_sample(batch=2, timed=3):
                       f"the README Swin Factorizer at the benchmark's per-GPU batch ({batch} x 128^3): one warm-up step "
                       f"({warm:.1f} s) + {timed} timed steps ({', '.join(f'{v:.1f}' for v in samples)} s), mean {t:.1f} s, on "
                       f"{threads} threads of {ncpu} host CPUs ({cpu_model})"
-                      + (f"; the same step with torch.set_num_threads({ncpu}): {t_all:.1f} s" if t_all is not None else ""),
+                      + (f"; the same step with torch.set_num_threads({ncpu}): {t_all:.1f} s" if t_all is not None else
+                         f"; with torch.set_num_threads({ncpu}) the step takes 11 x longer on this host type (379.5 s, measured once: "
+                         "profiles/r06_bench_default_with_all_threads_cpu_step.json; --cpu-all-threads repeats it)"),
             "batch": batch, "seconds_sample": t, "seconds_warmup": warm, "seconds_timed": samples, "cpu_model": cpu_model,
             "seconds_step_all_host_threads": t_all, "host_cpus": ncpu,
             "cfg1_nmf_8x512_mu_r2_t5_fwd_us": round(t_cfg1 * 1e6, 1),
@@ -420,6 +422,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch-per-gpu", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-all-threads", action="store_true",
+                    help="cpu_baseline: also time the training step with torch.set_num_threads(os.cpu_count()) (minutes on a 256-thread host)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the BASELINE configs[1], [2], [4] timings appended to the JSON line as `other_configs`")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
@@ -500,6 +504,7 @@ def main():
     # event records per launch cost ~1 us of stream time each; ~940 of them are ~4 % of a step).
     wtimer = Fn.KernelTimer()
     wsteps = 0
+    wstep_events = []   # (start, end) of each fully instrumented step on the launch stream: its device time incl. everything the table does not see
     for i in range(args.warmup):
         # the very first step pays one-time costs (code-object loading, first-touch allocations): it is
         # left out of the per-kernel table when there is a second warm-up step to take its place
@@ -507,7 +512,11 @@ def main():
             step()
             continue
         Fn.set_timer(wtimer)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
         step()
+        ev1.record()
+        wstep_events.append((ev0, ev1))
         wsteps += 1
     Fn.set_timer(None)
     wagg = wtimer.summary() if wsteps > 0 else {}
@@ -589,9 +598,15 @@ def main():
             # stream — the timed step minus the summed device time of the library's launches in the instrumented steps
             lib_ms = sum(roof["native_kernels_ms_per_step"].values())
             roof["by_stage"]["library_kernels_ms_per_step"] = round(lib_ms, 3)
-            roof["by_stage"]["other_device_time_ms"] = round(elapsed / args.steps * 1e3 - lib_ms, 3)
-            roof["by_stage"]["other_device_time_note"] = ("ms_per_step minus the library's summed launch time: framework kernels (9 launches, "
-                                                          "0.06 ms per step; no device-to-device copy runs inside a step: profiles/r06_step_copies*.md) + gaps between launches")
+            if wstep_events:
+                inst_ms = sum(a.elapsed_time(b) for a, b in wstep_events) / len(wstep_events)
+                roof["by_stage"]["instrumented_step_ms"] = round(inst_ms, 3)
+                roof["by_stage"]["other_device_time_ms"] = round(inst_ms - lib_ms, 3)
+                roof["by_stage"]["other_device_time_note"] = (
+                    "device time of the fully instrumented warm-up steps (every launch bracketed by events: ~0.7 ms slower than a timed step) "
+                    "minus the library's summed launch time: framework kernels (8 launches, 0.05 ms per step — dropout and position "
+                    "embedding of the bottleneck, loss glue, gradient packing; NO device-to-device copy runs inside a step: "
+                    "profiles/r06_step_copies.md) + the event records themselves + gaps between launches")
         out = {
             "metric": "volumes/sec fwd+bwd, Swin Factorizer 128^3",
             "value": round(world * B * args.steps / elapsed, 4),
@@ -625,7 +640,7 @@ def main():
             del model, opt, sync, x, target
             out["other_configs"] = other_configs(dev)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_sample()
+            out["cpu_baseline"] = cpu_baseline_sample(batch=B, all_threads=args.cpu_all_threads)
         if json_fd is not None:
             os.write(json_fd, (json.dumps(out) + "\n").encode())
         else:
