@@ -148,7 +148,10 @@ class ProjectedGradient(BCDSolver):
 
 class FastMultiplicativeUpdate(BCDSolver):
     """The multiplicative update written as three-operand contractions, with an explicit V half-step
-    (matrix_factorization.py:250-274).  Algebraically the "mu" update; it differs in rounding only."""
+    (matrix_factorization.py:250-274).  Algebraically the "mu" update — num = u ∘ (X V) + eps, den = u (VᵀV) + eps, and the
+    same with the roles swapped — it differs in rounding only: on device it runs the native MU kernels (pinned against the
+    reference's own fmu outputs, goldens g8, at the 1e-4 bound)."""
+    native_id = "mu"
 
     def __init__(self, factor=(0, 1), eps: float = 1e-16, **kwargs):
         super().__init__(factor=factor)
@@ -167,7 +170,9 @@ class FastMultiplicativeUpdate(BCDSolver):
 
 class WeightedMultiplicativeUpdate(BCDSolver):
     """Multiplicative update of min ||W ∘ (X - U V^T)||^2, U, V >= 0 (matrix_factorization.py:277-316);
-    `forward(x, (u, v), w=None)` — unit weights when `w` is omitted."""
+    `forward(x, (u, v), w=None)` — unit weights when `w` is omitted, and then it IS the "mu" update (num = u ∘ (X V) + eps,
+    den = (U Vᵀ) V + eps): `MatrixFactorization` runs the native MU kernels for it when no weights are passed."""
+    native_id = "mu"
 
     def __init__(self, factor=(0, 1), eps: float = 1e-16, **kwargs):
         super().__init__(factor=factor)
@@ -443,7 +448,7 @@ class MatrixFactorization(nn.Module):
     # -- API --------------------------------------------------------------------------
     def decompose(self, x: Tensor, *args, **kwargs):
         x = x.as_subclass(Tensor)
-        sid = self._native_solver(x)
+        sid = self._native_solver(x) if not args and not kwargs else None   # (extra solver arguments — wmu's weights — : composed)
         if sid is not None:
             fn = Fn.gnmf_decompose if self._wide else Fn.nmf_decompose
             return fn(x, self.init.u0, self.init.v0, self.num_iters,

@@ -1360,15 +1360,15 @@ class FactorizerBlockFn(torch.autograd.Function):
         pending = []   # single stream: the block's weight-gradient problems go out as ONE grid at the end (fz_wgrad_group)
 
         def wgrad(*args, **kw):
+            if _WGRAD_GROUP:   # (with a side stream too [r6]: the ONE grouped launch goes there, at the end of the block)
+                kw.pop("name", None)
+                pending.append((args[0], args[1], args[2], kw))   # (keeps gz1 alive until the launch)
+                return args[2]
             if side is None:
-                if _WGRAD_GROUP:
-                    kw.pop("name", None)
-                    pending.append((args[0], args[1], args[2], kw))   # (keeps gz1 alive until the launch)
-                    return args[2]
                 return _wgrad(*args, **kw)
             side.wait_stream(cur)
             keep.extend(t for t in (args[0], *args[1], kw.get("stats")) if t is not None)
-            with torch.cuda.stream(side), _no_defer():   # (a queue of deferred finishes belongs to ONE stream)
+            with torch.cuda.stream(side):   # (deferred finishes queue per stream since round 6: csrc/finish.hip)
                 return _wgrad(*args, **kw)
 
         # --- MLP ---
@@ -1426,7 +1426,16 @@ class FactorizerBlockFn(torch.autograd.Function):
             gwi = _GB.out_like(win2)
             wgrad(gt, [x], gwi, B=B, M=C, Cin=C, K=C, Vq=V, Ncols=V, stats=st1, ln=(n1w, n1b), name="wgrad_ln_linear")
         if pending:
-            _wgrad_group(pending, f"wgrad_block_{C}x{Hd}")
+            if side is None:
+                _wgrad_group(pending, f"wgrad_block_{C}x{Hd}")
+            else:
+                # the block's four weight gradients as one grid on the second stream: nothing in the backward reads them, and a
+                # launch of 64-512 workgroups of a deep stage leaves most of the chip to the next block's kernels on the main stream
+                side.wait_stream(cur)
+                for pr in pending:
+                    keep.extend(t for t in (pr[0], *pr[1], pr[3].get("stats"), pr[3].get("pmul")) if t is not None)
+                with torch.cuda.stream(side):
+                    _wgrad_group(pending, f"wgrad_block_{C}x{Hd}")
             pending.clear()
         if side is not None:
             if _LateJoin.enabled:

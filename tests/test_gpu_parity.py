@@ -735,3 +735,49 @@ def test_late_wgrad_join_refuses_copied_gradients(monkeypatch):
         PW._LateJoin.owed.clear()
         PW.late_wgrad_join(False)
         torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("name,kw", [("fmu", dict(solver="fmu", init="uniform")), ("mu_0", dict(solver="mu-0", init="uniform"))])
+def test_solver_keys_that_are_the_mu_update_run_native(golden, name, kw):
+    """`fmu` (matrix_factorization.py:250-274) is the multiplicative update written as three-operand contractions: the same
+    function, different rounding — on device it runs the native MU kernels and must reproduce the REFERENCE's own fmu outputs
+    (goldens g8: u, v, y, dL/dx).  `mu-0` (U half-steps only) is outside the native kernels' U-then-V alternation: composed, warned."""
+    g = golden("g8_solvers").case(name)
+    torch.manual_seed(0)
+    mf = ft.MatrixFactorization(size=(8, 24), rank=2, num_iters=3, **kw).to(DEV)
+    x = g["x"].to(DEV).requires_grad_(True)
+    if name == "fmu":
+        with Launches():
+            u, v = mf.decompose(x)
+            y = mf(x)
+            (gx,) = torch.autograd.grad(y, x, g["gy"].to(DEV))
+    else:
+        n0 = _native.launch_count()
+        u, v = mf.decompose(x)
+        y = mf(x)
+        (gx,) = torch.autograd.grad(y, x, g["gy"].to(DEV))
+        assert _native.launch_count() == n0      # composed ATen on device (the native kernels alternate U then V)
+    P.close("u", u, g["u"])
+    P.close("v", v, g["v"])
+    P.close("y", y, g["y"])
+    P.close("gx", gx, g["gx"])
+
+
+def test_wmu_without_weights_runs_native_and_equals_mu():
+    """wmu with no weights passed is the mu update (matrix_factorization.py:277-316 with w = 1): native kernels, same values as
+    solver="mu" bit for bit; with weights it stays composed (goldens g8 "wmu" on CPU)."""
+    torch.manual_seed(0)
+    a = ft.NMF(size=(8, 64), rank=2, num_iters=4, init="uniform", solver="wmu").to(DEV)
+    b = ft.NMF(size=(8, 64), rank=2, num_iters=4, init="uniform", solver="mu").to(DEV)
+    b.load_state_dict(a.state_dict())
+    x = torch.rand(5, 8, 64, device=DEV)
+    with Launches():
+        ya = a(x)
+    assert torch.equal(ya, b(x))
+    w = torch.rand(5, 8, 64, device=DEV)
+    u, v = a.decompose(x, w)          # weights: the composed path (same ops on CPU give the reference's values: goldens g8 "wmu")
+    ac = ft.NMF(size=(8, 64), rank=2, num_iters=4, init="uniform", solver="wmu")
+    ac.load_state_dict({k: t.cpu() for k, t in a.state_dict().items()})
+    uc, vc = ac.decompose(x.cpu(), w.cpu())
+    P.close("u (weighted, composed on device)", u, uc)
+    P.close("v (weighted, composed on device)", v, vc)
