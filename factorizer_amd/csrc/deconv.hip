@@ -223,6 +223,174 @@ __global__ __launch_bounds__(256) void gcorr_wgrad_kernel(GcwArgs a) {
   }
 }
 
+// ---- the same two operators for ANY odd kernel extent <= 7 per axis and ANY channel count per group [r6] ------------------
+// The templates above cover the reference's defaults (cubic / square 3-5-7, <= 16 channels per group); the reference's own test
+// suite also builds anisotropic kernels — kernel_size=(5, 3, 3) in tests/test_deconver.py — and `Deconv` allows any channel
+// count.  Those used to fall back to framework convolutions on device; they now run here: kernel extents are run-time values
+// (tap loops with compile-time bounds of 7 and a run-time guard, so every register array keeps compile-time indices — no
+// scratch), the output channels of a group go eight at a time (grid.y = groups x blocks of 8).  Same tile, same halo staging,
+// same deterministic two-stage reduction; a fallback in speed (half the register blocking, guards in the tap loops), not in
+// kind.
+constexpr int kAnyCO = 8, kAnyK = 7;
+
+__global__ __launch_bounds__(256) void gcorr_any_kernel(GcArgs a, int KD, int KH, int KW, int nob) {
+  const int PD = KD / 2, PH = KH / 2, PW = KW / 2;
+  const int LD = kTD + 2 * PD, LH = kTH + 2 * PH, LW = kTW + 2 * PW;
+  const int LWS = LW + 1;
+  extern __shared__ __attribute__((aligned(16))) float fz_lds_gca[];
+  float* tile = fz_lds_gca;
+  const int tid = threadIdx.x;
+  const int tw = tid & 15, th = (tid >> 4) & 3, td = tid >> 6;
+  int bid = blockIdx.x;
+  const int twi = bid % a.tiles_w; bid /= a.tiles_w;
+  const int thi = bid % a.tiles_h; bid /= a.tiles_h;
+  const int tiles_d = (a.D + kTD - 1) / kTD;
+  const int tdi = bid % tiles_d;
+  const int g = blockIdx.y / nob, o0 = (blockIdx.y % nob) * kAnyCO, b = blockIdx.z;
+  const int d0 = tdi * kTD, h0 = thi * kTH, w0 = twi * kTW;
+  const int64_t V = (int64_t)a.D * a.H * a.W;
+  const int K3 = KD * KH * KW;
+  const float* inb = a.in + ((int64_t)b * a.G + g) * a.Ci * V;
+  const float* wg = a.w + (((int64_t)(a.w_batched ? b : 0) * a.G + g) * a.Co) * a.Ci * K3;
+
+  float acc[kAnyCO][4];
+#pragma unroll
+  for (int o = 0; o < kAnyCO; ++o)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[o][e] = 0.f;
+
+  for (int ci = 0; ci < a.Ci; ++ci) {
+    __syncthreads();
+    const float* inc = inb + (int64_t)ci * V;
+    for (int idx = tid; idx < LD * LH * LW; idx += 256) {
+      const int lw = idx % LW, lh = (idx / LW) % LH, ld = idx / (LW * LH);
+      const int zd = d0 + ld - PD, zh = h0 + lh - PH, zw = w0 + lw - PW;
+      const bool ok = zd >= 0 && zd < a.D && zh >= 0 && zh < a.H && zw >= 0 && zw < a.W;
+      tile[(ld * LH + lh) * LWS + lw] = ok ? inc[((int64_t)zd * a.H + zh) * a.W + zw] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int kd = 0; kd < KD; ++kd)
+#pragma unroll 1
+      for (int kh = 0; kh < KH; ++kh) {
+        float row[4 + kAnyK - 1];
+        const float* rp = tile + ((td + kd) * LH + (th + kh)) * LWS + tw * 4;
+#pragma unroll
+        for (int e = 0; e < 4 + kAnyK - 1; ++e) row[e] = e < 4 + KW - 1 ? rp[e] : 0.f;
+#pragma unroll
+        for (int o = 0; o < kAnyCO; ++o) {
+          if (o0 + o < a.Co) {
+            const float* wp = wg + ((int64_t)(o0 + o) * a.Ci + ci) * K3 + (kd * KH + kh) * KW;   // uniform
+#pragma unroll
+            for (int kw = 0; kw < kAnyK; ++kw) {
+              if (kw < KW) {
+                const float wv = wp[kw];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[o][e] = acc[o][e] + row[e + kw] * wv;
+              }
+            }
+          }
+        }
+      }
+  }
+  const int zd = d0 + td, zh = h0 + th, zw = w0 + tw * 4;
+  if (zd >= a.D || zh >= a.H) return;
+  const int64_t vo = ((int64_t)zd * a.H + zh) * a.W + zw;
+#pragma unroll
+  for (int o = 0; o < kAnyCO; ++o) {
+    if (o0 + o >= a.Co) continue;
+    const int64_t base = (((int64_t)b * a.G + g) * a.Co + o0 + o) * V + vo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (zw + e >= a.W) continue;
+      float r = acc[o][e] + a.add_eps;
+      if (a.epilogue == 1) r = a.mul_a[base + e] * a.mul_b[base + e] / r;
+      a.out[base + e] = r;
+    }
+  }
+}
+
+// filter gradient, run-time extents: a work item is one (o, kd, kh) filter row of the block's eight output channels x one slice
+// of the tile's voxel quads; the per-item KW sums sit in registers (seven, guarded), slices are added through LDS in slice order,
+// tiles in LDS as well (`tot`: one float per (row, kw), owned by one thread — an LDS array because its length is a run-time value)
+__global__ __launch_bounds__(256) void gcorr_wgrad_any_kernel(GcwArgs a, int KD, int KH, int KW, int nob, int S) {
+  const int PD = KD / 2, PH = KH / 2, PW = KW / 2;
+  const int LD = kTD + 2 * PD, LH = kTH + 2 * PH, LW = kTW + 2 * PW;
+  const int LWS = LW + 1;
+  const int P = kAnyCO * KD * KH;                      // filter rows of the block
+  const int NR = P * KW;
+  constexpr int NQ = kTD * kTH * kTW / 4;
+  extern __shared__ __attribute__((aligned(16))) float fz_lds_gcwa[];
+  float* go = fz_lds_gcwa;                              // [8][kGoStride]
+  float* tile = go + kAnyCO * kGoStride;                // [LD][LH][LWS]
+  float* red = tile + LD * LH * LWS;                    // [S][NR]
+  float* tot = red + S * NR;                            // [NR]
+  const int tid = threadIdx.x;
+  const int chunk = blockIdx.x;
+  const int gi = blockIdx.y / nob, o0 = (blockIdx.y % nob) * kAnyCO;
+  const int g = gi / a.Ci, ci = gi % a.Ci, b = blockIdx.z;
+  const int64_t V = (int64_t)a.D * a.H * a.W;
+  const float* inc = a.in + (((int64_t)b * a.G + g) * a.Ci + ci) * V;
+  const float* gob = a.gout + (((int64_t)b * a.G + g) * a.Co + o0) * V;
+  const int ntiles = a.tiles_d * a.tiles_h * a.tiles_w;
+  for (int r = tid; r < NR; r += 256) tot[r] = 0.f;
+
+  const int t_lo = chunk * a.tiles_per_chunk;
+  const int t_hi = min(ntiles, t_lo + a.tiles_per_chunk);
+  for (int t = t_lo; t < t_hi; ++t) {
+    const int twi = t % a.tiles_w, thi = (t / a.tiles_w) % a.tiles_h, tdi = t / (a.tiles_w * a.tiles_h);
+    const int d0 = tdi * kTD, h0 = thi * kTH, w0 = twi * kTW;
+    __syncthreads();
+    for (int idx = tid; idx < kAnyCO * kTD * kTH * kTW; idx += 256) {
+      const int lw = idx % kTW, lh = (idx / kTW) % kTH, ld = (idx / (kTW * kTH)) % kTD, o = idx / (kTW * kTH * kTD);
+      const int zd = d0 + ld, zh = h0 + lh, zw = w0 + lw;
+      const bool ok = o0 + o < a.Co && zd < a.D && zh < a.H && zw < a.W;
+      go[o * kGoStride + (ld * kTH + lh) * kTW + lw] = ok ? gob[(int64_t)o * V + ((int64_t)zd * a.H + zh) * a.W + zw] : 0.f;
+    }
+    for (int idx = tid; idx < LD * LH * LW; idx += 256) {
+      const int lw = idx % LW, lh = (idx / LW) % LH, ld = idx / (LW * LH);
+      const int zd = d0 + ld - PD, zh = h0 + lh - PH, zw = w0 + lw - PW;
+      const bool ok = zd >= 0 && zd < a.D && zh >= 0 && zh < a.H && zw >= 0 && zw < a.W;
+      tile[(ld * LH + lh) * LWS + lw] = ok ? inc[((int64_t)zd * a.H + zh) * a.W + zw] : 0.f;
+    }
+    __syncthreads();
+    for (int item = tid; item < P * S; item += 256) {
+      const int pr = item / S, sl = item % S;
+      const int kh = pr % KH, kd = (pr / KH) % KD, o = pr / (KH * KD);
+      float acc[kAnyK];
+#pragma unroll
+      for (int kw = 0; kw < kAnyK; ++kw) acc[kw] = 0.f;
+      for (int q = sl; q < NQ; q += S) {
+        const int tw = q % (kTW / 4), th = (q / (kTW / 4)) % kTH, td = q / (kTW / 4 * kTH);
+        const float4 g4 = *reinterpret_cast<const float4*>(go + o * kGoStride + q * 4);
+        const float* rp = tile + ((td + kd) * LH + (th + kh)) * LWS + tw * 4;
+        float row[4 + kAnyK - 1];
+#pragma unroll
+        for (int e = 0; e < 4 + kAnyK - 1; ++e) row[e] = e < 4 + KW - 1 ? rp[e] : 0.f;
+#pragma unroll
+        for (int kw = 0; kw < kAnyK; ++kw)
+          acc[kw] = acc[kw] + g4.x * row[kw] + g4.y * row[kw + 1] + g4.z * row[kw + 2] + g4.w * row[kw + 3];
+      }
+#pragma unroll
+      for (int kw = 0; kw < kAnyK; ++kw)
+        if (kw < KW) red[sl * NR + pr * KW + kw] = acc[kw];
+    }
+    __syncthreads();
+    for (int r = tid; r < NR; r += 256) {
+      float v = 0.f;
+      for (int sl = 0; sl < S; ++sl) v += red[sl * NR + r];
+      tot[r] += v;
+    }
+  }
+  __syncthreads();
+  const int K3 = KD * KH * KW;
+  float* pp = a.part + (((int64_t)b * a.G + g) * a.nchunks + chunk) * a.Co * a.Ci * K3;
+  for (int r = tid; r < NR; r += 256) {
+    const int o = r / K3, tau = r % K3;
+    if (o0 + o < a.Co) pp[((int64_t)(o0 + o) * a.Ci + ci) * K3 + tau] = tot[r];
+  }
+}
+
 // gw[bw, g, e] = Σ_{b ∈ samples of bw} Σ_chunk part[b, g, chunk, e], ascending b then chunk
 __global__ void gcorr_wgrad_finish_kernel(const float* part, float* gw, int B, int G, int nchunks, int E, int w_batched) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -239,11 +407,16 @@ __global__ void gcorr_wgrad_finish_kernel(const float* part, float* gw, int B, i
 
 using namespace fz;
 
+static bool gc_fast_shape(int Co, int kd, int kh, int kw) {   // the compile-time instantiations
+  if (Co > 16) return false;
+  if (kd == kh && kh == kw && (kw == 3 || kw == 5 || kw == 7)) return true;
+  return kd == 1 && kh == kw && (kw == 3 || kw == 5 || kw == 7);
+}
+static bool gc_odd7(int k) { return k >= 1 && k <= kAnyK && (k & 1); }
+
 extern "C" int fz_gcorr_supported(int Ci, int Co, int kd, int kh, int kw) {
-  if (Ci < 1 || Co < 1 || Co > 16) return 0;
-  if (kd == kh && kh == kw && (kw == 3 || kw == 5 || kw == 7)) return 1;
-  if (kd == 1 && kh == kw && (kw == 3 || kw == 5 || kw == 7)) return 1;
-  return 0;
+  if (Ci < 1 || Co < 1) return 0;
+  return gc_odd7(kd) && gc_odd7(kh) && gc_odd7(kw) ? 1 : 0;   // (the generic kernels take what the instantiations do not)
 }
 
 // out = corr(in, w) [+ eps]  or, with mul_a / mul_b, the fused multiplicative update  mul_a ∘ mul_b / (corr + eps).
@@ -254,7 +427,7 @@ extern "C" int fz_gcorr(const float* in, const float* w, float* out, const float
   if (!in || !w || !out || ((mul_a == nullptr) != (mul_b == nullptr))) return fail(FZ_E_ARG, "fz_gcorr: null pointer");
   if (B < 0 || G < 1 || D < 1 || H < 1 || W < 1) return fail(FZ_E_SHAPE, "fz_gcorr: bad sizes");
   if (!fz_gcorr_supported(Ci, Co, kd, kh, kw))
-    return fail(FZ_E_UNSUPPORTED, "fz_gcorr: needs <= 16 output channels per group and a 3/5/7 cubic (or depth-1 square) kernel");
+    return fail(FZ_E_UNSUPPORTED, "fz_gcorr: needs odd kernel extents <= 7");
   if (B == 0) return FZ_OK;
   if (G > 65535 || B > 65535) return fail(FZ_E_UNSUPPORTED, "fz_gcorr: more than 65535 groups / samples");
   GcArgs a{in, w, out, mul_a, mul_b, B, G, Ci, Co, D, H, W, w_batched ? 1 : 0, mul_a ? 1 : 0, add_eps,
@@ -263,6 +436,14 @@ extern "C" int fz_gcorr(const float* in, const float* w, float* out, const float
   if (tiles > 0x7fffffff) return fail(FZ_E_UNSUPPORTED, "fz_gcorr: grid too large");
   dim3 grid((unsigned)tiles, (unsigned)G, (unsigned)B), block(256);
   hipStream_t st = (hipStream_t)stream;
+  if (!gc_fast_shape(Co, kd, kh, kw)) {   // anisotropic kernels, more than 16 channels per group: the run-time form
+    const int nob = (Co + kAnyCO - 1) / kAnyCO;
+    if ((int64_t)G * nob > 65535) return fail(FZ_E_UNSUPPORTED, "fz_gcorr: more than 65535 (group, channel block) pairs");
+    const int lds = (kTD + 2 * (kd / 2)) * (kTH + 2 * (kh / 2)) * (kTW + 2 * (kw / 2) + 1) * (int)sizeof(float);
+    hipLaunchKernelGGL(gcorr_any_kernel, dim3((unsigned)tiles, (unsigned)(G * nob), (unsigned)B), block, lds, st, a, kd, kh, kw, nob);
+    FZ_LAUNCH_CHECK();
+    return FZ_OK;
+  }
 #define FZ_GC(CO_, KD_, KH_, KW_) hipLaunchKernelGGL((gcorr_kernel<CO_, KD_, KH_, KW_>), grid, block, 0, st, a)
 #define FZ_GC_CO(KD_, KH_, KW_)                  \
   do {                                           \
@@ -303,7 +484,7 @@ extern "C" int fz_gcorr_wgrad(const float* in, const float* gout, float* gw, voi
   if (!in || !gout || !gw || !ws) return fail(FZ_E_ARG, "fz_gcorr_wgrad: null pointer");
   if (B < 1 || G < 1 || D < 1 || H < 1 || W < 1) return fail(FZ_E_SHAPE, "fz_gcorr_wgrad: bad sizes");
   if (!fz_gcorr_supported(Ci, Co, kd, kh, kw))
-    return fail(FZ_E_UNSUPPORTED, "fz_gcorr_wgrad: needs <= 16 output channels per group and a 3/5/7 cubic (or depth-1 square) kernel");
+    return fail(FZ_E_UNSUPPORTED, "fz_gcorr_wgrad: needs odd kernel extents <= 7");
   if ((int64_t)G * Ci > 65535 || B > 65535) return fail(FZ_E_UNSUPPORTED, "fz_gcorr_wgrad: more than 65535 (group, channel) pairs / samples");
   GcwArgs a{in, gout, (float*)ws, B, G, Ci, Co, D, H, W, (D + kTD - 1) / kTD, (H + kTH - 1) / kTH, (W + kTW - 1) / kTW, 0, 0};
   const int ntiles = a.tiles_d * a.tiles_h * a.tiles_w;
@@ -311,6 +492,25 @@ extern "C" int fz_gcorr_wgrad(const float* in, const float* gout, float* gw, voi
   a.tiles_per_chunk = (ntiles + a.nchunks - 1) / a.nchunks;
   dim3 grid((unsigned)a.nchunks, (unsigned)(G * Ci), (unsigned)B), block(256);
   hipStream_t st = (hipStream_t)stream;
+  if (!gc_fast_shape(Co, kd, kh, kw)) {
+    const int nob = (Co + kAnyCO - 1) / kAnyCO;
+    if ((int64_t)G * Ci * nob > 65535) return fail(FZ_E_UNSUPPORTED, "fz_gcorr_wgrad: more than 65535 (group, channel, channel block) triples");
+    const int P = kAnyCO * kd * kh, S = P >= 256 ? 1 : 256 / P;
+    const int lds = (kAnyCO * kGoStride + (kTD + 2 * (kd / 2)) * (kTH + 2 * (kh / 2)) * (kTW + 2 * (kw / 2) + 1) + (S + 1) * P * kw) *
+                    (int)sizeof(float);
+    if (lds > 160 * 1024) return fail(FZ_E_UNSUPPORTED, "fz_gcorr_wgrad: tile exceeds LDS");
+    if (lds > 65536)
+      FZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(gcorr_wgrad_any_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(gcorr_wgrad_any_kernel, dim3((unsigned)a.nchunks, (unsigned)(G * Ci * nob), (unsigned)B), block, lds, st, a, kd, kh,
+                       kw, nob, S);
+    FZ_LAUNCH_CHECK();
+    const int E = Co * Ci * kd * kh * kw;
+    const int64_t n = (int64_t)(w_batched ? B : 1) * G * E;
+    hipLaunchKernelGGL(gcorr_wgrad_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)ws, gw, B, G,
+                       a.nchunks, E, w_batched ? 1 : 0);
+    FZ_LAUNCH_CHECK();
+    return FZ_OK;
+  }
 #define FZ_GCW(CO_, KD_, KH_, KW_)                                                                                        \
   do {                                                                                                                    \
     constexpr int P_ = CO_ * KD_ * KH_, S_ = P_ >= 256 ? 1 : 256 / P_;                                                    \

@@ -146,7 +146,7 @@ class Deconv(nn.Module):
         if inp.is_cuda and inp.numel():
             composed.warn_once(f"deconv{tuple(inp.shape[1:])}{tuple(wg.shape)}",
                                f"Deconv: grouped correlation {tuple(wg.shape)} on {tuple(inp.shape)} ({inp.dtype}) is outside "
-                               "the native kernel set (fp32, <= 16 channels per group, cubic / square 3-5-7 kernels); "
+                               "the native kernel set (fp32, odd kernel extents <= 7); "
                                "using framework convolutions on device")
         out = _gcorr(inp, wg, self.padding)
         return out + add_eps if add_eps else out
@@ -157,7 +157,7 @@ class Deconv(nn.Module):
             return Fn.lag_corr(s, x, self.groups, self.kernel_size)
         if x.is_cuda and x.numel():
             composed.warn_once("deconv_update_h", "Deconv(update_filter=True): lag correlations outside the native kernel "
-                               "set (fp32, <= 16 channels per group, cubic / square 3-5-7 kernels); using framework "
+                               "set (fp32, odd kernel extents <= 7); using framework "
                                "convolutions on device")
         return _lag_corr(s, x, self.groups, self.padding)
 

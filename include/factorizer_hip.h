@@ -527,7 +527,10 @@ int fz_rowsum(const void* x /* activation */, float* part, float* out, int B, in
  *   in (B, G*Ci, D, H, W); w (Bw, G, Co, Ci, kd, kh, kw), Bw = B if w_batched else 1; out (B, G*Co, D, H, W); fp32.
  *   mul_a, mul_b: both NULL -> out = corr + add_eps; both given (shape of out) -> the fused multiplicative update
  *   out = mul_a * mul_b / (corr + add_eps)  (s * (H^T x + eps) / (H^T H s + eps)).
- * Supported: Co <= 16 per group, cubic 3/5/7 kernels, or depth-1 square 3/5/7 kernels (2-D layers as D = 1). */
+ * Supported: any odd kernel extent <= 7 per axis (2-D layers as D = 1, kd = 1) and any channel counts.  Compile-time
+ * instantiations serve Co <= 16 per group with cubic / depth-1 square 3-5-7 kernels (the reference's defaults); everything else —
+ * anisotropic kernels such as (5, 3, 3) of the reference's tests/test_deconver.py, more channels per group — runs the run-time-extent
+ * kernels (eight output channels per workgroup) [r6]. */
 int fz_gcorr_supported(int Ci, int Co, int kd, int kh, int kw);
 int fz_gcorr(const float* in, const float* w, float* out, const float* mul_a, const float* mul_b, int B, int G,
              int Ci, int Co, int D, int H, int W, int kd, int kh, int kw, int w_batched, float add_eps,

@@ -95,14 +95,60 @@ def test_grouped_correlation_kernel(nd, k, G, Ci, Co, S, batched):
     P.close("fused a*b/(corr+eps)", fused, a * b / (yc.detach() + 1e-3))
 
 
+@pytest.mark.parametrize("ks,G,Ci,Co,S,batched", [
+    ((5, 3, 3), 1, 8, 8, (6, 6, 8), False),        # the reference test suite's anisotropic kernel (tests/test_deconver.py)
+    ((3, 5, 7), 2, 3, 5, (5, 9, 70), True),        # every extent different, ragged tiles, per-sample filters
+    ((3, 3, 3), 2, 4, 20, (4, 6, 36), False),      # more than 16 output channels per group: three channel blocks of eight
+    ((1, 3, 5), 3, 24, 2, (1, 10, 66), False),     # > 16 INPUT channels of the adjoint (its Co), depth-1 volume
+    ((7, 1), 2, 2, 9, (12, 40), False)])           # 2-D anisotropic
+def test_grouped_correlation_any_kernel_extent_and_channel_count(ks, G, Ci, Co, S, batched):
+    """The run-time-extent kernels of csrc/deconv.hip (gcorr_any_kernel / gcorr_wgrad_any_kernel: any odd extent <= 7 per axis,
+    any channel count per group) against F.conv{2,3}d: forward, fused update epilogue, input gradient, filter gradient —
+    shapes the compile-time instantiations do not cover and that took framework convolutions on device until round 6."""
+    import torch.nn.functional as F
+    from factorizer_amd import functional as Fn
+    nd = len(ks)
+    torch.manual_seed(sum(ks) * 7 + Co)
+    B = 2
+    x = torch.rand(B, G * Ci, *S)
+    w = torch.rand(B if batched else 1, G, Co, Ci, *ks) / (Ci * float(torch.tensor(ks).prod())) ** 0.5
+    conv = F.conv3d if nd == 3 else F.conv2d
+    pad = tuple(k // 2 for k in ks)
+    xc, wc = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    if batched:
+        yc = conv(xc.reshape(1, B * G * Ci, *S), wc.reshape(B * G * Co, Ci, *ks), padding=pad, groups=B * G).reshape(B, G * Co, *S)
+    else:
+        yc = conv(xc, wc.reshape(G * Co, Ci, *ks), padding=pad, groups=G)
+    gy = torch.rand_like(yc)
+    gxc, gwc = torch.autograd.grad(yc, [xc, wc], gy)
+    xd, wd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    assert Fn.gcorr_supported(xd, wd)
+    n0 = _native.launch_count()
+    yd = Fn.gcorr(xd, wd, 0.0)
+    gxd, gwd = torch.autograd.grad(yd, [xd, wd], gy.to(DEV))
+    assert _native.launch_count() - n0 == 4
+    P.close("y", yd, yc)
+    P.close("gx", gxd, gxc)
+    P.close("gw", gwd, gwc)
+    gwd2 = torch.autograd.grad(Fn.gcorr(xd, wd, 0.0), wd, gy.to(DEV))[0]
+    assert torch.equal(gwd, gwd2)                    # fixed-order reduction: bit-identical when repeated
+    a, b = torch.rand_like(yc), torch.rand_like(yc)
+    fused = Fn.gcorr_mu_update(a.to(DEV), b.to(DEV), xd.detach(), wd.detach(), 1e-3)
+    P.close("fused a*b/(corr+eps)", fused, a * b / (yc.detach() + 1e-3))
+
+
 @pytest.mark.parametrize("tag", sorted(DECONV))
 def test_deconv_layer_on_device(golden, tag):
+    import warnings
     g = golden("g9_deconver")
     m = ft.Deconv(**DECONV[tag])
     m.load_state_dict(g.case(f"{tag}:sd"))
     m = m.to(DEV)
     x = g[f"{tag}:x"].to(DEV).requires_grad_(True)
-    y = m(x)
+    composed._warned.clear()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)     # every case of g9 — the anisotropic (5, 3, 3) one included — is native
+        y = m(x)
     (gx,) = torch.autograd.grad(y, x, g[f"{tag}:gy"].to(DEV))
     P.close("y", y, g[f"{tag}:y"])
     P.close("gx", gx, g[f"{tag}:gx"])
