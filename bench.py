@@ -78,8 +78,8 @@ MFMA_FLOP_PER_BYTE = {"mlp_chain_bwd_wgrad_": 16384 / 640}
 # read from inside the benchmark: the committed summary of the profiled run is quoted, and
 # `traffic_source` says which file (with its content hash and the commit it was measured at), so a stale
 # number is visible as such.
-PMC_TRAFFIC = os.path.join(ROOT, "profiles", os.environ.get("FZ_PMC_TRAFFIC", "r05_pmc_traffic.json"))
-PMC_TRAFFIC_BF16 = os.path.join(ROOT, "profiles", os.environ.get("FZ_PMC_TRAFFIC_BF16", "r05_pmc_traffic_bf16.json"))   # the --dtype bf16 command
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", os.environ.get("FZ_PMC_TRAFFIC", "r06_pmc_traffic.json"))
+PMC_TRAFFIC_BF16 = os.path.join(ROOT, "profiles", os.environ.get("FZ_PMC_TRAFFIC_BF16", "r06_pmc_traffic_bf16.json"))   # the --dtype bf16 command
 # What a hand-written streaming kernel of the same read : write mix reaches on MI355X (tools/probes/mem_ceilings.hip, 16 B per
 # lane, best over 4 / 8 / 16 waves per CU: profiles/r04_memory_ceilings.json).  `roofline.peak` stays the 8 TB/s of the
 # spec sheet; `stream_ceiling_GBps` is the number a memory-bound kernel can actually be held against.
