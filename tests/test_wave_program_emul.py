@@ -154,3 +154,19 @@ def test_gram_emul_vs_oracle(emu, M, N, T, G):
     s = gx64.abs().amax(dim=(1, 2)).clamp_min(1e-30)
     e = (gx.double() - gx64).abs().amax(dim=(1, 2)) / s
     assert e.max().item() <= 5e-6, e
+
+
+def test_emulation_under_asan(tmp_path):
+    """The wave programs under AddressSanitizer + UBSan on the host (tests/emul/asan_driver.cpp): GPU ASan is not available on the
+    pool, so the shared headers are sanitized where they compile for the CPU — ragged shapes, ranks 1-4, both solvers, the
+    decompose-gradient form, an all-zero matrix, the row-space backward; exact-size buffers."""
+    exe = str(tmp_path / "emul_asan")
+    drv = os.path.join(HERE, "emul", "asan_driver.cpp")
+    # (-O0: the sanitized template instantiations take 7 minutes to compile at -O1 -g, 33 s at -O0; the run is 0.2 s)
+    r = subprocess.run(["g++", "-O0", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-o", exe, drv, SRC],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "0 problem(s)" in r.stdout
